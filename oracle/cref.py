@@ -1,0 +1,78 @@
+"""TEST INFRASTRUCTURE ONLY — ctypes wrapper of the plain-C oracle (oracle/c/ovqe_oracle.c)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "c", "libovqe_oracle.so")
+_lib = None
+
+_u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_c128p = np.ctypeslib.ndpointer(np.complex128, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "c", "ovqe_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "c"), "libovqe_oracle.so"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = ctypes.CDLL(_SO)
+        L.orc_init_basis.argtypes = [_c128p, ctypes.c_int, ctypes.c_uint64]
+        L.orc_pauli_rotation.argtypes = [_c128p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_double]
+        L.orc_pauli_rotation_gates.argtypes = L.orc_pauli_rotation.argtypes
+        for f in (L.orc_expectation_termwise, L.orc_expectation_grouped):
+            f.argtypes = [_c128p, ctypes.c_int, ctypes.c_int64, _u64p, _u64p, _f64p]
+            f.restype = ctypes.c_double
+        L.orc_apply_gate.argtypes = [_c128p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+        L.orc_ucc_energy.argtypes = [_c128p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64, _u64p, _u64p, _f64p, _i32p,
+                                     _f64p, ctypes.c_int64, _u64p, _u64p, _f64p, ctypes.c_double, ctypes.c_int]
+        L.orc_ucc_energy.restype = ctypes.c_double
+        L.orc_gate_energy.argtypes = [_c128p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64, _i32p, _i32p, _i32p, _f64p,
+                                      _f64p, _i32p, _f64p, ctypes.c_int64, _u64p, _u64p, _f64p, ctypes.c_double]
+        L.orc_gate_energy.restype = ctypes.c_double
+        L.orc_max_threads.restype = ctypes.c_int
+        L.orc_set_threads.argtypes = [ctypes.c_int]
+        _lib = L
+    return _lib
+
+
+def sort_by_x(xs, zs, cs):
+    order = np.argsort(xs, kind="stable")
+    return (np.ascontiguousarray(xs[order]), np.ascontiguousarray(zs[order]), np.ascontiguousarray(cs[order]))
+
+
+def ucc_energy(n, hf_index, rx, rz, rcoef, pidx, theta, hx, hz, hc, constant, mode=0, psi=None):
+    """mode 0: fused (C2); mode 1: gate level (C1).  H coefficients must be real."""
+    L = lib()
+    if psi is None:
+        psi = np.empty(1 << n, dtype=np.complex128)
+    hx, hz, hc = sort_by_x(np.asarray(hx, np.uint64), np.asarray(hz, np.uint64), np.asarray(hc, np.float64))
+    e = L.orc_ucc_energy(psi, n, int(hf_index), len(rx), np.ascontiguousarray(rx, np.uint64),
+                         np.ascontiguousarray(rz, np.uint64), np.ascontiguousarray(rcoef, np.float64),
+                         np.ascontiguousarray(pidx, np.int32), np.ascontiguousarray(theta, np.float64),
+                         len(hx), hx, hz, hc, float(constant), int(mode))
+    return e, psi
+
+
+def gate_energy(n, hf_index, opcode, b0, b1, ascale, aconst, gpidx, theta, hx, hz, hc, constant, psi=None):
+    L = lib()
+    if psi is None:
+        psi = np.empty(1 << n, dtype=np.complex128)
+    e = L.orc_gate_energy(psi, n, int(hf_index), len(opcode), np.ascontiguousarray(opcode, np.int32),
+                          np.ascontiguousarray(b0, np.int32), np.ascontiguousarray(b1, np.int32),
+                          np.ascontiguousarray(ascale, np.float64), np.ascontiguousarray(aconst, np.float64),
+                          np.ascontiguousarray(gpidx, np.int32), np.ascontiguousarray(theta, np.float64),
+                          len(hx), np.ascontiguousarray(hx, np.uint64), np.ascontiguousarray(hz, np.uint64),
+                          np.ascontiguousarray(hc, np.float64), float(constant))
+    return e, psi

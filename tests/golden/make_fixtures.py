@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Regenerates the committed golden fixtures (run in the build container only).
+
+Sources are DATA held by the reference repository (never its code):
+  K1  notebooks/demo_WSSVQE.ipynb   stored stdout: the H2/STO-3G (r=0.98 A) JW
+      Hamiltonian printed by myQLM (15 terms, 17 digits), its 16 eigenvalues
+      and the VQE optimum -1.1053179360718883.
+  K2  openvqe/applications/quantum_batteries/CS_hams.pickle : 2..8-qubit
+      Pauli-dict Hamiltonians + HF bitstrings; logs/rotoselect.txt and
+      logs/adapt.txt: logged minima.
+The outputs are small JSON files of inputs and expected numbers.
+"""
+import json
+import os
+import pickle
+import re
+import sys
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+
+def notebook_stdout(path):
+    nb = json.load(open(path))
+    chunks = []
+    for cell in nb["cells"]:
+        for out in cell.get("outputs", []):
+            if out.get("output_type") == "stream":
+                chunks.append("".join(out["text"]))
+    return chunks
+
+
+def make_k1():
+    chunks = notebook_stdout(os.path.join(REF, "notebooks/demo_WSSVQE.ipynb"))
+    ham_txt = next(c for c in chunks if "I^4" in c and "XYYX" in c)
+    terms = []
+    constant = None
+    for line in ham_txt.strip().splitlines():
+        m = re.match(r"\(([-+0-9.e]+)\+0j\) \* I\^4", line)
+        if m:
+            constant = float(m.group(1))
+            continue
+        m = re.match(r"\(([-+0-9.e]+)\+0j\) \* \(([IXYZ]+)\|\[([0-9, ]+)\]\)", line)
+        assert m, line
+        terms.append([float(m.group(1)), m.group(2), [int(q) for q in m.group(3).split(",")]])
+    assert len(terms) == 14 and constant is not None
+    eig_txt = next(c for c in chunks if c.lstrip().startswith("[-0.34365999"))
+    eig_block = eig_txt[: eig_txt.index("]") + 1]
+    eigs = [float(v) for v in eig_block.strip("[] \n").split()]
+    assert len(eigs) == 16
+    fin = next(c for c in chunks if "Final energy for k=0000" in c)
+    e0 = float(re.search(r"k=0000: ([-0-9.]+)", fin).group(1))
+    e1 = float(re.search(r"k=0001: ([-0-9.]+)", fin).group(1))
+    out = {
+        "source": "ref:notebooks/demo_WSSVQE.ipynb stored outputs (cells 6, eigvals, final energies)",
+        "nbqbits": 4,
+        "constant_coeff": constant,
+        "terms": terms,
+        "printed_eigenvalues_8dp": eigs,
+        "vqe_final_energy_k0000": e0,
+        "vqe_final_energy_k0001": e1,
+        "hf_init": 12,
+    }
+    json.dump(out, open(os.path.join(HERE, "k1_h2_sto3g.json"), "w"), indent=1)
+    return out
+
+
+def make_k2():
+    class Safe(pickle.Unpickler):
+        def find_class(self, module, name):
+            if (module, name) in {("numpy.core.multiarray", "scalar"), ("numpy", "dtype"),
+                                  ("numpy._core.multiarray", "scalar")}:
+                return super().find_class(module, name)
+            raise pickle.UnpicklingError(f"blocked {module}.{name}")
+
+    p = os.path.join(REF, "openvqe/applications/quantum_batteries/CS_hams.pickle")
+    data = Safe(open(p, "rb")).load()
+    logs = {}
+    txt = open(os.path.join(REF, "openvqe/applications/quantum_batteries/logs/rotoselect.txt")).read()
+    for m in re.finditer(r"num qubits = (\d+)\nminimized <H> = ([-0-9.]+)", txt):
+        logs.setdefault("rotoselect_min", {})[m.group(1)] = float(m.group(2))
+    txt = open(os.path.join(REF, "openvqe/applications/quantum_batteries/logs/adapt.txt")).read()
+    for m in re.finditer(r"num qubits = (\d+)\nnum electrons = \d+\nTotal number of excitations = \d+\n"
+                         r"minimized <H> = ([-0-9.]+)", txt):
+        logs.setdefault("adapt_min", {})[m.group(1)] = float(m.group(2))
+    out = {"source": "ref:openvqe/applications/quantum_batteries/CS_hams.pickle + logs/*.txt", "logs": logs,
+           "hams": {}}
+    for n, entry in data.items():
+        assert all(abs(complex(c).imag) == 0 for c in entry["ham"].values())
+        out["hams"][str(n)] = {
+            "terms": [[s, float(complex(c).real)] for s, c in entry["ham"].items()],
+            "hf": {k: [float(complex(v).real), float(complex(v).imag)] for k, v in entry["hf"].items()},
+        }
+    json.dump(out, open(os.path.join(HERE, "k2_cs_hams.json"), "w"))
+    return out
+
+
+if __name__ == "__main__":
+    k1 = make_k1()
+    k2 = make_k2()
+    print("K1 terms", len(k1["terms"]), "K2 sizes", {k: len(v["terms"]) for k, v in k2["hams"].items()})
+    print(k2["logs"])
