@@ -1,0 +1,164 @@
+/* ovqe_sv.h — C ABI of the MI355X-native statevector backend for OpenVQE's VQE / ADAPT-VQE
+ * inner loop (libovqe_sv.so, gfx950 only).
+ *
+ * The reference (OpenVQE, pure Python) has no plugin ABI of its own: its hot path talks to the
+ * third-party myQLM objects.  Each entry point below names the reference call
+ * site(s) whose work it replaces ("ref:" = /root/reference/).
+ *
+ * Conventions
+ *   - n-qubit state = 2^n complex<double> amplitudes (re,im interleaved, 16 B) resident in HBM.
+ *   - reference qubit q  <->  basis-index bit (n-1-q)  (qubit 0 is the MSB:
+ *     ref:openvqe/ucc_family/get_energy_qucc.py:40-45,
+ *     ref:openvqe/common_files/molecule_factory_with_sparse.py:622-642,
+ *     ref:openvqe/adapt/qubit_adapt_vqe.py:111-120).  ALL masks / bit numbers in this header are in
+ *     basis-index bit space.
+ *   - a Pauli string is two uint64 masks (x,z): I=(0,0) X=(1,0) Z=(0,1) Y=(1,1);
+ *     P = i^{popcount(x&z)} X^x Z^z.
+ *   - every function returns 0 on success or a negative OVQE_ERR_*; ovqe_last_error() gives text.
+ *     No C++ exception crosses the ABI.  A handle is not thread-safe; distinct handles are
+ *     independent.  Calls are synchronous unless stated (results are on the host on return).
+ *   - host arrays are borrowed for the duration of the call only.
+ *   - sharded states (multi-GPU): a handle may own one shard of 2^n_local amplitudes of a
+ *     (n_local + n_global)-qubit state; shard s holds basis indices [s << n_local, (s+1) << n_local).
+ *     Masks then span n_local+n_global bits; x bits must be local (the host layer makes them so by
+ *     exchanging half shards, openvqe_amd/distributed.py), z bits may be global (rank-dependent sign).
+ */
+#ifndef OVQE_SV_H
+#define OVQE_SV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OVQE_OK 0
+#define OVQE_ERR_INVALID (-1)   /* bad argument */
+#define OVQE_ERR_NO_DEVICE (-2) /* no usable gfx950 device */
+#define OVQE_ERR_HIP (-3)       /* HIP runtime error (text in ovqe_last_error) */
+#define OVQE_ERR_ALLOC (-4)     /* device/host allocation failed */
+#define OVQE_ERR_STATE (-5)     /* call order: program / Hamiltonian not set */
+
+/* gate opcodes of ovqe_set_gate_program / ovqe_apply_gate
+ * (gate set of ref:openvqe/common_files/circuit.py:1 and ref:openvqe/ucc_family/get_energy_qucc.py:4;
+ *  RX(a)=exp(-iaX/2), RY(a)=exp(-iaY/2), RZ(a)=diag(e^{-ia/2},e^{ia/2}), CNOT(control,target)) */
+#define OVQE_GATE_X 0
+#define OVQE_GATE_H 1
+#define OVQE_GATE_RX 2
+#define OVQE_GATE_RY 3
+#define OVQE_GATE_RZ 4
+#define OVQE_GATE_CNOT 5
+
+/* pool-gradient modes */
+#define OVQE_GRAD_FERMIONIC 0 /* g = 2 Re <sigma|A|psi>   ref:openvqe/adapt/fermionic_adapt_vqe.py:67-73 */
+#define OVQE_GRAD_QUBIT 1     /* g = 2 |<sigma|P|psi>|    ref:openvqe/adapt/qubit_adapt_vqe.py:147-150 */
+
+typedef struct ovqe_sv *ovqe_handle;
+
+int ovqe_version(void);
+/* text of the last error on this handle (h may be NULL: last error of a failed create) */
+const char *ovqe_last_error(ovqe_handle h);
+int ovqe_device_count(int *count);
+
+/* ---- lifecycle.  Replaces the per-submit state allocation of qat.qpus.get_default_qpu().submit
+ * (ref:openvqe/ucc_family/get_energy_ucc.py:38-48): the library owns the device buffers. */
+int ovqe_create(int n_qubits, int device, ovqe_handle *out);
+/* one shard of a distributed state: n_local local bits, n_global rank bits, this shard's index */
+int ovqe_create_shard(int n_local, int n_global, uint64_t shard_index, int device, ovqe_handle *out);
+int ovqe_destroy(ovqe_handle h);
+/* run this handle's kernels on a caller-owned hipStream_t (NULL = default stream) */
+int ovqe_set_stream(ovqe_handle h, void *hip_stream);
+/* tuning knobs: "force_path" (0 auto, 1 fused small-register kernel, 2 streaming kernels),
+ * "small_max_qubits", "small_batch_max_qubits", "unroll" */
+int ovqe_set_option(ovqe_handle h, const char *name, int64_t value);
+/* device pointer to the 2^n_local amplitudes (for RCCL exchange by the host layer) */
+int ovqe_state_ptr(ovqe_handle h, void **dev_ptr);
+/* use caller-owned device memory (e.g. a torch tensor) of 2^n_local*16 bytes as the state buffer */
+int ovqe_adopt_state(ovqe_handle h, void *dev_ptr);
+
+/* ---- state set-up / read-back */
+/* |index> (global index).  HF reference state: X on qubit q iff bit (n-1-q) of hf_init is set
+ * (ref:openvqe/ucc_family/get_energy_ucc.py:43 `init`, get_energy_qucc.py:40-45;
+ *  ref:openvqe/adapt/fermionic_adapt_vqe.py:183-213 prepare_hf_state) */
+int ovqe_init_basis(ovqe_handle h, uint64_t index);
+int ovqe_set_state(ovqe_handle h, const double *amps_re_im);       /* 2*2^n_local doubles */
+/* full-statevector read-back (ref:openvqe/adapt/fermionic_adapt_vqe.py:309-328 get_statevector) */
+int ovqe_get_state(ovqe_handle h, double *amps_re_im);
+int ovqe_get_amplitudes(ovqe_handle h, int64_t count, const uint64_t *local_indices, double *amps_re_im);
+/* deterministic synthetic state: amp(i) = scale * (u1(i), u2(i)), u in [-1,1) from a counter-based
+ * integer hash of (seed, global index) (bit-reproducible on the host, see openvqe_amd/synth.py);
+ * scale normalises the FULL state when norm2_total > 0 is given, else this shard alone.
+ * Returns the scale used. */
+int ovqe_randomize(ovqe_handle h, uint64_t seed, double norm2_total, double *scale_out);
+int ovqe_norm2(ovqe_handle h, double *out); /* sum |a_i|^2 over this shard */
+
+/* ---- unit operations on the resident state (large-n, HBM-bound path) */
+/* psi <- exp(-i phi P) psi : the unit of work of build_ucc_ansatz([op], init, n_steps=1)([theta])
+ * (third-party; call sites ref:openvqe/ucc_family/get_energy_ucc.py:44,86,
+ *  ref:openvqe/adapt/fermionic_adapt_vqe.py:158,302, ref:openvqe/adapt/qubit_adapt_vqe.py:181,303) */
+int ovqe_apply_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi);
+/* R rotations in order; consecutive rotations sharing an x mask are fused into one sweep */
+int ovqe_apply_pauli_rotations(ovqe_handle h, int64_t R, const uint64_t *x, const uint64_t *z, const double *phi);
+/* one literal gate (ref:openvqe/common_files/circuit.py:13-93 templates); b0 = target/control bit, b1 = CNOT target */
+int ovqe_apply_gate(ovqe_handle h, int opcode, int b0, int b1, double angle);
+/* Re sum_t coeff[t] <psi|P_t|psi> + constant  (shard-local partial sum when sharded):
+ * circ.to_job(job_type="OBS", observable=H) + qpu.submit(job).value
+ * (ref:openvqe/ucc_family/get_energy_ucc.py:46-48, get_energy_qucc.py:52-54,
+ *  ref:openvqe/adapt/fermionic_adapt_vqe.py:161,237, ref:openvqe/adapt/qubit_adapt_vqe.py:209,267,306) */
+int ovqe_expectation(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff,
+                     double constant, double *out);
+/* sum_t coeff[t] <bra|P_t|ket> with explicit device buffers of 2^n_local amplitudes each
+ * (bra/ket NULL = this handle's state).  Used for global-x Hamiltonian terms across shards. */
+int ovqe_bilinear(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64_t T, const uint64_t *x,
+                  const uint64_t *z, const double *coeff_re, const double *coeff_im, double *out_re_im);
+
+/* ---- compiled evaluation: E(theta) of a whole ansatz circuit */
+/* observable H = constant + sum_t coeff[t] P_t (real coefficients; ref:...get_energy_ucc.py:47) */
+int ovqe_set_hamiltonian(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff,
+                         double constant);
+/* Pauli-rotation program on |hf_index>: rotation r is exp(-i (coeff[r]*theta[pidx[r]] + phi0[r]) P_r)
+ * (pidx[r] < 0: constant angle phi0[r]; phi0 may be NULL); K = number of parameters.
+ * This is the flattened form of the loop ref:openvqe/ucc_family/get_energy_ucc.py:42-45
+ * (and fermionic_adapt_vqe.py:156-159, qubit_adapt_vqe.py:301-304). */
+int ovqe_set_program(ovqe_handle h, int64_t R, const uint64_t *x, const uint64_t *z, const double *coeff,
+                     const double *phi0, const int32_t *pidx, int32_t K, uint64_t hf_index);
+/* literal gate program on |hf_index>: gate g has angle ascale[g]*theta[pidx[g]] + aconst[g]
+ * (ref:openvqe/ucc_family/get_energy_qucc.py:37-51 + circuit.py:95-106 efficient_fermionic_ansatz) */
+int ovqe_set_gate_program(ovqe_handle h, int64_t G, const int32_t *opcode, const int32_t *b0, const int32_t *b1,
+                          const double *ascale, const double *aconst, const int32_t *pidx, int32_t K,
+                          uint64_t hf_index);
+/* E(theta): one call == one ucc_action / action_quccsd evaluation
+ * (ref:openvqe/ucc_family/get_energy_ucc.py:8-50, get_energy_qucc.py:11-56) */
+int ovqe_energy(ovqe_handle h, const double *theta, int32_t K, double *energy);
+/* B parameter vectors (row-major B x K) in one launch — one finite-difference gradient of
+ * scipy.optimize.minimize(jac=None) (ref:openvqe/ucc_family/get_energy_ucc.py:158-175) is B = K+1 */
+int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, double *energies);
+/* run the program and leave U(theta)|hf> in the handle's state buffer
+ * (prepare_state_ansatz + get_statevector, ref:openvqe/adapt/fermionic_adapt_vqe.py:273-328) */
+int ovqe_prepare_state(ovqe_handle h, const double *theta, int32_t K);
+
+/* ---- ADAPT gradient screen on the resident state psi (uses the stored Hamiltonian):
+ * sigma = H psi once, then for pool operator k = sum_{j in [off[k],off[k+1])} c_j P_j
+ *   mode FERMIONIC: g_k = 2 Re sum_j c_j <sigma|P_j|psi>   (c complex; A_k anti-Hermitian)
+ *   mode QUBIT    : g_k = 2 | sum_j c_j <sigma|P_j|psi> |
+ * (ref:openvqe/adapt/fermionic_adapt_vqe.py:41-122, ref:openvqe/adapt/qubit_adapt_vqe.py:126-150,462-471) */
+int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, const uint64_t *x, const uint64_t *z,
+                        const double *coeff_re, const double *coeff_im, int mode, double *grads);
+/* psi <- exp(theta * A) psi with A = sum_t (coeff_re+i coeff_im)[t] P_t, exact (scaled Taylor series),
+ * the state evolution of the gradient screens
+ * (ref:openvqe/adapt/fermionic_adapt_vqe.py:12-38 expm_multiply; qubit_adapt_vqe.py:20-55 expm(-i theta P)) */
+int ovqe_apply_exp_pauli_sum(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff_re,
+                             const double *coeff_im, double theta);
+
+/* ---- measurement support (bench.py): average device time in ms of `reps` back-to-back launches of
+ * one Pauli-rotation sweep, bracketed by HIP events on the handle's stream */
+int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, int warmup, int reps,
+                             double *avg_ms);
+/* device time in ms of the most recent ovqe_energy_batch launch (HIP events) */
+int ovqe_last_batch_ms(ovqe_handle h, double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVQE_SV_H */

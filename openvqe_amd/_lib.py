@@ -1,0 +1,93 @@
+"""ctypes binding of libovqe_sv.so (include/ovqe_sv.h).  No fallback: if the HIP library is not
+built, importing this module's ``lib()`` raises; if no gfx950 device is present every compute
+call fails with the library's error text."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libovqe_sv.so")
+
+_u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_vp = ctypes.c_void_p
+_H = ctypes.c_void_p
+_int, _i64, _u64, _dbl = ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double
+
+
+class _OptF64(object):
+    """ndpointer that also accepts None (NULL)."""
+
+    @classmethod
+    def from_param(cls, obj):
+        if obj is None:
+            return None
+        return _f64p.from_param(obj)
+
+
+# every symbol declared in include/ovqe_sv.h: name -> (restype, argtypes)
+SIGNATURES = {
+    "ovqe_version": (_int, []),
+    "ovqe_last_error": (ctypes.c_char_p, [_H]),
+    "ovqe_device_count": (_int, [ctypes.POINTER(_int)]),
+    "ovqe_create": (_int, [_int, _int, ctypes.POINTER(_H)]),
+    "ovqe_create_shard": (_int, [_int, _int, _u64, _int, ctypes.POINTER(_H)]),
+    "ovqe_destroy": (_int, [_H]),
+    "ovqe_set_stream": (_int, [_H, _vp]),
+    "ovqe_set_option": (_int, [_H, ctypes.c_char_p, _i64]),
+    "ovqe_state_ptr": (_int, [_H, ctypes.POINTER(_vp)]),
+    "ovqe_adopt_state": (_int, [_H, _vp]),
+    "ovqe_init_basis": (_int, [_H, _u64]),
+    "ovqe_set_state": (_int, [_H, _f64p]),
+    "ovqe_get_state": (_int, [_H, _f64p]),
+    "ovqe_get_amplitudes": (_int, [_H, _i64, _u64p, _f64p]),
+    "ovqe_randomize": (_int, [_H, _u64, _dbl, ctypes.POINTER(_dbl)]),
+    "ovqe_norm2": (_int, [_H, ctypes.POINTER(_dbl)]),
+    "ovqe_apply_pauli_rotation": (_int, [_H, _u64, _u64, _dbl]),
+    "ovqe_apply_pauli_rotations": (_int, [_H, _i64, _u64p, _u64p, _f64p]),
+    "ovqe_apply_gate": (_int, [_H, _int, _int, _int, _dbl]),
+    "ovqe_expectation": (_int, [_H, _i64, _u64p, _u64p, _f64p, _dbl, ctypes.POINTER(_dbl)]),
+    "ovqe_bilinear": (_int, [_H, _vp, _vp, _i64, _u64p, _u64p, _f64p, _OptF64, _f64p]),
+    "ovqe_set_hamiltonian": (_int, [_H, _i64, _u64p, _u64p, _f64p, _dbl]),
+    "ovqe_set_program": (_int, [_H, _i64, _u64p, _u64p, _f64p, _OptF64, _i32p, ctypes.c_int32, _u64]),
+    "ovqe_set_gate_program": (_int, [_H, _i64, _i32p, _i32p, _i32p, _f64p, _f64p, _i32p, ctypes.c_int32, _u64]),
+    "ovqe_energy": (_int, [_H, _f64p, ctypes.c_int32, ctypes.POINTER(_dbl)]),
+    "ovqe_energy_batch": (_int, [_H, _i64, _f64p, ctypes.c_int32, _f64p]),
+    "ovqe_prepare_state": (_int, [_H, _f64p, ctypes.c_int32]),
+    "ovqe_pool_gradients": (_int, [_H, _i64, _i64p, _u64p, _u64p, _f64p, _OptF64, _int, _f64p]),
+    "ovqe_apply_exp_pauli_sum": (_int, [_H, _i64, _u64p, _u64p, _f64p, _OptF64, _dbl]),
+    "ovqe_time_pauli_rotation": (_int, [_H, _u64, _u64, _dbl, _int, _int, ctypes.POINTER(_dbl)]),
+    "ovqe_last_batch_ms": (_int, [_H, ctypes.POINTER(_dbl)]),
+}
+
+_lib = None
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libovqe_sv.so (built by ``__graft_entry__.build()``); raise loudly if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BackendError(
+                f"{LIB_PATH} is not built — run `python -c 'import __graft_entry__ as g; g.build()'`. "
+                "There is no CPU fallback for the statevector backend.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the header and the library disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, handle=None):
+    if rc != 0:
+        msg = lib().ovqe_last_error(handle)
+        raise BackendError(f"libovqe_sv error {rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,271 @@
+"""Python face of the HIP statevector backend (one object == one ``ovqe_handle``).
+
+Everything numerical happens in ``libovqe_sv.so``; this module only packs the reference's
+operator objects (``.terms[i].{coeff,op,qbits}``) into the mask arrays of
+``include/ovqe_sv.h`` and forwards.  No CPU implementation lives here.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .operators import pack_string, pack_terms
+
+GATE_OPCODES = {"X": 0, "H": 1, "RX": 2, "RY": 3, "RZ": 4, "CNOT": 5}
+GRAD_FERMIONIC, GRAD_QUBIT = 0, 1
+_REAL_TOL = 1e-12
+
+
+def _real_coeff(c, what):
+    c = complex(c)
+    if abs(c.imag) > _REAL_TOL * max(1.0, abs(c.real)):
+        raise ValueError(f"{what}: Pauli coefficient {c} is not real (generator must be Hermitian — "
+                         "multiply the anti-Hermitian cluster operator by 1j, ref:openvqe/algorithms/ucc.py:30-31)")
+    return c.real
+
+
+def compile_ucc_program(nbqbits, generators, n_params=None):
+    """Flatten ``for op_k, theta_k: build_ucc_ansatz([op_k], ...)([theta_k])``
+    (ref:openvqe/ucc_family/get_energy_ucc.py:42-45) into rotation arrays: rotation (k, j) is
+    exp(-i theta_k c_kj P_kj), k outer / j in ``terms`` order (one Trotter step)."""
+    K = len(generators) if n_params is None else min(len(generators), int(n_params))  # zip truncation
+    xs, zs, cs, ps = [], [], [], []
+    for k in range(K):
+        for term in generators[k].terms:
+            x, z = pack_string(nbqbits, term.op, term.qbits)
+            xs.append(x)
+            zs.append(z)
+            cs.append(_real_coeff(term.coeff, f"generator {k}"))
+            ps.append(k)
+    return (np.array(xs, np.uint64), np.array(zs, np.uint64), np.array(cs, np.float64),
+            np.array(ps, np.int32), K)
+
+
+class Statevector:
+    """n-qubit complex128 state resident on one MI355X (or one shard of a distributed state)."""
+
+    def __init__(self, n_qubits, device=0, n_global=0, shard_index=0):
+        self._L = _lib.lib()
+        self._h = ctypes.c_void_p()
+        self.nbqbits = int(n_qubits) + int(n_global)
+        self.n_local = int(n_qubits)
+        self.n_global = int(n_global)
+        self.shard_index = int(shard_index)
+        if n_global:
+            rc = self._L.ovqe_create_shard(n_qubits, n_global, shard_index, device, ctypes.byref(self._h))
+        else:
+            rc = self._L.ovqe_create(n_qubits, device, ctypes.byref(self._h))
+        if rc != 0:
+            self._h = ctypes.c_void_p()
+            _lib.check(rc, None)
+        self._K = 0
+
+    # -- lifecycle ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.ovqe_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, rc):
+        _lib.check(rc, self._h)
+
+    def set_option(self, name, value):
+        self._ck(self._L.ovqe_set_option(self._h, name.encode(), int(value)))
+
+    def set_stream(self, hip_stream_handle):
+        self._ck(self._L.ovqe_set_stream(self._h, ctypes.c_void_p(hip_stream_handle)))
+
+    def adopt_state(self, device_ptr):
+        self._ck(self._L.ovqe_adopt_state(self._h, ctypes.c_void_p(device_ptr)))
+
+    def state_ptr(self):
+        p = ctypes.c_void_p()
+        self._ck(self._L.ovqe_state_ptr(self._h, ctypes.byref(p)))
+        return p.value
+
+    # -- state ----------------------------------------------------------------------------------
+    def init_basis(self, index):
+        self._ck(self._L.ovqe_init_basis(self._h, int(index)))
+
+    def set_state(self, psi):
+        psi = np.ascontiguousarray(psi, dtype=np.complex128)
+        if psi.shape != (1 << self.n_local,):
+            raise ValueError("state has the wrong length")
+        self._ck(self._L.ovqe_set_state(self._h, psi.view(np.float64)))
+
+    def get_state(self):
+        out = np.empty(1 << self.n_local, dtype=np.complex128)
+        self._ck(self._L.ovqe_get_state(self._h, out.view(np.float64)))
+        return out
+
+    def get_amplitudes(self, local_indices):
+        idx = np.ascontiguousarray(local_indices, dtype=np.uint64)
+        out = np.empty(idx.shape[0], dtype=np.complex128)
+        self._ck(self._L.ovqe_get_amplitudes(self._h, idx.shape[0], idx, out.view(np.float64)))
+        return out
+
+    def randomize(self, seed, norm2_total=0.0):
+        scale = ctypes.c_double()
+        self._ck(self._L.ovqe_randomize(self._h, int(seed), float(norm2_total), ctypes.byref(scale)))
+        return scale.value
+
+    def norm2(self):
+        out = ctypes.c_double()
+        self._ck(self._L.ovqe_norm2(self._h, ctypes.byref(out)))
+        return out.value
+
+    # -- unit operations ------------------------------------------------------------------------
+    def apply_pauli_rotation(self, x, z, phi):
+        self._ck(self._L.ovqe_apply_pauli_rotation(self._h, int(x), int(z), float(phi)))
+
+    def apply_pauli_rotations(self, xs, zs, phis):
+        xs = np.ascontiguousarray(xs, np.uint64)
+        zs = np.ascontiguousarray(zs, np.uint64)
+        phis = np.ascontiguousarray(phis, np.float64)
+        self._ck(self._L.ovqe_apply_pauli_rotations(self._h, xs.shape[0], xs, zs, phis))
+
+    def rotate(self, op, qbits, phi):
+        """exp(-i phi P) with P given as (pauli string, reference qubit list)."""
+        x, z = pack_string(self.nbqbits, op, qbits)
+        self.apply_pauli_rotation(x, z, phi)
+
+    def apply_gate(self, name, qubits, angle=0.0):
+        """literal gate on reference qubit indices (ref:openvqe/common_files/circuit.py gate set)."""
+        n = self.nbqbits
+        b0 = n - 1 - int(qubits[0])
+        b1 = n - 1 - int(qubits[1]) if len(qubits) > 1 else 0
+        self._ck(self._L.ovqe_apply_gate(self._h, GATE_OPCODES[name], b0, b1, float(angle or 0.0)))
+
+    def expectation(self, hamiltonian):
+        """Re <psi|H|psi> (+ constant) — the OBS job value (get_energy_ucc.py:46-48)."""
+        xs, zs, cs = pack_terms(self.nbqbits, hamiltonian.terms)
+        coeff = np.array([_real_coeff(c, "observable") for c in cs], np.float64)
+        out = ctypes.c_double()
+        const = _real_coeff(getattr(hamiltonian, "constant_coeff", 0.0) or 0.0, "observable constant")
+        self._ck(self._L.ovqe_expectation(self._h, xs.shape[0], xs, zs, coeff, const, ctypes.byref(out)))
+        return out.value
+
+    def bilinear(self, xs, zs, coeff, bra_ptr=None, ket_ptr=None):
+        coeff = np.asarray(coeff, np.complex128)
+        out = np.zeros(2, np.float64)
+        self._ck(self._L.ovqe_bilinear(self._h, ctypes.c_void_p(bra_ptr), ctypes.c_void_p(ket_ptr), len(xs),
+                                       np.ascontiguousarray(xs, np.uint64), np.ascontiguousarray(zs, np.uint64),
+                                       np.ascontiguousarray(coeff.real), np.ascontiguousarray(coeff.imag), out))
+        return complex(out[0], out[1])
+
+    # -- compiled evaluation --------------------------------------------------------------------
+    def set_hamiltonian(self, hamiltonian):
+        xs, zs, cs = pack_terms(self.nbqbits, hamiltonian.terms)
+        coeff = np.array([_real_coeff(c, "observable") for c in cs], np.float64)
+        const = _real_coeff(getattr(hamiltonian, "constant_coeff", 0.0) or 0.0, "observable constant")
+        self._ck(self._L.ovqe_set_hamiltonian(self._h, xs.shape[0], xs, zs, coeff, const))
+
+    def set_rotation_program(self, xs, zs, coeffs, pidx, n_params, hf_init, phi0=None):
+        xs = np.ascontiguousarray(xs, np.uint64)
+        self._ck(self._L.ovqe_set_program(self._h, xs.shape[0], xs, np.ascontiguousarray(zs, np.uint64),
+                                          np.ascontiguousarray(coeffs, np.float64),
+                                          None if phi0 is None else np.ascontiguousarray(phi0, np.float64),
+                                          np.ascontiguousarray(pidx, np.int32), int(n_params), int(hf_init)))
+        self._K = int(n_params)
+
+    def set_ucc_program(self, generators, hf_init, n_params=None):
+        xs, zs, cs, ps, K = compile_ucc_program(self.nbqbits, generators, n_params)
+        self.set_rotation_program(xs, zs, cs, ps, K, hf_init)
+        return K
+
+    def set_gate_program(self, gates, n_params, hf_init):
+        """gates: list of (name, qubits, angle_scale, angle_const, param_index or -1)."""
+        n = self.nbqbits
+        G = len(gates)
+        opc = np.zeros(G, np.int32)
+        b0 = np.zeros(G, np.int32)
+        b1 = np.zeros(G, np.int32)
+        asc = np.zeros(G, np.float64)
+        aco = np.zeros(G, np.float64)
+        pid = np.full(G, -1, np.int32)
+        for g, (name, qubits, scale, const, p) in enumerate(gates):
+            opc[g] = GATE_OPCODES[name]
+            b0[g] = n - 1 - int(qubits[0])
+            b1[g] = n - 1 - int(qubits[1]) if len(qubits) > 1 else 0
+            asc[g], aco[g], pid[g] = scale, const, p
+        self._ck(self._L.ovqe_set_gate_program(self._h, G, opc, b0, b1, asc, aco, pid, int(n_params), int(hf_init)))
+        self._K = int(n_params)
+
+    def energy(self, theta):
+        theta = np.ascontiguousarray(theta, np.float64).reshape(-1)[: self._K]
+        if theta.shape[0] != self._K:
+            raise ValueError(f"expected {self._K} parameters")
+        out = ctypes.c_double()
+        self._ck(self._L.ovqe_energy(self._h, theta if self._K else np.zeros(1), self._K, ctypes.byref(out)))
+        return out.value
+
+    def energy_batch(self, thetas):
+        thetas = np.ascontiguousarray(thetas, np.float64)
+        if thetas.ndim != 2 or thetas.shape[1] != self._K:
+            raise ValueError(f"expected a (B, {self._K}) array")
+        out = np.empty(thetas.shape[0], np.float64)
+        self._ck(self._L.ovqe_energy_batch(self._h, thetas.shape[0], thetas if thetas.size else np.zeros(1),
+                                           self._K, out))
+        return out
+
+    def prepare_state(self, theta):
+        theta = np.ascontiguousarray(theta, np.float64).reshape(-1)[: self._K]
+        self._ck(self._L.ovqe_prepare_state(self._h, theta if self._K else np.zeros(1), self._K))
+
+    def last_batch_ms(self):
+        out = ctypes.c_double()
+        self._ck(self._L.ovqe_last_batch_ms(self._h, ctypes.byref(out)))
+        return out.value
+
+    # -- ADAPT ----------------------------------------------------------------------------------
+    def pool_gradients(self, pool_ops, mode):
+        """Gradient screen over ``pool_ops`` on the resident state, with the stored Hamiltonian."""
+        offsets = np.zeros(len(pool_ops) + 1, np.int64)
+        xs, zs, cs = [], [], []
+        for k, op in enumerate(pool_ops):
+            px, pz, pc = pack_terms(self.nbqbits, op.terms)
+            xs.append(px)
+            zs.append(pz)
+            cs.append(pc)
+            offsets[k + 1] = offsets[k] + px.shape[0]
+        xs = np.concatenate(xs) if xs else np.zeros(0, np.uint64)
+        zs = np.concatenate(zs) if zs else np.zeros(0, np.uint64)
+        cs = np.concatenate(cs) if cs else np.zeros(0, np.complex128)
+        if xs.shape[0] == 0:
+            xs, zs, cs = np.zeros(1, np.uint64), np.zeros(1, np.uint64), np.zeros(1, np.complex128)
+        out = np.zeros(len(pool_ops), np.float64)
+        self._ck(self._L.ovqe_pool_gradients(self._h, len(pool_ops), offsets, xs, zs,
+                                             np.ascontiguousarray(cs.real), np.ascontiguousarray(cs.imag),
+                                             int(mode), out))
+        return out
+
+    def apply_exp_pauli_sum(self, operator, theta, prefactor=1.0):
+        """psi <- exp(theta * prefactor * operator) psi, exact (no Trotter splitting)."""
+        xs, zs, cs = pack_terms(self.nbqbits, operator.terms)
+        cs = cs * prefactor
+        if getattr(operator, "constant_coeff", 0.0):
+            raise ValueError("apply_exp_pauli_sum: operator with a constant term")
+        self._ck(self._L.ovqe_apply_exp_pauli_sum(self._h, xs.shape[0], xs, zs, np.ascontiguousarray(cs.real),
+                                                  np.ascontiguousarray(cs.imag), float(theta)))
+
+    def time_pauli_rotation(self, x, z, phi, warmup=3, reps=20):
+        out = ctypes.c_double()
+        self._ck(self._L.ovqe_time_pauli_rotation(self._h, int(x), int(z), float(phi), int(warmup), int(reps),
+                                                  ctypes.byref(out)))
+        return out.value
+
+
+def device_count():
+    c = ctypes.c_int()
+    _lib.lib().ovqe_device_count(ctypes.byref(c))
+    return c.value

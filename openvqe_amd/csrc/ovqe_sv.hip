@@ -1,0 +1,1020 @@
+// ovqe_sv.hip — C ABI (include/ovqe_sv.h) + host-side engine of the MI355X statevector backend.
+// gfx950 only; no CPU fallback: every entry point needs a live device.
+#include "../../include/ovqe_sv.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "sv_kernels.hpp"
+#include "sv_small.hpp"
+
+using namespace ovqe;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct HamDev {  // grouped Pauli sum resident on the device
+    std::vector<HGroup> groups;
+    std::vector<HTerm> terms;
+    DevBuf d_groups, d_terms;
+    double constant = 0.0;
+    bool set = false;
+};
+
+}  // namespace
+
+struct ovqe_sv {
+    int n_local = 0, n_global = 0, device = 0;
+    uint64_t shard = 0, base = 0, namps = 0;
+    hipStream_t stream = nullptr;
+    amp_t *state = nullptr;
+    bool own_state = true;
+    amp_t *scratch[2] = {nullptr, nullptr};
+    std::string err;
+
+    // reduction workspace
+    DevBuf d_partials, d_result;
+    // rotation tables
+    DevBuf d_rp;
+    RotParam *h_rp = nullptr;  // pinned
+    size_t h_rp_cap = 0;
+    double2 *h_result = nullptr;  // pinned, small
+
+    HamDev ham;
+    // compiled program
+    bool prog_set = false;
+    int32_t K = 0;
+    uint64_t hf = 0;
+    std::vector<SmallOp> ops;
+    std::vector<SmallRot> rots;
+    std::vector<SmallSeg> segs;
+    DevBuf d_ops, d_rots, d_segs;
+    int cs_capacity = 512;
+    // batched evaluation workspace
+    DevBuf d_theta, d_energies, d_workspace;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_batch_ms = 0.f;
+    // options
+    int opt_force_path = 0;       // 0 auto, 1 small kernel, 2 streaming kernels
+    int opt_small_max = 14;       // always-small up to this many qubits
+    int opt_small_batch_max = 16; // small kernel for batches up to this many qubits
+    int opt_unroll = 4;
+};
+
+namespace {
+
+int fail(ovqe_handle h, int code, const std::string &msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPC(h, call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(h, OVQE_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+int ensure(ovqe_handle h, DevBuf &b, size_t bytes) {
+    if (b.cap >= bytes && b.p) return OVQE_OK;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = std::max<size_t>(bytes, 256);
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) return fail(h, OVQE_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+    b.cap = want;
+    return OVQE_OK;
+}
+
+int ensure_scratch(ovqe_handle h, int k) {
+    if (h->scratch[k]) return OVQE_OK;
+    hipError_t e = hipMalloc((void **)&h->scratch[k], h->namps * sizeof(amp_t));
+    if (e != hipSuccess) return fail(h, OVQE_ERR_ALLOC, std::string("hipMalloc scratch: ") + hipGetErrorString(e));
+    return OVQE_OK;
+}
+
+inline uint64_t local_mask(ovqe_handle h) { return h->namps - 1ull; }
+inline int reduce_blocks(uint64_t namps) {
+    return (int)std::min<uint64_t>(2048, std::max<uint64_t>(1, (namps + 255) / 256));
+}
+
+// sort terms by x (stable), fold i^ny into the coefficient, build per-x groups
+int build_groups(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *cr, const double *ci,
+                 bool allow_global_x, std::vector<HGroup> &groups, std::vector<HTerm> &terms,
+                 std::vector<uint64_t> *xs_out = nullptr, std::vector<int64_t> *perm_out = nullptr) {
+    const uint64_t lmask = local_mask(h);
+    const int ntot = h->n_local + h->n_global;
+    const uint64_t allmask = ntot >= 64 ? ~0ull : ((1ull << ntot) - 1ull);
+    std::vector<int64_t> order(T);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return x[a] < x[b]; });
+    groups.clear();
+    terms.clear();
+    terms.reserve(T);
+    for (int64_t oi = 0; oi < T; ++oi) {
+        const int64_t t = order[oi];
+        if ((x[t] | z[t]) & ~allmask) return fail(h, OVQE_ERR_INVALID, "Pauli mask has bits beyond the register");
+        if (!allow_global_x && (x[t] & ~lmask))
+            return fail(h, OVQE_ERR_INVALID,
+                        "x mask touches global (rank) bits: exchange shards first (openvqe_amd/distributed.py)");
+        const int ny = __builtin_popcountll(x[t] & z[t]) & 3;
+        const double a = cr[t], b = ci ? ci[t] : 0.0;
+        HTerm ht;
+        ht.z = z[t];
+        switch (ny) {  // (a + ib) * i^ny
+        case 0: ht.cr = a; ht.ci = b; break;
+        case 1: ht.cr = -b; ht.ci = a; break;
+        case 2: ht.cr = -a; ht.ci = -b; break;
+        default: ht.cr = b; ht.ci = -a; break;
+        }
+        if (groups.empty() || x[order[oi - 1]] != x[t]) {
+            HGroup g;
+            g.x = x[t] & lmask;
+            g.jbase = (h->base ^ x[t]) & ~lmask;
+            g.t0 = (int32_t)terms.size();
+            g.t1 = g.t0;
+            groups.push_back(g);
+        }
+        terms.push_back(ht);
+        groups.back().t1 = (int32_t)terms.size();
+        if (xs_out) xs_out->push_back(x[t] & lmask);
+    }
+    if (perm_out) *perm_out = order;
+    return OVQE_OK;
+}
+
+int upload(ovqe_handle h, DevBuf &b, const void *src, size_t bytes) {
+    int rc = ensure(h, b, bytes);
+    if (rc) return rc;
+    if (bytes) HIPC(h, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    return OVQE_OK;
+}
+
+// ---- streaming-path launches -------------------------------------------------------------------
+int launch_rot_run(ovqe_handle h, uint64_t x, const RotParam *d_rp, int nrot) {
+    if (nrot <= 0) return OVQE_OK;
+    if (x == 0) {
+        const uint64_t n = h->namps;
+        if (h->opt_unroll >= 4 && n >= 256u * 4u) {
+            hipLaunchKernelGGL(k_rot_diag<4>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, h->stream, h->state, n,
+                               h->base, d_rp, nrot);
+        } else {
+            hipLaunchKernelGGL(k_rot_diag<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->state, n,
+                               h->base, d_rp, nrot);
+        }
+    } else {
+        const uint64_t np = h->namps >> 1;
+        const int pivot = 63 - __builtin_clzll(x);
+        if (h->opt_unroll >= 4 && np >= 256u * 4u) {
+            hipLaunchKernelGGL(k_rot_pairs<4>, dim3((unsigned)((np + 1023) / 1024)), dim3(256), 0, h->stream, h->state,
+                               np, pivot, x, h->base, d_rp, nrot);
+        } else if (h->opt_unroll >= 2 && np >= 256u * 2u) {
+            hipLaunchKernelGGL(k_rot_pairs<2>, dim3((unsigned)((np + 511) / 512)), dim3(256), 0, h->stream, h->state, np,
+                               pivot, x, h->base, d_rp, nrot);
+        } else {
+            hipLaunchKernelGGL(k_rot_pairs<1>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, h->stream, h->state, np,
+                               pivot, x, h->base, d_rp, nrot);
+        }
+    }
+    HIPC(h, hipGetLastError());
+    return OVQE_OK;
+}
+
+int launch_gate(ovqe_handle h, int kind, int b0, int b1) {
+    const uint64_t nwork = kind == 2 ? (h->namps >> 2) : (h->namps >> 1);
+    if (nwork == 0) return fail(h, OVQE_ERR_INVALID, "register too small for this gate");
+    if (nwork >= 1024) {
+        hipLaunchKernelGGL(k_gate<4>, dim3((unsigned)((nwork + 1023) / 1024)), dim3(256), 0, h->stream, h->state, nwork,
+                           kind, b0, b1);
+    } else {
+        hipLaunchKernelGGL(k_gate<1>, dim3((unsigned)((nwork + 255) / 256)), dim3(256), 0, h->stream, h->state, nwork,
+                           kind, b0, b1);
+    }
+    HIPC(h, hipGetLastError());
+    return OVQE_OK;
+}
+
+inline RotParam make_rot(uint64_t x, uint64_t z, double phi) {
+    RotParam r;
+    const int ny = __builtin_popcountll(x & z) & 3;
+    r.z = z;
+    r.c = std::cos(phi);
+    const double s = std::sin(phi);
+    r.s = (ny & 2) ? -s : s;
+    r.odd = ny & 1;
+    r.pad = 0;
+    return r;
+}
+
+int ensure_rp(ovqe_handle h, size_t n) {
+    if (h->h_rp_cap < n) {
+        if (h->h_rp) (void)hipHostFree(h->h_rp);
+        h->h_rp = nullptr;
+        size_t cap = std::max<size_t>(n, 1024);
+        hipError_t e = hipHostMalloc((void **)&h->h_rp, cap * sizeof(RotParam), hipHostMallocDefault);
+        if (e != hipSuccess) return fail(h, OVQE_ERR_ALLOC, "hipHostMalloc rotation table");
+        h->h_rp_cap = cap;
+    }
+    return ensure(h, h->d_rp, n * sizeof(RotParam));
+}
+
+// sum over [bra|P|ket] groups -> complex result on host
+int run_bilinear(ovqe_handle h, const amp_t *bra, const amp_t *ket, const std::vector<HGroup> &groups,
+                 const HGroup *d_groups, const HTerm *d_terms, double2 *out) {
+    const int nb = reduce_blocks(h->namps);
+    const int G = (int)groups.size();
+    if (G == 0) {
+        *out = make_double2(0.0, 0.0);
+        return OVQE_OK;
+    }
+    // chunk the group loop so that one launch streams at most ~64 GiB
+    const double bytes_per_group = 32.0 * (double)h->namps;
+    int per_launch = (int)std::max(1.0, std::min((double)G, 6.4e10 / bytes_per_group));
+    const int nchunks = (G + per_launch - 1) / per_launch;
+    int rc = ensure(h, h->d_partials, (size_t)nchunks * nb * sizeof(double2));
+    if (rc) return rc;
+    rc = ensure(h, h->d_result, 64 * sizeof(double2));
+    if (rc) return rc;
+    for (int c = 0; c < nchunks; ++c) {
+        const int g0 = c * per_launch, g1 = std::min(G, g0 + per_launch);
+        hipLaunchKernelGGL(k_bilinear, dim3(nb), dim3(256), 0, h->stream, bra, ket, h->namps, d_groups, g0, g1, d_terms,
+                           (double2 *)h->d_partials.p + (size_t)c * nb);
+    }
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->stream, (const double2 *)h->d_partials.p,
+                       (int64_t)nchunks * nb, (double2 *)h->d_result.p, 0);
+    HIPC(h, hipGetLastError());
+    HIPC(h, hipMemcpyAsync(h->h_result, h->d_result.p, sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    *out = h->h_result[0];
+    return OVQE_OK;
+}
+
+int init_basis(ovqe_handle h, uint64_t index) {
+    const uint64_t lmask = local_mask(h);
+    const int has = ((index & ~lmask) == h->base) ? 1 : 0;
+    hipLaunchKernelGGL(k_init_basis, dim3(reduce_blocks(h->namps)), dim3(256), 0, h->stream, h->state, h->namps,
+                       index & lmask, has);
+    HIPC(h, hipGetLastError());
+    return OVQE_OK;
+}
+
+// run the compiled program with the streaming kernels (state left in h->state)
+int run_program_streaming(ovqe_handle h, const double *theta) {
+    int rc = init_basis(h, h->hf);
+    if (rc) return rc;
+    const size_t R = h->rots.size();
+    rc = ensure_rp(h, std::max<size_t>(R, 1));
+    if (rc) return rc;
+    // every op of a fused run shares x; the table needs x per rotation for the ny fold
+    for (const SmallOp &op : h->ops) {
+        if (op.kind != OP_PAIR && op.kind != OP_DIAG) continue;
+        for (int r = op.first; r < op.first + op.count; ++r) {
+            const SmallRot &sr = h->rots[r];
+            const double phi = sr.phi0 + (sr.pidx >= 0 ? sr.coeff * theta[sr.pidx] : 0.0);
+            RotParam rp;
+            rp.z = sr.z;
+            rp.c = std::cos(phi);
+            const double s = std::sin(phi);
+            rp.s = (sr.ny & 2) ? -s : s;
+            rp.odd = sr.ny & 1;
+            rp.pad = 0;
+            h->h_rp[r] = rp;
+        }
+    }
+    if (R) HIPC(h, hipMemcpyAsync(h->d_rp.p, h->h_rp, R * sizeof(RotParam), hipMemcpyHostToDevice, h->stream));
+    for (const SmallOp &op : h->ops) {
+        switch (op.kind) {
+        case OP_PAIR:
+        case OP_DIAG:
+            rc = launch_rot_run(h, op.kind == OP_PAIR ? op.x : 0ull, (const RotParam *)h->d_rp.p + op.first, op.count);
+            break;
+        case OP_X: rc = launch_gate(h, 0, op.pivot, 0); break;
+        case OP_H: rc = launch_gate(h, 1, op.pivot, 0); break;
+        case OP_CNOT: rc = launch_gate(h, 2, op.first, op.count); break;
+        default: rc = fail(h, OVQE_ERR_INVALID, "corrupt program");
+        }
+        if (rc) return rc;
+    }
+    // the pinned table may be rewritten by the next call: make sure the copy has been consumed
+    HIPC(h, hipStreamSynchronize(h->stream));
+    return OVQE_OK;
+}
+
+int finish_program(ovqe_handle h) {
+    // split fused runs longer than the LDS table, then cut segments
+    const int cap = h->cs_capacity;
+    std::vector<SmallOp> ops2;
+    for (const SmallOp &op : h->ops) {
+        if ((op.kind == OP_PAIR || op.kind == OP_DIAG) && op.count > cap) {
+            for (int o = 0; o < op.count; o += cap) {
+                SmallOp p = op;
+                p.first = op.first + o;
+                p.count = std::min(cap, op.count - o);
+                ops2.push_back(p);
+            }
+        } else {
+            ops2.push_back(op);
+        }
+    }
+    h->ops.swap(ops2);
+    h->segs.clear();
+    SmallSeg cur = {0, 0, 0, 0};
+    for (int o = 0; o < (int)h->ops.size(); ++o) {
+        const SmallOp &op = h->ops[o];
+        if (op.kind == OP_PAIR || op.kind == OP_DIAG) {
+            if (op.first + op.count - cur.rot0 > cap) {
+                if (cur.op1 > cur.op0) h->segs.push_back(cur);
+                cur = {o, o, op.first, op.first};
+            }
+            cur.rot1 = op.first + op.count;
+        }
+        cur.op1 = o + 1;
+    }
+    if (cur.op1 > cur.op0) h->segs.push_back(cur);
+    int rc = upload(h, h->d_ops, h->ops.data(), h->ops.size() * sizeof(SmallOp));
+    if (rc) return rc;
+    rc = upload(h, h->d_rots, h->rots.data(), h->rots.size() * sizeof(SmallRot));
+    if (rc) return rc;
+    rc = upload(h, h->d_segs, h->segs.data(), h->segs.size() * sizeof(SmallSeg));
+    if (rc) return rc;
+    h->prog_set = true;
+    return OVQE_OK;
+}
+
+void push_rotation(ovqe_handle h, uint64_t x, uint64_t z, double coeff, double phi0, int32_t pidx) {
+    SmallRot sr;
+    sr.z = z;
+    sr.coeff = coeff;
+    sr.phi0 = phi0;
+    sr.pidx = pidx;
+    sr.ny = __builtin_popcountll(x & z) & 3;
+    const int32_t idx = (int32_t)h->rots.size();
+    h->rots.push_back(sr);
+    const int32_t kind = x ? OP_PAIR : OP_DIAG;
+    if (!h->ops.empty()) {
+        SmallOp &last = h->ops.back();
+        if (last.kind == kind && last.x == x && last.first + last.count == idx) {
+            last.count++;
+            return;
+        }
+    }
+    SmallOp op;
+    op.x = x;
+    op.kind = kind;
+    op.first = idx;
+    op.count = 1;
+    op.pivot = x ? 63 - __builtin_clzll(x) : 0;
+    h->ops.push_back(op);
+}
+
+bool use_small_path(ovqe_handle h, int64_t B) {
+    if (h->n_global != 0) return false;
+    if (h->opt_force_path == 1) return h->n_local <= 16;
+    if (h->opt_force_path == 2) return false;
+    if (h->n_local <= h->opt_small_max) return true;
+    return h->n_local <= h->opt_small_batch_max && B >= 32;
+}
+
+template <bool LDS, int NT>
+int launch_small(ovqe_handle h, const SmallArgs &A, int grid, size_t smem) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_vqe<LDS, NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_small_vqe<LDS, NT>), dim3(grid), dim3(NT), smem, h->stream, A);
+    HIPC(h, hipGetLastError());
+    return OVQE_OK;
+}
+
+// B evaluations with the fused kernel; energies -> host; optionally leave state of b=0 in h->state
+int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies, bool keep_state) {
+    const int n = h->n_local;
+    const size_t state_bytes = (size_t)h->namps * sizeof(amp_t);
+    const bool lds_state = state_bytes <= 128 * 1024;
+    int max_slices = (int)std::max<size_t>(1, std::min<size_t>(512, ((size_t)512 << 20) / state_bytes));
+    if (lds_state) max_slices = n <= 12 ? 1024 : 512;
+    const int grid = (int)std::min<int64_t>(B, max_slices);
+    int rc = ensure(h, h->d_theta, (size_t)B * std::max(1, h->K) * sizeof(double));
+    if (rc) return rc;
+    rc = ensure(h, h->d_energies, (size_t)B * sizeof(double));
+    if (rc) return rc;
+    rc = ensure(h, h->d_workspace, lds_state ? state_bytes : (size_t)grid * state_bytes);
+    if (rc) return rc;
+    if (h->K > 0)
+        HIPC(h, hipMemcpyAsync(h->d_theta.p, theta, (size_t)B * h->K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    SmallArgs A;
+    A.n = n;
+    A.B = B;
+    A.theta = (const double *)h->d_theta.p;
+    A.K = h->K;
+    A.ops = (const SmallOp *)h->d_ops.p;
+    A.rots = (const SmallRot *)h->d_rots.p;
+    A.segs = (const SmallSeg *)h->d_segs.p;
+    A.nsegs = (int)h->segs.size();
+    A.groups = (const HGroup *)h->ham.d_groups.p;
+    A.ngroups = (int)h->ham.groups.size();
+    A.terms = (const HTerm *)h->ham.d_terms.p;
+    A.constant = h->ham.constant;
+    A.hf = h->hf;
+    A.workspace = (amp_t *)h->d_workspace.p;
+    A.energies = (double *)h->d_energies.p;
+    A.keep_state = keep_state ? 1 : 0;
+    A.cs_capacity = h->cs_capacity;
+    const size_t smem = (lds_state ? state_bytes : 0) + (size_t)h->cs_capacity * sizeof(double2) + 16 * sizeof(double2);
+    const uint64_t npairs = h->namps >> 1;
+    HIPC(h, hipEventRecord(h->ev0, h->stream));
+    if (lds_state) {
+        if (npairs >= 1024) rc = launch_small<true, 1024>(h, A, grid, smem);
+        else if (npairs >= 256) rc = launch_small<true, 256>(h, A, grid, smem);
+        else rc = launch_small<true, 64>(h, A, grid, smem);
+    } else {
+        rc = launch_small<false, 1024>(h, A, grid, smem);
+    }
+    if (rc) return rc;
+    HIPC(h, hipEventRecord(h->ev1, h->stream));
+    HIPC(h, hipMemcpyAsync(energies, h->d_energies.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (keep_state)
+        HIPC(h, hipMemcpyAsync(h->state, h->d_workspace.p, state_bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    HIPC(h, hipEventElapsedTime(&h->last_batch_ms, h->ev0, h->ev1));
+    return OVQE_OK;
+}
+
+int check_theta(ovqe_handle h, const double *theta, int32_t K) {
+    if (!h->prog_set) return fail(h, OVQE_ERR_STATE, "no program set (ovqe_set_program / ovqe_set_gate_program)");
+    if (K != h->K) return fail(h, OVQE_ERR_INVALID, "K does not match the program's parameter count");
+    if (K > 0 && !theta) return fail(h, OVQE_ERR_INVALID, "theta is NULL");
+    return OVQE_OK;
+}
+
+int create_common(int n_local, int n_global, uint64_t shard, int device, ovqe_handle *out) {
+    if (!out) return fail(nullptr, OVQE_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_local < 1 || n_local > 36 || n_global < 0 || n_local + n_global > 64)
+        return fail(nullptr, OVQE_ERR_INVALID, "qubit count out of range (1 <= n_local <= 36, total <= 64)");
+    if (n_global < 64 && shard >> n_global) return fail(nullptr, OVQE_ERR_INVALID, "shard index out of range");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, OVQE_ERR_NO_DEVICE, "no HIP device visible: libovqe_sv has no CPU fallback");
+    if (device < 0 || device >= count) return fail(nullptr, OVQE_ERR_INVALID, "device index out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, OVQE_ERR_NO_DEVICE,
+                    std::string("device is not gfx950 (MI355X): ") + prop.gcnArchName + " — code objects are gfx950 only");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, OVQE_ERR_HIP, "hipSetDevice failed");
+    ovqe_handle h = new (std::nothrow) ovqe_sv();
+    if (!h) return fail(nullptr, OVQE_ERR_ALLOC, "host allocation failed");
+    h->n_local = n_local;
+    h->n_global = n_global;
+    h->device = device;
+    h->shard = shard;
+    h->namps = 1ull << n_local;
+    h->base = shard << n_local;
+    e = hipMalloc((void **)&h->state, h->namps * sizeof(amp_t));
+    if (e != hipSuccess) {
+        delete h;
+        return fail(nullptr, OVQE_ERR_ALLOC, std::string("hipMalloc state: ") + hipGetErrorString(e));
+    }
+    if (hipHostMalloc((void **)&h->h_result, 64 * sizeof(double2), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        (void)hipFree(h->state);
+        delete h;
+        return fail(nullptr, OVQE_ERR_ALLOC, "host staging / event creation failed");
+    }
+    *out = h;
+    return OVQE_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int ovqe_version(void) { return 100; }
+
+const char *ovqe_last_error(ovqe_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ovqe_device_count(int *count) {
+    if (!count) return OVQE_ERR_INVALID;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    *count = c;
+    return OVQE_OK;
+}
+
+int ovqe_create(int n_qubits, int device, ovqe_handle *out) { return create_common(n_qubits, 0, 0, device, out); }
+
+int ovqe_create_shard(int n_local, int n_global, uint64_t shard_index, int device, ovqe_handle *out) {
+    return create_common(n_local, n_global, shard_index, device, out);
+}
+
+int ovqe_destroy(ovqe_handle h) {
+    if (!h) return OVQE_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->own_state && h->state) (void)hipFree(h->state);
+    for (int k = 0; k < 2; ++k)
+        if (h->scratch[k]) (void)hipFree(h->scratch[k]);
+    DevBuf *bufs[] = {&h->d_partials, &h->d_result, &h->d_rp, &h->ham.d_groups, &h->ham.d_terms, &h->d_ops,
+                      &h->d_rots, &h->d_segs, &h->d_theta, &h->d_energies, &h->d_workspace};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (h->h_rp) (void)hipHostFree(h->h_rp);
+    if (h->h_result) (void)hipHostFree(h->h_result);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+    return OVQE_OK;
+}
+
+int ovqe_set_stream(ovqe_handle h, void *hip_stream) {
+    if (!h) return OVQE_ERR_INVALID;
+    HIPC(h, hipStreamSynchronize(h->stream));
+    h->stream = (hipStream_t)hip_stream;
+    return OVQE_OK;
+}
+
+int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
+    if (!h || !name) return OVQE_ERR_INVALID;
+    const std::string k(name);
+    if (k == "force_path") h->opt_force_path = (int)value;
+    else if (k == "small_max_qubits") h->opt_small_max = (int)value;
+    else if (k == "small_batch_max_qubits") h->opt_small_batch_max = (int)value;
+    else if (k == "unroll") h->opt_unroll = (int)value;
+    else return fail(h, OVQE_ERR_INVALID, "unknown option " + k);
+    return OVQE_OK;
+}
+
+int ovqe_state_ptr(ovqe_handle h, void **dev_ptr) {
+    if (!h || !dev_ptr) return OVQE_ERR_INVALID;
+    *dev_ptr = h->state;
+    return OVQE_OK;
+}
+
+int ovqe_adopt_state(ovqe_handle h, void *dev_ptr) {
+    if (!h || !dev_ptr) return OVQE_ERR_INVALID;
+    HIPC(h, hipStreamSynchronize(h->stream));
+    if (h->own_state && h->state) (void)hipFree(h->state);
+    h->state = (amp_t *)dev_ptr;
+    h->own_state = false;
+    return OVQE_OK;
+}
+
+int ovqe_init_basis(ovqe_handle h, uint64_t index) {
+    if (!h) return OVQE_ERR_INVALID;
+    const int ntot = h->n_local + h->n_global;
+    if (ntot < 64 && (index >> ntot)) return fail(h, OVQE_ERR_INVALID, "basis index out of range");
+    int rc = init_basis(h, index);
+    if (rc) return rc;
+    HIPC(h, hipStreamSynchronize(h->stream));
+    return OVQE_OK;
+}
+
+int ovqe_set_state(ovqe_handle h, const double *amps) {
+    if (!h || !amps) return OVQE_ERR_INVALID;
+    HIPC(h, hipMemcpyAsync(h->state, amps, h->namps * sizeof(amp_t), hipMemcpyHostToDevice, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    return OVQE_OK;
+}
+
+int ovqe_get_state(ovqe_handle h, double *amps) {
+    if (!h || !amps) return OVQE_ERR_INVALID;
+    HIPC(h, hipMemcpyAsync(amps, h->state, h->namps * sizeof(amp_t), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    return OVQE_OK;
+}
+
+int ovqe_get_amplitudes(ovqe_handle h, int64_t count, const uint64_t *idx, double *amps) {
+    if (!h || count < 0 || (count && (!idx || !amps))) return OVQE_ERR_INVALID;
+    if (count == 0) return OVQE_OK;
+    for (int64_t i = 0; i < count; ++i)
+        if (idx[i] >= h->namps) return fail(h, OVQE_ERR_INVALID, "amplitude index out of range");
+    DevBuf d_idx, d_out;
+    int rc = ensure(h, d_idx, count * sizeof(uint64_t));
+    if (!rc) rc = ensure(h, d_out, count * sizeof(amp_t));
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(d_idx.p, idx, count * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_gather, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, h->state, count,
+                               (const uint64_t *)d_idx.p, (amp_t *)d_out.p);
+            e = hipMemcpyAsync(amps, d_out.p, count * sizeof(amp_t), hipMemcpyDeviceToHost, h->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, OVQE_ERR_HIP, std::string("get_amplitudes: ") + hipGetErrorString(e));
+    }
+    if (d_idx.p) (void)hipFree(d_idx.p);
+    if (d_out.p) (void)hipFree(d_out.p);
+    return rc;
+}
+
+int ovqe_randomize(ovqe_handle h, uint64_t seed, double norm2_total, double *scale_out) {
+    if (!h) return OVQE_ERR_INVALID;
+    const int nb = reduce_blocks(h->namps);
+    int rc = ensure(h, h->d_partials, (size_t)nb * sizeof(double2));
+    if (!rc) rc = ensure(h, h->d_result, 64 * sizeof(double2));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_randomize, dim3(nb), dim3(256), 0, h->stream, h->state, h->namps, h->base, seed, 1.0,
+                       (double2 *)h->d_partials.p);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->stream, (const double2 *)h->d_partials.p, (int64_t)nb,
+                       (double2 *)h->d_result.p, 0);
+    HIPC(h, hipGetLastError());
+    HIPC(h, hipMemcpyAsync(h->h_result, h->d_result.p, sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    const double n2 = norm2_total > 0.0 ? norm2_total : h->h_result[0].x;
+    const double scale = 1.0 / std::sqrt(n2);
+    hipLaunchKernelGGL(k_scale, dim3(nb), dim3(256), 0, h->stream, h->state, h->namps, scale);
+    HIPC(h, hipGetLastError());
+    HIPC(h, hipStreamSynchronize(h->stream));
+    if (scale_out) *scale_out = scale;
+    return OVQE_OK;
+}
+
+int ovqe_norm2(ovqe_handle h, double *out) {
+    if (!h || !out) return OVQE_ERR_INVALID;
+    const int nb = reduce_blocks(h->namps);
+    int rc = ensure(h, h->d_partials, (size_t)nb * sizeof(double2));
+    if (!rc) rc = ensure(h, h->d_result, 64 * sizeof(double2));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_norm2, dim3(nb), dim3(256), 0, h->stream, h->state, h->namps, (double2 *)h->d_partials.p);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->stream, (const double2 *)h->d_partials.p, (int64_t)nb,
+                       (double2 *)h->d_result.p, 0);
+    HIPC(h, hipGetLastError());
+    HIPC(h, hipMemcpyAsync(h->h_result, h->d_result.p, sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    *out = h->h_result[0].x;
+    return OVQE_OK;
+}
+
+// ---- unit operations ----------------------------------------------------------------------------
+int ovqe_apply_pauli_rotations(ovqe_handle h, int64_t R, const uint64_t *x, const uint64_t *z, const double *phi) {
+    if (!h || R < 0 || (R && (!x || !z || !phi))) return OVQE_ERR_INVALID;
+    if (R == 0) return OVQE_OK;
+    const uint64_t lmask = local_mask(h);
+    const int ntot = h->n_local + h->n_global;
+    const uint64_t allmask = ntot >= 64 ? ~0ull : ((1ull << ntot) - 1ull);
+    for (int64_t r = 0; r < R; ++r) {
+        if ((x[r] | z[r]) & ~allmask) return fail(h, OVQE_ERR_INVALID, "Pauli mask has bits beyond the register");
+        if (x[r] & ~lmask)
+            return fail(h, OVQE_ERR_INVALID,
+                        "x mask touches global (rank) bits: exchange shards first (openvqe_amd/distributed.py)");
+    }
+    int rc = ensure_rp(h, (size_t)R);
+    if (rc) return rc;
+    for (int64_t r = 0; r < R; ++r) h->h_rp[r] = make_rot(x[r], z[r], phi[r]);
+    HIPC(h, hipMemcpyAsync(h->d_rp.p, h->h_rp, (size_t)R * sizeof(RotParam), hipMemcpyHostToDevice, h->stream));
+    int64_t r0 = 0;
+    while (r0 < R) {
+        int64_t r1 = r0 + 1;
+        while (r1 < R && x[r1] == x[r0]) ++r1;
+        rc = launch_rot_run(h, x[r0], (const RotParam *)h->d_rp.p + r0, (int)(r1 - r0));
+        if (rc) return rc;
+        r0 = r1;
+    }
+    HIPC(h, hipStreamSynchronize(h->stream));
+    return OVQE_OK;
+}
+
+int ovqe_apply_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi) {
+    return ovqe_apply_pauli_rotations(h, 1, &x, &z, &phi);
+}
+
+int ovqe_apply_gate(ovqe_handle h, int opcode, int b0, int b1, double angle) {
+    if (!h) return OVQE_ERR_INVALID;
+    if (b0 < 0 || b0 >= h->n_local) return fail(h, OVQE_ERR_INVALID, "gate bit out of (local) range");
+    const uint64_t bit = 1ull << b0;
+    int rc;
+    switch (opcode) {
+    case OVQE_GATE_X: rc = launch_gate(h, 0, b0, 0); break;
+    case OVQE_GATE_H: rc = launch_gate(h, 1, b0, 0); break;
+    case OVQE_GATE_RX: return ovqe_apply_pauli_rotation(h, bit, 0, 0.5 * angle);
+    case OVQE_GATE_RY: return ovqe_apply_pauli_rotation(h, bit, bit, 0.5 * angle);
+    case OVQE_GATE_RZ: return ovqe_apply_pauli_rotation(h, 0, bit, 0.5 * angle);
+    case OVQE_GATE_CNOT:
+        if (b1 < 0 || b1 >= h->n_local || b1 == b0) return fail(h, OVQE_ERR_INVALID, "CNOT target bit invalid");
+        rc = launch_gate(h, 2, b0, b1);
+        break;
+    default: return fail(h, OVQE_ERR_INVALID, "unknown gate opcode");
+    }
+    if (rc) return rc;
+    HIPC(h, hipStreamSynchronize(h->stream));
+    return OVQE_OK;
+}
+
+int ovqe_bilinear(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64_t T, const uint64_t *x,
+                  const uint64_t *z, const double *coeff_re, const double *coeff_im, double *out_re_im) {
+    if (!h || T < 0 || !out_re_im || (T && (!x || !z || !coeff_re))) return OVQE_ERR_INVALID;
+    std::vector<HGroup> groups;
+    std::vector<HTerm> terms;
+    int rc = build_groups(h, T, x, z, coeff_re, coeff_im, /*allow_global_x=*/ket_dev != nullptr, groups, terms);
+    if (rc) return rc;
+    DevBuf dg, dt;
+    rc = upload(h, dg, groups.data(), groups.size() * sizeof(HGroup));
+    if (!rc) rc = upload(h, dt, terms.data(), terms.size() * sizeof(HTerm));
+    double2 res = make_double2(0.0, 0.0);
+    if (!rc)
+        rc = run_bilinear(h, bra_dev ? (const amp_t *)bra_dev : h->state, ket_dev ? (const amp_t *)ket_dev : h->state,
+                          groups, (const HGroup *)dg.p, (const HTerm *)dt.p, &res);
+    if (dg.p) (void)hipFree(dg.p);
+    if (dt.p) (void)hipFree(dt.p);
+    out_re_im[0] = res.x;
+    out_re_im[1] = res.y;
+    return rc;
+}
+
+int ovqe_expectation(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff,
+                     double constant, double *out) {
+    if (!out) return OVQE_ERR_INVALID;
+    double res[2] = {0.0, 0.0};
+    int rc = ovqe_bilinear(h, nullptr, nullptr, T, x, z, coeff, nullptr, res);
+    if (rc) return rc;
+    *out = res[0] + constant;
+    return OVQE_OK;
+}
+
+// ---- compiled evaluation ------------------------------------------------------------------------
+int ovqe_set_hamiltonian(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff,
+                         double constant) {
+    if (!h || T < 0 || (T && (!x || !z || !coeff))) return OVQE_ERR_INVALID;
+    h->ham.set = false;
+    int rc = build_groups(h, T, x, z, coeff, nullptr, false, h->ham.groups, h->ham.terms);
+    if (rc) return rc;
+    rc = upload(h, h->ham.d_groups, h->ham.groups.data(), h->ham.groups.size() * sizeof(HGroup));
+    if (!rc) rc = upload(h, h->ham.d_terms, h->ham.terms.data(), h->ham.terms.size() * sizeof(HTerm));
+    if (rc) return rc;
+    h->ham.constant = constant;
+    h->ham.set = true;
+    return OVQE_OK;
+}
+
+int ovqe_set_program(ovqe_handle h, int64_t R, const uint64_t *x, const uint64_t *z, const double *coeff,
+                     const double *phi0, const int32_t *pidx, int32_t K, uint64_t hf_index) {
+    if (!h || R < 0 || K < 0 || (R && (!x || !z || !coeff || !pidx))) return OVQE_ERR_INVALID;
+    const int ntot = h->n_local + h->n_global;
+    const uint64_t allmask = ntot >= 64 ? ~0ull : ((1ull << ntot) - 1ull);
+    if (hf_index & ~allmask) return fail(h, OVQE_ERR_INVALID, "hf_index out of range");
+    for (int64_t r = 0; r < R; ++r) {
+        if ((x[r] | z[r]) & ~allmask) return fail(h, OVQE_ERR_INVALID, "Pauli mask has bits beyond the register");
+        if (x[r] & ~local_mask(h)) return fail(h, OVQE_ERR_INVALID, "x mask touches global (rank) bits");
+        if (pidx[r] >= K) return fail(h, OVQE_ERR_INVALID, "parameter index >= K");
+    }
+    h->prog_set = false;
+    h->ops.clear();
+    h->rots.clear();
+    h->K = K;
+    h->hf = hf_index;
+    for (int64_t r = 0; r < R; ++r) push_rotation(h, x[r], z[r], coeff[r], phi0 ? phi0[r] : 0.0, pidx[r]);
+    return finish_program(h);
+}
+
+int ovqe_set_gate_program(ovqe_handle h, int64_t G, const int32_t *opcode, const int32_t *b0, const int32_t *b1,
+                          const double *ascale, const double *aconst, const int32_t *pidx, int32_t K,
+                          uint64_t hf_index) {
+    if (!h || G < 0 || K < 0 || (G && (!opcode || !b0 || !b1 || !ascale || !aconst || !pidx))) return OVQE_ERR_INVALID;
+    if (h->n_global) return fail(h, OVQE_ERR_INVALID, "gate programs are single-device");
+    if (hf_index >> h->n_local) return fail(h, OVQE_ERR_INVALID, "hf_index out of range");
+    for (int64_t g = 0; g < G; ++g) {
+        if (b0[g] < 0 || b0[g] >= h->n_local) return fail(h, OVQE_ERR_INVALID, "gate bit out of range");
+        if (opcode[g] == OVQE_GATE_CNOT && (b1[g] < 0 || b1[g] >= h->n_local || b1[g] == b0[g]))
+            return fail(h, OVQE_ERR_INVALID, "CNOT target bit invalid");
+        if (opcode[g] < 0 || opcode[g] > OVQE_GATE_CNOT) return fail(h, OVQE_ERR_INVALID, "unknown gate opcode");
+        if (pidx[g] >= K) return fail(h, OVQE_ERR_INVALID, "parameter index >= K");
+    }
+    h->prog_set = false;
+    h->ops.clear();
+    h->rots.clear();
+    h->K = K;
+    h->hf = hf_index;
+    for (int64_t g = 0; g < G; ++g) {
+        const uint64_t bit = 1ull << b0[g];
+        SmallOp op;
+        switch (opcode[g]) {
+        case OVQE_GATE_RX: push_rotation(h, bit, 0, 0.5 * ascale[g], 0.5 * aconst[g], pidx[g]); break;
+        case OVQE_GATE_RY: push_rotation(h, bit, bit, 0.5 * ascale[g], 0.5 * aconst[g], pidx[g]); break;
+        case OVQE_GATE_RZ: push_rotation(h, 0, bit, 0.5 * ascale[g], 0.5 * aconst[g], pidx[g]); break;
+        case OVQE_GATE_X:
+        case OVQE_GATE_H:
+            op.x = bit;
+            op.kind = opcode[g] == OVQE_GATE_X ? OP_X : OP_H;
+            op.first = 0;
+            op.count = 0;
+            op.pivot = b0[g];
+            h->ops.push_back(op);
+            break;
+        default:  // CNOT
+            op.x = 1ull << b1[g];
+            op.kind = OP_CNOT;
+            op.first = b0[g];
+            op.count = b1[g];
+            op.pivot = b1[g];
+            h->ops.push_back(op);
+        }
+    }
+    return finish_program(h);
+}
+
+int ovqe_prepare_state(ovqe_handle h, const double *theta, int32_t K) {
+    if (!h) return OVQE_ERR_INVALID;
+    int rc = check_theta(h, theta, K);
+    if (rc) return rc;
+    return run_program_streaming(h, theta);
+}
+
+int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, double *energies) {
+    if (!h || B < 0 || (B && !energies)) return OVQE_ERR_INVALID;
+    int rc = check_theta(h, theta, K);
+    if (rc) return rc;
+    if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
+    if (B == 0) return OVQE_OK;
+    if (use_small_path(h, B)) return run_small(h, B, theta, energies, false);
+    HIPC(h, hipEventRecord(h->ev0, h->stream));
+    for (int64_t b = 0; b < B; ++b) {
+        rc = run_program_streaming(h, theta + b * (int64_t)K);
+        if (rc) return rc;
+        double2 res;
+        rc = run_bilinear(h, h->state, h->state, h->ham.groups, (const HGroup *)h->ham.d_groups.p,
+                          (const HTerm *)h->ham.d_terms.p, &res);
+        if (rc) return rc;
+        energies[b] = res.x + h->ham.constant;
+    }
+    HIPC(h, hipEventRecord(h->ev1, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    HIPC(h, hipEventElapsedTime(&h->last_batch_ms, h->ev0, h->ev1));
+    return OVQE_OK;
+}
+
+int ovqe_energy(ovqe_handle h, const double *theta, int32_t K, double *energy) {
+    return ovqe_energy_batch(h, 1, theta, K, energy);
+}
+
+// ---- ADAPT --------------------------------------------------------------------------------------
+int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, const uint64_t *x, const uint64_t *z,
+                        const double *coeff_re, const double *coeff_im, int mode, double *grads) {
+    if (!h || n_ops < 0 || !offsets || (n_ops && !grads)) return OVQE_ERR_INVALID;
+    if (mode != OVQE_GRAD_FERMIONIC && mode != OVQE_GRAD_QUBIT) return fail(h, OVQE_ERR_INVALID, "unknown gradient mode");
+    if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
+    if (n_ops == 0) return OVQE_OK;
+    const int64_t T = offsets[n_ops];
+    if (T < 0 || (T && (!x || !z || !coeff_re))) return OVQE_ERR_INVALID;
+    for (int64_t k = 0; k < n_ops; ++k)
+        if (offsets[k] > offsets[k + 1] || offsets[k] < 0) return fail(h, OVQE_ERR_INVALID, "offsets not monotone");
+    int rc = ensure_scratch(h, 0);
+    if (rc) return rc;
+    amp_t *sig = h->scratch[0];
+    const int nb = reduce_blocks(h->namps);
+    // sigma = H psi (constant included)
+    hipLaunchKernelGGL(k_apply_sum, dim3(nb), dim3(256), 0, h->stream, sig, (const amp_t *)h->state, (amp_t *)nullptr,
+                       h->namps, h->base, (const HGroup *)h->ham.d_groups.p, (int)h->ham.groups.size(),
+                       (const HTerm *)h->ham.d_terms.p, 1.0, 0.0, h->ham.constant, 0.0);
+    HIPC(h, hipGetLastError());
+    std::vector<double2> vals(n_ops);
+    if (h->n_local <= 22) {
+        // one block per pool operator, terms in caller order with i^ny folded
+        const uint64_t lmask = local_mask(h);
+        std::vector<HTerm> terms(T);
+        std::vector<uint64_t> xs(T);
+        for (int64_t t = 0; t < T; ++t) {
+            if (x[t] & ~lmask) return fail(h, OVQE_ERR_INVALID, "x mask touches global (rank) bits");
+            const int ny = __builtin_popcountll(x[t] & z[t]) & 3;
+            const double a = coeff_re[t], b = coeff_im ? coeff_im[t] : 0.0;
+            HTerm ht;
+            ht.z = z[t];
+            switch (ny) {
+            case 0: ht.cr = a; ht.ci = b; break;
+            case 1: ht.cr = -b; ht.ci = a; break;
+            case 2: ht.cr = -a; ht.ci = -b; break;
+            default: ht.cr = b; ht.ci = -a; break;
+            }
+            terms[t] = ht;
+            xs[t] = x[t];
+        }
+        DevBuf d_off, d_xs, d_terms, d_out;
+        rc = upload(h, d_off, offsets, (n_ops + 1) * sizeof(int64_t));
+        if (!rc) rc = upload(h, d_xs, xs.data(), T * sizeof(uint64_t));
+        if (!rc) rc = upload(h, d_terms, terms.data(), T * sizeof(HTerm));
+        if (!rc) rc = ensure(h, d_out, n_ops * sizeof(double2));
+        if (!rc) {
+            hipLaunchKernelGGL(k_pool_grad, dim3((unsigned)n_ops), dim3(256), 0, h->stream, (const amp_t *)sig,
+                               (const amp_t *)h->state, h->namps, h->base, (const int64_t *)d_off.p,
+                               (const uint64_t *)d_xs.p, (const HTerm *)d_terms.p, (double2 *)d_out.p);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(vals.data(), d_out.p, n_ops * sizeof(double2), hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) rc = fail(h, OVQE_ERR_HIP, std::string("pool_gradients: ") + hipGetErrorString(e));
+        }
+        for (DevBuf *b : {&d_off, &d_xs, &d_terms, &d_out})
+            if (b->p) (void)hipFree(b->p);
+        if (rc) return rc;
+    } else {
+        for (int64_t k = 0; k < n_ops; ++k) {
+            const int64_t t0 = offsets[k], nt = offsets[k + 1] - t0;
+            double res[2];
+            rc = ovqe_bilinear(h, sig, nullptr, nt, x + t0, z + t0, coeff_re + t0, coeff_im ? coeff_im + t0 : nullptr, res);
+            if (rc) return rc;
+            vals[k] = make_double2(res[0], res[1]);
+        }
+    }
+    for (int64_t k = 0; k < n_ops; ++k)
+        grads[k] = mode == OVQE_GRAD_FERMIONIC ? 2.0 * vals[k].x : 2.0 * std::hypot(vals[k].x, vals[k].y);
+    return OVQE_OK;
+}
+
+int ovqe_apply_exp_pauli_sum(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff_re,
+                             const double *coeff_im, double theta) {
+    if (!h || T < 0 || (T && (!x || !z || !coeff_re))) return OVQE_ERR_INVALID;
+    if (T == 0 || theta == 0.0) return OVQE_OK;
+    std::vector<HGroup> groups;
+    std::vector<HTerm> terms;
+    int rc = build_groups(h, T, x, z, coeff_re, coeff_im, false, groups, terms);
+    if (rc) return rc;
+    double beta = 0.0;
+    for (int64_t t = 0; t < T; ++t) beta += std::hypot(coeff_re[t], coeff_im ? coeff_im[t] : 0.0);
+    beta *= std::fabs(theta);
+    const int steps = std::max(1, (int)std::ceil(beta));
+    const double tau = theta / steps, bstep = beta / steps;
+    int M = 2;
+    {
+        double term = bstep * bstep / 2.0;
+        while (term > 1e-19 && M < 64) {
+            ++M;
+            term *= bstep / M;
+        }
+    }
+    rc = ensure_scratch(h, 0);
+    if (!rc) rc = ensure_scratch(h, 1);
+    if (rc) return rc;
+    DevBuf dg, dt;
+    rc = upload(h, dg, groups.data(), groups.size() * sizeof(HGroup));
+    if (!rc) rc = upload(h, dt, terms.data(), terms.size() * sizeof(HTerm));
+    const int nb = reduce_blocks(h->namps);
+    for (int s = 0; s < steps && !rc; ++s) {
+        amp_t *va = h->scratch[0], *vb = h->scratch[1];
+        hipError_t e = hipMemcpyAsync(va, h->state, h->namps * sizeof(amp_t), hipMemcpyDeviceToDevice, h->stream);
+        if (e != hipSuccess) {
+            rc = fail(h, OVQE_ERR_HIP, "exp_pauli_sum: copy failed");
+            break;
+        }
+        for (int m = 1; m <= M; ++m) {
+            hipLaunchKernelGGL(k_apply_sum, dim3(nb), dim3(256), 0, h->stream, vb, (const amp_t *)va, h->state, h->namps,
+                               h->base, (const HGroup *)dg.p, (int)groups.size(), (const HTerm *)dt.p, tau / m, 0.0, 0.0,
+                               0.0);
+            std::swap(va, vb);
+        }
+        if (hipGetLastError() != hipSuccess) rc = fail(h, OVQE_ERR_HIP, "exp_pauli_sum: launch failed");
+    }
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, OVQE_ERR_HIP, "exp_pauli_sum: sync failed");
+    if (dg.p) (void)hipFree(dg.p);
+    if (dt.p) (void)hipFree(dt.p);
+    return rc;
+}
+
+// ---- measurement support ------------------------------------------------------------------------
+int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, int warmup, int reps, double *avg_ms) {
+    if (!h || !avg_ms || reps <= 0 || warmup < 0) return OVQE_ERR_INVALID;
+    if (x & ~local_mask(h)) return fail(h, OVQE_ERR_INVALID, "x mask touches global (rank) bits");
+    int rc = ensure_rp(h, 1);
+    if (rc) return rc;
+    h->h_rp[0] = make_rot(x, z, phi);
+    HIPC(h, hipMemcpyAsync(h->d_rp.p, h->h_rp, sizeof(RotParam), hipMemcpyHostToDevice, h->stream));
+    for (int i = 0; i < warmup; ++i) {
+        rc = launch_rot_run(h, x, (const RotParam *)h->d_rp.p, 1);
+        if (rc) return rc;
+    }
+    HIPC(h, hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < reps; ++i) {
+        rc = launch_rot_run(h, x, (const RotParam *)h->d_rp.p, 1);
+        if (rc) return rc;
+    }
+    HIPC(h, hipEventRecord(h->ev1, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPC(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *avg_ms = (double)ms / reps;
+    return OVQE_OK;
+}
+
+int ovqe_last_batch_ms(ovqe_handle h, double *ms) {
+    if (!h || !ms) return OVQE_ERR_INVALID;
+    *ms = h->last_batch_ms;
+    return OVQE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,370 @@
+// sv_kernels.hpp — gfx950 device code of the statevector backend (HBM-streaming path).
+//
+// Every sweep is bandwidth-bound (≈0.25–0.5 flop/B), so the design rules are: each amplitude is read
+// once and written once per sweep with 16-byte accesses, consecutive lanes touch consecutive
+// amplitudes (or an XOR-permutation inside the same aligned 64-B segments), several independent
+// 16-B loads are in flight per lane, and no MFMA/LDS tiling is attempted — there is no reuse to
+// capture.  Reductions are wave-shuffle + LDS trees with a fixed order (deterministic, so ADAPT
+// rankings are reproducible).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ovqe {
+
+typedef double2 amp_t;  // .x = re, .y = im
+
+// one Pauli rotation of a fused same-x run, angles already resolved
+struct RotParam {
+    uint64_t z;   // z mask (global index space)
+    double c;     // cos(phi)
+    double s;     // sin(phi) * (ny&2 ? -1 : +1)
+    int32_t odd;  // ny & 1  (ny = popcount(x&z)): 1 -> real mixing, 0 -> multiply partner by -i
+    int32_t pad;
+};
+
+// Hamiltonian / pool term with i^{ny} folded into the coefficient
+struct HTerm {
+    uint64_t z;
+    double cr, ci;
+};
+
+struct HGroup {
+    uint64_t x;      // local part of the x mask
+    uint64_t jbase;  // high (global) bits of the partner's global index
+    int32_t t0, t1;  // term range
+};
+
+__device__ __forceinline__ uint64_t insert_zero(uint64_t k, int p) {
+    const uint64_t low = (1ull << p) - 1ull;
+    return ((k & ~low) << 1) | (k & low);
+}
+__device__ __forceinline__ int parity64(uint64_t v) { return __popcll(v) & 1; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block-wide deterministic sum of a complex value; result valid in thread 0
+template <int NT>
+__device__ __forceinline__ double2 block_sum(double2 v, double2 *lds /* NT/64 entries */) {
+    v.x = wave_sum(v.x);
+    v.y = wave_sum(v.y);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) lds[w] = v;
+    __syncthreads();
+    double2 t = make_double2(0.0, 0.0);
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < NT / 64; ++i) {
+            t.x += lds[i].x;
+            t.y += lds[i].y;
+        }
+    }
+    __syncthreads();
+    return t;
+}
+
+// apply one rotation of a fused run to the pair (u = a_i, v = a_j), j = i ^ x
+__device__ __forceinline__ void rot_pair(amp_t &u, amp_t &v, const RotParam &r, uint64_t gi) {
+    const int pi = parity64(gi & r.z);  // sign for <j|P|i>
+    const int pj = pi ^ r.odd;          // parity(gj & z) = pi ^ parity(x & z)
+    const double si = pj ? -r.s : r.s;
+    const double sj = pi ? -r.s : r.s;
+    amp_t nu, nv;
+    if (r.odd) {
+        nu.x = r.c * u.x + si * v.x;
+        nu.y = r.c * u.y + si * v.y;
+        nv.x = r.c * v.x + sj * u.x;
+        nv.y = r.c * v.y + sj * u.y;
+    } else {
+        nu.x = r.c * u.x + si * v.y;
+        nu.y = r.c * u.y - si * v.x;
+        nv.x = r.c * v.x + sj * u.y;
+        nv.y = r.c * v.y - sj * u.x;
+    }
+    u = nu;
+    v = nv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exp(-i phi_r P_r) for a run of rotations sharing the x mask (x != 0): one thread per pair (i, i^x),
+// i has the pivot bit (highest x bit) clear.  In place; each amplitude is read once, written once.
+template <int U>
+__global__ __launch_bounds__(256) void k_rot_pairs(amp_t *__restrict__ st, uint64_t npairs, int pivot, uint64_t x,
+                                                   uint64_t base, const RotParam *__restrict__ rp, int nrot) {
+    const uint64_t k0 = (uint64_t)blockIdx.x * (256u * U) + threadIdx.x;
+    amp_t u[U], v[U];
+    uint64_t ii[U];
+#pragma unroll
+    for (int m = 0; m < U; ++m) {
+        const uint64_t k = k0 + (uint64_t)m * 256u;
+        ii[m] = insert_zero(k, pivot);
+        if (k < npairs) {
+            u[m] = st[ii[m]];
+            v[m] = st[ii[m] ^ x];
+        }
+    }
+    for (int r = 0; r < nrot; ++r) {
+        const RotParam rr = rp[r];
+#pragma unroll
+        for (int m = 0; m < U; ++m) rot_pair(u[m], v[m], rr, base | ii[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < U; ++m) {
+        const uint64_t k = k0 + (uint64_t)m * 256u;
+        if (k < npairs) {
+            st[ii[m]] = u[m];
+            st[ii[m] ^ x] = v[m];
+        }
+    }
+}
+
+// diagonal run (x == 0): a_i <- prod_r (c_r - i s_r (-1)^{parity(i & z_r)}) a_i
+template <int U>
+__global__ __launch_bounds__(256) void k_rot_diag(amp_t *__restrict__ st, uint64_t namps, uint64_t base,
+                                                  const RotParam *__restrict__ rp, int nrot) {
+    const uint64_t i0 = (uint64_t)blockIdx.x * (256u * U) + threadIdx.x;
+    amp_t a[U];
+#pragma unroll
+    for (int m = 0; m < U; ++m) {
+        const uint64_t i = i0 + (uint64_t)m * 256u;
+        if (i < namps) a[m] = st[i];
+    }
+    for (int r = 0; r < nrot; ++r) {
+        const RotParam rr = rp[r];
+#pragma unroll
+        for (int m = 0; m < U; ++m) {
+            const uint64_t i = i0 + (uint64_t)m * 256u;
+            const double s = parity64((base | i) & rr.z) ? -rr.s : rr.s;
+            amp_t t;
+            t.x = rr.c * a[m].x + s * a[m].y;
+            t.y = rr.c * a[m].y - s * a[m].x;
+            a[m] = t;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < U; ++m) {
+        const uint64_t i = i0 + (uint64_t)m * 256u;
+        if (i < namps) st[i] = a[m];
+    }
+}
+
+// literal non-rotation gates: kind 0 = X(bit b0) swap, 1 = H(bit b0), 2 = CNOT(control b0, target b1)
+template <int U>
+__global__ __launch_bounds__(256) void k_gate(amp_t *__restrict__ st, uint64_t nwork, int kind, int b0, int b1) {
+    const uint64_t k0 = (uint64_t)blockIdx.x * (256u * U) + threadIdx.x;
+#pragma unroll
+    for (int m = 0; m < U; ++m) {
+        const uint64_t k = k0 + (uint64_t)m * 256u;
+        if (k >= nwork) continue;
+        uint64_t i, j;
+        if (kind == 2) {
+            const int lo = b0 < b1 ? b0 : b1, hi = b0 < b1 ? b1 : b0;
+            i = insert_zero(insert_zero(k, lo), hi) | (1ull << b0);
+            j = i | (1ull << b1);
+        } else {
+            i = insert_zero(k, b0);
+            j = i | (1ull << b0);
+        }
+        amp_t a = st[i], b = st[j];
+        if (kind == 1) {
+            const double r = 0.70710678118654752440;
+            amp_t s, d;
+            s.x = (a.x + b.x) * r;
+            s.y = (a.y + b.y) * r;
+            d.x = (a.x - b.x) * r;
+            d.y = (a.y - b.y) * r;
+            st[i] = s;
+            st[j] = d;
+        } else {
+            st[i] = b;
+            st[j] = a;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sum_g sum_i conj(bra_i) D_g(i) ket_{i^x_g},  D_g(i) = sum_{t in g} (-1)^{parity(gj & z_t)} (cr_t + i ci_t),
+// gj = jbase_g | (i ^ x_g) the partner's global index.  Grid-stride over amplitudes, loop over the
+// groups [g0,g1) inside; one complex partial per block (fixed reduction order).
+__global__ __launch_bounds__(256) void k_bilinear(const amp_t *__restrict__ bra, const amp_t *__restrict__ ket,
+                                                  uint64_t namps, const HGroup *__restrict__ groups, int g0, int g1,
+                                                  const HTerm *__restrict__ terms, double2 *__restrict__ partials) {
+    __shared__ double2 red[4];
+    double2 acc = make_double2(0.0, 0.0);
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (int g = g0; g < g1; ++g) {
+        const HGroup gr = groups[g];
+        for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) {
+            const uint64_t jl = i ^ gr.x;
+            const amp_t b = bra[i], k = ket[jl];
+            const uint64_t gj = gr.jbase | jl;
+            double dr = 0.0, di = 0.0;
+            for (int t = gr.t0; t < gr.t1; ++t) {
+                const HTerm ht = terms[t];
+                const bool neg = parity64(gj & ht.z);
+                dr += neg ? -ht.cr : ht.cr;
+                di += neg ? -ht.ci : ht.ci;
+            }
+            // v = conj(b) * k
+            const double vx = b.x * k.x + b.y * k.y;
+            const double vy = b.x * k.y - b.y * k.x;
+            acc.x += dr * vx - di * vy;
+            acc.y += dr * vy + di * vx;
+        }
+    }
+    double2 t = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// out[slot] = sum of `count` complex partials (single block, fixed order)
+__global__ __launch_bounds__(256) void k_reduce(const double2 *__restrict__ partials, int64_t count,
+                                                double2 *__restrict__ out, int slot) {
+    __shared__ double2 red[4];
+    double2 acc = make_double2(0.0, 0.0);
+    for (int64_t i = threadIdx.x; i < count; i += 256) {
+        acc.x += partials[i].x;
+        acc.y += partials[i].y;
+    }
+    double2 t = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) out[slot] = t;
+}
+
+// out_i (+)= scale * sum_g D_g(i) in_{i ^ x_g}   (sigma = H psi, Taylor steps of exp(theta A))
+// mode 0: out = val ; mode 1: out = val and acc += val
+__global__ __launch_bounds__(256) void k_apply_sum(amp_t *__restrict__ out, const amp_t *__restrict__ in,
+                                                   amp_t *__restrict__ acc, uint64_t namps, uint64_t base,
+                                                   const HGroup *__restrict__ groups, int ngroups,
+                                                   const HTerm *__restrict__ terms, double scale_re, double scale_im,
+                                                   double ident_re, double ident_im) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) {
+        const amp_t self = in[i];
+        double sx = ident_re * self.x - ident_im * self.y;
+        double sy = ident_re * self.y + ident_im * self.x;
+        for (int g = 0; g < ngroups; ++g) {
+            const HGroup gr = groups[g];
+            const uint64_t jl = i ^ gr.x;
+            const amp_t k = in[jl];
+            const uint64_t gj = base | jl;
+            double dr = 0.0, di = 0.0;
+            for (int t = gr.t0; t < gr.t1; ++t) {
+                const HTerm ht = terms[t];
+                const bool neg = parity64(gj & ht.z);
+                dr += neg ? -ht.cr : ht.cr;
+                di += neg ? -ht.ci : ht.ci;
+            }
+            sx += dr * k.x - di * k.y;
+            sy += dr * k.y + di * k.x;
+        }
+        amp_t r;
+        r.x = scale_re * sx - scale_im * sy;
+        r.y = scale_re * sy + scale_im * sx;
+        out[i] = r;
+        if (acc) {
+            amp_t a = acc[i];
+            a.x += r.x;
+            a.y += r.y;
+            acc[i] = a;
+        }
+    }
+}
+
+// pool gradient screen, one block per pool operator (state small enough to re-stream from L2/MALL):
+// val_k = sum_{t in op k} sum_i conj(sig_i) (-1)^{parity((i^x_t)&z_t)} (cr_t + i ci_t) psi_{i^x_t}
+__global__ __launch_bounds__(256) void k_pool_grad(const amp_t *__restrict__ sig, const amp_t *__restrict__ psi,
+                                                   uint64_t namps, uint64_t base, const int64_t *__restrict__ offsets,
+                                                   const uint64_t *__restrict__ xs, const HTerm *__restrict__ terms,
+                                                   double2 *__restrict__ out) {
+    __shared__ double2 red[4];
+    const int64_t op = blockIdx.x;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int64_t t = offsets[op]; t < offsets[op + 1]; ++t) {
+        const uint64_t x = xs[t];
+        const HTerm ht = terms[t];
+        for (uint64_t i = threadIdx.x; i < namps; i += 256) {
+            const uint64_t jl = i ^ x;
+            const amp_t b = sig[i], k = psi[jl];
+            const bool neg = parity64((base | jl) & ht.z);
+            const double cr = neg ? -ht.cr : ht.cr, ci = neg ? -ht.ci : ht.ci;
+            const double vx = b.x * k.x + b.y * k.y;
+            const double vy = b.x * k.y - b.y * k.x;
+            acc.x += cr * vx - ci * vy;
+            acc.y += cr * vy + ci * vx;
+        }
+    }
+    double2 t = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) out[op] = t;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_basis(amp_t *__restrict__ st, uint64_t namps, uint64_t local_index,
+                                                    int has_one) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) {
+        st[i] = make_double2((has_one && i == local_index) ? 1.0 : 0.0, 0.0);
+    }
+}
+
+// counter-based integer hash -> two doubles in [-1,1): exactly reproducible on the host
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t v) {
+    v += 0x9E3779B97F4A7C15ull;
+    v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ull;
+    v = (v ^ (v >> 27)) * 0x94D049BB133111EBull;
+    return v ^ (v >> 31);
+}
+__host__ __device__ __forceinline__ double unit_pm1(uint64_t bits) {
+    // 53 random bits -> [0,1) -> [-1,1)
+    return (double)(bits >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
+}
+
+__global__ __launch_bounds__(256) void k_randomize(amp_t *__restrict__ st, uint64_t namps, uint64_t base,
+                                                   uint64_t seed, double scale, double2 *__restrict__ partials) {
+    __shared__ double2 red[4];
+    double2 acc = make_double2(0.0, 0.0);
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) {
+        const uint64_t g = base | i;
+        const uint64_t h = mix64(seed ^ mix64(g));
+        amp_t a;
+        a.x = unit_pm1(mix64(h ^ 0x1234567ull)) * scale;
+        a.y = unit_pm1(mix64(h ^ 0x89ABCDEFull)) * scale;
+        st[i] = a;
+        acc.x += a.x * a.x + a.y * a.y;
+    }
+    double2 t = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void k_scale(amp_t *__restrict__ st, uint64_t namps, double scale) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) {
+        amp_t a = st[i];
+        a.x *= scale;
+        a.y *= scale;
+        st[i] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_norm2(const amp_t *__restrict__ st, uint64_t namps,
+                                               double2 *__restrict__ partials) {
+    __shared__ double2 red[4];
+    double2 acc = make_double2(0.0, 0.0);
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) {
+        const amp_t a = st[i];
+        acc.x += a.x * a.x + a.y * a.y;
+    }
+    double2 t = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void k_gather(const amp_t *__restrict__ st, int64_t count,
+                                                const uint64_t *__restrict__ idx, amp_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) out[i] = st[idx[i]];
+}
+
+}  // namespace ovqe

@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    """Build (if stale) and load the HIP library; GPU tests call the product only through it."""
+    import __graft_entry__ as g
+    g.build()
+    from openvqe_amd import _lib
+    return _lib.lib()

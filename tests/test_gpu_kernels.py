@@ -1,0 +1,197 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on seeded inputs.
+
+Tolerances: amplitudes max-abs 1e-12, energies 1e-10 relative to |H|_1 scale (north_star: 1e-9 Ha).
+"""
+import numpy as np
+import pytest
+
+from oracle import dense, masks
+from tests.util import random_generators, random_hamiltonian, random_state, random_string
+
+pytestmark = pytest.mark.gpu
+
+AMP_TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def SV(gpu_lib):
+    from openvqe_amd.backend import Statevector
+    return Statevector
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 11, 12])
+def test_single_pauli_rotation_matches_oracle(SV, n):
+    rng = np.random.default_rng(100 + n)
+    with SV(n) as sv:
+        for _ in range(12):
+            psi = random_state(rng, n)
+            op, qs = random_string(rng, n)
+            phi = float(rng.uniform(-np.pi, np.pi))
+            x, z = masks.pack_pauli(n, op, qs)
+            ref = masks.rotate(psi, x, z, phi) if n > 8 else dense.pauli_rotation(psi, n, op, qs, phi)
+            sv.set_state(psi)
+            sv.rotate(op, qs, phi)
+            assert np.abs(sv.get_state() - ref).max() < AMP_TOL, (op, qs)
+
+
+@pytest.mark.parametrize("n", [2, 6, 10, 13])
+def test_fused_rotation_sequence(SV, n):
+    rng = np.random.default_rng(200 + n)
+    with SV(n) as sv:
+        psi = random_state(rng, n)
+        xs, zs, phis = [], [], []
+        ref = psi.copy()
+        for _ in range(40):
+            if xs and rng.random() < 0.6:  # same x mask, different z: fused into one sweep
+                x = xs[-1]
+                z = int(rng.integers(0, 1 << n))
+            else:
+                op, qs = random_string(rng, n)
+                x, z = masks.pack_pauli(n, op, qs)
+            phi = float(rng.uniform(-1, 1))
+            xs.append(x); zs.append(z); phis.append(phi)
+            ref = masks.rotate(ref, x, z, phi)
+        sv.set_state(psi)
+        sv.apply_pauli_rotations(xs, zs, phis)
+        assert np.abs(sv.get_state() - ref).max() < AMP_TOL
+
+
+@pytest.mark.parametrize("n", [2, 4, 7, 11])
+def test_gates_match_oracle(SV, n):
+    rng = np.random.default_rng(300 + n)
+    with SV(n) as sv:
+        psi = random_state(rng, n)
+        sv.set_state(psi)
+        ref = psi.copy()
+        for _ in range(30):
+            name = str(rng.choice(["X", "H", "RX", "RY", "RZ", "CNOT"]))
+            if name == "CNOT":
+                c, t = rng.choice(n, 2, replace=False).tolist()
+                sv.apply_gate("CNOT", [c, t])
+                ref = masks.gate_cnot(ref, n, c, t)
+            else:
+                q = int(rng.integers(0, n))
+                ang = float(rng.uniform(-3, 3)) if name.startswith("R") else None
+                sv.apply_gate(name, [q], ang)
+                ref = masks.gate_1q(ref, n, q, dense.gate_matrix(name, ang))
+        assert np.abs(sv.get_state() - ref).max() < AMP_TOL
+
+
+@pytest.mark.parametrize("n,nterms", [(1, 2), (3, 10), (6, 60), (10, 200), (12, 300)])
+def test_expectation(SV, n, nterms):
+    rng = np.random.default_rng(400 + n)
+    nterms = min(nterms, 4 ** n - 1)
+    H = random_hamiltonian(rng, n, nterms)
+    psi = random_state(rng, n)
+    xs, zs, cs = H.packed()
+    ref = masks.expectation(psi, xs, zs, cs.real, H.constant_coeff)
+    if n <= 6:
+        assert abs(ref - dense.expectation(H, psi)) < 1e-12
+    with SV(n) as sv:
+        sv.set_state(psi)
+        got = sv.expectation(H)
+    assert abs(got - ref) < 1e-11 * max(1.0, np.abs(cs).sum())
+
+
+@pytest.mark.parametrize("force_path", [1, 2])
+@pytest.mark.parametrize("n,k", [(2, 3), (4, 6), (7, 10), (10, 12), (12, 20), (13, 8), (14, 6)])
+def test_ucc_energy_and_state(SV, n, k, force_path):
+    rng = np.random.default_rng(500 + 10 * n + force_path)
+    H = random_hamiltonian(rng, n, min(40, 4 ** n - 1))
+    gens = random_generators(rng, n, k)
+    hf = int(rng.integers(0, 1 << n))
+    thetas = rng.uniform(-0.5, 0.5, size=(5, k))
+    xs, zs, cs = H.packed()
+    with SV(n) as sv:
+        sv.set_option("force_path", force_path)
+        sv.set_hamiltonian(H)
+        sv.set_ucc_program(gens, hf)
+        e_batch = sv.energy_batch(thetas)
+        for b in range(thetas.shape[0]):
+            ref = masks  # mask oracle, validated against the dense one in tests/test_oracle.py
+            psi = np.zeros(1 << n, complex); psi[hf] = 1
+            for g, th in zip(gens, thetas[b]):
+                for t in g.terms:
+                    x, z = masks.pack_pauli(n, t.op, t.qbits)
+                    psi = masks.rotate(psi, x, z, th * t.coeff)
+            e_ref = masks.expectation(psi, xs, zs, cs.real, H.constant_coeff)
+            assert abs(e_batch[b] - e_ref) < 1e-10 * max(1.0, np.abs(cs).sum())
+            if b == 0:
+                assert abs(sv.energy(thetas[0]) - e_ref) < 1e-10 * max(1.0, np.abs(cs).sum())
+                sv.prepare_state(thetas[0])
+                assert np.abs(sv.get_state() - psi).max() < AMP_TOL
+
+
+@pytest.mark.parametrize("force_path", [1, 2])
+def test_gate_program_energy(SV, force_path):
+    n = 6
+    rng = np.random.default_rng(77)
+    H = random_hamiltonian(rng, n, 30)
+    gates = []
+    K = 4
+    for _ in range(60):
+        name = str(rng.choice(["X", "H", "RX", "RY", "RZ", "CNOT"]))
+        if name == "CNOT":
+            c, t = rng.choice(n, 2, replace=False).tolist()
+            gates.append((name, [c, t], 0.0, 0.0, -1))
+        elif name in ("X", "H"):
+            gates.append((name, [int(rng.integers(0, n))], 0.0, 0.0, -1))
+        else:
+            p = int(rng.integers(-1, K))
+            gates.append((name, [int(rng.integers(0, n))], float(rng.choice([1.0, -1.0, -2.0])), float(rng.uniform(-1, 1)), p))
+    theta = rng.uniform(-1, 1, K)
+    hf = 0b101100
+    psi = dense.basis_state(n, hf)
+    for name, qs, sc, co, p in gates:
+        ang = co + (sc * theta[p] if p >= 0 else 0.0)
+        psi = dense.apply_gate(psi, n, name, qs, ang)
+    e_ref = dense.expectation(H, psi)
+    with SV(n) as sv:
+        sv.set_option("force_path", force_path)
+        sv.set_hamiltonian(H)
+        sv.set_gate_program(gates, K, hf)
+        assert abs(sv.energy(theta) - e_ref) < 1e-11 * 30
+        sv.prepare_state(theta)
+        assert np.abs(sv.get_state() - psi).max() < AMP_TOL
+
+
+@pytest.mark.parametrize("n", [3, 6, 9])
+def test_pool_gradients_and_exact_exponential(SV, n):
+    from openvqe_amd.operators import Hamiltonian, Term
+    rng = np.random.default_rng(600 + n)
+    H = random_hamiltonian(rng, n, min(30, 4 ** n - 1))
+    # anti-Hermitian pool operators: i * (real Pauli sum)
+    pool = []
+    for _ in range(7):
+        terms = []
+        for _ in range(int(rng.integers(1, 5))):
+            op, qs = random_string(rng, n)
+            terms.append(Term(1j * float(rng.normal()), op, qs))
+        pool.append(Hamiltonian(n, terms, do_clean_up=False))
+    psi = random_state(rng, n)
+    hmat = dense.operator_matrix(H, sparse=True)
+    pool_mats = [dense.operator_matrix(a, sparse=True, with_constant=False) for a in pool]
+    g_ref = dense.fermionic_pool_gradients(pool_mats, hmat, psi)
+    q_ref = [2.0 * abs(np.vdot(psi, hmat @ (m @ psi))) for m in pool_mats]
+    with SV(n) as sv:
+        sv.set_hamiltonian(H)
+        sv.set_state(psi)
+        g = sv.pool_gradients(pool, 0)
+        q = sv.pool_gradients(pool, 1)
+        scale = max(1.0, np.abs(H.packed()[2]).sum())
+        assert np.abs(np.array(g) - np.array(g_ref)).max() < 1e-11 * scale
+        assert np.abs(np.array(q) - np.array(q_ref)).max() < 1e-11 * scale
+        # exact exp(theta A) psi
+        ref = dense.exact_exp_state(psi, pool_mats[:3], [0.3, -0.7, 1.9])
+        for a, th in zip(pool[:3], [0.3, -0.7, 1.9]):
+            sv.apply_exp_pauli_sum(a, th)
+        assert np.abs(sv.get_state() - ref).max() < 1e-11
+
+
+def test_errors_are_reported(SV):
+    from openvqe_amd._lib import BackendError
+    with SV(3) as sv:
+        with pytest.raises(BackendError):
+            sv.energy([0.1])  # no program
+        with pytest.raises(BackendError):
+            sv.apply_pauli_rotation(1 << 5, 0, 0.1)  # mask beyond the register
