@@ -1,0 +1,211 @@
+"""Fermion -> qubit front-end producing the packed Pauli inputs of the hot path.
+
+The reference obtains these objects from myQLM (``qat.fermion``): the JW-transformed molecular
+Hamiltonian (ref:openvqe/common_files/molecule_factory.py:336-350), the UCCSD cluster operators
+(ref:openvqe/common_files/generator_excitations.py:40-80, ref:openvqe/algorithms/ucc.py:24-31) and the
+HF integer (ref:openvqe/common_files/molecule_factory_with_sparse.py:487-491).  This module restates the
+published Jordan-Wigner mapping so that workloads can be built where myQLM / PySCF are absent (the
+GPU box): a_p = Z_0..Z_{p-1} (X_p + iY_p)/2, qubit p <-> spin orbital p, spin orbitals interleaved
+(alpha even, beta odd — SURVEY.md Appendix A).
+
+Internally a Pauli string is (x, z) bit masks in QUBIT space (bit q <-> qubit q), P = i^{|x&z|} X^x Z^z.
+"""
+from __future__ import annotations
+
+import itertools
+
+import numpy as np
+
+from .operators import Hamiltonian, Term
+
+
+# ---------------------------------------------------------------- Pauli-sum algebra on masks
+def _mul_string(a, b):
+    """(x1,z1)*(x2,z2) -> (phase, (x,z)) with P1 P2 = phase * P12."""
+    x1, z1 = a
+    x2, z2 = b
+    x, z = x1 ^ x2, z1 ^ z2
+    k = (bin(x1 & z1).count("1") + bin(x2 & z2).count("1") - bin(x & z).count("1")) % 4
+    phase = (1, 1j, -1, -1j)[k]
+    if bin(z1 & x2).count("1") & 1:
+        phase = -phase
+    return phase, (x, z)
+
+
+def psum_mul(A, B):
+    out = {}
+    for ka, ca in A.items():
+        for kb, cb in B.items():
+            ph, k = _mul_string(ka, kb)
+            out[k] = out.get(k, 0) + ph * ca * cb
+    return out
+
+
+def psum_add(A, B, scale=1.0):
+    out = dict(A)
+    for k, c in B.items():
+        out[k] = out.get(k, 0) + scale * c
+    return out
+
+
+def jw_ladder(p, dagger):
+    """a_p (dagger=False) or a_p^dagger as a Pauli sum."""
+    zchain = (1 << p) - 1
+    xs = (1 << p, zchain)             # Z..Z X_p
+    ys = (1 << p, zchain | (1 << p))  # Z..Z Y_p
+    return {xs: 0.5, ys: (-0.5j if dagger else 0.5j)}
+
+
+def jw_product(ladder_ops):
+    """JW image of a product of ladder operators [(p, dagger), ...] (left to right)."""
+    out = {(0, 0): 1.0}
+    for p, dag in ladder_ops:
+        out = psum_mul(out, jw_ladder(p, dag))
+    return out
+
+
+def psum_to_hamiltonian(nqbits, psum, constant=0.0, tol=1e-13, real=False):
+    """dict[(x,z)] -> Hamiltonian (insertion order kept); the identity string goes to the constant."""
+    terms = []
+    const = constant
+    for (x, z), c in psum.items():
+        if abs(c) <= tol:
+            continue
+        if x == 0 and z == 0:
+            const = const + c
+            continue
+        qs = [q for q in range(nqbits) if ((x | z) >> q) & 1]
+        op = "".join("Y" if ((x >> q) & 1 and (z >> q) & 1) else "X" if (x >> q) & 1 else "Z" for q in qs)
+        if real:
+            if abs(complex(c).imag) > 1e-10:
+                raise ValueError("non-real coefficient in a Hermitian operator")
+            c = complex(c).real
+        terms.append(Term(c, op, qs))
+    if real:
+        const = complex(const).real
+    return Hamiltonian(nqbits, terms, const, do_clean_up=False)
+
+
+# ---------------------------------------------------------------- molecular Hamiltonian
+def spin_orbital_integrals(h1_spatial, eri_chem):
+    """Spatial integrals -> spin-orbital (interleaved) h_pq and physicist-ordered h_pqrs with
+    H = sum h_pq a+_p a_q + 1/2 sum h_pqrs a+_p a+_q a_r a_s  (h_pqrs = (ps|qr) in chemist notation)."""
+    m = h1_spatial.shape[0]
+    n = 2 * m
+    hpq = np.zeros((n, n))
+    hpqrs = np.zeros((n, n, n, n))
+    for p in range(n):
+        for q in range(n):
+            if p % 2 == q % 2:
+                hpq[p, q] = h1_spatial[p // 2, q // 2]
+    for p, q, r, s in itertools.product(range(n), repeat=4):
+        if p % 2 == s % 2 and q % 2 == r % 2:
+            hpqrs[p, q, r, s] = eri_chem[p // 2, s // 2, q // 2, r // 2]
+    return hpq, hpqrs
+
+
+def jw_molecular_hamiltonian(hpq, hpqrs, constant=0.0, tol=1e-12):
+    """JW transform of the electronic-structure Hamiltonian (spin-orbital integrals)."""
+    n = hpq.shape[0]
+    ladders_c = [jw_ladder(p, True) for p in range(n)]
+    ladders_a = [jw_ladder(p, False) for p in range(n)]
+    total = {}
+    for p in range(n):
+        for q in range(n):
+            if abs(hpq[p, q]) > tol:
+                total = psum_add(total, psum_mul(ladders_c[p], ladders_a[q]), hpq[p, q])
+    # cache a+_p a+_q and a_r a_s
+    cc = {}
+    aa = {}
+    for p in range(n):
+        for q in range(n):
+            if p != q:
+                cc[(p, q)] = psum_mul(ladders_c[p], ladders_c[q])
+                aa[(p, q)] = psum_mul(ladders_a[p], ladders_a[q])
+    for p, q in cc:
+        for r, s in aa:
+            v = hpqrs[p, q, r, s]
+            if abs(v) > tol:
+                total = psum_add(total, psum_mul(cc[(p, q)], aa[(r, s)]), 0.5 * v)
+    return psum_to_hamiltonian(n, total, constant, tol=tol, real=True)
+
+
+def hf_integer(nqbits, n_electrons):
+    """HF determinant: lowest n_electrons spin orbitals occupied; qubit q <-> bit (n-1-q)."""
+    return sum(1 << (nqbits - 1 - q) for q in range(n_electrons))
+
+
+# ---------------------------------------------------------------- UCCSD generators
+def _excitation_generator(nqbits, creators, annihilators):
+    """Hermitian generator i(T - T^+) for T = prod a+_creators prod a_annihilators, as a Hamiltonian
+    with real coefficients (what ucc_action receives after the `*1j` of ref:openvqe/algorithms/ucc.py:31)."""
+    t = jw_product([(p, True) for p in creators] + [(p, False) for p in annihilators])
+    tdag = jw_product([(p, True) for p in reversed(annihilators)] + [(p, False) for p in reversed(creators)])
+    anti = psum_add(t, tdag, -1.0)
+    herm = {k: 1j * c for k, c in anti.items()}
+    return psum_to_hamiltonian(nqbits, herm, tol=1e-13, real=True)
+
+
+def _anti_excitation(nqbits, creators, annihilators):
+    """Anti-Hermitian T - T^+ (the un-multiplied pool operator whose sparse matrix the ADAPT screen uses)."""
+    t = jw_product([(p, True) for p in creators] + [(p, False) for p in annihilators])
+    tdag = jw_product([(p, True) for p in reversed(annihilators)] + [(p, False) for p in reversed(creators)])
+    return psum_to_hamiltonian(nqbits, psum_add(t, tdag, -1.0), tol=1e-13)
+
+
+def uccsd_excitations(n_spatial, n_occ_spatial):
+    """Spin-conserving single and double excitations (occupied -> virtual), spin orbitals interleaved.
+    Counts: singles 2*o*v, doubles 2*C(o,2)*C(v,2) + (o*v)^2."""
+    nso = 2 * n_spatial
+    nocc = 2 * n_occ_spatial
+    occ = list(range(nocc))
+    virt = list(range(nocc, nso))
+    singles = [(i, a) for i in occ for a in virt if i % 2 == a % 2]
+    doubles = []
+    for i, j in itertools.combinations(occ, 2):
+        for a, b in itertools.combinations(virt, 2):
+            # spin conservation: multiset of spins equal
+            if sorted((i % 2, j % 2)) == sorted((a % 2, b % 2)):
+                doubles.append((i, j, a, b))
+    return singles, doubles
+
+
+def uccsd_generators(n_spatial, n_occ_spatial):
+    """Hermitian JW generators of UCCSD: singles then doubles (2 resp. 8 Pauli strings each)."""
+    nq = 2 * n_spatial
+    singles, doubles = uccsd_excitations(n_spatial, n_occ_spatial)
+    gens = [_excitation_generator(nq, [a], [i]) for i, a in singles]
+    gens += [_excitation_generator(nq, [b, a], [i, j]) for i, j, a, b in doubles]
+    return gens
+
+
+def uccsd_pool_antihermitian(n_spatial, n_occ_spatial):
+    nq = 2 * n_spatial
+    singles, doubles = uccsd_excitations(n_spatial, n_occ_spatial)
+    pool = [_anti_excitation(nq, [a], [i]) for i, a in singles]
+    pool += [_anti_excitation(nq, [b, a], [i, j]) for i, j, a, b in doubles]
+    return pool
+
+
+# ---------------------------------------------------------------- synthetic molecule-shaped workloads
+def synthetic_integrals(n_spatial, seed, h_scale=0.5, eri_scale=0.1):
+    """Random symmetric h_pq ~ N(0, h_scale^2) and 8-fold-symmetric (pq|rs) ~ N(0, eri_scale^2)
+    (generic spin-conserving integrals without point-group symmetry)."""
+    rng = np.random.default_rng(seed)
+    m = n_spatial
+    h = rng.normal(0.0, h_scale, (m, m))
+    h = 0.5 * (h + h.T)
+    g = rng.normal(0.0, eri_scale, (m, m, m, m))
+    g = g + g.transpose(1, 0, 2, 3)
+    g = g + g.transpose(0, 1, 3, 2)
+    g = g + g.transpose(2, 3, 0, 1)
+    return h, g / 8.0
+
+
+def synthetic_molecule(n_spatial, n_occ_spatial, seed):
+    """(hamiltonian, uccsd generators, hf integer) of a molecule-shaped synthetic problem."""
+    h, g = synthetic_integrals(n_spatial, seed)
+    hpq, hpqrs = spin_orbital_integrals(h, g)
+    ham = jw_molecular_hamiltonian(hpq, hpqrs, 0.0)
+    gens = uccsd_generators(n_spatial, n_occ_spatial)
+    return ham, gens, hf_integer(2 * n_spatial, 2 * n_occ_spatial)

@@ -32,6 +32,9 @@ typedef double complex cplx;
 
 static inline int parity64(uint64_t v) { return __builtin_parityll(v); }
 
+/* 1: sweeps are OpenMP-parallel (large n); 0: sweeps run serially (batch mode: one thread per evaluation) */
+static int g_par = 1;
+
 void orc_init_basis(cplx *psi, int n, uint64_t index) {
     uint64_t dim = 1ull << n;
     memset(psi, 0, dim * sizeof(cplx));
@@ -46,7 +49,7 @@ void orc_pauli_rotation(cplx *psi, int n, uint64_t x, uint64_t z, double phi) {
     static const cplx ipow[4] = {1.0, I, -1.0, -I};
     const cplx mis = -I * s * ipow[ny]; /* -i sin(phi) i^ny */
     if (x == 0) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for if (g_par) schedule(static)
         for (uint64_t i = 0; i < dim; ++i) {
             double sg = parity64(i & z) ? -1.0 : 1.0;
             psi[i] = (c + mis * sg) * psi[i];
@@ -55,7 +58,7 @@ void orc_pauli_rotation(cplx *psi, int n, uint64_t x, uint64_t z, double phi) {
     }
     const int p = 63 - __builtin_clzll(x); /* pivot: highest x bit */
     const uint64_t low = (1ull << p) - 1;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for if (g_par) schedule(static)
     for (uint64_t k = 0; k < dim / 2; ++k) {
         uint64_t i = ((k & ~low) << 1) | (k & low); /* bit p clear */
         uint64_t j = i ^ x;
@@ -77,7 +80,7 @@ double orc_expectation_termwise(const cplx *psi, int n, int64_t T, const uint64_
         const uint64_t x = xs[t], z = zs[t];
         const cplx ph = ipow[__builtin_popcountll(x & z) & 3];
         double re = 0.0, im = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : re, im)
+#pragma omp parallel for if (g_par) schedule(static) reduction(+ : re, im)
         for (uint64_t i = 0; i < dim; ++i) {
             uint64_t j = i ^ x;
             double sg = parity64(j & z) ? -1.0 : 1.0;
@@ -101,7 +104,7 @@ double orc_expectation_grouped(const cplx *psi, int n, int64_t T, const uint64_t
         while (t1 < T && xs[t1] == xs[t0]) ++t1;
         const uint64_t x = xs[t0];
         double acc = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : acc)
+#pragma omp parallel for if (g_par) schedule(static) reduction(+ : acc)
         for (uint64_t i = 0; i < dim; ++i) {
             uint64_t j = i ^ x;
             cplx v = conj(psi[i]) * psi[j];
@@ -127,7 +130,7 @@ double orc_expectation_grouped(const cplx *psi, int n, int64_t T, const uint64_t
 void orc_gate_1q(cplx *psi, int n, int bit, const double *m /* row-major 2x2 as re,im pairs */) {
     const uint64_t dim = 1ull << n, stride = 1ull << bit, low = stride - 1;
     const cplx m00 = m[0] + I * m[1], m01 = m[2] + I * m[3], m10 = m[4] + I * m[5], m11 = m[6] + I * m[7];
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for if (g_par) schedule(static)
     for (uint64_t k = 0; k < dim / 2; ++k) {
         uint64_t i = ((k & ~low) << 1) | (k & low), j = i | stride;
         cplx a = psi[i], b = psi[j];
@@ -138,7 +141,7 @@ void orc_gate_1q(cplx *psi, int n, int bit, const double *m /* row-major 2x2 as 
 
 void orc_gate_cnot(cplx *psi, int n, int cbit, int tbit) {
     const uint64_t dim = 1ull << n, cm = 1ull << cbit, tm = 1ull << tbit;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for if (g_par) schedule(static)
     for (uint64_t i = 0; i < dim; ++i) {
         if ((i & cm) && !(i & tm)) {
             cplx a = psi[i];
@@ -244,6 +247,30 @@ double orc_gate_energy(cplx *psi, int n, uint64_t hf_index, int64_t G, const int
         orc_apply_gate(psi, n, opcode[g], b0[g], b1[g], a);
     }
     return orc_expectation_termwise(psi, n, T, hx, hz, hc) + constant;
+}
+
+/* B independent evaluations, one host thread each (the fastest CPU arrangement when the state is
+ * small: sweeps run single-threaded inside a thread, evaluations run in parallel across cores).
+ * scratch: nthreads * 2^n amplitudes. */
+void orc_ucc_energy_batch(cplx *scratch, int nthreads, int n, uint64_t hf_index, int64_t R, const uint64_t *rx,
+                          const uint64_t *rz, const double *rcoef, const int32_t *pidx, int64_t B, int K,
+                          const double *thetas, int64_t T, const uint64_t *hx, const uint64_t *hz, const double *hc,
+                          double constant, int mode, double *energies) {
+#ifdef _OPENMP
+    extern int omp_get_thread_num(void);
+#endif
+    g_par = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int64_t b = 0; b < B; ++b) {
+#ifdef _OPENMP
+        int tid = omp_get_thread_num();
+#else
+        int tid = 0;
+#endif
+        energies[b] = orc_ucc_energy(scratch + ((uint64_t)tid << n), n, hf_index, R, rx, rz, rcoef, pidx,
+                                     thetas + b * K, T, hx, hz, hc, constant, mode);
+    }
+    g_par = 1;
 }
 
 int orc_max_threads(void) {

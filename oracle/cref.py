@@ -41,6 +41,9 @@ def lib():
         L.orc_gate_energy.argtypes = [_c128p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64, _i32p, _i32p, _i32p, _f64p,
                                       _f64p, _i32p, _f64p, ctypes.c_int64, _u64p, _u64p, _f64p, ctypes.c_double]
         L.orc_gate_energy.restype = ctypes.c_double
+        L.orc_ucc_energy_batch.argtypes = [_c128p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64, _u64p,
+                                           _u64p, _f64p, _i32p, ctypes.c_int64, ctypes.c_int, _f64p, ctypes.c_int64,
+                                           _u64p, _u64p, _f64p, ctypes.c_double, ctypes.c_int, _f64p]
         L.orc_max_threads.restype = ctypes.c_int
         L.orc_set_threads.argtypes = [ctypes.c_int]
         _lib = L
@@ -76,3 +79,20 @@ def gate_energy(n, hf_index, opcode, b0, b1, ascale, aconst, gpidx, theta, hx, h
                           len(hx), np.ascontiguousarray(hx, np.uint64), np.ascontiguousarray(hz, np.uint64),
                           np.ascontiguousarray(hc, np.float64), float(constant))
     return e, psi
+
+
+def ucc_energy_batch(n, hf_index, rx, rz, rcoef, pidx, thetas, hx, hz, hc, constant, mode=0, nthreads=None):
+    """B independent evaluations, one host thread each (nested OpenMP inside a thread stays serial)."""
+    L = lib()
+    nthreads = nthreads or L.orc_max_threads()
+    thetas = np.ascontiguousarray(thetas, np.float64)
+    B, K = thetas.shape
+    nthreads = max(1, min(nthreads, B))
+    scratch = np.empty(nthreads << n, dtype=np.complex128)
+    hx, hz, hc = sort_by_x(np.asarray(hx, np.uint64), np.asarray(hz, np.uint64), np.asarray(hc, np.float64))
+    out = np.empty(B, np.float64)
+    L.orc_ucc_energy_batch(scratch, nthreads, n, int(hf_index), len(rx), np.ascontiguousarray(rx, np.uint64),
+                           np.ascontiguousarray(rz, np.uint64), np.ascontiguousarray(rcoef, np.float64),
+                           np.ascontiguousarray(pidx, np.int32), B, K, thetas, len(hx), hx, hz, hc, float(constant),
+                           int(mode), out)
+    return out
