@@ -1,0 +1,237 @@
+"""Fermionic ADAPT-VQE on the MI355X backend — mirror of ref:openvqe/adapt/fermionic_adapt_vqe.py
+(function names, argument order, printed lines, convergence logic and result schemas are the
+reference's).  Differences are confined to WHERE the arithmetic runs:
+
+  * energies: compiled Pauli-rotation program in libovqe_sv (``ucc_action``);
+  * gradient screen: sigma = H psi and g_i = 2 Re <sigma|A_i|psi> on the device from the SPIN
+    operators (``hamiltonian_sp``, ``cluster_ops_sp``) — the scipy matrices ``hamiltonian_sparse`` /
+    ``cluster_ops_sparse`` that the reference multiplies on the CPU (fermionic_adapt_vqe.py:41-122) are the
+    JW images of the same operators and may be passed as ``None``;
+  * screen state: prod_k exp(theta_k A_k)|HF> with the EXACT exponential of each pool operator
+    (``prepare_adapt_state``, fermionic_adapt_vqe.py:12-38 uses expm_multiply), not the Trotterised circuit.
+"""
+import numpy as np
+import scipy.optimize
+import scipy.sparse.linalg
+from numpy import binary_repr
+
+from ..backend import GRAD_FERMIONIC, Statevector
+from ..common_files.circuit import count
+from ..common_files.sorted_gradient import abs_sort_desc, corresponding_index, index_without_0, value_without_0
+from ..evaluator import UCCEvaluator
+from ..qat_compat import Program, X, build_ucc_ansatz, get_default_qpu
+
+_DENSE_EIGH_MAX_QUBITS = 12
+_screens = {}
+
+
+def _screen_backend(nbqbits):
+    if nbqbits not in _screens:
+        _screens[nbqbits] = Statevector(nbqbits)
+    return _screens[nbqbits]
+
+
+def prepare_adapt_state(hf_init_sp, pool_ops_sp, parameters, hamiltonian_sp=None):
+    """Device state prod_k exp(theta_k A_k)|HF> (exact exponentials); returns the backend holding it."""
+    nbqbits = pool_ops_sp[0].nbqbits if pool_ops_sp else hamiltonian_sp.nbqbits
+    sv = _screen_backend(nbqbits)
+    sv.init_basis(hf_init_sp)
+    for theta, op in zip(parameters, pool_ops_sp):
+        sv.apply_exp_pauli_sum(op, theta)
+    return sv
+
+
+def return_gradient_list(cluster_ops_sp, hamiltonian_sp, screen):
+    """|g_i| for every pool operator, sum g_i^2, the signed gradient of largest magnitude and its index
+    (fermionic_adapt_vqe.py:77-122; strict '>' keeps the first maximum)."""
+    if getattr(screen, "_ham_token", None) is not hamiltonian_sp:
+        screen.set_hamiltonian(hamiltonian_sp)
+        screen._ham_token = hamiltonian_sp
+    grads = screen.pool_gradients(cluster_ops_sp, GRAD_FERMIONIC)
+    list_grad = []
+    curr_norm = 0
+    next_deriv = 0
+    next_index = 0
+    for oi, gi in enumerate(grads):
+        gi = float(gi)
+        list_grad.append(abs(gi))
+        curr_norm += gi * gi
+        if abs(gi) > abs(next_deriv):
+            next_deriv = gi
+            next_index = oi
+    return list_grad, curr_norm, next_deriv, next_index
+
+
+_evaluators = {}
+
+
+def ucc_action(hamiltonian_sp, cluster_ops_sp, hf_init_sp, theta_current):
+    """E(theta) of the Trotterised ansatz (fermionic_adapt_vqe.py:126-162)."""
+    n_params = min(len(cluster_ops_sp), len(theta_current))
+    key = (id(hamiltonian_sp), id(cluster_ops_sp), int(hf_init_sp), n_params)
+    ev = _evaluators.get(key)
+    if ev is None or ev.hamiltonian is not hamiltonian_sp or ev.generators_ref is not cluster_ops_sp \
+            or ev.generators[:n_params] != list(cluster_ops_sp[:n_params]):
+        ev = UCCEvaluator(hamiltonian_sp, cluster_ops_sp, hf_init_sp, n_params)
+        ev.generators_ref = cluster_ops_sp
+        _evaluators.clear()
+        _evaluators[key] = ev
+    return ev.energy(np.asarray(theta_current, dtype=float)[:n_params])
+
+
+def print_gradient_lists_and_indices(list_grad):
+    """non-zero gradients by decreasing magnitude and the matching pool indices (ties -> lower index)"""
+    values = value_without_0(list_grad)
+    indices = index_without_0(list_grad)
+    ordered = abs_sort_desc(value_without_0(list_grad))
+    return ordered, corresponding_index(values, indices, ordered)
+
+
+def prepare_hf_state(hf_init_sp, cluster_ops_sp):
+    prog = Program()
+    nbqbits = cluster_ops_sp[0].nbqbits
+    bits = [int(c) for c in binary_repr(hf_init_sp)]
+    qb = prog.qalloc(nbqbits)
+    for j in range(nbqbits):
+        if bits[j] == 1:
+            prog.apply(X, qb[j])
+    return prog.to_circ()
+
+
+def hf_energy(hf_state, hamiltonian_sp):
+    return get_default_qpu().submit(hf_state.to_job(job_type="OBS", observable=hamiltonian_sp)).value
+
+
+def prepare_state_ansatz(cluster_ops_sp, hf_init_sp, parameters):
+    prog = Program()
+    reg = prog.qalloc(cluster_ops_sp[0].nbqbits)
+    for n_term, (term, theta_term) in enumerate(zip(cluster_ops_sp, parameters)):
+        init = hf_init_sp if n_term == 0 else 0
+        prog.apply(build_ucc_ansatz([term], init, n_steps=1)([theta_term]), reg)
+    return prog.to_circ()
+
+
+def get_statevector(result, nbqbits):
+    statevector = np.zeros((2 ** nbqbits), np.complex128)
+    for sample in result:
+        statevector[sample.state.int] = sample.amplitude
+    return statevector
+
+
+def fun_fidelity(circ, eigenvalues, eigenvectors, nbqbits):
+    """|<ground|psi>|^2 with the ansatz state read back from the device (fermionic_adapt_vqe.py:331-361)."""
+    ee = eigenvectors[:, np.argmin(eigenvalues)]
+    res = get_default_qpu().submit(circ.to_job())
+    return abs(np.vdot(ee, get_statevector(res, nbqbits))) ** 2
+
+
+def _ground_space(hamiltonian_sp):
+    """dense eigh like the reference (line 474) while it is feasible, sparse Lanczos above"""
+    if hamiltonian_sp.nbqbits <= _DENSE_EIGH_MAX_QUBITS:
+        return np.linalg.eigh(hamiltonian_sp.get_matrix())
+    vals, vecs = scipy.sparse.linalg.eigsh(hamiltonian_sp.get_matrix(sparse=True), k=1, which="SA")
+    return vals, vecs
+
+
+def fermionic_adapt_vqe(hamiltonian_sparse, cluster_ops_sparse, reference_ket, hamiltonian_sp, cluster_ops_sp,
+                        hf_init_sp, n_max_grads, fci, optimizer, tolerance, type_conver, threshold_needed,
+                        max_external_iterations=30):
+    """The ADAPT grow / optimise / converge loop of fermionic_adapt_vqe.py:371-593."""
+    iterations = {"energies": [], "energies_substracted_from_FCI": [], "norms": [], "Max_gradients": [],
+                  "fidelity": [], "CNOTs": [], "Hadamard": [], "RY": [], "RX": []}
+    result = {}
+    print("threshold needed for convergence", threshold_needed)
+    print("Max_external_iterations:", max_external_iterations)
+    print("how many maximum gradient are selected", n_max_grads)
+    print("The optimizer method used:", optimizer)
+    print("Tolerance for reaching convergence", tolerance)
+    ansatz_ops = []      # Hermitian generators 1j * A_k (energy circuit)
+    ansatz_pool = []     # anti-Hermitian A_k (exact-exponential screen state)
+    op_indices = []
+    parameters_ansatz = []
+    eigenvalues, eigenvectors = _ground_space(hamiltonian_sp)
+    hf_state = prepare_hf_state(hf_init_sp, cluster_ops_sp)
+    ref_energy = hf_energy(hf_state, hamiltonian_sp)
+    print(ref_energy)
+    print(" The reference energy of the molecular system is: %12.8f" % ref_energy)
+    curr_state = hf_state
+    screen = prepare_adapt_state(hf_init_sp, [], [], hamiltonian_sp)
+    prev_norm = 0.0
+    opt_result = None
+    for n_iter in range(0, max_external_iterations):
+        print("\n\n\n")
+        print(" --------------------------------------------------------------------------")
+        print("                     Fermionic_ADAPT-VQE iteration: ", n_iter)
+        print(" --------------------------------------------------------------------------")
+        print(" Check gradient list chronological order")
+        list_grad, curr_norm, next_deriv, next_index = return_gradient_list(cluster_ops_sp, hamiltonian_sp, screen)
+        sorted_values, sorted_index = print_gradient_lists_and_indices(list_grad)
+        curr_norm = np.sqrt(curr_norm)
+        print(" Norm of the gradients in current iteration = %12.8f" % curr_norm)
+        print(" Max gradient in current iteration= %12.8f" % next_deriv)
+        print(" Index of the Max gradient in current iteration= ", next_index)
+        nbqbits = hamiltonian_sp.nbqbits
+        fid = fun_fidelity(curr_state, eigenvalues, eigenvectors, nbqbits)
+        converged = False
+        if type_conver == "norm":
+            if curr_norm < threshold_needed:
+                converged = True
+        else:
+            print(" type convergence is not defined")
+            raise SystemExit()
+        if converged or (abs(curr_norm - prev_norm) < 10 ** (-8)):
+            print("Convergence is done")
+            result["indices"] = op_indices
+            result["Number_operators"] = len(ansatz_ops)
+            result["final_norm"] = curr_norm
+            result["parameters"] = parameters_ansatz
+            gates = curr_state.ops
+            result["Number_CNOT_gates"] = count("CNOT", gates)
+            result["Number_Hadamard_gates"] = count("H", gates)
+            result["Number_RX_gates"] = count("RX", gates)
+            print(" -----------Final ansatz----------- ")
+            # the reference reads opt_result here and dies with NameError when it converges at iteration 0
+            print(" *final converged energy iteration is %20.12f" % opt_result.fun)
+            result["final_energy_last_iteration"] = opt_result.fun
+            break
+        chosen_batch = sorted_values
+        gamma1 = []
+        sorted_index1 = []
+        curr_norm1 = 0
+        for z in chosen_batch:
+            curr_norm1 += z * z
+        curr_norm1 = np.sqrt(curr_norm1)
+        for i in range(n_max_grads):
+            gamma1.append(chosen_batch[i] / curr_norm1)
+            sorted_index1.append(sorted_index[i])
+        print("sorted_index1: ", sorted_index1)
+        for idx in sorted_index1:
+            parameters_ansatz.append(0.01)
+            ansatz_ops.append(complex(0.0, 1.0) * cluster_ops_sp[idx])
+            ansatz_pool.append(cluster_ops_sp[idx])
+            op_indices.append(idx)
+        opt_result = scipy.optimize.minimize(
+            lambda parameters: ucc_action(hamiltonian_sp, ansatz_ops, hf_init_sp, parameters),
+            x0=parameters_ansatz, method=optimizer, tol=tolerance, options={"maxiter": 100000, "disp": True})
+        xlist = opt_result.x
+        print(" Finished energy iteration_i: %20.12f" % opt_result.fun)
+        print(" -----------New ansatz created----------- ")
+        print(" %4s \t%s \t%s" % ("#", "Coefficients", "Term"))
+        parameters_ansatz = []
+        for si in range(len(ansatz_ops)):
+            print(" %4i \t%f \t%s" % (si, xlist[si], op_indices[si]))
+            parameters_ansatz.append(xlist[si])
+        curr_state = prepare_state_ansatz(ansatz_ops, hf_init_sp, parameters_ansatz)
+        screen = prepare_adapt_state(hf_init_sp, ansatz_pool, parameters_ansatz, hamiltonian_sp)
+        prev_norm = curr_norm
+        gates = curr_state.ops
+        iterations["energies"].append(opt_result.fun)
+        iterations["energies_substracted_from_FCI"].append(abs(opt_result.fun - fci))
+        iterations["norms"].append(curr_norm1)
+        iterations["Max_gradients"].append(sorted_values[0])
+        iterations["fidelity"].append(fid)
+        iterations["CNOTs"].append(count("CNOT", gates))
+        iterations["Hadamard"].append(count("H", gates))
+        iterations["RY"].append(count("RY", gates))
+        iterations["RX"].append(count("RX", gates))
+    return iterations, result

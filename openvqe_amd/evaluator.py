@@ -1,0 +1,82 @@
+"""Compiled energy evaluators shared by the L1 mirrors: build the device program ONCE per ansatz and
+then call ``ovqe_energy`` / ``ovqe_energy_batch`` per optimiser step, instead of rebuilding a
+Program/Circuit/Job for every evaluation as the reference does
+(ref:openvqe/ucc_family/get_energy_ucc.py:36-48)."""
+from __future__ import annotations
+
+import numpy as np
+
+from .backend import Statevector
+
+_BACKENDS = {}
+
+
+def shared_backend(nbqbits, device=0):
+    """one resident statevector handle per register size"""
+    key = (int(nbqbits), int(device))
+    if key not in _BACKENDS:
+        _BACKENDS[key] = Statevector(nbqbits, device=device)
+    return _BACKENDS[key]
+
+
+def release_backends():
+    for sv in _BACKENDS.values():
+        sv.close()
+    _BACKENDS.clear()
+
+
+class _Evaluator:
+    _owner = {}  # backend key -> evaluator whose program/Hamiltonian are loaded
+
+    def __init__(self, hamiltonian, device=0):
+        self.hamiltonian = hamiltonian
+        self.nbqbits = hamiltonian.nbqbits
+        self.device = device
+        self.sv = shared_backend(self.nbqbits, device)
+
+    def _load(self):
+        raise NotImplementedError
+
+    def _activate(self):
+        key = (self.nbqbits, self.device)
+        if _Evaluator._owner.get(key) is not self:
+            self.sv.set_hamiltonian(self.hamiltonian)
+            self._load()
+            _Evaluator._owner[key] = self
+
+    def energy(self, theta):
+        self._activate()
+        return self.sv.energy(np.asarray(theta, dtype=np.float64))
+
+    def energy_batch(self, thetas):
+        self._activate()
+        return self.sv.energy_batch(np.asarray(thetas, dtype=np.float64)[:, : self.n_params])
+
+    def state(self, theta):
+        self._activate()
+        self.sv.prepare_state(np.asarray(theta, dtype=np.float64))
+        return self.sv.get_state()
+
+
+class UCCEvaluator(_Evaluator):
+    """E(theta) = <HF| U(theta)^+ H U(theta) |HF>, U = prod_k prod_j exp(-i theta_k c_kj P_kj)."""
+
+    def __init__(self, hamiltonian, generators, hf_init, n_params=None, device=0):
+        super().__init__(hamiltonian, device)
+        self.generators = list(generators)
+        self.hf_init = int(hf_init)
+        self.n_params = len(self.generators) if n_params is None else min(len(self.generators), int(n_params))
+
+    def _load(self):
+        self.sv.set_ucc_program(self.generators, self.hf_init, self.n_params)
+
+
+class GateEvaluator(_Evaluator):
+    """E(theta) of a traced literal gate circuit (QUCCSD templates)."""
+
+    def __init__(self, hamiltonian, gates, n_params, hf_init, device=0):
+        super().__init__(hamiltonian, device)
+        self.gates, self.n_params, self.hf_init = gates, int(n_params), int(hf_init)
+
+    def _load(self):
+        self.sv.set_gate_program(self.gates, self.n_params, self.hf_init)

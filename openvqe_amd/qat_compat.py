@@ -1,0 +1,394 @@
+"""Stand-ins for the slice of myQLM (``qat.*``) that OpenVQE's L1 hot path touches, executing on the
+HIP backend.  With ``install()`` these modules are registered under the ``qat`` names so that the
+reference's own ``openvqe/ucc_family/*.py`` and ``openvqe/adapt/*.py`` import and run unchanged
+(INTEGRATION.md); the in-tree mirrors under ``openvqe_amd/ucc_family`` / ``openvqe_amd/adapt`` use
+the same objects for circuits and gate counting.
+
+Surface covered: ``Program().qalloc/apply/to_circ``, gates ``X H CNOT RX RY RZ``,
+``build_ucc_ansatz([op], init, n_steps=1)([theta])``, ``Circuit.to_job(job_type="OBS", observable=H)``,
+``Circuit.to_job()``, ``Circuit.ops``, ``get_default_qpu().submit(job)`` -> ``Result.value`` /
+iteration over samples with ``.state.int`` and ``.amplitude``, ``Term`` / ``Hamiltonian``.
+
+myQLM conventions restated here (third-party, not in /root/reference): qubit 0 is the most
+significant bit of a basis index; ``build_ucc_ansatz`` prepares ``init`` with X gates and appends a
+one-step Trotter slice prod_j exp(-i theta c_j P_j) in ``terms`` order, each factor synthesised as
+basis change (H for X, RX(pi/2) for Y) + CNOT staircase + RZ(2 theta c) + uncompute — that synthesis
+is what ``Circuit.ops`` lists for gate counting (ref:openvqe/common_files/circuit.py:186-205
+``count``: 2(w-1) CNOT and 2 H per X per weight-w string, cf. the stored
+``"CNOTs": [6, 12, ...]`` of ref:notebooks/demo_qubit_adapt.ipynb).
+"""
+from __future__ import annotations
+
+import math
+import sys
+import types
+
+import numpy as np
+
+from .operators import Hamiltonian, Observable, SpinHamiltonian, Term, pack_string  # noqa: F401
+
+
+# ------------------------------------------------------------------------------------ parameters
+class AffineParam:
+    """scale * theta[index] + const — lets the gate templates of circuit.py be traced once
+    (``RY(-2 * theta)``) instead of rebuilt for every energy evaluation."""
+
+    __slots__ = ("index", "scale", "const")
+
+    def __init__(self, index, scale=1.0, const=0.0):
+        self.index, self.scale, self.const = int(index), float(scale), float(const)
+
+    def __neg__(self):
+        return AffineParam(self.index, -self.scale, -self.const)
+
+    def __mul__(self, k):
+        return AffineParam(self.index, self.scale * k, self.const * k)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, k):
+        return self * (1.0 / k)
+
+    def __add__(self, c):
+        return AffineParam(self.index, self.scale, self.const + c)
+
+    __radd__ = __add__
+
+    def __sub__(self, c):
+        return self + (-c)
+
+    def value(self, theta):
+        return self.scale * theta[self.index] + self.const
+
+
+def _affine(angle):
+    """-> (scale, const, index) with index -1 for a plain number."""
+    if isinstance(angle, AffineParam):
+        return angle.scale, angle.const, angle.index
+    return 0.0, float(angle), -1
+
+
+# ------------------------------------------------------------------------------------ gates
+class Gate:
+    def __init__(self, name, arity=1, angle=None):
+        self.name, self.arity, self.angle = name, arity, angle
+
+    def __repr__(self):
+        return f"Gate({self.name})"
+
+
+X = Gate("X")
+Y = Gate("Y")
+Z = Gate("Z")
+H = Gate("H")
+CNOT = Gate("CNOT", 2)
+
+
+def RX(angle):
+    return Gate("RX", 1, angle)
+
+
+def RY(angle):
+    return Gate("RY", 1, angle)
+
+
+def RZ(angle):
+    return Gate("RZ", 1, angle)
+
+
+class Op:
+    """One circuit instruction as listed by ``Circuit.ops``; ``str()`` carries ``gate='NAME'``."""
+
+    __slots__ = ("gate", "qbits", "angle")
+
+    def __init__(self, gate, qbits, angle=None):
+        self.gate, self.qbits, self.angle = gate, list(qbits), angle
+
+    def __str__(self):
+        return f"Op(gate='{self.gate}', qbits={self.qbits}, type=0, cbits=None, formula=None, remap=None)"
+
+    __repr__ = __str__
+
+
+class PauliEvolution:
+    """Routine returned by ``build_ucc_ansatz(ops, init, n_steps)(thetas)``."""
+
+    def __init__(self, operators, init, thetas, nbqbits):
+        self.operators, self.init, self.thetas, self.arity = operators, int(init), list(thetas), nbqbits
+
+    def rotations(self):
+        """[(op_string, qbits, angle)] in application order; angle = theta * coeff (may be affine)."""
+        out = []
+        for op, theta in zip(self.operators, self.thetas):
+            for term in op.terms:
+                c = complex(term.coeff)
+                if abs(c.imag) > 1e-12 * max(1.0, abs(c.real)):
+                    raise ValueError("build_ucc_ansatz: generator has a non-real Pauli coefficient "
+                                     "(pass the Hermitian operator, i.e. cluster_op * 1j)")
+                out.append((term.op, list(term.qbits), theta * c.real))
+        return out
+
+
+def build_ucc_ansatz(cluster_ops, ket_hf_init, n_steps=1):
+    """Stand-in of qat.fermion.chemistry.ucc_deprecated.build_ucc_ansatz (call sites
+    ref:openvqe/ucc_family/get_energy_ucc.py:44,86, ref:openvqe/adapt/fermionic_adapt_vqe.py:158,302,
+    ref:openvqe/adapt/qubit_adapt_vqe.py:181,303).  Returns a callable taking the list of angles."""
+    if n_steps != 1:
+        raise NotImplementedError("only the single Trotter step used by OpenVQE is supported")
+    nbq = cluster_ops[0].nbqbits
+
+    def routine(thetas):
+        return PauliEvolution(list(cluster_ops), ket_hf_init, thetas, nbq)
+
+    return routine
+
+
+# ------------------------------------------------------------------------------------ program / circuit
+class Program:
+    def __init__(self):
+        self.nbqbits = 0
+        self.items = []  # ("gate", Gate, [qubits]) | ("evolution", PauliEvolution, [qubits])
+
+    def qalloc(self, n):
+        start = self.nbqbits
+        self.nbqbits += int(n)
+        return list(range(start, start + int(n)))
+
+    def apply(self, what, *qargs):
+        qubits = []
+        for q in qargs:
+            qubits.extend(q if isinstance(q, (list, tuple)) else [q])
+        if isinstance(what, PauliEvolution):
+            if len(qubits) != what.arity:
+                raise ValueError("routine arity does not match the register")
+            self.items.append(("evolution", what, qubits))
+        elif isinstance(what, Gate):
+            if len(qubits) != what.arity:
+                raise ValueError(f"gate {what.name} takes {what.arity} qubit(s)")
+            self.items.append(("gate", what, qubits))
+        elif isinstance(what, Program):
+            self.items.extend(what.items)
+        else:
+            raise TypeError(f"cannot apply {what!r}")
+        return self
+
+    def to_circ(self, **_):
+        return Circuit(self.nbqbits, list(self.items))
+
+
+QRoutine = Program
+
+
+class Circuit:
+    def __init__(self, nbqbits, items):
+        self.nbqbits, self.items = nbqbits, items
+
+    @property
+    def ops(self):
+        """Gate list after synthesis of the Pauli evolutions (CNOT staircase), for ``count``."""
+        out = []
+        for kind, what, qubits in self.items:
+            if kind == "gate":
+                out.append(Op(what.name, qubits, what.angle))
+                continue
+            n = what.arity
+            for q in range(n):
+                if (what.init >> (n - 1 - q)) & 1:
+                    out.append(Op("X", [qubits[q]]))
+            for pauli, qs, angle in what.rotations():
+                qs = [qubits[q] for q in qs]
+                act = [(q, p) for q, p in zip(qs, pauli) if p != "I"]
+                if not act:
+                    continue
+                for q, p in act:
+                    if p == "X":
+                        out.append(Op("H", [q]))
+                    elif p == "Y":
+                        out.append(Op("RX", [q], math.pi / 2))
+                for (a, _), (b, _) in zip(act[:-1], act[1:]):
+                    out.append(Op("CNOT", [a, b]))
+                out.append(Op("RZ", [act[-1][0]], 2 * angle if not isinstance(angle, AffineParam) else angle * 2))
+                for (a, _), (b, _) in reversed(list(zip(act[:-1], act[1:]))):
+                    out.append(Op("CNOT", [a, b]))
+                for q, p in act:
+                    if p == "X":
+                        out.append(Op("H", [q]))
+                    elif p == "Y":
+                        out.append(Op("RX", [q], -math.pi / 2))
+        return out
+
+    def to_job(self, job_type="SAMPLE", observable=None, nbshots=0, **_):
+        if job_type not in ("SAMPLE", "OBS"):
+            raise ValueError(job_type)
+        if job_type == "OBS" and observable is None:
+            raise ValueError("OBS job without observable")
+        return Job(self, job_type, observable)
+
+
+class Job:
+    def __init__(self, circuit, job_type, observable):
+        self.circuit, self.type, self.observable = circuit, job_type, observable
+
+
+class _State:
+    __slots__ = ("int", "nbqbits")
+
+    def __init__(self, value, nbqbits):
+        self.int, self.nbqbits = int(value), nbqbits
+
+    def __str__(self):
+        return "|" + format(self.int, f"0{self.nbqbits}b") + ">"
+
+
+class Sample:
+    __slots__ = ("state", "amplitude", "probability")
+
+    def __init__(self, index, amplitude, nbqbits):
+        self.state = _State(index, nbqbits)
+        self.amplitude = complex(amplitude)
+        self.probability = abs(amplitude) ** 2
+
+
+class Result:
+    def __init__(self, value=None, samples=None):
+        self.value = value
+        self.raw_data = samples or []
+
+    def __iter__(self):
+        return iter(self.raw_data)
+
+    def __len__(self):
+        return len(self.raw_data)
+
+
+# ------------------------------------------------------------------------------------ execution
+def lower_circuit(circuit, theta=None):
+    """-> (hf_index, kind, payload): kind 'rotations' -> (xs, zs, coeff, phi0, pidx);
+    kind 'gates' -> list of (name, qubits, scale, const, pidx).  Leading X gates / the ``init`` of a leading
+    evolution become the HF basis state.  A circuit mixing literal gates and evolutions is lowered to
+    gates only if every evolution is first expanded by the caller (not needed by OpenVQE's L1)."""
+    n = circuit.nbqbits
+    hf = 0
+    pristine = True
+    rot = []
+    gates = []
+    for kind, what, qubits in circuit.items:
+        if kind == "gate":
+            if what.name == "X" and pristine and not rot and not gates:
+                hf ^= 1 << (n - 1 - qubits[0])
+                continue
+            pristine = False
+            sc, co, pi = _affine(what.angle) if what.angle is not None else (0.0, 0.0, -1)
+            gates.append((what.name, list(qubits), sc, co, pi))
+        else:
+            if what.init:
+                if not (pristine and not rot and not gates):
+                    for q in range(what.arity):
+                        if (what.init >> (what.arity - 1 - q)) & 1:
+                            gates.append(("X", [qubits[q]], 0.0, 0.0, -1))
+                else:
+                    for q in range(what.arity):
+                        if (what.init >> (what.arity - 1 - q)) & 1:
+                            hf ^= 1 << (n - 1 - qubits[q])
+            pristine = False
+            for pauli, qs, angle in what.rotations():
+                x, z = pack_string(n, pauli, [qubits[q] for q in qs])
+                sc, co, pi = _affine(angle)
+                rot.append((x, z, sc, co, pi))
+    if rot and gates:
+        raise NotImplementedError("circuit mixes Pauli evolutions and literal gates")
+    if gates:
+        return hf, "gates", gates
+    xs = np.array([r[0] for r in rot], np.uint64)
+    zs = np.array([r[1] for r in rot], np.uint64)
+    sc = np.array([r[2] for r in rot], np.float64)
+    co = np.array([r[3] for r in rot], np.float64)
+    pi = np.array([r[4] for r in rot], np.int32)
+    return hf, "rotations", (xs, zs, sc, co, pi)
+
+
+class HipQPU:
+    """``get_default_qpu()`` stand-in: exact (nbshots=0) simulation on the MI355X backend."""
+
+    def __init__(self, device=0):
+        self.device = device
+        self._sv = {}
+
+    def _backend(self, n):
+        from .backend import Statevector
+        if n not in self._sv:
+            self._sv[n] = Statevector(n, device=self.device)
+        return self._sv[n]
+
+    def _load(self, sv, circuit):
+        hf, kind, payload = lower_circuit(circuit)
+        if kind == "gates":
+            npar = 1 + max([g[4] for g in payload] + [-1])
+            if npar:
+                raise ValueError("circuit still has free parameters")
+            sv.set_gate_program(payload, 0, hf)
+        else:
+            xs, zs, sc, co, pi = payload
+            if len(pi) and pi.max() >= 0:
+                raise ValueError("circuit still has free parameters")
+            sv.set_rotation_program(xs, zs, sc, pi, 0, hf, phi0=co)
+
+    def submit(self, job):
+        circ = job.circuit
+        sv = self._backend(circ.nbqbits)
+        self._load(sv, circ)
+        if job.type == "OBS":
+            sv.set_hamiltonian(job.observable)
+            return Result(value=sv.energy(np.zeros(0)))
+        sv.prepare_state(np.zeros(0))
+        psi = sv.get_state()
+        nz = np.nonzero(psi)[0]
+        return Result(samples=[Sample(int(i), psi[i], circ.nbqbits) for i in nz])
+
+
+_default_qpu = None
+
+
+def get_default_qpu():
+    global _default_qpu
+    if _default_qpu is None:
+        _default_qpu = HipQPU()
+    return _default_qpu
+
+
+# ------------------------------------------------------------------------------------ sys.modules hook
+def install(force=False):
+    """Register these stand-ins as ``qat.lang.AQASM``, ``qat.qpus``, ``qat.core``,
+    ``qat.fermion(.chemistry.ucc_deprecated)`` so reference modules import unchanged.
+    Does nothing when a real myQLM is importable unless ``force``."""
+    if not force:
+        try:
+            import qat  # noqa: F401
+            if not getattr(qat, "__ovqe_shim__", False):
+                return False
+        except ImportError:
+            pass
+    me = sys.modules[__name__]
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        m.__ovqe_shim__ = True
+        sys.modules[name] = m
+        return m
+
+    gates = dict(X=X, Y=Y, Z=Z, H=H, CNOT=CNOT, RX=RX, RY=RY, RZ=RZ)
+    qat = mod("qat")
+    qat.lang = mod("qat.lang")
+    qat.lang.AQASM = mod("qat.lang.AQASM", Program=Program, QRoutine=QRoutine, **gates)
+    qat.lang.AQASM.gates = mod("qat.lang.AQASM.gates", Gate=Gate, **gates)
+    qat.qpus = mod("qat.qpus", get_default_qpu=get_default_qpu)
+    qat.core = mod("qat.core", Term=Term, Observable=Observable, Circuit=Circuit, Job=Job, Result=Result)
+    qat.fermion = mod("qat.fermion", Hamiltonian=Hamiltonian, SpinHamiltonian=SpinHamiltonian)
+    qat.fermion.chemistry = mod("qat.fermion.chemistry")
+    qat.fermion.chemistry.ucc_deprecated = mod("qat.fermion.chemistry.ucc_deprecated",
+                                               build_ucc_ansatz=build_ucc_ansatz)
+    qat.fermion.hamiltonians = mod("qat.fermion.hamiltonians", Hamiltonian=Hamiltonian,
+                                   SpinHamiltonian=SpinHamiltonian)
+    del me
+    return True
