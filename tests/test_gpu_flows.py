@@ -1,0 +1,166 @@
+"""GPU tests of the L1 entry points (get_energies / fermionic_adapt_vqe / qubit_adapt_vqe / action_quccsd)
+running on libovqe_sv, against the same flows on the oracle-backed engine and the exact ground energy of
+the reference's printed H2/STO-3G Hamiltonian (K1)."""
+import contextlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from openvqe_amd import fermion
+from openvqe_amd.operators import Hamiltonian, Term
+from tests.oracle_backend import OracleStatevector
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _reset():
+    import openvqe_amd.adapt.fermionic_adapt_vqe as fa
+    import openvqe_amd.adapt.qubit_adapt_vqe as qa
+    import openvqe_amd.evaluator as ev
+    import openvqe_amd.qat_compat as qc
+    for sv in list(ev._BACKENDS.values()) + list(fa._screens.values()) + list(qa._screens.values()) + (
+            list(qc._default_qpu._sv.values()) if qc._default_qpu else []):
+        sv.close()
+    ev._BACKENDS.clear(); ev._Evaluator._owner.clear()
+    fa._screens.clear(); fa._evaluators.clear(); qa._screens.clear(); qa._evaluators.clear()
+    qc._default_qpu = None
+
+
+@contextlib.contextmanager
+def engine(kind):
+    """'hip' = the product; 'oracle' = checker engine swapped in underneath the same host code"""
+    import openvqe_amd.adapt.fermionic_adapt_vqe as fa
+    import openvqe_amd.adapt.qubit_adapt_vqe as qa
+    import openvqe_amd.backend as be
+    import openvqe_amd.evaluator as ev
+    mods = (be, ev, fa, qa)
+    saved = [m.Statevector for m in mods]
+    _reset()
+    if kind == "oracle":
+        for m in mods:
+            m.Statevector = OracleStatevector
+    try:
+        yield
+    finally:
+        _reset()
+        for m, s in zip(mods, saved):
+            m.Statevector = s
+
+
+@pytest.fixture(scope="module")
+def h2(gpu_lib):
+    k1 = json.load(open(os.path.join(GOLD, "k1_h2_sto3g.json")))
+    H = Hamiltonian(4, [Term(c, o, q) for c, o, q in k1["terms"]], k1["constant_coeff"])
+    return H, k1["hf_init"], np.linalg.eigvalsh(H.get_matrix())[0]
+
+
+def test_get_energies_ucc(h2):
+    from openvqe_amd.ucc_family.get_energy_ucc import EnergyUCC
+    ham, hf, e0 = h2
+    gens = fermion.uccsd_generators(2, 1)
+    pool = [Hamiltonian(4, [Term(1.0, s, [0, 1, 2, 3])], do_clean_up=False) for s in ("XXXY", "YXXX", "XYXX")]
+    out = {}
+    for kind in ("hip", "oracle"):
+        with engine(kind):
+            out[kind] = EnergyUCC().get_energies(ham, gens, pool, hf, [0.0] * 3, [0.01] * 3, e0)
+    (it_h, res_h), (it_o, res_o) = out["hip"], out["oracle"]
+    assert abs(it_h["minimum_energy_result1_guess"][0] - e0) < 1e-7
+    assert abs(it_h["minimum_energy_result1_guess"][0] - it_o["minimum_energy_result1_guess"][0]) < 1e-9
+    assert abs(it_h["minimum_energy_result2_guess"][0] - it_o["minimum_energy_result2_guess"][0]) < 1e-9
+    assert np.abs(np.array(res_h["energies_1"][:4]) - np.array(res_o["energies_1"][:4])).max() < 1e-12
+    assert res_h["CNOT1"] == res_o["CNOT1"] == 64
+
+
+def test_batched_gradient_option_gives_same_minimum(h2):
+    from openvqe_amd.ucc_family.get_energy_ucc import EnergyUCC
+    ham, hf, e0 = h2
+    gens = fermion.uccsd_generators(2, 1)
+    with engine("hip"):
+        plain = EnergyUCC()
+        e_plain = []
+        r1 = plain._minimize(ham, gens, hf, [0.0] * 3, e_plain, "BFGS", 1e-4)
+        fast = EnergyUCC()
+        fast.batched_gradient = True
+        e_fast = []
+        r2 = fast._minimize(ham, gens, hf, [0.0] * 3, e_fast, "BFGS", 1e-4)
+    assert abs(r1.fun - r2.fun) < 1e-10 and np.abs(r1.x - r2.x).max() < 1e-6
+    assert len(e_fast) < len(e_plain)
+
+
+def test_quccsd_action_and_minimisation(h2):
+    from openvqe_amd.ucc_family.get_energy_qucc import EnergyUCC
+    ham, hf, e0 = h2
+    mk = lambda qs: Hamiltonian(4, [Term(1.0, "X" * len(qs), qs)], do_clean_up=False)  # noqa: E731
+    ops = [mk([0, 2]), mk([1, 3]), mk([0, 1, 2, 3])]
+    theta = [0.11, -0.07, 0.23]
+    vals = {}
+    for kind in ("hip", "oracle"):
+        with engine(kind):
+            q = EnergyUCC()
+            vals[kind] = (q.action_quccsd(theta, ham, ops, hf, []), q.get_energies(ham, ops, hf, [0.0] * 3, [0.01] * 3, e0))
+    assert abs(vals["hip"][0] - vals["oracle"][0]) < 1e-12
+    it_h, res_h = vals["hip"][1]
+    it_o, res_o = vals["oracle"][1]
+    assert abs(it_h["minimum_energy_result1_guess"][0] - it_o["minimum_energy_result1_guess"][0]) < 1e-9
+    assert res_h["CNOT1"] == res_o["CNOT1"]
+
+
+def test_fermionic_adapt(h2):
+    from openvqe_amd.adapt.fermionic_adapt_vqe import fermionic_adapt_vqe
+    ham, hf, e0 = h2
+    pool = fermion.uccsd_pool_antihermitian(2, 1)
+    args = dict(n_max_grads=1, fci=e0, optimizer="COBYLA", tolerance=1e-6, type_conver="norm",
+                threshold_needed=1e-2, max_external_iterations=10)
+    out = {}
+    for kind in ("hip", "oracle"):
+        with engine(kind):
+            out[kind] = fermionic_adapt_vqe(None, None, None, ham, pool, hf, **args)
+    (it_h, res_h), (it_o, res_o) = out["hip"], out["oracle"]
+    assert res_h["indices"] == res_o["indices"] == [2]
+    assert abs(res_h["final_energy_last_iteration"] - e0) < 1e-6
+    assert np.abs(np.array(it_h["energies"]) - np.array(it_o["energies"])).max() < 1e-9
+    assert np.abs(np.array(it_h["norms"]) - np.array(it_o["norms"])).max() < 1e-10
+    assert np.abs(np.array(it_h["fidelity"]) - np.array(it_o["fidelity"])).max() < 1e-10
+    assert it_h["CNOTs"] == it_o["CNOTs"]
+
+
+def test_qubit_adapt(h2):
+    from openvqe_amd.adapt.qubit_adapt_vqe import qubit_adapt_vqe
+    ham, hf, e0 = h2
+    pool = [Hamiltonian(4, [Term(-1.0, s, [0, 1, 2, 3])], do_clean_up=False) for s in ("YXXX", "XYXX", "XXYX", "XXXY")]
+    pool += [Hamiltonian(4, [Term(-1.0, "YX", [0, 2])], do_clean_up=False),
+             Hamiltonian(4, [Term(-1.0, "XY", [1, 3])], do_clean_up=False)]
+    kw = dict(n_max_grads=1, adapt_conver="norm", adapt_thresh=1e-5, adapt_maxiter=6, tolerance_sim=1e-9,
+              method_sim="BFGS")
+    out = {}
+    for kind in ("hip", "oracle"):
+        with engine(kind):
+            out[kind] = qubit_adapt_vqe(ham, None, None, 4, pool, hf, e0, **kw)
+    it_h, _, res_h, _ = out["hip"]
+    it_o, _, res_o, _ = out["oracle"]
+    assert res_h["indices"] == res_o["indices"]
+    assert abs(res_h["final_energy"] - e0) < 1e-8
+    assert np.abs(np.array(it_h["norms"]) - np.array(it_o["norms"])).max() < 1e-9
+    # first-iteration gradient multiset: the four XXXY-type strings tie to the last bit in the reference
+    # (ref:notebooks/demo_qubit_adapt.ipynb iteration 0) and the lower pool index wins
+    assert res_h["indices"][0] == 0
+
+
+def test_adapt_screen_on_synthetic_8_qubits(gpu_lib):
+    """pool of 8-qubit UCCSD operators, ranking identical to the oracle's under the sorted_gradient tie rule"""
+    from openvqe_amd.adapt.fermionic_adapt_vqe import print_gradient_lists_and_indices, return_gradient_list
+    ham, gens, hf = fermion.synthetic_molecule(4, 2, seed=11)
+    pool = fermion.uccsd_pool_antihermitian(4, 2)
+    ranks = {}
+    for kind in ("hip", "oracle"):
+        with engine(kind):
+            import openvqe_amd.adapt.fermionic_adapt_vqe as fa
+            screen = fa.prepare_adapt_state(hf, pool[:3], [0.2, -0.1, 0.05], ham)
+            lg, norm, nd, ni = return_gradient_list(pool, ham, screen)
+            ranks[kind] = (np.array(lg), print_gradient_lists_and_indices([round(v, 12) for v in lg])[1], ni)
+    assert np.abs(ranks["hip"][0] - ranks["oracle"][0]).max() < 1e-12
+    assert ranks["hip"][1] == ranks["oracle"][1]
+    assert ranks["hip"][2] == ranks["oracle"][2]
