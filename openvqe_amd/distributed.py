@@ -1,0 +1,272 @@
+"""Index-bit-partitioned statevector across the GPUs of one node (one process per GPU, RCCL over xGMI
+through ``torch.distributed`` — backend "nccl" IS RCCL on ROCm; "gloo" in the CPU tests).
+
+Layout: W = 2^g ranks, rank r owns the 2^(n-g) amplitudes whose PHYSICAL index has r in its top g bits.
+A logical->physical bit permutation is tracked, so "which logical qubits are global" is a planner
+decision, not a fixed property of the register.
+
+Per Pauli rotation exp(-i phi P), P = (x, z):
+  * z on a global bit  -> a rank-dependent sign inside the local kernel, zero traffic;
+  * x only on local bits -> the local HIP sweep of libovqe_sv (shard handle, ``ovqe_create_shard``);
+  * x on a global bit  -> that logical qubit is first made local by a HALF-SHARD EXCHANGE with the
+    partner rank (swap of one global with one local physical bit: each rank sends the half of its shard
+    it no longer owns and receives the half it now owns — S/2 bytes each way over one xGMI link), after
+    which the rotation is local.  The swap is NOT undone: the permutation is updated instead, and the
+    victim local bit is chosen Belady-style (the qubit whose next X/Y use is farthest away), so a run of
+    rotations touching the same qubits pays for one exchange only.
+
+Expectation values: Hamiltonian terms are grouped by the global part of their x mask; the x_g = 0 group
+is a local partial sum; for each of the <= 2^g - 1 other groups the partner's shard is received
+(read-only) and ``ovqe_bilinear`` contracts own-shard bra with partner-shard ket; one scalar
+all-reduce at the end.  No other collective exists on the data path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def permute_mask(mask, perm):
+    out = 0
+    m = int(mask)
+    b = 0
+    while m:
+        if m & 1:
+            out |= 1 << perm[b]
+        m >>= 1
+        b += 1
+    return out
+
+
+class HipShardEngine:
+    """Shard-local compute on one MI355X through the C ABI; the state buffer is a torch tensor so that
+    torch.distributed can send/receive slices of it."""
+
+    def __init__(self, n_local, n_global, rank, device):
+        from .backend import Statevector
+        self.device = torch.device("cuda", device)
+        self.tensor = torch.zeros(1 << n_local, dtype=torch.complex128, device=self.device)
+        self.sv = Statevector(n_local, device=device, n_global=n_global, shard_index=rank)
+        self.sv.adopt_state(self.tensor.data_ptr())
+
+    def new_buffer(self, count):
+        return torch.empty(count, dtype=torch.complex128, device=self.device)
+
+    def sync(self):
+        torch.cuda.synchronize(self.device)
+
+    def init_basis(self, global_index):
+        self.sv.init_basis(global_index)
+
+    def randomize(self, seed, norm2_total=0.0):
+        return self.sv.randomize(seed, norm2_total)
+
+    def norm2(self):
+        return self.sv.norm2()
+
+    def rotations(self, xs, zs, phis):
+        self.sv.apply_pauli_rotations(xs, zs, phis)
+
+    def bilinear(self, xs, zs, coeffs, ket=None):
+        return self.sv.bilinear(xs, zs, coeffs, ket_ptr=None if ket is None else ket.data_ptr())
+
+
+class ShardedStatevector:
+    """n-qubit state over ``dist.get_world_size()`` ranks (a power of two)."""
+
+    def __init__(self, n_qubits, engine_factory=None, group=None, device=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        g = self.world.bit_length() - 1
+        if (1 << g) != self.world:
+            raise ValueError("world size must be a power of two")
+        if n_qubits - g < 1:
+            raise ValueError("too few qubits for this many ranks")
+        self.n, self.g, self.n_local = int(n_qubits), g, int(n_qubits) - g
+        self.perm = list(range(self.n))  # logical index bit -> physical index bit
+        if engine_factory is None:
+            dev = device if device is not None else torch.cuda.current_device()
+            engine_factory = lambda nl, ng, r: HipShardEngine(nl, ng, r, dev)  # noqa: E731
+        self.engine = engine_factory(self.n_local, self.g, self.rank)
+        self.stats = {"swaps": 0, "bytes_sent": 0, "full_shard_reads": 0}
+        self._tmp = None
+
+    # -- helpers ----------------------------------------------------------------------------
+    def _phys(self, mask):
+        return permute_mask(mask, self.perm)
+
+    def _local_mask(self):
+        return (1 << self.n_local) - 1
+
+    def _tmp_buffer(self, count):
+        if self._tmp is None or self._tmp.numel() < count:
+            self._tmp = self.engine.new_buffer(count)
+        return self._tmp[:count]
+
+    def _swap(self, gbit, lbit):
+        """exchange physical global bit ``gbit`` with physical local bit ``lbit`` (half-shard exchange)"""
+        k = gbit - self.n_local
+        alpha = (self.rank >> k) & 1
+        partner = self.rank ^ (1 << k)
+        t = self.engine.tensor.view(1 << (self.n_local - 1 - lbit), 2, 1 << lbit)
+        mine_out = t[:, 1 - alpha, :]          # the half this rank gives away / receives into
+        half = mine_out.numel()
+        if lbit == self.n_local - 1:
+            send = mine_out.reshape(-1)        # contiguous slice: no staging copy
+        else:
+            send = mine_out.contiguous().view(-1)
+        recv = self._tmp_buffer(half)
+        self.engine.sync()
+        ops = [dist.P2POp(dist.isend, send, partner, self.group), dist.P2POp(dist.irecv, recv, partner, self.group)]
+        if self.rank > partner:
+            ops.reverse()
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        self.engine.sync()
+        mine_out.copy_(recv.view(mine_out.shape))
+        self.engine.sync()
+        # the logical qubits living on these two physical bits trade places
+        la, lb = self.perm.index(gbit), self.perm.index(lbit)
+        self.perm[la], self.perm[lb] = lbit, gbit
+        self.stats["swaps"] += 1
+        self.stats["bytes_sent"] += half * 16
+
+    def _localise(self, x_logical_seq, r):
+        """make every X/Y qubit of rotation r local; victims by farthest next X/Y use"""
+        lmask = self._local_mask()
+        while True:
+            xp = self._phys(x_logical_seq[r])
+            xg = xp & ~lmask
+            if not xg:
+                return xp
+            gbit = xg.bit_length() - 1
+            # candidate local physical bits not touched by this rotation's x
+            best, best_next = None, -1
+            for lbit in range(self.n_local - 1, -1, -1):
+                if (xp >> lbit) & 1:
+                    continue
+                logical = self.perm.index(lbit)
+                nxt = len(x_logical_seq) + 1
+                for s in range(r + 1, len(x_logical_seq)):
+                    if (x_logical_seq[s] >> logical) & 1:
+                        nxt = s
+                        break
+                if nxt > best_next:
+                    best, best_next = lbit, nxt
+            if best is None:
+                raise ValueError("rotation touches more qubits than fit in one shard")
+            self._swap(gbit, best)
+
+    # -- state ------------------------------------------------------------------------------
+    def init_basis(self, logical_index):
+        self.engine.init_basis(self._phys(logical_index))
+
+    def randomize(self, seed):
+        """synthetic state defined on PHYSICAL indices (bench/scaling use; permutation reset)"""
+        self.perm = list(range(self.n))
+        self.engine.randomize(seed, 1.0)
+        n2 = torch.tensor([self.engine.norm2()], dtype=torch.float64, device=self.engine.tensor.device)
+        if self.world > 1:
+            dist.all_reduce(n2, group=self.group)
+        self.engine.tensor.mul_(1.0 / float(n2.item()) ** 0.5)
+        return float(n2.item())
+
+    def norm2(self):
+        n2 = torch.tensor([self.engine.norm2()], dtype=torch.float64, device=self.engine.tensor.device)
+        if self.world > 1:
+            dist.all_reduce(n2, group=self.group)
+        return float(n2.item())
+
+    # -- operations ---------------------------------------------------------------------------
+    def apply_pauli_rotations(self, xs, zs, phis):
+        """rotations in order, masks in LOGICAL index-bit space of the full register"""
+        xs = [int(v) for v in xs]
+        zs = [int(v) for v in zs]
+        batch_x, batch_z, batch_p = [], [], []
+
+        def flush():
+            if batch_x:
+                self.engine.rotations(np.array(batch_x, np.uint64), np.array(batch_z, np.uint64),
+                                      np.array(batch_p, np.float64))
+                batch_x.clear(); batch_z.clear(); batch_p.clear()
+
+        for r in range(len(xs)):
+            if self._phys(xs[r]) & ~self._local_mask():
+                flush()  # the permutation is about to change: masks already queued used the old one
+                xp = self._localise(xs, r)
+            else:
+                xp = self._phys(xs[r])
+            batch_x.append(xp)
+            batch_z.append(self._phys(zs[r]))
+            batch_p.append(float(phis[r]))
+        flush()
+
+    def apply_pauli_rotation(self, x, z, phi):
+        self.apply_pauli_rotations([x], [z], [phi])
+
+    def expectation(self, xs, zs, coeffs, constant=0.0):
+        """Re sum_t c_t <psi|P_t|psi> + constant over the whole register (same value on every rank)"""
+        lmask = self._local_mask()
+        groups = {}
+        for x, z, c in zip(xs, zs, coeffs):
+            xp, zp = self._phys(int(x)), self._phys(int(z))
+            groups.setdefault(xp >> self.n_local, []).append((xp, zp, complex(c)))
+        total = 0.0 + 0.0j
+        # every rank walks the partner patterns in the same order
+        for xg in sorted(groups):  # identical term list + permutation on every rank -> same order everywhere
+            terms = groups.get(xg, [])
+            tx = np.array([t[0] for t in terms], np.uint64)
+            tz = np.array([t[1] for t in terms], np.uint64)
+            tc = np.array([t[2] for t in terms], np.complex128)
+            if xg == 0:
+                if len(terms):
+                    total += self.engine.bilinear(tx, tz, tc, None)
+                continue
+            partner = self.rank ^ xg
+            recv = self._tmp_buffer(1 << self.n_local)
+            self.engine.sync()
+            ops = [dist.P2POp(dist.isend, self.engine.tensor, partner, self.group),
+                   dist.P2POp(dist.irecv, recv, partner, self.group)]
+            if self.rank > partner:
+                ops.reverse()
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            self.engine.sync()
+            self.stats["full_shard_reads"] += 1
+            self.stats["bytes_sent"] += (1 << self.n_local) * 16
+            if len(terms):
+                total += self.engine.bilinear(tx, tz, tc, recv)
+        val = torch.tensor([total.real], dtype=torch.float64, device=self.engine.tensor.device)
+        if self.world > 1:
+            dist.all_reduce(val, group=self.group)
+        return float(val.item()) + float(np.real(constant))
+
+    def energy(self, ham_xs, ham_zs, ham_coeffs, constant, rot_xs, rot_zs, rot_phis, hf_index):
+        """one whole evaluation: |hf> -> rotations -> <H>"""
+        self.perm = list(range(self.n))
+        self.init_basis(hf_index)
+        self.apply_pauli_rotations(rot_xs, rot_zs, rot_phis)
+        return self.expectation(ham_xs, ham_zs, ham_coeffs, constant)
+
+    # -- read-back (tests / small registers) ------------------------------------------------------
+    def gather_state(self):
+        """full state in LOGICAL index order on every rank (small n only)"""
+        shard = self.engine.tensor.detach().to("cpu")
+        if self.world > 1:
+            parts = [torch.empty_like(shard) for _ in range(self.world)]
+            if self.engine.tensor.is_cuda:
+                dev_parts = [torch.empty_like(self.engine.tensor) for _ in range(self.world)]
+                dist.all_gather(dev_parts, self.engine.tensor, group=self.group)
+                parts = [p.cpu() for p in dev_parts]
+            else:
+                dist.all_gather(parts, shard, group=self.group)
+            phys = torch.cat(parts).numpy()
+        else:
+            phys = shard.numpy()
+        idx = np.arange(1 << self.n, dtype=np.int64)
+        pidx = np.zeros_like(idx)
+        for b in range(self.n):
+            pidx |= ((idx >> b) & 1) << self.perm[b]
+        return phys[pidx]
