@@ -70,7 +70,8 @@ int ovqe_destroy(ovqe_handle h);
 /* run this handle's kernels on a caller-owned hipStream_t (NULL = default stream) */
 int ovqe_set_stream(ovqe_handle h, void *hip_stream);
 /* tuning knobs: "force_path" (0 auto, 1 fused small-register kernel, 2 streaming kernels),
- * "small_max_qubits", "small_batch_max_qubits", "unroll" */
+ * "small_max_qubits", "small_batch_max_qubits", "unroll", "real_mode" (1: allow the real-amplitude
+ * specialisation of the fused kernel when every rotation string has an odd number of Y) */
 int ovqe_set_option(ovqe_handle h, const char *name, int64_t value);
 /* device pointer to the 2^n_local amplitudes (for RCCL exchange by the host layer) */
 int ovqe_state_ptr(ovqe_handle h, void **dev_ptr);

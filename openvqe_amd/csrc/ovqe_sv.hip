@@ -65,6 +65,9 @@ struct ovqe_sv {
     int cs_capacity = 512;
     // batched evaluation workspace
     DevBuf d_theta, d_energies, d_workspace;
+    // pair-index-space expectation tables of the fused kernel, built per (thread bits, real mode)
+    DevBuf d_egroups, d_eterms;
+    int exp_lbits = -1, exp_real = -1, exp_ngroups = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_batch_ms = 0.f;
     // options
@@ -72,6 +75,7 @@ struct ovqe_sv {
     int opt_small_max = 14;       // always-small up to this many qubits
     int opt_small_batch_max = 16; // small kernel for batches up to this many qubits
     int opt_unroll = 4;
+    int opt_real_mode = 1;        // allow the real-amplitude specialisation of the fused kernel
 };
 
 namespace {
@@ -390,32 +394,88 @@ bool use_small_path(ovqe_handle h, int64_t B) {
     return h->n_local <= h->opt_small_batch_max && B >= 32;
 }
 
-template <bool LDS, int NT>
+template <bool REAL, bool LDS, int NT, int LBITS>
 int launch_small(ovqe_handle h, const SmallArgs &A, int grid, size_t smem) {
     static bool attr_done = false;
     if (!attr_done) {
-        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_vqe<LDS, NT>),
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_vqe<REAL, LDS, NT, LBITS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_small_vqe<LDS, NT>), dim3(grid), dim3(NT), smem, h->stream, A);
+    hipLaunchKernelGGL((k_small_vqe<REAL, LDS, NT, LBITS>), dim3(grid), dim3(NT), smem, h->stream, A);
     HIPC(h, hipGetLastError());
     return OVQE_OK;
 }
 
-// B evaluations with the fused kernel; energies -> host; optionally leave state of b=0 in h->state
-int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies, bool keep_state) {
+// pair-index-space expectation tables (sv_small.hpp): pivot bit removed from z, sign of parity(x & z) and
+// i^ny folded into the coefficient, terms bucketed by the 3 z bits above the thread bits
+int build_exp_tables(ovqe_handle h, int lbits, bool real) {
+    if (h->exp_lbits == lbits && h->exp_real == (int)real) return OVQE_OK;
+    std::vector<ExpGroup> eg;
+    std::vector<ExpTerm> et;
+    for (const HGroup &g : h->ham.groups) {
+        ExpGroup out;
+        out.x = (uint32_t)g.x;
+        out.pivot = g.x ? 63 - __builtin_clzll(g.x) : 0;
+        out.t0 = (int32_t)et.size();
+        std::vector<ExpTerm> bucket[8];
+        for (int t = g.t0; t < g.t1; ++t) {
+            const HTerm &ht = h->ham.terms[t];
+            const int ny = __builtin_popcountll(g.x & ht.z);
+            if (real && (ny & 1)) continue;  // imaginary antisymmetric string: zero on a real state
+            uint64_t zk = ht.z;
+            if (g.x) {
+                const uint64_t low = (1ull << out.pivot) - 1ull;
+                zk = ((ht.z >> (out.pivot + 1)) << out.pivot) | (ht.z & low);
+            }
+            // D uses parity(j & z) with j = i ^ x:  = parity(i & z) ^ parity(x & z)
+            const double sg = (ny & 1) ? -1.0 : 1.0;
+            ExpTerm e;
+            e.zk = (uint32_t)zk;
+            e.pad = 0;
+            e.cr = sg * ht.cr;
+            e.ci = sg * ht.ci;
+            bucket[(zk >> lbits) & 7].push_back(e);
+        }
+        int off = 0;
+        for (int b = 0; b < 8; ++b) {
+            out.off[b] = off;
+            for (const ExpTerm &e : bucket[b]) et.push_back(e);
+            off += (int)bucket[b].size();
+        }
+        out.off[8] = off;
+        if (off) eg.push_back(out);
+    }
+    int rc = upload(h, h->d_egroups, eg.data(), eg.size() * sizeof(ExpGroup));
+    if (!rc) rc = upload(h, h->d_eterms, et.data(), et.size() * sizeof(ExpTerm));
+    if (rc) return rc;
+    h->exp_lbits = lbits;
+    h->exp_real = (int)real;
+    h->exp_ngroups = (int)eg.size();
+    return OVQE_OK;
+}
+
+// B evaluations with the fused kernel; energies -> host
+int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies) {
     const int n = h->n_local;
-    const size_t state_bytes = (size_t)h->namps * sizeof(amp_t);
+    bool real = h->opt_real_mode != 0;
+    for (const SmallRot &sr : h->rots) real = real && (sr.ny & 1);
+    const size_t amp_bytes = real ? sizeof(double) : sizeof(amp_t);
+    const size_t state_bytes = (size_t)h->namps * amp_bytes;
     const bool lds_state = state_bytes <= 128 * 1024;
+    const uint64_t npairs = h->namps >> 1;
+    const int nt = (!lds_state || npairs >= 1024) ? 1024 : (npairs >= 256 ? 256 : 64);
+    const int lbits = nt == 1024 ? 10 : (nt == 256 ? 8 : 6);
+    int rc = build_exp_tables(h, lbits, real);
+    if (rc) return rc;
     int max_slices = (int)std::max<size_t>(1, std::min<size_t>(512, ((size_t)512 << 20) / state_bytes));
-    if (lds_state) max_slices = n <= 12 ? 1024 : 512;
+    if (lds_state) max_slices = 1024;
     const int grid = (int)std::min<int64_t>(B, max_slices);
-    int rc = ensure(h, h->d_theta, (size_t)B * std::max(1, h->K) * sizeof(double));
+    rc = ensure(h, h->d_theta, (size_t)B * std::max(1, h->K) * sizeof(double));
     if (rc) return rc;
     rc = ensure(h, h->d_energies, (size_t)B * sizeof(double));
     if (rc) return rc;
-    rc = ensure(h, h->d_workspace, lds_state ? state_bytes : (size_t)grid * state_bytes);
+    rc = ensure(h, h->d_workspace, lds_state ? 256 : (size_t)grid * state_bytes);
     if (rc) return rc;
     if (h->K > 0)
         HIPC(h, hipMemcpyAsync(h->d_theta.p, theta, (size_t)B * h->K * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -428,30 +488,30 @@ int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies, b
     A.rots = (const SmallRot *)h->d_rots.p;
     A.segs = (const SmallSeg *)h->d_segs.p;
     A.nsegs = (int)h->segs.size();
-    A.groups = (const HGroup *)h->ham.d_groups.p;
-    A.ngroups = (int)h->ham.groups.size();
-    A.terms = (const HTerm *)h->ham.d_terms.p;
+    A.groups = (const ExpGroup *)h->d_egroups.p;
+    A.ngroups = h->exp_ngroups;
+    A.terms = (const ExpTerm *)h->d_eterms.p;
     A.constant = h->ham.constant;
     A.hf = h->hf;
-    A.workspace = (amp_t *)h->d_workspace.p;
+    A.workspace = h->d_workspace.p;
     A.energies = (double *)h->d_energies.p;
-    A.keep_state = keep_state ? 1 : 0;
     A.cs_capacity = h->cs_capacity;
     const size_t smem = (lds_state ? state_bytes : 0) + (size_t)h->cs_capacity * sizeof(double2) + 16 * sizeof(double2);
-    const uint64_t npairs = h->namps >> 1;
     HIPC(h, hipEventRecord(h->ev0, h->stream));
-    if (lds_state) {
-        if (npairs >= 1024) rc = launch_small<true, 1024>(h, A, grid, smem);
-        else if (npairs >= 256) rc = launch_small<true, 256>(h, A, grid, smem);
-        else rc = launch_small<true, 64>(h, A, grid, smem);
+    if (real) {
+        if (!lds_state) rc = launch_small<true, false, 1024, 10>(h, A, grid, smem);
+        else if (nt == 1024) rc = launch_small<true, true, 1024, 10>(h, A, grid, smem);
+        else if (nt == 256) rc = launch_small<true, true, 256, 8>(h, A, grid, smem);
+        else rc = launch_small<true, true, 64, 6>(h, A, grid, smem);
     } else {
-        rc = launch_small<false, 1024>(h, A, grid, smem);
+        if (!lds_state) rc = launch_small<false, false, 1024, 10>(h, A, grid, smem);
+        else if (nt == 1024) rc = launch_small<false, true, 1024, 10>(h, A, grid, smem);
+        else if (nt == 256) rc = launch_small<false, true, 256, 8>(h, A, grid, smem);
+        else rc = launch_small<false, true, 64, 6>(h, A, grid, smem);
     }
     if (rc) return rc;
     HIPC(h, hipEventRecord(h->ev1, h->stream));
     HIPC(h, hipMemcpyAsync(energies, h->d_energies.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (keep_state)
-        HIPC(h, hipMemcpyAsync(h->state, h->d_workspace.p, state_bytes, hipMemcpyDeviceToDevice, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
     HIPC(h, hipEventElapsedTime(&h->last_batch_ms, h->ev0, h->ev1));
     return OVQE_OK;
@@ -534,7 +594,8 @@ int ovqe_destroy(ovqe_handle h) {
     for (int k = 0; k < 2; ++k)
         if (h->scratch[k]) (void)hipFree(h->scratch[k]);
     DevBuf *bufs[] = {&h->d_partials, &h->d_result, &h->d_rp, &h->ham.d_groups, &h->ham.d_terms, &h->d_ops,
-                      &h->d_rots, &h->d_segs, &h->d_theta, &h->d_energies, &h->d_workspace};
+                      &h->d_rots, &h->d_segs, &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups,
+                      &h->d_eterms};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (h->h_rp) (void)hipHostFree(h->h_rp);
@@ -559,6 +620,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "small_max_qubits") h->opt_small_max = (int)value;
     else if (k == "small_batch_max_qubits") h->opt_small_batch_max = (int)value;
     else if (k == "unroll") h->opt_unroll = (int)value;
+    else if (k == "real_mode") h->opt_real_mode = (int)value;
     else return fail(h, OVQE_ERR_INVALID, "unknown option " + k);
     return OVQE_OK;
 }
@@ -761,6 +823,7 @@ int ovqe_set_hamiltonian(ovqe_handle h, int64_t T, const uint64_t *x, const uint
     if (rc) return rc;
     h->ham.constant = constant;
     h->ham.set = true;
+    h->exp_lbits = -1;
     return OVQE_OK;
 }
 
@@ -843,7 +906,7 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
     if (rc) return rc;
     if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
     if (B == 0) return OVQE_OK;
-    if (use_small_path(h, B)) return run_small(h, B, theta, energies, false);
+    if (use_small_path(h, B)) return run_small(h, B, theta, energies);
     HIPC(h, hipEventRecord(h->ev0, h->stream));
     for (int64_t b = 0; b < B; ++b) {
         rc = run_program_streaming(h, theta + b * (int64_t)K);

@@ -245,3 +245,36 @@ def test_randomize_is_reproducible_on_host(SV):
         want = synth.amplitudes(4242, np.arange(1 << 10, dtype=np.uint64)) * scale
         assert np.array_equal(got, want)
         assert abs(sv.norm2() - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("n,m,o", [(8, 4, 2), (12, 6, 2), (14, 7, 5)])
+def test_real_mode_matches_complex_mode_and_oracle(SV, n, m, o):
+    """UCCSD generators (odd #Y everywhere) select the real-amplitude fused kernel; it must agree with the
+    complex kernel (real_mode = 0), the streaming path and the oracle."""
+    from openvqe_amd import fermion
+    ham, gens, hf = fermion.synthetic_molecule(m, o, seed=77 + n)
+    rng = np.random.default_rng(n)
+    K = len(gens)
+    thetas = rng.uniform(-0.2, 0.2, size=(3, K))
+    xs, zs, cs = ham.packed()
+    psi = np.zeros(1 << n, complex); psi[hf] = 1
+    for g, th in zip(gens, thetas[0]):
+        for t in g.terms:
+            x, z = masks.pack_pauli(n, t.op, t.qbits)
+            psi = masks.rotate(psi, x, z, th * t.coeff)
+    e_ref = masks.expectation(psi, xs, zs, cs.real, ham.constant_coeff)
+    assert np.abs(psi.imag).max() < 1e-15  # the state really is real
+    scale = max(1.0, np.abs(cs).sum())
+    res = {}
+    with SV(n) as sv:
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, hf)
+        for label, opts in (("real", {"force_path": 1, "real_mode": 1}), ("complex", {"force_path": 1, "real_mode": 0}),
+                            ("stream", {"force_path": 2})):
+            for k, v in opts.items():
+                sv.set_option(k, v)
+            res[label] = sv.energy_batch(thetas)
+    for label in res:
+        assert abs(res[label][0] - e_ref) < 1e-10 * scale, label
+    assert np.abs(res["real"] - res["complex"]).max() < 1e-10 * scale
+    assert np.abs(res["real"] - res["stream"]).max() < 1e-10 * scale
