@@ -71,7 +71,8 @@ int ovqe_destroy(ovqe_handle h);
 int ovqe_set_stream(ovqe_handle h, void *hip_stream);
 /* tuning knobs: "force_path" (0 auto, 1 fused small-register kernel, 2 streaming kernels),
  * "small_max_qubits", "small_batch_max_qubits", "unroll", "real_mode" (1: allow the real-amplitude
- * specialisation of the fused kernel when every rotation string has an odd number of Y) */
+ * specialisation of the fused kernel when every rotation string has an odd number of Y),
+ * "table_fusion" (1: commuting same-x runs become single sparse pair rotations in the fused kernel) */
 int ovqe_set_option(ovqe_handle h, const char *name, int64_t value);
 /* device pointer to the 2^n_local amplitudes (for RCCL exchange by the host layer) */
 int ovqe_state_ptr(ovqe_handle h, void **dev_ptr);

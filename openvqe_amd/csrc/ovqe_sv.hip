@@ -58,16 +58,18 @@ struct ovqe_sv {
     bool prog_set = false;
     int32_t K = 0;
     uint64_t hf = 0;
-    std::vector<SmallOp> ops;
+    std::vector<SmallOp> ops;    // sequential program (streaming path)
     std::vector<SmallRot> rots;
+    std::vector<SmallOp> sops;   // fused-kernel program: ops with commuting runs turned into OP_TAB
+    std::vector<SmallRot> srots; // its table entries (sequential rotations and OP_TAB patterns)
     std::vector<SmallSeg> segs;
     DevBuf d_ops, d_rots, d_segs;
     int cs_capacity = 512;
     // batched evaluation workspace
     DevBuf d_theta, d_energies, d_workspace;
     // pair-index-space expectation tables of the fused kernel, built per (thread bits, real mode)
-    DevBuf d_egroups, d_eterms;
-    int exp_lbits = -1, exp_real = -1, exp_ngroups = 0;
+    DevBuf d_egroups, d_eterms, d_echunks, d_eflat;
+    int exp_lbits = -1, exp_real = -1, exp_ngroups = 0, exp_nchunks = 0, exp_nflat = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_batch_ms = 0.f;
     // options
@@ -75,10 +77,13 @@ struct ovqe_sv {
     int opt_small_max = 14;       // always-small up to this many qubits
     int opt_small_batch_max = 16; // small kernel for batches up to this many qubits
     int opt_unroll = 4;
+    int opt_table_fusion = 1;     // turn commuting same-x runs into single sparse pair rotations (OP_TAB)
     int opt_real_mode = 1;        // allow the real-amplitude specialisation of the fused kernel
 };
 
 namespace {
+
+int rebuild_small_program(ovqe_handle h);
 
 int fail(ovqe_handle h, int code, const std::string &msg) {
     if (h) h->err = msg; else g_create_error = msg;
@@ -319,28 +324,83 @@ int run_program_streaming(ovqe_handle h, const double *theta) {
     return OVQE_OK;
 }
 
-int finish_program(ovqe_handle h) {
-    // split fused runs longer than the LDS table, then cut segments
+// commuting-run fusion analysis of one same-x run (see sv_small.hpp OP_TAB); returns false when the run
+// does not have the structure (then it stays a sequential OP_PAIR)
+bool try_table_op(ovqe_handle h, const SmallOp &op, SmallOp &out, std::vector<SmallRot> &entries) {
+    if (op.kind != OP_PAIR || op.count < 1) return false;
+    const uint64_t x = op.x;
+    const int w = __builtin_popcountll(x);
+    if (w > 7 || h->n_local > 32) return false;
+    const SmallRot &r0 = h->rots[op.first];
+    if (r0.pidx < 0) return false;
+    const uint64_t zc = r0.z & ~x;
+    for (int r = op.first; r < op.first + op.count; ++r) {
+        const SmallRot &sr = h->rots[r];
+        if (sr.pidx != r0.pidx || sr.phi0 != 0.0 || !(sr.ny & 1) || (sr.z & ~x) != zc) return false;
+    }
+    int pos[8], np = 0;
+    for (int b = 0; b < 64; ++b)
+        if ((x >> b) & 1) pos[np++] = b;
+    out = op;
+    out.kind = OP_TAB;
+    out.zc = (uint32_t)zc;
+    out.fixmask = (uint32_t)x;
+    out.first = (int32_t)entries.size();
+    out.count = 0;
+    // patterns over the non-pivot x bits (the pivot bit of i is 0)
+    for (uint32_t e = 0; e < (1u << (w - 1)); ++e) {
+        uint64_t ibits = 0;
+        for (int f = 0; f < w - 1; ++f)
+            if ((e >> f) & 1) ibits |= 1ull << pos[f];
+        // rotation angle of the pair = chainsign(i) * theta * K_e,
+        // K_e = sum_t -(-1)^{parity(ibits & z_t)} coeff_t (ny&2 ? -1 : 1)     [odd ny]
+        double K = 0.0;
+        for (int r = op.first; r < op.first + op.count; ++r) {
+            const SmallRot &sr = h->rots[r];
+            double c = (sr.ny & 2) ? -sr.coeff : sr.coeff;
+            if (!(__builtin_popcountll(ibits & sr.z) & 1)) c = -c;
+            K += c;
+        }
+        if (K == 0.0) continue;  // structurally untouched pairs
+        SmallRot pe;
+        pe.z = ibits;
+        pe.coeff = K;
+        pe.phi0 = 0.0;
+        pe.pidx = r0.pidx;
+        pe.ny = 1;
+        entries.push_back(pe);
+        out.count++;
+    }
+    return true;
+}
+
+int rebuild_small_program(ovqe_handle h) {
     const int cap = h->cs_capacity;
-    std::vector<SmallOp> ops2;
+    h->sops.clear();
+    h->srots.clear();
     for (const SmallOp &op : h->ops) {
-        if ((op.kind == OP_PAIR || op.kind == OP_DIAG) && op.count > cap) {
-            for (int o = 0; o < op.count; o += cap) {
+        if (op.kind == OP_PAIR || op.kind == OP_DIAG) {
+            SmallOp t;
+            if (h->opt_table_fusion && try_table_op(h, op, t, h->srots)) {
+                if (t.count > 0) h->sops.push_back(t);  // count == 0: the run is the identity
+                continue;
+            }
+            for (int o = 0; o < op.count; o += cap) {  // split runs longer than the LDS table
                 SmallOp p = op;
-                p.first = op.first + o;
+                p.first = (int32_t)h->srots.size();
                 p.count = std::min(cap, op.count - o);
-                ops2.push_back(p);
+                for (int r = 0; r < p.count; ++r) h->srots.push_back(h->rots[op.first + o + r]);
+                h->sops.push_back(p);
             }
         } else {
-            ops2.push_back(op);
+            h->sops.push_back(op);
         }
     }
-    h->ops.swap(ops2);
     h->segs.clear();
     SmallSeg cur = {0, 0, 0, 0};
-    for (int o = 0; o < (int)h->ops.size(); ++o) {
-        const SmallOp &op = h->ops[o];
-        if (op.kind == OP_PAIR || op.kind == OP_DIAG) {
+    for (int o = 0; o < (int)h->sops.size(); ++o) {
+        const SmallOp &op = h->sops[o];
+        if (op.kind == OP_PAIR || op.kind == OP_DIAG || op.kind == OP_TAB) {
             if (op.first + op.count - cur.rot0 > cap) {
                 if (cur.op1 > cur.op0) h->segs.push_back(cur);
                 cur = {o, o, op.first, op.first};
@@ -350,11 +410,15 @@ int finish_program(ovqe_handle h) {
         cur.op1 = o + 1;
     }
     if (cur.op1 > cur.op0) h->segs.push_back(cur);
-    int rc = upload(h, h->d_ops, h->ops.data(), h->ops.size() * sizeof(SmallOp));
+    int rc = upload(h, h->d_ops, h->sops.data(), h->sops.size() * sizeof(SmallOp));
     if (rc) return rc;
-    rc = upload(h, h->d_rots, h->rots.data(), h->rots.size() * sizeof(SmallRot));
+    rc = upload(h, h->d_rots, h->srots.data(), h->srots.size() * sizeof(SmallRot));
     if (rc) return rc;
-    rc = upload(h, h->d_segs, h->segs.data(), h->segs.size() * sizeof(SmallSeg));
+    return upload(h, h->d_segs, h->segs.data(), h->segs.size() * sizeof(SmallSeg));
+}
+
+int finish_program(ovqe_handle h) {
+    int rc = rebuild_small_program(h);
     if (rc) return rc;
     h->prog_set = true;
     return OVQE_OK;
@@ -377,7 +441,7 @@ void push_rotation(ovqe_handle h, uint64_t x, uint64_t z, double coeff, double p
             return;
         }
     }
-    SmallOp op;
+    SmallOp op = {};
     op.x = x;
     op.kind = kind;
     op.first = idx;
@@ -402,41 +466,60 @@ int launch_small(ovqe_handle h, const SmallArgs &A, int grid, size_t smem) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_small_vqe<REAL, LDS, NT, LBITS>), dim3(grid), dim3(NT), smem, h->stream, A);
+    hipLaunchKernelGGL((k_small_vqe<REAL, LDS, NT, LBITS>), dim3(grid), dim3(NT), smem, h->stream, A,
+                       (const double *)h->d_theta.p, (const SmallOp *)h->d_ops.p, (const SmallRot *)h->d_rots.p,
+                       (const SmallSeg *)h->d_segs.p, (const ExpGroup *)h->d_egroups.p, (const ExpChunk *)h->d_echunks.p,
+                       (const ExpTerm *)h->d_eterms.p, (const FlatItem *)h->d_eflat.p, h->d_workspace.p,
+                       (double *)h->d_energies.p);
     HIPC(h, hipGetLastError());
     return OVQE_OK;
 }
 
-// pair-index-space expectation tables (sv_small.hpp): pivot bit removed from z, sign of parity(x & z) and
-// i^ny folded into the coefficient, terms bucketed by the 3 z bits above the thread bits
+// free-index-space expectation tables (sv_small.hpp): one entry per (x-group, pattern of the x-position
+// bits) with a non-vanishing coefficient table; the fixed positions are squeezed out of the z masks, the
+// sign of parity(x & z), i^ny and the pattern-dependent sign are folded into the coefficients, terms with
+// equal outside masks are merged, terms bucketed by the 3 free-index bits above the thread bits
 int build_exp_tables(ovqe_handle h, int lbits, bool real) {
     if (h->exp_lbits == lbits && h->exp_real == (int)real) return OVQE_OK;
     std::vector<ExpGroup> eg;
     std::vector<ExpTerm> et;
-    for (const HGroup &g : h->ham.groups) {
-        ExpGroup out;
-        out.x = (uint32_t)g.x;
-        out.pivot = g.x ? 63 - __builtin_clzll(g.x) : 0;
+    std::vector<FlatItem> flat;
+    const int n = h->n_local;
+    auto squeeze = [](uint64_t z, const int *pos, int np) {  // remove the bit positions pos[] (ascending)
+        for (int f = np - 1; f >= 0; --f) {
+            const uint64_t low = (1ull << pos[f]) - 1ull;
+            z = ((z >> (pos[f] + 1)) << pos[f]) | (z & low);
+        }
+        return z;
+    };
+    auto emit = [&](uint32_t x, uint32_t ibits, const int *pos, int np, std::vector<ExpTerm> &list,
+                    const std::vector<uint64_t> *zc_index_space) {
+        if (list.empty()) return;
+        if (zc_index_space && list.size() == 1 && list[0].ci == 0.0 && x != 0 && n <= 16) {
+            // single real term: entry-per-lane flat item(s)
+            const uint32_t nk = 1u << (n - np);
+            const uint32_t nslices = nk >= 64 ? 4 : 1;
+            for (uint32_t sl = 0; sl < nslices; ++sl) {
+                FlatItem fi;
+                fi.x = (uint16_t)x;
+                fi.ibits = (uint16_t)ibits;
+                fi.zc = (uint16_t)(*zc_index_space)[0];
+                fi.slice = (uint16_t)sl;
+                fi.count = nk / nslices;
+                fi.stride = nslices;
+                fi.c = 2.0 * list[0].cr;
+                flat.push_back(fi);
+            }
+            return;
+        }
+        ExpGroup out = {};
+        out.x = x;
+        out.ibits = ibits;
+        out.fixmask = 0;
+        for (int f = 0; f < np; ++f) out.fixmask |= 1u << pos[f];
         out.t0 = (int32_t)et.size();
         std::vector<ExpTerm> bucket[8];
-        for (int t = g.t0; t < g.t1; ++t) {
-            const HTerm &ht = h->ham.terms[t];
-            const int ny = __builtin_popcountll(g.x & ht.z);
-            if (real && (ny & 1)) continue;  // imaginary antisymmetric string: zero on a real state
-            uint64_t zk = ht.z;
-            if (g.x) {
-                const uint64_t low = (1ull << out.pivot) - 1ull;
-                zk = ((ht.z >> (out.pivot + 1)) << out.pivot) | (ht.z & low);
-            }
-            // D uses parity(j & z) with j = i ^ x:  = parity(i & z) ^ parity(x & z)
-            const double sg = (ny & 1) ? -1.0 : 1.0;
-            ExpTerm e;
-            e.zk = (uint32_t)zk;
-            e.pad = 0;
-            e.cr = sg * ht.cr;
-            e.ci = sg * ht.ci;
-            bucket[(zk >> lbits) & 7].push_back(e);
-        }
+        for (const ExpTerm &e : list) bucket[(e.zk >> lbits) & 7].push_back(e);
         int off = 0;
         for (int b = 0; b < 8; ++b) {
             out.off[b] = off;
@@ -444,14 +527,107 @@ int build_exp_tables(ovqe_handle h, int lbits, bool real) {
             off += (int)bucket[b].size();
         }
         out.off[8] = off;
-        if (off) eg.push_back(out);
+        eg.push_back(out);
+    };
+    for (const HGroup &g : h->ham.groups) {
+        const uint64_t x = g.x;
+        const int w = __builtin_popcountll(x);
+        int pos[64], np = 0;
+        for (int b = 0; b < 64; ++b)
+            if ((x >> b) & 1) pos[np++] = b;
+        // folded coefficients: D uses parity(j & z), j = i ^ x  ->  parity(i & z) ^ parity(x & z)
+        std::vector<HTerm> ts;
+        for (int t = g.t0; t < g.t1; ++t) {
+            HTerm ht = h->ham.terms[t];
+            const int ny = __builtin_popcountll(x & ht.z);
+            if (real && (ny & 1)) continue;  // imaginary antisymmetric string: zero on a real state
+            if (ny & 1) {
+                ht.cr = -ht.cr;
+                ht.ci = -ht.ci;
+            }
+            ts.push_back(ht);
+        }
+        if (ts.empty()) continue;
+        if (w == 0 || w > 7 || !h->opt_table_fusion) {
+            // dense form: only the pivot is fixed (diag group: nothing fixed)
+            const int piv = w ? pos[np - 1] : 0;
+            std::vector<ExpTerm> list;
+            for (const HTerm &ht : ts) {
+                ExpTerm e;
+                e.zk = (uint32_t)(w ? squeeze(ht.z, &piv, 1) : ht.z);
+                e.pad = 0;
+                e.cr = ht.cr;
+                e.ci = ht.ci;
+                list.push_back(e);
+            }
+            emit((uint32_t)x, 0, &piv, w ? 1 : 0, list, nullptr);
+            continue;
+        }
+        for (uint32_t e = 0; e < (1u << (w - 1)); ++e) {
+            uint64_t ibits = 0;
+            for (int f = 0; f < w - 1; ++f)
+                if ((e >> f) & 1) ibits |= 1ull << pos[f];
+            std::vector<ExpTerm> list;  // merged by outside mask
+            std::vector<uint64_t> zcs;  // the outside masks in index space, parallel to list
+            for (const HTerm &ht : ts) {
+                const uint64_t zc = ht.z & ~x;
+                const double sg = (__builtin_popcountll(ibits & ht.z) & 1) ? -1.0 : 1.0;
+                const uint32_t zk = (uint32_t)squeeze(zc, pos, np);
+                bool found = false;
+                for (ExpTerm &q : list)
+                    if (q.zk == zk) {
+                        q.cr += sg * ht.cr;
+                        q.ci += sg * ht.ci;
+                        found = true;
+                        break;
+                    }
+                if (!found) {
+                    ExpTerm q;
+                    q.zk = zk;
+                    q.pad = 0;
+                    q.cr = sg * ht.cr;
+                    q.ci = sg * ht.ci;
+                    list.push_back(q);
+                    zcs.push_back(zc);
+                }
+            }
+            std::vector<ExpTerm> nz;
+            std::vector<uint64_t> nzc;
+            for (size_t q = 0; q < list.size(); ++q)
+                if (list[q].cr != 0.0 || list[q].ci != 0.0) {  // exact cancellations only
+                    nz.push_back(list[q]);
+                    nzc.push_back(zcs[q]);
+                }
+            emit((uint32_t)x, (uint32_t)ibits, pos, np, nz, &nzc);
+        }
+    }
+    // chunks of general groups whose terms fit the LDS staging area (the idle rotation table)
+    const int stage_cap = (int)((size_t)h->cs_capacity * sizeof(RotLds) / sizeof(ExpTerm));
+    std::vector<ExpChunk> chunks;
+    {
+        ExpChunk cur = {0, 0, 0, 0};
+        for (int g = 0; g < (int)eg.size(); ++g) {
+            const int gt1 = eg[g].t0 + eg[g].off[8];
+            if (eg[g].off[8] > stage_cap) return fail(h, OVQE_ERR_INVALID, "x-group with too many terms for the fused kernel");
+            if (gt1 - cur.t0 > stage_cap) {
+                if (cur.g1 > cur.g0) chunks.push_back(cur);
+                cur = {g, g, eg[g].t0, eg[g].t0};
+            }
+            cur.g1 = g + 1;
+            cur.t1 = gt1;
+        }
+        if (cur.g1 > cur.g0) chunks.push_back(cur);
     }
     int rc = upload(h, h->d_egroups, eg.data(), eg.size() * sizeof(ExpGroup));
     if (!rc) rc = upload(h, h->d_eterms, et.data(), et.size() * sizeof(ExpTerm));
+    if (!rc) rc = upload(h, h->d_echunks, chunks.data(), chunks.size() * sizeof(ExpChunk));
+    if (!rc) rc = upload(h, h->d_eflat, flat.data(), flat.size() * sizeof(FlatItem));
     if (rc) return rc;
     h->exp_lbits = lbits;
     h->exp_real = (int)real;
     h->exp_ngroups = (int)eg.size();
+    h->exp_nchunks = (int)chunks.size();
+    h->exp_nflat = (int)flat.size();
     return OVQE_OK;
 }
 
@@ -481,22 +657,16 @@ int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies) {
         HIPC(h, hipMemcpyAsync(h->d_theta.p, theta, (size_t)B * h->K * sizeof(double), hipMemcpyHostToDevice, h->stream));
     SmallArgs A;
     A.n = n;
-    A.B = B;
-    A.theta = (const double *)h->d_theta.p;
     A.K = h->K;
-    A.ops = (const SmallOp *)h->d_ops.p;
-    A.rots = (const SmallRot *)h->d_rots.p;
-    A.segs = (const SmallSeg *)h->d_segs.p;
     A.nsegs = (int)h->segs.size();
-    A.groups = (const ExpGroup *)h->d_egroups.p;
     A.ngroups = h->exp_ngroups;
-    A.terms = (const ExpTerm *)h->d_eterms.p;
+    A.nchunks = h->exp_nchunks;
+    A.nflat = h->exp_nflat;
+    A.cs_capacity = h->cs_capacity;
+    A.B = B;
     A.constant = h->ham.constant;
     A.hf = h->hf;
-    A.workspace = h->d_workspace.p;
-    A.energies = (double *)h->d_energies.p;
-    A.cs_capacity = h->cs_capacity;
-    const size_t smem = (lds_state ? state_bytes : 0) + (size_t)h->cs_capacity * sizeof(double2) + 16 * sizeof(double2);
+    const size_t smem = (lds_state ? state_bytes : 0) + (size_t)h->cs_capacity * sizeof(RotLds) + 16 * sizeof(double2);
     HIPC(h, hipEventRecord(h->ev0, h->stream));
     if (real) {
         if (!lds_state) rc = launch_small<true, false, 1024, 10>(h, A, grid, smem);
@@ -595,7 +765,7 @@ int ovqe_destroy(ovqe_handle h) {
         if (h->scratch[k]) (void)hipFree(h->scratch[k]);
     DevBuf *bufs[] = {&h->d_partials, &h->d_result, &h->d_rp, &h->ham.d_groups, &h->ham.d_terms, &h->d_ops,
                       &h->d_rots, &h->d_segs, &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups,
-                      &h->d_eterms};
+                      &h->d_eterms, &h->d_echunks, &h->d_eflat};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (h->h_rp) (void)hipHostFree(h->h_rp);
@@ -621,6 +791,15 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "small_batch_max_qubits") h->opt_small_batch_max = (int)value;
     else if (k == "unroll") h->opt_unroll = (int)value;
     else if (k == "real_mode") h->opt_real_mode = (int)value;
+    else if (k == "table_fusion") {
+        if (h->opt_table_fusion != (int)value && h->prog_set) {
+            h->opt_table_fusion = (int)value;
+            h->exp_lbits = -1;
+            return rebuild_small_program(h);
+        }
+        h->opt_table_fusion = (int)value;
+        h->exp_lbits = -1;
+    }
     else return fail(h, OVQE_ERR_INVALID, "unknown option " + k);
     return OVQE_OK;
 }
@@ -867,7 +1046,7 @@ int ovqe_set_gate_program(ovqe_handle h, int64_t G, const int32_t *opcode, const
     h->hf = hf_index;
     for (int64_t g = 0; g < G; ++g) {
         const uint64_t bit = 1ull << b0[g];
-        SmallOp op;
+        SmallOp op = {};
         switch (opcode[g]) {
         case OVQE_GATE_RX: push_rotation(h, bit, 0, 0.5 * ascale[g], 0.5 * aconst[g], pidx[g]); break;
         case OVQE_GATE_RY: push_rotation(h, bit, bit, 0.5 * ascale[g], 0.5 * aconst[g], pidx[g]); break;

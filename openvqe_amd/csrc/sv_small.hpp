@@ -25,14 +25,21 @@
 
 namespace ovqe {
 
-enum SmallOpKind : int32_t { OP_PAIR = 0, OP_DIAG = 1, OP_X = 2, OP_H = 3, OP_CNOT = 4 };
+enum SmallOpKind : int32_t { OP_PAIR = 0, OP_DIAG = 1, OP_X = 2, OP_H = 3, OP_CNOT = 4, OP_TAB = 5 };
 
+// OP_TAB — "commuting-run fusion": a run of rotations sharing the x mask, the parameter and the z part
+// outside x (the JW strings of one fermionic excitation) commutes, so its product is ONE rotation of each
+// pair (i, i^x) by chainsign(i) * theta * K_e, where e = the bits of i on the x positions and K_e a
+// host-computed constant.  Patterns with K_e == 0 exactly (the fermionic selection rule: 7 of 8 for a
+// double, 1 of 2 for a single excitation) are untouched pairs and are never visited.
 struct SmallOp {
-    uint64_t x;       // OP_PAIR: x mask;  OP_X/OP_H: 1<<bit;  OP_CNOT: 1<<target
+    uint64_t x;       // OP_PAIR/OP_TAB: x mask;  OP_X/OP_H: 1<<bit;  OP_CNOT: 1<<target
     int32_t kind;
-    int32_t first;    // first rotation entry (OP_PAIR / OP_DIAG);  OP_CNOT: control bit
-    int32_t count;    // rotations in the fused run;                OP_CNOT: target bit
+    int32_t first;    // first table entry (rotations of the run / active patterns);  OP_CNOT: control bit
+    int32_t count;    // entries;                                                    OP_CNOT: target bit
     int32_t pivot;    // highest x bit (OP_PAIR); bit (OP_X/OP_H)
+    uint32_t zc;      // OP_TAB: z mask outside x (sign of the pair = parity(i & zc))
+    uint32_t fixmask; // OP_TAB: index bits that are fixed by the pattern (= x)
 };
 
 struct SmallRot {
@@ -50,34 +57,57 @@ struct SmallSeg {
 
 // expectation tables in PAIR-INDEX space (k): built by the host for a given thread count (lbits)
 struct ExpTerm {
-    uint32_t zk;   // z mask with the pivot bit removed (diag group: z itself)
+    uint32_t zk;   // z mask in free-index (k) space: the fixed positions squeezed out
     uint32_t pad;
     double cr, ci; // coefficient * i^ny * (-1)^{parity(x & z)}
 };
+// one (x-group, active pattern of the x-position bits) pair: the free index k runs over the bits NOT in
+// fixmask; i = deposit(k) | ibits, j = i ^ x.  Fallback for wide x masks: fixmask = {pivot}, ibits = 0.
 struct ExpGroup {
     uint32_t x;        // 0 for the diagonal group
-    int32_t pivot;
+    uint32_t ibits;    // values of the fixed bits
     int32_t t0;        // first term
     int32_t off[9];    // bucket b (bits [lbits, lbits+3) of zk == b) = terms [t0+off[b], t0+off[b+1])
+    uint32_t fixmask;  // index bits fixed by the pattern
+};
+
+// a (x-group, pattern) entry with ONE real-coefficient term, sliced over lanes: this lane visits the free
+// indices k = slice + nslices*m.  Entries are laid out entry-per-lane (adjacent lanes = adjacent slices of one
+// entry, so their amplitudes differ in the low free bits -> different LDS banks).
+struct FlatItem {
+    uint16_t x;       // pair mask (also the fixed positions)
+    uint16_t ibits;   // pattern bits on the non-pivot x positions
+    uint16_t zc;      // sign mask OUTSIDE x, index space
+    uint16_t slice;   // first free index
+    uint32_t count;   // free indices visited by this lane
+    uint32_t stride;  // nslices (power of two)
+    double c;         // 2 * coefficient (pair trick), signs folded
+};
+
+// run of general groups whose terms fit the LDS staging area
+struct ExpChunk {
+    int32_t g0, g1, t0, t1;
 };
 
 struct SmallArgs {
     int n;
-    int64_t B;
-    const double *theta;  // B x K
     int K;
-    const SmallOp *ops;
-    const SmallRot *rots;
-    const SmallSeg *segs;
     int nsegs;
-    const ExpGroup *groups;
     int ngroups;
-    const ExpTerm *terms;
+    int nchunks;
+    int nflat;
+    int cs_capacity;    // entries of the LDS rotation table
+    int64_t B;
     double constant;
     uint64_t hf;
-    void *workspace;    // gridDim.x slices of 2^n amplitudes (global-state variant)
-    double *energies;   // B
-    int cs_capacity;    // entries of the LDS cos/sin table
+};
+
+// per-rotation entry of the LDS table: angles resolved for this parameter vector + the z mask
+struct RotLds {
+    double c, s;     // cos(phi), sin(phi) * (ny&2 ? -1 : 1)
+    uint32_t z;
+    uint32_t odd;    // ny & 1
+    uint64_t pad;
 };
 
 // ---- amplitude helpers, REAL = double, complex = double2 -----------------------------------------
@@ -99,10 +129,8 @@ __device__ __forceinline__ void mix_real(double &u, double &v, double c, double 
     v = nv;
 }
 
-template <bool REAL, int NT, typename A>
-__device__ __forceinline__ void small_pass_pair(A *st, uint32_t npairs, const SmallOp &op,
-                                                const SmallRot *__restrict__ rots, const double2 *cs, int rot_base) {
-    constexpr int U = 4;
+template <bool REAL, int NT, int U, typename A>
+__device__ __forceinline__ void small_pass_pair(A *st, uint32_t npairs, const SmallOp &op, const RotLds *tab) {
     const uint32_t x = (uint32_t)op.x;
     const int pivot = op.pivot;
     for (uint32_t k0 = threadIdx.x; k0 < npairs; k0 += NT * U) {
@@ -118,24 +146,22 @@ __device__ __forceinline__ void small_pass_pair(A *st, uint32_t npairs, const Sm
             }
         }
         for (int r = 0; r < op.count; ++r) {
-            const uint32_t z = (uint32_t)rots[op.first + r].z;
-            const int odd = rots[op.first + r].ny & 1;
-            const double2 c = cs[op.first + r - rot_base];
+            const RotLds rl = tab[r];
 #pragma unroll
             for (int m = 0; m < U; ++m) {
-                const int pi = __popc(ii[m] & z) & 1;
-                const int pj = pi ^ odd;
-                const double si = pj ? -c.y : c.y;
-                const double sj = pi ? -c.y : c.y;
+                const int pi = __popc(ii[m] & rl.z) & 1;
+                const int pj = pi ^ (int)rl.odd;
+                const double si = pj ? -rl.s : rl.s;
+                const double sj = pi ? -rl.s : rl.s;
                 if constexpr (REAL) {
-                    mix_real(u[m], v[m], c.x, si, sj);
+                    mix_real(u[m], v[m], rl.c, si, sj);
                 } else {
-                    if (odd) {
-                        mix_real(u[m].x, v[m].x, c.x, si, sj);
-                        mix_real(u[m].y, v[m].y, c.x, si, sj);
+                    if (rl.odd) {
+                        mix_real(u[m].x, v[m].x, rl.c, si, sj);
+                        mix_real(u[m].y, v[m].y, rl.c, si, sj);
                     } else {
-                        const double ux = c.x * u[m].x + si * v[m].y, uy = c.x * u[m].y - si * v[m].x;
-                        const double vx = c.x * v[m].x + sj * u[m].y, vy = c.x * v[m].y - sj * u[m].x;
+                        const double ux = rl.c * u[m].x + si * v[m].y, uy = rl.c * u[m].y - si * v[m].x;
+                        const double vx = rl.c * v[m].x + sj * u[m].y, vy = rl.c * v[m].y - sj * u[m].x;
                         u[m] = make_double2(ux, uy);
                         v[m] = make_double2(vx, vy);
                     }
@@ -155,17 +181,47 @@ __device__ __forceinline__ void small_pass_pair(A *st, uint32_t npairs, const Sm
 
 // x == 0 runs are complex phases: only reachable in complex mode
 template <int NT>
-__device__ __forceinline__ void small_pass_diag(double2 *st, uint32_t namps, const SmallOp &op,
-                                                const SmallRot *__restrict__ rots, const double2 *cs, int rot_base) {
+__device__ __forceinline__ void small_pass_diag(double2 *st, uint32_t namps, const SmallOp &op, const RotLds *tab) {
     for (uint32_t i = threadIdx.x; i < namps; i += NT) {
         double2 a = st[i];
         for (int r = 0; r < op.count; ++r) {
-            const uint32_t z = (uint32_t)rots[op.first + r].z;
-            const double2 c = cs[op.first + r - rot_base];
-            const double s = (__popc(i & z) & 1) ? -c.y : c.y;
-            a = make_double2(c.x * a.x + s * a.y, c.x * a.y - s * a.x);
+            const RotLds rl = tab[r];
+            const double s = (__popc(i & rl.z) & 1) ? -rl.s : rl.s;
+            a = make_double2(rl.c * a.x + s * a.y, rl.c * a.y - s * a.x);
         }
         st[i] = a;
+    }
+}
+
+// spread the free index k over the bit positions NOT in fixmask (zeros at the fixed positions)
+__device__ __forceinline__ uint32_t deposit_index(uint32_t k, uint32_t fixmask) {
+    while (fixmask) {  // wave-uniform: scalar loop, ascending positions
+        const int p = __ffs(fixmask) - 1;
+        k = (uint32_t)insert_zero(k, p);
+        fixmask &= fixmask - 1;
+    }
+    return k;
+}
+
+template <bool REAL, int NT, typename A>
+__device__ __forceinline__ void small_pass_tab(A *st, int n, const SmallOp &op, const RotLds *tab) {
+    const uint32_t nk = 1u << (n - __popc(op.fixmask));
+    const uint32_t x = (uint32_t)op.x;
+    for (int p = 0; p < op.count; ++p) {
+        const RotLds rl = tab[p];  // z = the pattern's fixed bits
+        for (uint32_t k = threadIdx.x; k < nk; k += NT) {
+            const uint32_t i = deposit_index(k, op.fixmask) | rl.z, j = i ^ x;
+            const double s = (__popc(i & op.zc) & 1) ? -rl.s : rl.s;
+            A u = st[i], v = st[j];
+            if constexpr (REAL) {
+                mix_real(u, v, rl.c, s, -s);
+            } else {
+                mix_real(u.x, v.x, rl.c, s, -s);
+                mix_real(u.y, v.y, rl.c, s, -s);
+            }
+            st[i] = u;
+            st[j] = v;
+        }
     }
 }
 
@@ -217,120 +273,173 @@ __device__ __forceinline__ void wht8(double *w) {
     }
 }
 
-// sum over the groups of 2 Re sum_k D(k) conj(a_i) a_j  (x = 0 group: sum_i D(i) |a_i|^2)
+// flat single-term entries, entry-per-lane: sum c * (-1)^{parity(i & zc)} Re(conj(a_i) a_j)
+template <bool REAL, int NT, typename A>
+__device__ __forceinline__ double small_expectation_flat(const A *st, const FlatItem *__restrict__ items, int nflat) {
+    double acc = 0.0;
+    for (int it = threadIdx.x; it < nflat; it += NT) {
+        const FlatItem fi = items[it];
+        const uint32_t x = fi.x, keep = ~x;
+        // first index: deposit(slice) | ibits ; step: deposit(stride) (a single bit at a free position)
+        uint32_t i = fi.slice, step = fi.stride, m = x;
+        while (m) {
+            const int p = __ffs(m) - 1;
+            i = (uint32_t)insert_zero(i, p);
+            step = (uint32_t)insert_zero(step, p);
+            m &= m - 1;
+        }
+        i |= fi.ibits;
+        double part = 0.0;
+        for (uint32_t c = 0; c < fi.count; ++c) {
+            const A a = st[i], b = st[i ^ x];
+            double w;
+            if constexpr (REAL) w = a * b; else w = a.x * b.x + a.y * b.y;
+            part += (__popc(i & fi.zc) & 1) ? -w : w;
+            i = ((((i | x) + step) & keep) | fi.ibits);
+        }
+        acc += fi.c * part;
+    }
+    return acc;
+}
+
+// general (group, pattern) entries: 2 Re sum_k D(k) conj(a_i) a_j  (x = 0 entry: sum_i D(i) |a_i|^2);
+// the term tables are staged chunk-wise into LDS (``lterms``) so the per-term reads are LDS broadcasts
 template <bool REAL, int NT, int LBITS, typename A>
-__device__ __forceinline__ double small_expectation(const A *st, int n, const ExpGroup *__restrict__ groups, int ngroups,
-                                                    const ExpTerm *__restrict__ terms) {
+__device__ __forceinline__ double small_expectation(const A *st, int n, const ExpGroup *__restrict__ groups,
+                                                    const ExpChunk *__restrict__ chunks, int nchunks,
+                                                    const ExpTerm *__restrict__ terms, ExpTerm *lterms) {
     double acc = 0.0;
     const uint32_t tid = threadIdx.x;
-    for (int g = 0; g < ngroups; ++g) {
-        const ExpGroup gr = groups[g];
-        const bool diag = gr.x == 0;
-        const uint32_t nk = diag ? (1u << n) : (1u << (n - 1));
-        const double weight = diag ? 1.0 : 2.0;
-        if (nk >= 8u * NT) {
-            // chunks of 8*NT pair indices: k = cbase + m*NT + tid, m = 0..7
-            for (uint32_t cbase = 0; cbase < nk; cbase += 8u * NT) {
-                double wr[8], wi[8];
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const ExpChunk ck = chunks[ch];
+        __syncthreads();
+        for (int t = ck.t0 + (int)tid; t < ck.t1; t += NT) lterms[t - ck.t0] = terms[t];
+        __syncthreads();
+        for (int g = ck.g0; g < ck.g1; ++g) {
+            const ExpGroup gr = groups[g];
+            const ExpTerm *gt = lterms + (gr.t0 - ck.t0);
+            const bool diag = gr.x == 0;
+            const uint32_t nk = 1u << (n - __popc(gr.fixmask));
+            const double weight = diag ? 1.0 : 2.0;
+            if (nk >= 8u * NT) {
+                // chunks of 8*NT free indices: k = cbase + m*NT + tid, m = 0..7
+                for (uint32_t cbase = 0; cbase < nk; cbase += 8u * NT) {
+                    double wr[8], wi[8];
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const uint32_t k = cbase + m * NT + tid;
-                    if (diag) {
-                        const A a = st[k];
-                        if constexpr (REAL) wr[m] = a * a; else wr[m] = a.x * a.x + a.y * a.y;
-                        wi[m] = 0.0;
-                    } else {
-                        const uint32_t i = (uint32_t)insert_zero(k, gr.pivot), j = i ^ gr.x;
-                        const A a = st[i], c = st[j];
-                        if constexpr (REAL) {
-                            wr[m] = a * c;
+                    for (int m = 0; m < 8; ++m) {
+                        const uint32_t k = cbase + m * NT + tid;
+                        const uint32_t i = deposit_index(k, gr.fixmask) | gr.ibits;
+                        const A a = st[i];
+                        if (diag) {
+                            if constexpr (REAL) wr[m] = a * a; else wr[m] = a.x * a.x + a.y * a.y;
                             wi[m] = 0.0;
                         } else {
-                            wr[m] = a.x * c.x + a.y * c.y;  // conj(a_i) a_j
-                            wi[m] = a.x * c.y - a.y * c.x;
+                            const A c = st[i ^ gr.x];
+                            if constexpr (REAL) {
+                                wr[m] = a * c;
+                                wi[m] = 0.0;
+                            } else {
+                                wr[m] = a.x * c.x + a.y * c.y;  // conj(a_i) a_j
+                                wi[m] = a.x * c.y - a.y * c.x;
+                            }
                         }
                     }
-                }
-                wht8(wr);
-                if constexpr (!REAL) wht8(wi);
-                double part = 0.0;
+                    wht8(wr);
+                    if constexpr (!REAL) wht8(wi);
+                    double part = 0.0;
 #pragma unroll
-                for (int h = 0; h < 8; ++h) {
-                    for (int t = gr.t0 + gr.off[h]; t < gr.t0 + gr.off[h + 1]; ++t) {
-                        const ExpTerm et = terms[t];
-                        // sign from the thread bits and the chunk bits; the 3 m-bits are in the bucket
-                        const uint32_t kk = (cbase | tid) & et.zk;
-                        const bool neg = __popc(kk) & 1;
-                        double v;
-                        if constexpr (REAL) v = et.cr * wr[h]; else v = et.cr * wr[h] - et.ci * wi[h];
-                        part += neg ? -v : v;
+                    for (int h = 0; h < 8; ++h) {
+                        for (int t = gr.off[h]; t < gr.off[h + 1]; ++t) {
+                            const ExpTerm et = gt[t];
+                            // sign from the thread bits and the chunk bits; the 3 m-bits are in the bucket
+                            const uint32_t kk = (cbase | tid) & et.zk;
+                            const bool neg = __popc(kk) & 1;
+                            double v;
+                            if constexpr (REAL) v = et.cr * wr[h]; else v = et.cr * wr[h] - et.ci * wi[h];
+                            part += neg ? -v : v;
+                        }
                     }
+                    acc += weight * part;
+                }
+            } else {
+                // few free indices per thread: direct evaluation
+                double part = 0.0;
+                for (uint32_t k = tid; k < nk; k += NT) {
+                    const uint32_t i = deposit_index(k, gr.fixmask) | gr.ibits;
+                    const A a = st[i];
+                    double wr, wi = 0.0;
+                    if (diag) {
+                        if constexpr (REAL) wr = a * a; else wr = a.x * a.x + a.y * a.y;
+                    } else {
+                        const A c = st[i ^ gr.x];
+                        if constexpr (REAL) {
+                            wr = a * c;
+                        } else {
+                            wr = a.x * c.x + a.y * c.y;
+                            wi = a.x * c.y - a.y * c.x;
+                        }
+                    }
+                    double dr = 0.0, di = 0.0;
+                    for (int t = 0; t < gr.off[8]; ++t) {
+                        const ExpTerm et = gt[t];
+                        const bool neg = __popc(k & et.zk) & 1;
+                        dr += neg ? -et.cr : et.cr;
+                        di += neg ? -et.ci : et.ci;
+                    }
+                    part += dr * wr - di * wi;
                 }
                 acc += weight * part;
             }
-        } else {
-            // small registers: direct evaluation
-            double part = 0.0;
-            for (uint32_t k = tid; k < nk; k += NT) {
-                double wr, wi = 0.0;
-                if (diag) {
-                    const A a = st[k];
-                    if constexpr (REAL) wr = a * a; else wr = a.x * a.x + a.y * a.y;
-                } else {
-                    const uint32_t i = (uint32_t)insert_zero(k, gr.pivot), j = i ^ gr.x;
-                    const A a = st[i], c = st[j];
-                    if constexpr (REAL) {
-                        wr = a * c;
-                    } else {
-                        wr = a.x * c.x + a.y * c.y;
-                        wi = a.x * c.y - a.y * c.x;
-                    }
-                }
-                double dr = 0.0, di = 0.0;
-                for (int t = gr.t0; t < gr.t0 + gr.off[8]; ++t) {
-                    const ExpTerm et = terms[t];
-                    const bool neg = __popc(k & et.zk) & 1;
-                    dr += neg ? -et.cr : et.cr;
-                    di += neg ? -et.ci : et.ci;
-                }
-                part += dr * wr - di * wi;
-            }
-            acc += weight * part;
         }
     }
     return acc;
 }
 
 template <bool REAL, bool LDS_STATE, int NT, int LBITS>
-__global__ __launch_bounds__(NT) void k_small_vqe(SmallArgs A) {
+__global__ __launch_bounds__(NT) void k_small_vqe(SmallArgs A, const double *__restrict__ theta,
+                                                  const SmallOp *__restrict__ ops, const SmallRot *__restrict__ rots,
+                                                  const SmallSeg *__restrict__ segs,
+                                                  const ExpGroup *__restrict__ groups,
+                                                  const ExpChunk *__restrict__ chunks,
+                                                  const ExpTerm *__restrict__ terms,
+                                                  const FlatItem *__restrict__ flat, void *__restrict__ workspace,
+                                                  double *__restrict__ energies) {
     typedef typename Amp<REAL>::T amp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t namps = 1u << A.n;
-    // LDS layout: [state (LDS_STATE)] [cos/sin table] [reduction scratch]
-    amp *st = LDS_STATE ? reinterpret_cast<amp *>(smem) : reinterpret_cast<amp *>(A.workspace) + (size_t)blockIdx.x * namps;
-    double2 *cs = reinterpret_cast<double2 *>(smem + (LDS_STATE ? (size_t)namps * sizeof(amp) : 0));
-    double2 *red = cs + A.cs_capacity;
+    // LDS layout: [state (LDS_STATE)] [rotation table] [reduction scratch]
+    amp *st = LDS_STATE ? reinterpret_cast<amp *>(smem) : reinterpret_cast<amp *>(workspace) + (size_t)blockIdx.x * namps;
+    RotLds *tab = reinterpret_cast<RotLds *>(smem + (LDS_STATE ? (size_t)namps * sizeof(amp) : 0));
+    double2 *red = reinterpret_cast<double2 *>(tab + A.cs_capacity);
 
     for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
-        const double *th = A.theta + b * A.K;
+        const double *th = theta + b * A.K;
         for (uint32_t i = threadIdx.x; i < namps; i += NT) st[i] = Amp<REAL>::basis(i == (uint32_t)A.hf);
         for (int sgi = 0; sgi < A.nsegs; ++sgi) {
-            const SmallSeg sg = A.segs[sgi];
-            __syncthreads();  // previous users of cs / state writes done
+            const SmallSeg sg = segs[sgi];
+            __syncthreads();  // previous users of the table / state writes done
             for (int r = sg.rot0 + threadIdx.x; r < sg.rot1; r += NT) {
-                const SmallRot sr = A.rots[r];
+                const SmallRot sr = rots[r];
                 const double phi = sr.phi0 + (sr.pidx >= 0 ? sr.coeff * th[sr.pidx] : 0.0);
                 double s, c;
                 sincos(phi, &s, &c);
-                cs[r - sg.rot0] = make_double2(c, (sr.ny & 2) ? -s : s);
+                RotLds rl;
+                rl.c = c;
+                rl.s = (sr.ny & 2) ? -s : s;
+                rl.z = (uint32_t)sr.z;
+                rl.odd = sr.ny & 1;
+                rl.pad = 0;
+                tab[r - sg.rot0] = rl;
             }
             __syncthreads();
             for (int o = sg.op0; o < sg.op1; ++o) {
-                const SmallOp op = A.ops[o];
+                const SmallOp op = ops[o];
                 if (op.kind == OP_PAIR) {
-                    small_pass_pair<REAL, NT>(st, namps >> 1, op, A.rots, cs, sg.rot0);
+                    small_pass_pair<REAL, NT, REAL ? 8 : 4>(st, namps >> 1, op, tab + (op.first - sg.rot0));
+                } else if (op.kind == OP_TAB) {
+                    small_pass_tab<REAL, NT>(st, A.n, op, tab + (op.first - sg.rot0));
                 } else if (op.kind == OP_DIAG) {
-                    if constexpr (!REAL) small_pass_diag<NT>(st, namps, op, A.rots, cs, sg.rot0);
+                    if constexpr (!REAL) small_pass_diag<NT>(st, namps, op, tab + (op.first - sg.rot0));
                 } else {
                     small_pass_gate<REAL, NT>(st, namps, op);
                 }
@@ -338,9 +447,12 @@ __global__ __launch_bounds__(NT) void k_small_vqe(SmallArgs A) {
             }
         }
         __syncthreads();
-        const double acc = small_expectation<REAL, NT, LBITS>(st, A.n, A.groups, A.ngroups, A.terms);
+        double acc = small_expectation_flat<REAL, NT>(st, flat, A.nflat);
+        // the rotation table is idle now: its LDS space stages the term tables of the general entries
+        acc += small_expectation<REAL, NT, LBITS>(st, A.n, groups, chunks, A.nchunks, terms,
+                                                  reinterpret_cast<ExpTerm *>(tab));
         const double2 tot = block_sum<NT>(make_double2(acc, 0.0), red);
-        if (threadIdx.x == 0) A.energies[b] = tot.x + A.constant;
+        if (threadIdx.x == 0) energies[b] = tot.x + A.constant;
         __syncthreads();
     }
 }

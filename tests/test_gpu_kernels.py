@@ -269,12 +269,15 @@ def test_real_mode_matches_complex_mode_and_oracle(SV, n, m, o):
     with SV(n) as sv:
         sv.set_hamiltonian(ham)
         sv.set_ucc_program(gens, hf)
-        for label, opts in (("real", {"force_path": 1, "real_mode": 1}), ("complex", {"force_path": 1, "real_mode": 0}),
+        for label, opts in (("real", {"force_path": 1, "real_mode": 1, "table_fusion": 1}),
+                            ("complex", {"force_path": 1, "real_mode": 0, "table_fusion": 1}),
+                            ("real_seq", {"force_path": 1, "real_mode": 1, "table_fusion": 0}),
+                            ("complex_seq", {"force_path": 1, "real_mode": 0, "table_fusion": 0}),
                             ("stream", {"force_path": 2})):
             for k, v in opts.items():
                 sv.set_option(k, v)
             res[label] = sv.energy_batch(thetas)
     for label in res:
         assert abs(res[label][0] - e_ref) < 1e-10 * scale, label
-    assert np.abs(res["real"] - res["complex"]).max() < 1e-10 * scale
-    assert np.abs(res["real"] - res["stream"]).max() < 1e-10 * scale
+    for label in res:
+        assert np.abs(res[label] - res["stream"]).max() < 1e-10 * scale, label

@@ -22,3 +22,9 @@ run("full (1000 rot, 3381 terms)", ham, gens)
 run("rotations only (10 H terms)", Hamiltonian(14, ham.terms[:10], 0.0, do_clean_up=False), gens)
 run("expectation only (1 generator)", ham, gens[:1])
 run("diag group only", Hamiltonian(14, [t for t in ham.terms if set(t.op) <= {"Z"}], 0.0, do_clean_up=False), gens[:1])
+def xw(t):
+    return sum(1 for c in t.op if c in "XY")
+run("weight-2 groups only", Hamiltonian(14, [t for t in ham.terms if xw(t) == 2], 0.0, do_clean_up=False), gens[:1])
+run("weight-4 groups only", Hamiltonian(14, [t for t in ham.terms if xw(t) == 4], 0.0, do_clean_up=False), gens[:1])
+w4 = [t for t in ham.terms if xw(t) == 4]
+run("weight-4, first 400 terms", Hamiltonian(14, w4[:400], 0.0, do_clean_up=False), gens[:1])
