@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=2048, help="parameter vectors per step per GPU")
+    ap.add_argument("--batch", type=int, default=4096, help="parameter vectors per step per GPU")
     ap.add_argument("--roofline-qubits", type=int, default=30)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")

@@ -78,6 +78,8 @@ struct ovqe_sv {
     int opt_small_batch_max = 16; // small kernel for batches up to this many qubits
     int opt_unroll = 4;
     int opt_table_fusion = 1;     // turn commuting same-x runs into single sparse pair rotations (OP_TAB)
+    int opt_dbg = 0;
+    int opt_small_threads = 0;    // 0: automatic; 256/512/1024: workgroup size of the fused kernel
     int opt_real_mode = 1;        // allow the real-amplitude specialisation of the fused kernel
 };
 
@@ -407,6 +409,10 @@ int rebuild_small_program(ovqe_handle h) {
             }
             cur.rot1 = op.first + op.count;
         }
+        if (o - cur.op0 >= SMALL_OPS_CAP) {  // ops of a segment are staged in LDS
+            h->segs.push_back(cur);
+            cur = {o, o, cur.rot1, cur.rot1};
+        }
         cur.op1 = o + 1;
     }
     if (cur.op1 > cur.op0) h->segs.push_back(cur);
@@ -640,8 +646,11 @@ int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies) {
     const size_t state_bytes = (size_t)h->namps * amp_bytes;
     const bool lds_state = state_bytes <= 128 * 1024;
     const uint64_t npairs = h->namps >> 1;
-    const int nt = (!lds_state || npairs >= 1024) ? 1024 : (npairs >= 256 ? 256 : 64);
-    const int lbits = nt == 1024 ? 10 : (nt == 256 ? 8 : 6);
+    int nt = (!lds_state || npairs >= 1024) ? 1024 : (npairs >= 256 ? 256 : 64);
+    if (lds_state && h->opt_small_threads && npairs >= (uint64_t)h->opt_small_threads &&
+        (h->opt_small_threads == 256 || h->opt_small_threads == 512 || h->opt_small_threads == 1024))
+        nt = h->opt_small_threads;
+    const int lbits = nt == 1024 ? 10 : (nt == 512 ? 9 : (nt == 256 ? 8 : 6));
     int rc = build_exp_tables(h, lbits, real);
     if (rc) return rc;
     int max_slices = (int)std::max<size_t>(1, std::min<size_t>(512, ((size_t)512 << 20) / state_bytes));
@@ -662,20 +671,23 @@ int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies) {
     A.ngroups = h->exp_ngroups;
     A.nchunks = h->exp_nchunks;
     A.nflat = h->exp_nflat;
+    A.dbg = h->opt_dbg;
     A.cs_capacity = h->cs_capacity;
     A.B = B;
     A.constant = h->ham.constant;
     A.hf = h->hf;
-    const size_t smem = (lds_state ? state_bytes : 0) + (size_t)h->cs_capacity * sizeof(RotLds) + 16 * sizeof(double2);
+    const size_t smem = (lds_state ? state_bytes : 0) + (size_t)h->cs_capacity * sizeof(RotLds) + SMALL_OPS_CAP * sizeof(SmallOp) + 16 * sizeof(double2);
     HIPC(h, hipEventRecord(h->ev0, h->stream));
     if (real) {
         if (!lds_state) rc = launch_small<true, false, 1024, 10>(h, A, grid, smem);
         else if (nt == 1024) rc = launch_small<true, true, 1024, 10>(h, A, grid, smem);
+        else if (nt == 512) rc = launch_small<true, true, 512, 9>(h, A, grid, smem);
         else if (nt == 256) rc = launch_small<true, true, 256, 8>(h, A, grid, smem);
         else rc = launch_small<true, true, 64, 6>(h, A, grid, smem);
     } else {
         if (!lds_state) rc = launch_small<false, false, 1024, 10>(h, A, grid, smem);
         else if (nt == 1024) rc = launch_small<false, true, 1024, 10>(h, A, grid, smem);
+        else if (nt == 512) rc = launch_small<false, true, 512, 9>(h, A, grid, smem);
         else if (nt == 256) rc = launch_small<false, true, 256, 8>(h, A, grid, smem);
         else rc = launch_small<false, true, 64, 6>(h, A, grid, smem);
     }
@@ -791,6 +803,11 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "small_batch_max_qubits") h->opt_small_batch_max = (int)value;
     else if (k == "unroll") h->opt_unroll = (int)value;
     else if (k == "real_mode") h->opt_real_mode = (int)value;
+    else if (k == "dbg") h->opt_dbg = (int)value;
+    else if (k == "small_threads") {
+        h->opt_small_threads = (int)value;
+        h->exp_lbits = -1;
+    }
     else if (k == "table_fusion") {
         if (h->opt_table_fusion != (int)value && h->prog_set) {
             h->opt_table_fusion = (int)value;

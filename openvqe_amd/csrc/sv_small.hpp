@@ -89,6 +89,8 @@ struct ExpChunk {
     int32_t g0, g1, t0, t1;
 };
 
+constexpr int SMALL_OPS_CAP = 192;  // ops per segment staged in LDS
+
 struct SmallArgs {
     int n;
     int K;
@@ -96,6 +98,7 @@ struct SmallArgs {
     int ngroups;
     int nchunks;
     int nflat;
+    int dbg;            // timing experiments only (results become wrong): 1 = no per-op barrier, 2 = no deposit
     int cs_capacity;    // entries of the LDS rotation table
     int64_t B;
     double constant;
@@ -129,6 +132,20 @@ __device__ __forceinline__ void mix_real(double &u, double &v, double c, double 
     v = nv;
 }
 
+__device__ __forceinline__ uint32_t insert_zero32(uint32_t k, uint32_t lowmask) {
+    return ((k & ~lowmask) << 1) | (k & lowmask);
+}
+
+// spread the free index k over the bit positions NOT in fixmask (zeros at the fixed positions)
+__device__ __forceinline__ uint32_t deposit_index(uint32_t k, uint32_t fixmask) {
+    while (fixmask) {  // wave-uniform: scalar loop, ascending positions
+        const uint32_t lowbit = fixmask & (0u - fixmask);
+        k = insert_zero32(k, lowbit - 1u);
+        fixmask ^= lowbit;
+    }
+    return k;
+}
+
 template <bool REAL, int NT, int U, typename A>
 __device__ __forceinline__ void small_pass_pair(A *st, uint32_t npairs, const SmallOp &op, const RotLds *tab) {
     const uint32_t x = (uint32_t)op.x;
@@ -139,7 +156,7 @@ __device__ __forceinline__ void small_pass_pair(A *st, uint32_t npairs, const Sm
 #pragma unroll
         for (int m = 0; m < U; ++m) {
             const uint32_t k = k0 + m * NT;
-            ii[m] = (uint32_t)insert_zero(k, pivot);
+            ii[m] = insert_zero32(k, (1u << pivot) - 1u);
             if (k < npairs) {
                 u[m] = st[ii[m]];
                 v[m] = st[ii[m] ^ x];
@@ -193,16 +210,6 @@ __device__ __forceinline__ void small_pass_diag(double2 *st, uint32_t namps, con
     }
 }
 
-// spread the free index k over the bit positions NOT in fixmask (zeros at the fixed positions)
-__device__ __forceinline__ uint32_t deposit_index(uint32_t k, uint32_t fixmask) {
-    while (fixmask) {  // wave-uniform: scalar loop, ascending positions
-        const int p = __ffs(fixmask) - 1;
-        k = (uint32_t)insert_zero(k, p);
-        fixmask &= fixmask - 1;
-    }
-    return k;
-}
-
 template <bool REAL, int NT, typename A>
 __device__ __forceinline__ void small_pass_tab(A *st, int n, const SmallOp &op, const RotLds *tab) {
     const uint32_t nk = 1u << (n - __popc(op.fixmask));
@@ -231,7 +238,7 @@ __device__ __forceinline__ void small_pass_gate(A *st, uint32_t namps, const Sma
         const int cb = op.first, tb = op.count;
         const int lo = cb < tb ? cb : tb, hi = cb < tb ? tb : cb;
         for (uint32_t k = threadIdx.x; k < (namps >> 2); k += NT) {
-            const uint32_t i = (uint32_t)insert_zero(insert_zero(k, lo), hi) | (1u << cb), j = i | (1u << tb);
+            const uint32_t i = insert_zero32(insert_zero32(k, (1u << lo) - 1u), (1u << hi) - 1u) | (1u << cb), j = i | (1u << tb);
             const A a = st[i], b = st[j];
             st[i] = b;
             st[j] = a;
@@ -240,7 +247,7 @@ __device__ __forceinline__ void small_pass_gate(A *st, uint32_t namps, const Sma
     }
     const uint32_t bit = (uint32_t)op.x;
     for (uint32_t k = threadIdx.x; k < (namps >> 1); k += NT) {
-        const uint32_t i = (uint32_t)insert_zero(k, op.pivot), j = i | bit;
+        const uint32_t i = insert_zero32(k, (1u << op.pivot) - 1u), j = i | bit;
         const A a = st[i], b = st[j];
         if (op.kind == OP_H) {
             const double r = 0.70710678118654752440;
@@ -258,12 +265,13 @@ __device__ __forceinline__ void small_pass_gate(A *st, uint32_t namps, const Sma
     }
 }
 
-// 8-point Walsh-Hadamard transform in registers (natural ordering: W[h] = sum_m (-1)^{parity(m&h)} w[m])
-__device__ __forceinline__ void wht8(double *w) {
+// M-point Walsh-Hadamard transform in registers (natural ordering: W[h] = sum_m (-1)^{parity(m&h)} w[m])
+template <int M>
+__device__ __forceinline__ void wht(double *w) {
 #pragma unroll
-    for (int s = 1; s < 8; s <<= 1) {
+    for (int s = 1; s < M; s <<= 1) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < M; ++m) {
             if (!(m & s)) {
                 const double a = w[m], b = w[m | s];
                 w[m] = a + b;
@@ -283,10 +291,10 @@ __device__ __forceinline__ double small_expectation_flat(const A *st, const Flat
         // first index: deposit(slice) | ibits ; step: deposit(stride) (a single bit at a free position)
         uint32_t i = fi.slice, step = fi.stride, m = x;
         while (m) {
-            const int p = __ffs(m) - 1;
-            i = (uint32_t)insert_zero(i, p);
-            step = (uint32_t)insert_zero(step, p);
-            m &= m - 1;
+            const uint32_t lowbit = m & (0u - m);
+            i = insert_zero32(i, lowbit - 1u);
+            step = insert_zero32(step, lowbit - 1u);
+            m ^= lowbit;
         }
         i |= fi.ibits;
         double part = 0.0;
@@ -300,6 +308,52 @@ __device__ __forceinline__ double small_expectation_flat(const A *st, const Flat
         acc += fi.c * part;
     }
     return acc;
+}
+
+// chunks of M*NT free indices: k = cbase + m*NT + tid, m = 0..M-1.  The M values a thread owns differ only in
+// log2(M) index bits: after their M-point WHT one sign evaluation + FMA per term suffices (terms are bucketed
+// on the host by exactly those bits of their mask).
+template <bool REAL, int NT, int M, typename A>
+__device__ __forceinline__ double exp_chunked(const A *st, const ExpGroup &gr, const ExpTerm *gt, uint32_t nk, bool diag) {
+    const uint32_t tid = threadIdx.x;
+    double part = 0.0;
+    for (uint32_t cbase = 0; cbase < nk; cbase += (uint32_t)M * NT) {
+        double wr[M], wi[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const uint32_t k = cbase + m * NT + tid;
+            const uint32_t i = deposit_index(k, gr.fixmask) | gr.ibits;
+            const A a = st[i];
+            if (diag) {
+                if constexpr (REAL) wr[m] = a * a; else wr[m] = a.x * a.x + a.y * a.y;
+                wi[m] = 0.0;
+            } else {
+                const A c = st[i ^ gr.x];
+                if constexpr (REAL) {
+                    wr[m] = a * c;
+                    wi[m] = 0.0;
+                } else {
+                    wr[m] = a.x * c.x + a.y * c.y;  // conj(a_i) a_j
+                    wi[m] = a.x * c.y - a.y * c.x;
+                }
+            }
+        }
+        wht<M>(wr);
+        if constexpr (!REAL) wht<M>(wi);
+#pragma unroll
+        for (int h = 0; h < M; ++h) {
+            for (int t = gr.off[h]; t < gr.off[h + 1]; ++t) {
+                const ExpTerm et = gt[t];
+                // sign from the thread bits and the chunk bits; the m-bits are in the bucket
+                const uint32_t kk = (cbase | tid) & et.zk;
+                const bool neg = __popc(kk) & 1;
+                double v;
+                if constexpr (REAL) v = et.cr * wr[h]; else v = et.cr * wr[h] - et.ci * wi[h];
+                part += neg ? -v : v;
+            }
+        }
+    }
+    return part;
 }
 
 // general (group, pattern) entries: 2 Re sum_k D(k) conj(a_i) a_j  (x = 0 entry: sum_i D(i) |a_i|^2);
@@ -322,45 +376,11 @@ __device__ __forceinline__ double small_expectation(const A *st, int n, const Ex
             const uint32_t nk = 1u << (n - __popc(gr.fixmask));
             const double weight = diag ? 1.0 : 2.0;
             if (nk >= 8u * NT) {
-                // chunks of 8*NT free indices: k = cbase + m*NT + tid, m = 0..7
-                for (uint32_t cbase = 0; cbase < nk; cbase += 8u * NT) {
-                    double wr[8], wi[8];
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) {
-                        const uint32_t k = cbase + m * NT + tid;
-                        const uint32_t i = deposit_index(k, gr.fixmask) | gr.ibits;
-                        const A a = st[i];
-                        if (diag) {
-                            if constexpr (REAL) wr[m] = a * a; else wr[m] = a.x * a.x + a.y * a.y;
-                            wi[m] = 0.0;
-                        } else {
-                            const A c = st[i ^ gr.x];
-                            if constexpr (REAL) {
-                                wr[m] = a * c;
-                                wi[m] = 0.0;
-                            } else {
-                                wr[m] = a.x * c.x + a.y * c.y;  // conj(a_i) a_j
-                                wi[m] = a.x * c.y - a.y * c.x;
-                            }
-                        }
-                    }
-                    wht8(wr);
-                    if constexpr (!REAL) wht8(wi);
-                    double part = 0.0;
-#pragma unroll
-                    for (int h = 0; h < 8; ++h) {
-                        for (int t = gr.off[h]; t < gr.off[h + 1]; ++t) {
-                            const ExpTerm et = gt[t];
-                            // sign from the thread bits and the chunk bits; the 3 m-bits are in the bucket
-                            const uint32_t kk = (cbase | tid) & et.zk;
-                            const bool neg = __popc(kk) & 1;
-                            double v;
-                            if constexpr (REAL) v = et.cr * wr[h]; else v = et.cr * wr[h] - et.ci * wi[h];
-                            part += neg ? -v : v;
-                        }
-                    }
-                    acc += weight * part;
-                }
+                acc += weight * exp_chunked<REAL, NT, 8>(st, gr, gt, nk, diag);
+            } else if (nk >= 4u * NT) {
+                acc += weight * exp_chunked<REAL, NT, 4>(st, gr, gt, nk, diag);
+            } else if (nk >= 2u * NT) {
+                acc += weight * exp_chunked<REAL, NT, 2>(st, gr, gt, nk, diag);
             } else {
                 // few free indices per thread: direct evaluation
                 double part = 0.0;
@@ -410,7 +430,8 @@ __global__ __launch_bounds__(NT) void k_small_vqe(SmallArgs A, const double *__r
     // LDS layout: [state (LDS_STATE)] [rotation table] [reduction scratch]
     amp *st = LDS_STATE ? reinterpret_cast<amp *>(smem) : reinterpret_cast<amp *>(workspace) + (size_t)blockIdx.x * namps;
     RotLds *tab = reinterpret_cast<RotLds *>(smem + (LDS_STATE ? (size_t)namps * sizeof(amp) : 0));
-    double2 *red = reinterpret_cast<double2 *>(tab + A.cs_capacity);
+    SmallOp *lops = reinterpret_cast<SmallOp *>(tab + A.cs_capacity);  // ops of the current segment
+    double2 *red = reinterpret_cast<double2 *>(lops + SMALL_OPS_CAP);
 
     for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
         const double *th = theta + b * A.K;
@@ -431,9 +452,18 @@ __global__ __launch_bounds__(NT) void k_small_vqe(SmallArgs A, const double *__r
                 rl.pad = 0;
                 tab[r - sg.rot0] = rl;
             }
+            for (int o = sg.op0 + threadIdx.x; o < sg.op1; o += NT) lops[o - sg.op0] = ops[o];
             __syncthreads();
             for (int o = sg.op0; o < sg.op1; ++o) {
-                const SmallOp op = ops[o];
+                // LDS broadcast -> make the fields wave-uniform scalars again (scalar loops / branches below)
+                SmallOp op = lops[o - sg.op0];
+                op.x = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)op.x);
+                op.kind = __builtin_amdgcn_readfirstlane(op.kind);
+                op.first = __builtin_amdgcn_readfirstlane(op.first);
+                op.count = __builtin_amdgcn_readfirstlane(op.count);
+                op.pivot = __builtin_amdgcn_readfirstlane(op.pivot);
+                op.zc = __builtin_amdgcn_readfirstlane(op.zc);
+                op.fixmask = __builtin_amdgcn_readfirstlane(op.fixmask);
                 if (op.kind == OP_PAIR) {
                     small_pass_pair<REAL, NT, REAL ? 8 : 4>(st, namps >> 1, op, tab + (op.first - sg.rot0));
                 } else if (op.kind == OP_TAB) {
@@ -443,7 +473,7 @@ __global__ __launch_bounds__(NT) void k_small_vqe(SmallArgs A, const double *__r
                 } else {
                     small_pass_gate<REAL, NT>(st, namps, op);
                 }
-                __syncthreads();
+                if (!(A.dbg & 1)) __syncthreads();
             }
         }
         __syncthreads();

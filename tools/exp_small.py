@@ -28,3 +28,6 @@ run("weight-2 groups only", Hamiltonian(14, [t for t in ham.terms if xw(t) == 2]
 run("weight-4 groups only", Hamiltonian(14, [t for t in ham.terms if xw(t) == 4], 0.0, do_clean_up=False), gens[:1])
 w4 = [t for t in ham.terms if xw(t) == 4]
 run("weight-4, first 400 terms", Hamiltonian(14, w4[:400], 0.0, do_clean_up=False), gens[:1])
+run("floor: 1 generator, 10 H terms", Hamiltonian(14, ham.terms[:10], 0.0, do_clean_up=False), gens[:1])
+run("20 singles only, 10 H terms", Hamiltonian(14, ham.terms[:10], 0.0, do_clean_up=False), gens[:20])
+run("first 60 doubles only, 10 H terms", Hamiltonian(14, ham.terms[:10], 0.0, do_clean_up=False), gens[20:80])
