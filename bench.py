@@ -201,7 +201,7 @@ def main():
             achieved = 32.0 * (1 << nq) / (mean_ms * 1e-3) / 1e9
             out["roofline"] = {
                 "bound": "hbm",
-                "kernel": "k_rot_pairs<4> (single-Pauli-string sweep, in place)",
+                "kernel": "k_rot_pairs_v<64|128,1,nt> (single-Pauli-string sweep, in place, one pair per thread)",
                 "workload": f"exp(-i 0.1 P) on a {nq}-qubit random state, {len(pair_rows)} strings (SURVEY §8d M1), "
                             "mean over strings of the HIP-event average of 20 launches",
                 "achieved": achieved,

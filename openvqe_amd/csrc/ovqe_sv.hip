@@ -79,6 +79,8 @@ struct ovqe_sv {
     int opt_unroll = 4;
     int opt_table_fusion = 1;     // turn commuting same-x runs into single sparse pair rotations (OP_TAB)
     int opt_dbg = 0;
+    int opt_rot_variant = 0;      // tuning variant of the streaming pair sweep (0 = default kernel)
+    int opt_persist_blocks = 2048;
     int opt_small_threads = 0;    // 0: automatic; 256/512/1024: workgroup size of the fused kernel
     int opt_real_mode = 1;        // allow the real-amplitude specialisation of the fused kernel
 };
@@ -177,30 +179,77 @@ int upload(ovqe_handle h, DevBuf &b, const void *src, size_t bytes) {
 }
 
 // ---- streaming-path launches -------------------------------------------------------------------
+// Launch geometry of the streaming sweeps, from measurements on MI355X (tools/exp_rot*.py, profiles/):
+// one pair (resp. amplitude) per thread and small workgroups win — more independent workgroups in flight
+// beat more loads in flight per thread — and non-temporal accesses help exactly when the state is far
+// beyond the 256 MiB Infinity Cache:
+//   n_local >= 25 : non-temporal; 64-thread groups when the pivot bit >= 7, else 128-thread groups
+//   21..24        : 256-thread groups, cached accesses (the state lives in the Infinity Cache)
+//   14..20        : 64-thread groups (L2-resident)
+//   smaller       : legacy multi-pair kernels (launch-bound anyway)
+// "rot_variant" > 0 forces one geometry (experiments); -1 forces the legacy kernel.
 int launch_rot_run(ovqe_handle h, uint64_t x, const RotParam *d_rp, int nrot) {
     if (nrot <= 0) return OVQE_OK;
+    const int nl = h->n_local;
+    int variant = h->opt_rot_variant;
     if (x == 0) {
         const uint64_t n = h->namps;
-        if (h->opt_unroll >= 4 && n >= 256u * 4u) {
-            hipLaunchKernelGGL(k_rot_diag<4>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, h->stream, h->state, n,
-                               h->base, d_rp, nrot);
-        } else {
-            hipLaunchKernelGGL(k_rot_diag<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->state, n,
-                               h->base, d_rp, nrot);
+#define OVQE_LAUNCH_D(NT, U, NTL)                                                                                \
+    hipLaunchKernelGGL((k_rot_diag_v<NT, U, NTL>), dim3((unsigned)((n + (uint64_t)NT * U - 1) / ((uint64_t)NT * U))), \
+                       dim3(NT), 0, h->stream, h->state, n, h->base, d_rp, nrot);
+        if (variant == 0 && nl >= 14) variant = nl >= 25 ? 100 : (nl >= 21 ? 108 : 100);
+        if (nl < 14 || variant < 100) variant = (variant == -1 || nl < 14) ? -1 : 100;
+        switch (variant) {
+        case 100: OVQE_LAUNCH_D(64, 1, true) break;
+        case 101: OVQE_LAUNCH_D(128, 1, true) break;
+        case 102: OVQE_LAUNCH_D(256, 1, true) break;
+        case 104: OVQE_LAUNCH_D(128, 2, true) break;
+        case 108: OVQE_LAUNCH_D(256, 1, false) break;
+        default:
+            if (h->opt_unroll >= 4 && n >= 256u * 4u) {
+                hipLaunchKernelGGL(k_rot_diag<4>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, h->stream, h->state,
+                                   n, h->base, d_rp, nrot);
+            } else {
+                hipLaunchKernelGGL(k_rot_diag<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->state,
+                                   n, h->base, d_rp, nrot);
+            }
         }
+#undef OVQE_LAUNCH_D
     } else {
         const uint64_t np = h->namps >> 1;
         const int pivot = 63 - __builtin_clzll(x);
-        if (h->opt_unroll >= 4 && np >= 256u * 4u) {
-            hipLaunchKernelGGL(k_rot_pairs<4>, dim3((unsigned)((np + 1023) / 1024)), dim3(256), 0, h->stream, h->state,
-                               np, pivot, x, h->base, d_rp, nrot);
-        } else if (h->opt_unroll >= 2 && np >= 256u * 2u) {
-            hipLaunchKernelGGL(k_rot_pairs<2>, dim3((unsigned)((np + 511) / 512)), dim3(256), 0, h->stream, h->state, np,
-                               pivot, x, h->base, d_rp, nrot);
-        } else {
-            hipLaunchKernelGGL(k_rot_pairs<1>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, h->stream, h->state, np,
-                               pivot, x, h->base, d_rp, nrot);
+#define OVQE_LAUNCH_V(NT, U, NTL, PERSIST)                                                                          \
+    {                                                                                                              \
+        const uint64_t ntiles = (np + (uint64_t)NT * U - 1) / ((uint64_t)NT * U);                                  \
+        const unsigned grid = (unsigned)(PERSIST ? std::min<uint64_t>(ntiles, (uint64_t)h->opt_persist_blocks) : ntiles); \
+        hipLaunchKernelGGL((k_rot_pairs_v<NT, U, NTL, PERSIST>), dim3(grid), dim3(NT), 0, h->stream, h->state, np,  \
+                           pivot, x, h->base, d_rp, nrot);                                                         \
+    }
+        if (variant == 0 && nl >= 14) variant = nl >= 25 ? (pivot >= 7 ? 16 : 13) : (nl >= 21 ? 17 : 16);
+        if (nl < 14 || variant >= 100) variant = -1;
+        switch (variant) {
+        case 1: OVQE_LAUNCH_V(256, 4, true, false) break;
+        case 4: OVQE_LAUNCH_V(256, 4, false, true) break;
+        case 8: OVQE_LAUNCH_V(256, 2, true, false) break;
+        case 12: OVQE_LAUNCH_V(256, 1, true, false) break;
+        case 13: OVQE_LAUNCH_V(128, 1, true, false) break;
+        case 14: OVQE_LAUNCH_V(512, 1, true, false) break;
+        case 16: OVQE_LAUNCH_V(64, 1, true, false) break;
+        case 17: OVQE_LAUNCH_V(256, 1, false, false) break;
+        case 19: OVQE_LAUNCH_V(64, 2, true, false) break;
+        default:
+            if (h->opt_unroll >= 4 && np >= 256u * 4u) {
+                hipLaunchKernelGGL(k_rot_pairs<4>, dim3((unsigned)((np + 1023) / 1024)), dim3(256), 0, h->stream,
+                                   h->state, np, pivot, x, h->base, d_rp, nrot);
+            } else if (h->opt_unroll >= 2 && np >= 256u * 2u) {
+                hipLaunchKernelGGL(k_rot_pairs<2>, dim3((unsigned)((np + 511) / 512)), dim3(256), 0, h->stream, h->state,
+                                   np, pivot, x, h->base, d_rp, nrot);
+            } else {
+                hipLaunchKernelGGL(k_rot_pairs<1>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, h->stream, h->state,
+                                   np, pivot, x, h->base, d_rp, nrot);
+            }
         }
+#undef OVQE_LAUNCH_V
     }
     HIPC(h, hipGetLastError());
     return OVQE_OK;
@@ -804,6 +853,8 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "unroll") h->opt_unroll = (int)value;
     else if (k == "real_mode") h->opt_real_mode = (int)value;
     else if (k == "dbg") h->opt_dbg = (int)value;
+    else if (k == "rot_variant") h->opt_rot_variant = (int)value;
+    else if (k == "persist_blocks") h->opt_persist_blocks = (int)value;
     else if (k == "small_threads") {
         h->opt_small_threads = (int)value;
         h->exp_lbits = -1;

@@ -121,6 +121,63 @@ __global__ __launch_bounds__(256) void k_rot_pairs(amp_t *__restrict__ st, uint6
     }
 }
 
+// tuning variants of the pair sweep (selected with ovqe_set_option("rot_variant", v)):
+//   NT threads per block, U pairs per thread per trip, NTL non-temporal loads/stores, PERSIST grid-stride loop
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+template <int NT, int U, bool NTL, bool PERSIST>
+__global__ __launch_bounds__(NT) void k_rot_pairs_v(amp_t *__restrict__ st, uint64_t npairs, int pivot, uint64_t x,
+                                                    uint64_t base, const RotParam *__restrict__ rp, int nrot) {
+    v2d *p = reinterpret_cast<v2d *>(st);
+    const uint64_t tile = (uint64_t)NT * U;
+    const uint64_t ntiles = (npairs + tile - 1) / tile;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += PERSIST ? gridDim.x : ntiles) {
+        const uint64_t k0 = t * tile + threadIdx.x;
+        amp_t u[U], v[U];
+        uint64_t ii[U];
+#pragma unroll
+        for (int m = 0; m < U; ++m) {
+            const uint64_t k = k0 + (uint64_t)m * NT;
+            ii[m] = insert_zero(k, pivot);
+        }
+#pragma unroll
+        for (int m = 0; m < U; ++m) {
+            const uint64_t k = k0 + (uint64_t)m * NT;
+            if (k < npairs) {
+                v2d a, b;
+                if (NTL) {
+                    a = __builtin_nontemporal_load(&p[ii[m]]);
+                    b = __builtin_nontemporal_load(&p[ii[m] ^ x]);
+                } else {
+                    a = p[ii[m]];
+                    b = p[ii[m] ^ x];
+                }
+                u[m] = make_double2(a.x, a.y);
+                v[m] = make_double2(b.x, b.y);
+            }
+        }
+        for (int r = 0; r < nrot; ++r) {
+            const RotParam rr = rp[r];
+#pragma unroll
+            for (int m = 0; m < U; ++m) rot_pair(u[m], v[m], rr, base | ii[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < U; ++m) {
+            const uint64_t k = k0 + (uint64_t)m * NT;
+            if (k < npairs) {
+                v2d a = {u[m].x, u[m].y}, b = {v[m].x, v[m].y};
+                if (NTL) {
+                    __builtin_nontemporal_store(a, &p[ii[m]]);
+                    __builtin_nontemporal_store(b, &p[ii[m] ^ x]);
+                } else {
+                    p[ii[m]] = a;
+                    p[ii[m] ^ x] = b;
+                }
+            }
+        }
+    }
+}
+
 // diagonal run (x == 0): a_i <- prod_r (c_r - i s_r (-1)^{parity(i & z_r)}) a_i
 template <int U>
 __global__ __launch_bounds__(256) void k_rot_diag(amp_t *__restrict__ st, uint64_t namps, uint64_t base,
@@ -148,6 +205,39 @@ __global__ __launch_bounds__(256) void k_rot_diag(amp_t *__restrict__ st, uint64
     for (int m = 0; m < U; ++m) {
         const uint64_t i = i0 + (uint64_t)m * 256u;
         if (i < namps) st[i] = a[m];
+    }
+}
+
+template <int NT, int U, bool NTL>
+__global__ __launch_bounds__(NT) void k_rot_diag_v(amp_t *__restrict__ st, uint64_t namps, uint64_t base,
+                                                   const RotParam *__restrict__ rp, int nrot) {
+    v2d *p = reinterpret_cast<v2d *>(st);
+    const uint64_t i0 = (uint64_t)blockIdx.x * ((uint64_t)NT * U) + threadIdx.x;
+    amp_t a[U];
+#pragma unroll
+    for (int m = 0; m < U; ++m) {
+        const uint64_t i = i0 + (uint64_t)m * NT;
+        if (i < namps) {
+            const v2d t = NTL ? __builtin_nontemporal_load(&p[i]) : p[i];
+            a[m] = make_double2(t.x, t.y);
+        }
+    }
+    for (int r = 0; r < nrot; ++r) {
+        const RotParam rr = rp[r];
+#pragma unroll
+        for (int m = 0; m < U; ++m) {
+            const uint64_t i = i0 + (uint64_t)m * NT;
+            const double s = parity64((base | i) & rr.z) ? -rr.s : rr.s;
+            a[m] = make_double2(rr.c * a[m].x + s * a[m].y, rr.c * a[m].y - s * a[m].x);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < U; ++m) {
+        const uint64_t i = i0 + (uint64_t)m * NT;
+        if (i < namps) {
+            const v2d t = {a[m].x, a[m].y};
+            if (NTL) __builtin_nontemporal_store(t, &p[i]); else p[i] = t;
+        }
     }
 }
 
