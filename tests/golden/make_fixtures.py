@@ -98,8 +98,41 @@ def make_k2():
     return out
 
 
+def _dict_after(text, label):
+    m = re.search(label + r" (\{.*?\})\n", text)
+    return eval(m.group(1), {"__builtins__": {}}, {"array": list, "nan": float("nan")}) if m else None
+
+
+def make_k3_k5():
+    """Stored outputs of notebooks/demo_fermionic_adapt.ipynb (H2/6-31G, spin_complement_gsd, non-active run)
+    and notebooks/demo_quccsd.ipynb (H4/STO-3G molecule data)."""
+    out = {"source": "ref:notebooks/demo_fermionic_adapt.ipynb cell 3 (first run), ref:notebooks/demo_quccsd.ipynb cell 3"}
+    run = "\n".join(notebook_stdout(os.path.join(REF, "notebooks/demo_fermionic_adapt.ipynb")))
+    run = run[: run.index("results are:") + 4000].split("length of active noons")[0]  # first (non-active) run
+    info = re.search(r"Hamiltonian info (\{.*?\})", run)
+    out["h2_631g_info"] = eval(info.group(1))
+    out["h2_631g_pool_size"] = 175
+    it = _dict_after(run, "iterations are:")
+    res = _dict_after(run, "results are:")
+    out["h2_631g_adapt_iterations"] = {k: it[k] for k in ("energies", "norms", "Max_gradients", "CNOTs", "Hadamard", "fidelity")}
+    out["h2_631g_adapt_result"] = {k: res[k] for k in ("indices", "Number_operators", "final_norm", "parameters",
+                                                       "Number_CNOT_gates", "Number_Hadamard_gates",
+                                                       "final_energy_last_iteration")}
+    out["h2_631g_adapt_options"] = {"n_max_grads": 1, "optimizer": "COBYLA", "tolerance": 1e-6, "type_conver": "norm",
+                                    "threshold_needed": 1e-2, "max_external_iterations": 35}
+    run = "\n".join(notebook_stdout(os.path.join(REF, "notebooks/demo_quccsd.ipynb")))
+    out["h4_sto3g_info"] = eval(re.search(r"Hamiltonian info (\{.*?\})", run).group(1))
+    out["h4_sto3g_nuclear_repulsion"] = float(re.search(r"Nuclear repulsion =\s+([0-9.]+)", run).group(1))
+    out["h4_sto3g_orbital_energies"] = [float(v) for v in
+                                        re.search(r"Orbital energies =\s+\[([^\]]+)\]", run).group(1).split()]
+    json.dump(out, open(os.path.join(HERE, "k3_k5_notebook_traces.json"), "w"), indent=1)
+    return out
+
+
 if __name__ == "__main__":
     k1 = make_k1()
     k2 = make_k2()
+    k3 = make_k3_k5()
+    print("K3 indices", k3["h2_631g_adapt_result"]["indices"], "H4 info", k3["h4_sto3g_info"])
     print("K1 terms", len(k1["terms"]), "K2 sizes", {k: len(v["terms"]) for k, v in k2["hams"].items()})
     print(k2["logs"])

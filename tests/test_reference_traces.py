@@ -1,0 +1,126 @@
+"""Known answers stored by the reference (notebook outputs) replayed END TO END through the in-repo
+front-end: s-type Gaussian integrals -> RHF -> MO integrals -> Jordan-Wigner Hamiltonian -> pool -> ADAPT.
+
+  K1  ref:notebooks/demo_WSSVQE.ipynb      the 15 coefficients of myQLM's printed H2/STO-3G Hamiltonian
+  K3  ref:notebooks/demo_fermionic_adapt.ipynb   H2/6-31G: HF, FCI, and the whole fermionic-ADAPT trace
+      (selected pool indices, energies, gradient norms, CNOT / Hadamard counts, fidelities)
+  K5  ref:notebooks/demo_quccsd.ipynb      H4/STO-3G: HF, FCI, nuclear repulsion, orbital energies
+
+Tolerances: the reference's orbitals come from PySCF with default SCF thresholds, so quantities that are not
+invariant under orbital rotations (gradients at the HF point) agree to ~2e-7, not 1e-12; optimiser end points carry
+the COBYLA tolerance (1e-6 on theta -> ~1e-8 on energies).  Invariants (HF/FCI energies, Hamiltonian coefficients,
+indices, gate counts) are checked tightly.
+"""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse.linalg
+
+from openvqe_amd import chem, pools
+from openvqe_amd.operators import Hamiltonian, Term
+from tests.oracle_backend import OracleStatevector
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def traces():
+    return json.load(open(os.path.join(GOLD, "k3_k5_notebook_traces.json")))
+
+
+def test_k1_hamiltonian_coefficients_from_first_principles():
+    k1 = json.load(open(os.path.join(GOLD, "k1_h2_sto3g.json")))
+    mol = chem.molecule("H2-STO3G-WSSVQE")
+    mol.rhf()
+    ham = mol.jw_hamiltonian()
+    ref = {(o, tuple(q)): c for c, o, q in k1["terms"]}
+    got = {(t.op, tuple(t.qbits)): t.coeff for t in ham.terms}
+    assert set(ref) == set(got)
+    assert max(abs(ref[k] - got[k]) for k in ref) < 1e-12
+    assert abs(ham.constant_coeff - k1["constant_coeff"]) < 1e-12
+    assert mol.hf_init() == k1["hf_init"]
+
+
+def test_k3_k5_molecular_energies(traces):
+    h2 = chem.molecule("H2")
+    assert abs(h2.rhf() - traces["h2_631g_info"]["HF"]) < 1e-10
+    fci = scipy.sparse.linalg.eigsh(h2.jw_hamiltonian().get_matrix(sparse=True), k=1, which="SA")[0][0]
+    assert abs(fci - traces["h2_631g_info"]["FCI"]) < 1e-10
+    h4 = chem.molecule("H4")
+    assert abs(h4.rhf() - traces["h4_sto3g_info"]["HF"]) < 1e-10
+    assert abs(h4.nuclear_repulsion() - traces["h4_sto3g_nuclear_repulsion"]) < 1e-12
+    assert np.abs(h4.mo_energy - np.array(traces["h4_sto3g_orbital_energies"])).max() < 1e-6
+    fci4 = scipy.sparse.linalg.eigsh(h4.jw_hamiltonian().get_matrix(sparse=True), k=1, which="SA")[0][0]
+    assert abs(fci4 - traces["h4_sto3g_info"]["FCI"]) < 1e-10
+
+
+def test_pool_sizes_pinned_by_reference_tests():
+    """ref:tests/test_main_fermionic_adapt.py:11,15 — 175 (H4, 4 orbitals) / 69 (active space, 3 orbitals)"""
+    assert pools.spin_complement_gsd(4, 4)[0] == 175
+    assert pools.spin_complement_gsd(2, 3)[0] == 69
+
+
+def _replay_adapt(traces, engine_cls):
+    import openvqe_amd.adapt.fermionic_adapt_vqe as fa
+    import openvqe_amd.backend as be
+    import openvqe_amd.evaluator as ev
+    import openvqe_amd.qat_compat as qc
+    saved = [(m, m.Statevector) for m in (be, ev, fa)]
+    for m, _ in saved:
+        m.Statevector = engine_cls if engine_cls else m.Statevector
+    for cache in (ev._BACKENDS, ev._Evaluator._owner, fa._screens, fa._evaluators):
+        cache.clear()
+    qc._default_qpu = None
+    try:
+        mol = chem.molecule("H2")
+        mol.rhf()
+        ham = mol.jw_hamiltonian()
+        _, pool = pools.spin_complement_gsd(mol.n_elec, mol.nao)
+        o = traces["h2_631g_adapt_options"]
+        with contextlib.redirect_stdout(io.StringIO()):
+            return fa.fermionic_adapt_vqe(None, None, None, ham, pool, mol.hf_init(), o["n_max_grads"],
+                                          traces["h2_631g_info"]["FCI"], o["optimizer"], o["tolerance"], o["type_conver"],
+                                          o["threshold_needed"], o["max_external_iterations"])
+    finally:
+        for cache in (ev._BACKENDS, fa._screens):
+            for sv in cache.values():
+                sv.close()
+        for cache in (ev._BACKENDS, ev._Evaluator._owner, fa._screens, fa._evaluators):
+            cache.clear()
+        if qc._default_qpu:
+            for sv in qc._default_qpu._sv.values():
+                sv.close()
+        qc._default_qpu = None
+        for m, s in saved:
+            m.Statevector = s
+
+
+def _check_trace(traces, it, res):
+    ref_it, ref_res = traces["h2_631g_adapt_iterations"], traces["h2_631g_adapt_result"]
+    assert res["indices"] == ref_res["indices"] == [38, 32, 29, 23, 2]          # ADAPT ranking identical
+    assert it["CNOTs"] == ref_it["CNOTs"] and it["Hadamard"] == ref_it["Hadamard"]
+    assert res["Number_CNOT_gates"] == ref_res["Number_CNOT_gates"] == 368
+    assert res["Number_Hadamard_gates"] == ref_res["Number_Hadamard_gates"] == 168
+    assert np.abs(np.array(it["energies"]) - np.array(ref_it["energies"])).max() < 2e-8
+    # iteration 0 is evaluated at the HF determinant (no optimiser involved); later screens sit on COBYLA end points
+    assert abs(it["norms"][0] - ref_it["norms"][0]) < 5e-7 and abs(it["Max_gradients"][0] - ref_it["Max_gradients"][0]) < 5e-7
+    assert np.abs(np.array(it["norms"]) - np.array(ref_it["norms"])).max() < 2e-5
+    assert np.abs(np.array(it["Max_gradients"]) - np.array(ref_it["Max_gradients"])).max() < 2e-5
+    assert np.abs(np.array(it["fidelity"]) - np.array(ref_it["fidelity"])).max() < 1e-6
+    assert np.abs(np.abs(res["parameters"]) - np.abs(ref_res["parameters"])).max() < 2e-5
+    assert abs(res["final_energy_last_iteration"] - ref_res["final_energy_last_iteration"]) < 1e-9
+
+
+def test_k3_fermionic_adapt_trace_oracle_engine(traces):
+    it, res = _replay_adapt(traces, OracleStatevector)
+    _check_trace(traces, it, res)
+
+
+@pytest.mark.gpu
+def test_k3_fermionic_adapt_trace_on_gpu(traces, gpu_lib):
+    it, res = _replay_adapt(traces, None)
+    _check_trace(traces, it, res)
