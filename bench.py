@@ -111,14 +111,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("OVQE_BENCH_BACKEND", "nccl")  # "gloo": functional test of the N>1 path on one GPU
+    if os.environ.get("OVQE_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
 
     import __graft_entry__ as entry
-    entry.build()
+    if world > 1:
+        # one builder per node (the .so is shared in-tree); the others wait for it
+        if local_rank == 0:
+            entry.build()
+        dist.barrier()
+    else:
+        entry.build()
     from openvqe_amd.backend import Statevector
 
     ham, gens, hf = build_workload()
@@ -152,7 +164,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_evals = world * B * args.steps
@@ -214,7 +226,7 @@ def main():
                 "worst_string": worst,
                 "per_string": rows,
             }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:
             cpu, cores = cpu_baseline_leg(ham, gens, hf, thetas[0], args.cpu_seconds)
             e_gpu0 = energy_check(ham, gens, hf, thetas[0, 0], local_rank)
             out["cpu_baseline"] = {
