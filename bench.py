@@ -25,10 +25,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
-def build_workload(n_spatial=7, n_occ=5, seed=1086):
-    from openvqe_amd import fermion
-    ham, gens, hf = fermion.synthetic_molecule(n_spatial, n_occ, seed)
-    return ham, gens, hf
+def build_workload():
+    """H2O/STO-3G at the reference's geometry (ref:openvqe/common_files/molecule_factory.py:138-148): integrals, RHF
+    and the Jordan-Wigner Hamiltonian from the in-repo front-end (no PySCF / myQLM on the GPU box), all-electron
+    UCCSD generators (5 occupied, 2 virtual spatial orbitals: 140 generators = 1000 Pauli rotations)."""
+    from openvqe_amd import chem, fermion
+    mol = chem.molecule("H2O")
+    mol.rhf()
+    ham = mol.jw_hamiltonian()
+    gens = fermion.uccsd_generators(mol.nao, mol.n_elec // 2)
+    return ham, gens, mol.hf_init()
 
 
 def m1_strings(n):
@@ -77,7 +83,7 @@ def cpu_baseline_leg(ham, gens, hf, thetas, budget_s=12.0):
     hx, hz, hc = ham.packed()
     hc = hc.real.copy()
     L = cref.lib()
-    cores = L.orc_max_threads()
+    cores = cref.usable_cpus()
     out = {}
     for mode, label in ((0, "fused"), (1, "gate_level")):
         cref.ucc_energy_batch(n, hf, rx, rz, rc, pidx, thetas[:cores], hx, hz, hc, ham.constant_coeff, mode)  # warm
@@ -182,11 +188,11 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic",
+        "data": "synthetic parameter vectors theta ~ U(-0.1, 0.1); H2O/STO-3G Hamiltonian and UCCSD generators "
+                "computed in-repo from first principles (no dataset / checkpoint involved)",
         "config": {
-            "workload": "H2O/STO-3G-shaped UCCSD energy evaluation (configs[2]/metric config): 14 qubits, "
-                        f"{K} generators = {R} Pauli rotations, JW Hamiltonian {len(ham.terms)} terms / {G} x-groups, "
-                        "synthetic spin-conserving integrals seed 1086 (no PySCF on the box)",
+            "workload": "H2O/STO-3G UCCSD energy evaluation (the metric's config): 14 qubits, "
+                        f"{K} generators = {R} Pauli rotations, JW Hamiltonian {len(ham.terms) + 1} terms / {G} x-groups",
             "batch_per_gpu": B,
             "parallelism": f"batch-replicas x{world}",
         },

@@ -19,6 +19,19 @@ from . import fermion
 BOHR = 0.52917721092  # Angstrom per Bohr (the value PySCF uses)
 
 # exponents / contraction coefficients (normalised primitives), EMSL basis-set exchange tables
+_STO3G_1S = [0.15432897, 0.53532814, 0.44463454]
+_STO3G_2S = [-0.09996723, 0.39951283, 0.70011547]
+_STO3G_2P = [0.15591627, 0.60768372, 0.39195739]
+# shells with p functions: (l, exponents, coefficients); handled by the general McMurchie-Davidson code (gto.py)
+BASIS_SP = {
+    "sto-3g": {
+        "H": [(0, [3.42525091, 0.62391373, 0.16885540], _STO3G_1S)],
+        "Li": [(0, [16.1195750, 2.9362007, 0.7946505], _STO3G_1S),
+               (0, [0.6362897, 0.1478601, 0.0480887], _STO3G_2S), (1, [0.6362897, 0.1478601, 0.0480887], _STO3G_2P)],
+        "O": [(0, [130.7093200, 23.8088610, 6.4436083], _STO3G_1S),
+              (0, [5.0331513, 1.1695961, 0.3803890], _STO3G_2S), (1, [5.0331513, 1.1695961, 0.3803890], _STO3G_2P)],
+    },
+}
 BASIS = {
     "sto-3g": {
         "H": [([3.42525091, 0.62391373, 0.16885540], [0.15432897, 0.53532814, 0.44463454])],
@@ -31,7 +44,7 @@ BASIS = {
                ([0.2979640], [1.0])],
     },
 }
-CHARGE = {"H": 1, "He": 2}
+CHARGE = {"H": 1, "He": 2, "Li": 3, "O": 8}
 
 
 def _f0(t):
@@ -50,7 +63,17 @@ class Molecule:
         self.basis_name = basis.lower()
         self.charge = charge
         self.n_elec = sum(CHARGE[s] for s, _ in self.atoms) - charge
-        # contracted functions: (centre, exponents, coefficients incl. primitive normalisation)
+        self.general = any(sym not in BASIS.get(self.basis_name, {}) for sym, _ in self.atoms)
+        if self.general:
+            from . import gto
+            self.functions = []
+            for sym, pos in self.atoms:
+                for l, exps, coefs in BASIS_SP[self.basis_name][sym]:
+                    for lmn in ([(0, 0, 0)] if l == 0 else [(1, 0, 0), (0, 1, 0), (0, 0, 1)]):
+                        self.functions.append(gto.BasisFunction(pos, lmn, exps, coefs))
+            self.nao = len(self.functions)
+            return
+        # contracted s functions: (centre, exponents, coefficients incl. primitive normalisation)
         self.shells = []
         for sym, pos in self.atoms:
             for exps, coefs in BASIS[self.basis_name][sym]:
@@ -118,8 +141,12 @@ class Molecule:
 
     # -- restricted Hartree-Fock ------------------------------------------------------------------
     def rhf(self, tol=1e-12, max_iter=200):
-        S, T, V = self.one_electron()
-        eri = self.two_electron()
+        if self.general:
+            from . import gto
+            S, T, V, eri = gto.integrals(self.functions, [(CHARGE[s], r) for s, r in self.atoms])
+        else:
+            S, T, V = self.one_electron()
+            eri = self.two_electron()
         hcore = T + V
         nocc = self.n_elec // 2
         sval, svec = np.linalg.eigh(S)
@@ -194,6 +221,12 @@ def molecule(symbol):
     if s == "H6":
         r = 1.0
         return Molecule([("H", (0, 0, k * r)) for k in range(6)], "sto-3g")
+    if s == "LIH":
+        return Molecule([("Li", (0, 0, 0)), ("H", (0, 0, 1.45))], "sto-3g")
+    if s == "H2O":
+        r, theta = 1.0285, 0.538 * np.pi
+        return Molecule([("O", (0, 0, 0)), ("H", (0, 0, r)),
+                         ("H", (0, r * np.sin(np.pi - theta), r * np.cos(np.pi - theta)))], "sto-3g")
     if s == "HEH+":
         return Molecule([("He", (0, 0, 0)), ("H", (0, 0, 1.0))], "6-31g", charge=1)
     raise KeyError(symbol)

@@ -1,0 +1,182 @@
+"""General (s, p, ...) contracted Cartesian Gaussian integrals by the McMurchie-Davidson scheme — the
+published textbook algorithm (Helgaker, Jorgensen, Olsen, "Molecular Electronic-Structure Theory", ch. 9):
+Hermite expansion coefficients E_t^{ij}, Hermite Coulomb integrals R_{tuv} from the Boys function.
+Used by ``chem.Molecule`` for the molecules of the reference's table that carry p shells (LiH, H2O — STO-3G),
+replacing the PySCF call of ref:openvqe/common_files/molecule_factory.py:306-322 on machines without PySCF.
+Pure numpy/scipy, runs once per molecule (seconds)."""
+from __future__ import annotations
+
+import itertools
+from functools import lru_cache
+
+import numpy as np
+from scipy.special import hyp1f1
+
+
+def boys(n, t):
+    return hyp1f1(n + 0.5, n + 1.5, -t) / (2.0 * n + 1.0)
+
+
+def _E(i, j, t, Qx, a, b):
+    """Hermite expansion coefficient E_t^{ij} for exponents a, b and centre separation Qx = Ax - Bx"""
+    p = a + b
+    q = a * b / p
+    if t < 0 or t > i + j:
+        return 0.0
+    if i == j == t == 0:
+        return np.exp(-q * Qx * Qx)
+    if j == 0:
+        return (1.0 / (2 * p)) * _E(i - 1, j, t - 1, Qx, a, b) - (q * Qx / a) * _E(i - 1, j, t, Qx, a, b) + \
+            (t + 1) * _E(i - 1, j, t + 1, Qx, a, b)
+    return (1.0 / (2 * p)) * _E(i, j - 1, t - 1, Qx, a, b) + (q * Qx / b) * _E(i, j - 1, t, Qx, a, b) + \
+        (t + 1) * _E(i, j - 1, t + 1, Qx, a, b)
+
+
+def _R(t, u, v, n, p, PC, RPC2, cache):
+    key = (t, u, v, n)
+    if key in cache:
+        return cache[key]
+    if t == u == v == 0:
+        val = (-2.0 * p) ** n * boys(n, p * RPC2)
+    elif t == u == 0:
+        val = PC[2] * _R(t, u, v - 1, n + 1, p, PC, RPC2, cache)
+        if v > 1:
+            val += (v - 1) * _R(t, u, v - 2, n + 1, p, PC, RPC2, cache)
+    elif t == 0:
+        val = PC[1] * _R(t, u - 1, v, n + 1, p, PC, RPC2, cache)
+        if u > 1:
+            val += (u - 1) * _R(t, u - 2, v, n + 1, p, PC, RPC2, cache)
+    else:
+        val = PC[0] * _R(t - 1, u, v, n + 1, p, PC, RPC2, cache)
+        if t > 1:
+            val += (t - 1) * _R(t - 2, u, v, n + 1, p, PC, RPC2, cache)
+    cache[key] = val
+    return val
+
+
+def _dfact(n):
+    return 1 if n <= 0 else n * _dfact(n - 2)
+
+
+class BasisFunction:
+    """contracted Cartesian Gaussian x^l y^m z^n sum_k c_k exp(-a_k r^2) at ``origin`` (Bohr)"""
+
+    def __init__(self, origin, lmn, exps, coefs):
+        self.origin = np.asarray(origin, float)
+        self.lmn = tuple(lmn)
+        self.exps = np.asarray(exps, float)
+        l, m, n = lmn
+        L = l + m + n
+        norm = np.sqrt(2.0 ** (2 * L + 1.5) * self.exps ** (L + 1.5) /
+                       (_dfact(2 * l - 1) * _dfact(2 * m - 1) * _dfact(2 * n - 1) * np.pi ** 1.5))
+        self.coefs = np.asarray(coefs, float) * norm
+        # renormalise the contraction (as PySCF / libcint do)
+        s = 0.0
+        pref = np.pi ** 1.5 * _dfact(2 * l - 1) * _dfact(2 * m - 1) * _dfact(2 * n - 1) / 2.0 ** L
+        for a, ca in zip(self.exps, self.coefs):
+            for b, cb in zip(self.exps, self.coefs):
+                s += ca * cb * pref / (a + b) ** (L + 1.5)
+        self.coefs = self.coefs / np.sqrt(s)
+
+
+def _overlap_prim(a, lmn1, A, b, lmn2, B):
+    p = a + b
+    return (_E(lmn1[0], lmn2[0], 0, A[0] - B[0], a, b) * _E(lmn1[1], lmn2[1], 0, A[1] - B[1], a, b) *
+            _E(lmn1[2], lmn2[2], 0, A[2] - B[2], a, b) * (np.pi / p) ** 1.5)
+
+
+def _kinetic_prim(a, lmn1, A, b, lmn2, B):
+    l2, m2, n2 = lmn2
+    t0 = b * (2 * (l2 + m2 + n2) + 3) * _overlap_prim(a, lmn1, A, b, lmn2, B)
+    t1 = -2.0 * b * b * (_overlap_prim(a, lmn1, A, b, (l2 + 2, m2, n2), B) +
+                         _overlap_prim(a, lmn1, A, b, (l2, m2 + 2, n2), B) +
+                         _overlap_prim(a, lmn1, A, b, (l2, m2, n2 + 2), B))
+    t2 = -0.5 * (l2 * (l2 - 1) * _overlap_prim(a, lmn1, A, b, (l2 - 2, m2, n2), B) +
+                 m2 * (m2 - 1) * _overlap_prim(a, lmn1, A, b, (l2, m2 - 2, n2), B) +
+                 n2 * (n2 - 1) * _overlap_prim(a, lmn1, A, b, (l2, m2, n2 - 2), B))
+    return t0 + t1 + t2
+
+
+def _nuclear_prim(a, lmn1, A, b, lmn2, B, C):
+    p = a + b
+    P = (a * A + b * B) / p
+    PC = P - C
+    cache = {}
+    val = 0.0
+    for t in range(lmn1[0] + lmn2[0] + 1):
+        Et = _E(lmn1[0], lmn2[0], t, A[0] - B[0], a, b)
+        for u in range(lmn1[1] + lmn2[1] + 1):
+            Eu = _E(lmn1[1], lmn2[1], u, A[1] - B[1], a, b)
+            for v in range(lmn1[2] + lmn2[2] + 1):
+                Ev = _E(lmn1[2], lmn2[2], v, A[2] - B[2], a, b)
+                val += Et * Eu * Ev * _R(t, u, v, 0, p, PC, float(PC @ PC), cache)
+    return val * 2.0 * np.pi / p
+
+
+def _pair_hermite(f1, f2):
+    """per primitive pair: (p, P, coefficient, list of (t,u,v,E))"""
+    out = []
+    for a, ca in zip(f1.exps, f1.coefs):
+        for b, cb in zip(f2.exps, f2.coefs):
+            p = a + b
+            P = (a * f1.origin + b * f2.origin) / p
+            Q = f1.origin - f2.origin
+            herm = []
+            for t in range(f1.lmn[0] + f2.lmn[0] + 1):
+                Et = _E(f1.lmn[0], f2.lmn[0], t, Q[0], a, b)
+                for u in range(f1.lmn[1] + f2.lmn[1] + 1):
+                    Eu = _E(f1.lmn[1], f2.lmn[1], u, Q[1], a, b)
+                    for v in range(f1.lmn[2] + f2.lmn[2] + 1):
+                        Ev = _E(f1.lmn[2], f2.lmn[2], v, Q[2], a, b)
+                        e = Et * Eu * Ev
+                        if e != 0.0:
+                            herm.append((t, u, v, e))
+            out.append((p, P, ca * cb, herm))
+    return out
+
+
+def integrals(functions, charges):
+    """functions: [BasisFunction]; charges: [(Z, position)] -> S, T, V, eri (chemists' (ij|kl))"""
+    n = len(functions)
+    S = np.zeros((n, n))
+    T = np.zeros((n, n))
+    V = np.zeros((n, n))
+    for i, fi in enumerate(functions):
+        for j, fj in enumerate(functions):
+            if j > i:
+                continue
+            s = t = v = 0.0
+            for a, ca in zip(fi.exps, fi.coefs):
+                for b, cb in zip(fj.exps, fj.coefs):
+                    s += ca * cb * _overlap_prim(a, fi.lmn, fi.origin, b, fj.lmn, fj.origin)
+                    t += ca * cb * _kinetic_prim(a, fi.lmn, fi.origin, b, fj.lmn, fj.origin)
+                    for Z, C in charges:
+                        v -= Z * ca * cb * _nuclear_prim(a, fi.lmn, fi.origin, b, fj.lmn, fj.origin, C)
+            S[i, j] = S[j, i] = s
+            T[i, j] = T[j, i] = t
+            V[i, j] = V[j, i] = v
+    pairs = {(i, j): _pair_hermite(functions[i], functions[j]) for i in range(n) for j in range(i + 1)}
+    eri = np.zeros((n, n, n, n))
+    for i in range(n):
+        for j in range(i + 1):
+            ij = i * (i + 1) // 2 + j
+            for k in range(n):
+                for l in range(k + 1):
+                    if ij < k * (k + 1) // 2 + l:
+                        continue
+                    val = 0.0
+                    for p, P, cp, hp in pairs[(i, j)]:
+                        for q, Q, cq, hq in pairs[(k, l)]:
+                            alpha = p * q / (p + q)
+                            PQ = P - Q
+                            cache = {}
+                            acc = 0.0
+                            for (t, u, v, e1) in hp:
+                                for (tt, uu, vv, e2) in hq:
+                                    acc += e1 * e2 * (-1) ** (tt + uu + vv) * _R(t + tt, u + uu, v + vv, 0, alpha, PQ,
+                                                                                 float(PQ @ PQ), cache)
+                            val += cp * cq * acc * 2.0 * np.pi ** 2.5 / (p * q * np.sqrt(p + q))
+                    for (w, x, y, z) in ((i, j, k, l), (j, i, k, l), (i, j, l, k), (j, i, l, k),
+                                         (k, l, i, j), (l, k, i, j), (k, l, j, i), (l, k, j, i)):
+                        eri[w, x, y, z] = val
+    return S, T, V, eri

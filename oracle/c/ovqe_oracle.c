@@ -49,7 +49,7 @@ void orc_pauli_rotation(cplx *psi, int n, uint64_t x, uint64_t z, double phi) {
     static const cplx ipow[4] = {1.0, I, -1.0, -I};
     const cplx mis = -I * s * ipow[ny]; /* -i sin(phi) i^ny */
     if (x == 0) {
-#pragma omp parallel for if (g_par) schedule(static)
+#pragma omp parallel for if (g_par && dim >= (1ull << 18)) schedule(static)
         for (uint64_t i = 0; i < dim; ++i) {
             double sg = parity64(i & z) ? -1.0 : 1.0;
             psi[i] = (c + mis * sg) * psi[i];
@@ -58,7 +58,7 @@ void orc_pauli_rotation(cplx *psi, int n, uint64_t x, uint64_t z, double phi) {
     }
     const int p = 63 - __builtin_clzll(x); /* pivot: highest x bit */
     const uint64_t low = (1ull << p) - 1;
-#pragma omp parallel for if (g_par) schedule(static)
+#pragma omp parallel for if (g_par && dim >= (1ull << 18)) schedule(static)
     for (uint64_t k = 0; k < dim / 2; ++k) {
         uint64_t i = ((k & ~low) << 1) | (k & low); /* bit p clear */
         uint64_t j = i ^ x;
@@ -80,7 +80,7 @@ double orc_expectation_termwise(const cplx *psi, int n, int64_t T, const uint64_
         const uint64_t x = xs[t], z = zs[t];
         const cplx ph = ipow[__builtin_popcountll(x & z) & 3];
         double re = 0.0, im = 0.0;
-#pragma omp parallel for if (g_par) schedule(static) reduction(+ : re, im)
+#pragma omp parallel for if (g_par && dim >= (1ull << 18)) schedule(static) reduction(+ : re, im)
         for (uint64_t i = 0; i < dim; ++i) {
             uint64_t j = i ^ x;
             double sg = parity64(j & z) ? -1.0 : 1.0;
@@ -104,7 +104,7 @@ double orc_expectation_grouped(const cplx *psi, int n, int64_t T, const uint64_t
         while (t1 < T && xs[t1] == xs[t0]) ++t1;
         const uint64_t x = xs[t0];
         double acc = 0.0;
-#pragma omp parallel for if (g_par) schedule(static) reduction(+ : acc)
+#pragma omp parallel for if (g_par && dim >= (1ull << 18)) schedule(static) reduction(+ : acc)
         for (uint64_t i = 0; i < dim; ++i) {
             uint64_t j = i ^ x;
             cplx v = conj(psi[i]) * psi[j];
@@ -130,7 +130,7 @@ double orc_expectation_grouped(const cplx *psi, int n, int64_t T, const uint64_t
 void orc_gate_1q(cplx *psi, int n, int bit, const double *m /* row-major 2x2 as re,im pairs */) {
     const uint64_t dim = 1ull << n, stride = 1ull << bit, low = stride - 1;
     const cplx m00 = m[0] + I * m[1], m01 = m[2] + I * m[3], m10 = m[4] + I * m[5], m11 = m[6] + I * m[7];
-#pragma omp parallel for if (g_par) schedule(static)
+#pragma omp parallel for if (g_par && dim >= (1ull << 18)) schedule(static)
     for (uint64_t k = 0; k < dim / 2; ++k) {
         uint64_t i = ((k & ~low) << 1) | (k & low), j = i | stride;
         cplx a = psi[i], b = psi[j];
@@ -141,7 +141,7 @@ void orc_gate_1q(cplx *psi, int n, int bit, const double *m /* row-major 2x2 as 
 
 void orc_gate_cnot(cplx *psi, int n, int cbit, int tbit) {
     const uint64_t dim = 1ull << n, cm = 1ull << cbit, tm = 1ull << tbit;
-#pragma omp parallel for if (g_par) schedule(static)
+#pragma omp parallel for if (g_par && dim >= (1ull << 18)) schedule(static)
     for (uint64_t i = 0; i < dim; ++i) {
         if ((i & cm) && !(i & tm)) {
             cplx a = psi[i];

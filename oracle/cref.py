@@ -46,8 +46,25 @@ def lib():
                                            _u64p, _u64p, _f64p, ctypes.c_double, ctypes.c_int, _f64p]
         L.orc_max_threads.restype = ctypes.c_int
         L.orc_set_threads.argtypes = [ctypes.c_int]
+        # never more OpenMP threads than CPUs this process may run on (cgroup / affinity limited boxes)
+        L.orc_set_threads(usable_cpus())
         _lib = L
     return _lib
+
+
+def usable_cpus():
+    """CPUs this process can really use: affinity mask capped by the cgroup CPU quota"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def sort_by_x(xs, zs, cs):
@@ -84,7 +101,7 @@ def gate_energy(n, hf_index, opcode, b0, b1, ascale, aconst, gpidx, theta, hx, h
 def ucc_energy_batch(n, hf_index, rx, rz, rcoef, pidx, thetas, hx, hz, hc, constant, mode=0, nthreads=None):
     """B independent evaluations, one host thread each (nested OpenMP inside a thread stays serial)."""
     L = lib()
-    nthreads = nthreads or L.orc_max_threads()
+    nthreads = nthreads or usable_cpus()
     thetas = np.ascontiguousarray(thetas, np.float64)
     B, K = thetas.shape
     nthreads = max(1, min(nthreads, B))
