@@ -63,7 +63,8 @@ struct ovqe_sv {
     std::vector<SmallOp> sops;   // fused-kernel program: ops with commuting runs turned into OP_TAB
     std::vector<SmallRot> srots; // its table entries (sequential rotations and OP_TAB patterns)
     std::vector<SmallSeg> segs;
-    DevBuf d_ops, d_rots, d_segs;
+    DevBuf d_ops, d_rots, d_segs, d_stream;
+    std::vector<uint16_t> idx_stream;  // precomputed (sign<<15 | index) streams of the OP_TAB ops
     int cs_capacity = 512;
     // batched evaluation workspace
     DevBuf d_theta, d_energies, d_workspace;
@@ -77,8 +78,8 @@ struct ovqe_sv {
     int opt_small_max = 14;       // always-small up to this many qubits
     int opt_small_batch_max = 16; // small kernel for batches up to this many qubits
     int opt_unroll = 4;
+    int opt_index_streams = 1;    // precompute the pair-index streams of OP_TAB ops on the host
     int opt_table_fusion = 1;     // turn commuting same-x runs into single sparse pair rotations (OP_TAB)
-    int opt_dbg = 0;
     int opt_rot_variant = 0;      // tuning variant of the streaming pair sweep (0 = default kernel)
     int opt_persist_blocks = 2048;
     int opt_small_threads = 0;    // 0: automatic; 256/512/1024: workgroup size of the fused kernel
@@ -398,6 +399,10 @@ bool try_table_op(ovqe_handle h, const SmallOp &op, SmallOp &out, std::vector<Sm
     out.fixmask = (uint32_t)x;
     out.first = (int32_t)entries.size();
     out.count = 0;
+    out.stream = -1;
+    out.lognk = (uint32_t)(h->n_local - w);
+    const bool want_stream = h->opt_index_streams && h->n_local <= 15 && h->n_local - w >= 0;
+    const int32_t stream0 = (int32_t)h->idx_stream.size();
     // patterns over the non-pivot x bits (the pivot bit of i is 0)
     for (uint32_t e = 0; e < (1u << (w - 1)); ++e) {
         uint64_t ibits = 0;
@@ -421,7 +426,21 @@ bool try_table_op(ovqe_handle h, const SmallOp &op, SmallOp &out, std::vector<Sm
         pe.ny = 1;
         entries.push_back(pe);
         out.count++;
+        if (want_stream) {
+            const uint64_t nk = 1ull << (h->n_local - w);
+            for (uint64_t k = 0; k < nk; ++k) {
+                uint64_t i = k;
+                for (int f = 0; f < w; ++f) {  // deposit: zeros at the x positions (ascending)
+                    const uint64_t low = (1ull << pos[f]) - 1ull;
+                    i = ((i & ~low) << 1) | (i & low);
+                }
+                i |= ibits;
+                const uint16_t sgn = (__builtin_popcountll(i & zc) & 1) ? 0x8000u : 0u;
+                h->idx_stream.push_back((uint16_t)(i | sgn));
+            }
+        }
     }
+    if (want_stream && out.count > 0) out.stream = stream0;
     return true;
 }
 
@@ -429,6 +448,7 @@ int rebuild_small_program(ovqe_handle h) {
     const int cap = h->cs_capacity;
     h->sops.clear();
     h->srots.clear();
+    h->idx_stream.clear();
     for (const SmallOp &op : h->ops) {
         if (op.kind == OP_PAIR || op.kind == OP_DIAG) {
             SmallOp t;
@@ -449,18 +469,26 @@ int rebuild_small_program(ovqe_handle h) {
     }
     h->segs.clear();
     SmallSeg cur = {0, 0, 0, 0};
+    bool rot_init = false;  // cur.rot0 is set by the first op of the segment that owns table entries
     for (int o = 0; o < (int)h->sops.size(); ++o) {
         const SmallOp &op = h->sops[o];
-        if (op.kind == OP_PAIR || op.kind == OP_DIAG || op.kind == OP_TAB) {
-            if (op.first + op.count - cur.rot0 > cap) {
-                if (cur.op1 > cur.op0) h->segs.push_back(cur);
-                cur = {o, o, op.first, op.first};
-            }
-            cur.rot1 = op.first + op.count;
-        }
-        if (o - cur.op0 >= SMALL_OPS_CAP) {  // ops of a segment are staged in LDS
+        const bool has = op.kind == OP_PAIR || op.kind == OP_DIAG || op.kind == OP_TAB;
+        const int nent = op.count;
+        bool split = (o - cur.op0 >= SMALL_OPS_CAP);  // ops of a segment are staged in LDS
+        if (has && rot_init && op.first + nent - cur.rot0 > cap) split = true;
+        if (split && cur.op1 > cur.op0) {
             h->segs.push_back(cur);
-            cur = {o, o, cur.rot1, cur.rot1};
+            cur = {o, o, 0, 0};
+            rot_init = false;
+        }
+        if (has) {
+            if (!rot_init) {
+                cur.rot0 = op.first;
+                cur.rot1 = op.first + nent;
+                rot_init = true;
+            } else {
+                cur.rot1 = std::max(cur.rot1, op.first + nent);
+            }
         }
         cur.op1 = o + 1;
     }
@@ -468,6 +496,8 @@ int rebuild_small_program(ovqe_handle h) {
     int rc = upload(h, h->d_ops, h->sops.data(), h->sops.size() * sizeof(SmallOp));
     if (rc) return rc;
     rc = upload(h, h->d_rots, h->srots.data(), h->srots.size() * sizeof(SmallRot));
+    if (rc) return rc;
+    rc = upload(h, h->d_stream, h->idx_stream.data(), h->idx_stream.size() * sizeof(uint16_t));
     if (rc) return rc;
     return upload(h, h->d_segs, h->segs.data(), h->segs.size() * sizeof(SmallSeg));
 }
@@ -524,7 +554,8 @@ int launch_small(ovqe_handle h, const SmallArgs &A, int grid, size_t smem) {
     hipLaunchKernelGGL((k_small_vqe<REAL, LDS, NT, LBITS>), dim3(grid), dim3(NT), smem, h->stream, A,
                        (const double *)h->d_theta.p, (const SmallOp *)h->d_ops.p, (const SmallRot *)h->d_rots.p,
                        (const SmallSeg *)h->d_segs.p, (const ExpGroup *)h->d_egroups.p, (const ExpChunk *)h->d_echunks.p,
-                       (const ExpTerm *)h->d_eterms.p, (const FlatItem *)h->d_eflat.p, h->d_workspace.p,
+                       (const ExpTerm *)h->d_eterms.p, (const FlatItem *)h->d_eflat.p, (const uint16_t *)h->d_stream.p,
+                       h->d_workspace.p,
                        (double *)h->d_energies.p);
     HIPC(h, hipGetLastError());
     return OVQE_OK;
@@ -720,7 +751,6 @@ int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies) {
     A.ngroups = h->exp_ngroups;
     A.nchunks = h->exp_nchunks;
     A.nflat = h->exp_nflat;
-    A.dbg = h->opt_dbg;
     A.cs_capacity = h->cs_capacity;
     A.B = B;
     A.constant = h->ham.constant;
@@ -825,7 +855,7 @@ int ovqe_destroy(ovqe_handle h) {
     for (int k = 0; k < 2; ++k)
         if (h->scratch[k]) (void)hipFree(h->scratch[k]);
     DevBuf *bufs[] = {&h->d_partials, &h->d_result, &h->d_rp, &h->ham.d_groups, &h->ham.d_terms, &h->d_ops,
-                      &h->d_rots, &h->d_segs, &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups,
+                      &h->d_rots, &h->d_segs, &h->d_stream, &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups,
                       &h->d_eterms, &h->d_echunks, &h->d_eflat};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -852,7 +882,10 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "small_batch_max_qubits") h->opt_small_batch_max = (int)value;
     else if (k == "unroll") h->opt_unroll = (int)value;
     else if (k == "real_mode") h->opt_real_mode = (int)value;
-    else if (k == "dbg") h->opt_dbg = (int)value;
+    else if (k == "index_streams") {
+        h->opt_index_streams = (int)value;
+        if (h->prog_set) return rebuild_small_program(h);
+    }
     else if (k == "rot_variant") h->opt_rot_variant = (int)value;
     else if (k == "persist_blocks") h->opt_persist_blocks = (int)value;
     else if (k == "small_threads") {

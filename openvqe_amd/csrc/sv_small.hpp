@@ -40,6 +40,8 @@ struct SmallOp {
     int32_t pivot;    // highest x bit (OP_PAIR); bit (OP_X/OP_H)
     uint32_t zc;      // OP_TAB: z mask outside x (sign of the pair = parity(i & zc))
     uint32_t fixmask; // OP_TAB: index bits that are fixed by the pattern (= x)
+    int32_t stream;   // OP_TAB: offset of the precomputed index stream (-1: compute indices in the kernel)
+    uint32_t lognk;   // OP_TAB: log2 of the pairs per pattern
 };
 
 struct SmallRot {
@@ -98,7 +100,6 @@ struct SmallArgs {
     int ngroups;
     int nchunks;
     int nflat;
-    int dbg;            // timing experiments only (results become wrong): 1 = no per-op barrier, 2 = no deposit
     int cs_capacity;    // entries of the LDS rotation table
     int64_t B;
     double constant;
@@ -207,6 +208,31 @@ __device__ __forceinline__ void small_pass_diag(double2 *st, uint32_t namps, con
             a = make_double2(rl.c * a.x + s * a.y, rl.c * a.y - s * a.x);
         }
         st[i] = a;
+    }
+}
+
+// OP_TAB with a host-precomputed index stream: entry e = pattern * 2^lognk + k holds (sign << 15) | i, so the pass
+// is load-index, two LDS reads, one real rotation, two LDS writes — no per-op index arithmetic
+template <bool REAL, int NT, typename A>
+__device__ __forceinline__ void small_pass_tab_stream(A *st, const SmallOp &op, const RotLds *tab,
+                                                      const uint16_t *__restrict__ stream) {
+    const uint32_t x = (uint32_t)op.x;
+    const uint32_t nent = (uint32_t)op.count << op.lognk;
+    const uint16_t *sp = stream + op.stream;
+    for (uint32_t e = threadIdx.x; e < nent; e += NT) {
+        const uint32_t v = sp[e];
+        const RotLds rl = tab[e >> op.lognk];
+        const uint32_t i = v & 0x7fffu, j = i ^ x;
+        const double s = (v & 0x8000u) ? -rl.s : rl.s;
+        A u = st[i], w = st[j];
+        if constexpr (REAL) {
+            mix_real(u, w, rl.c, s, -s);
+        } else {
+            mix_real(u.x, w.x, rl.c, s, -s);
+            mix_real(u.y, w.y, rl.c, s, -s);
+        }
+        st[i] = u;
+        st[j] = w;
     }
 }
 
@@ -422,7 +448,8 @@ __global__ __launch_bounds__(NT) void k_small_vqe(SmallArgs A, const double *__r
                                                   const ExpGroup *__restrict__ groups,
                                                   const ExpChunk *__restrict__ chunks,
                                                   const ExpTerm *__restrict__ terms,
-                                                  const FlatItem *__restrict__ flat, void *__restrict__ workspace,
+                                                  const FlatItem *__restrict__ flat,
+                                                  const uint16_t *__restrict__ stream, void *__restrict__ workspace,
                                                   double *__restrict__ energies) {
     typedef typename Amp<REAL>::T amp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -464,16 +491,24 @@ __global__ __launch_bounds__(NT) void k_small_vqe(SmallArgs A, const double *__r
                 op.pivot = __builtin_amdgcn_readfirstlane(op.pivot);
                 op.zc = __builtin_amdgcn_readfirstlane(op.zc);
                 op.fixmask = __builtin_amdgcn_readfirstlane(op.fixmask);
+                op.stream = __builtin_amdgcn_readfirstlane(op.stream);
+                op.lognk = __builtin_amdgcn_readfirstlane(op.lognk);
                 if (op.kind == OP_PAIR) {
                     small_pass_pair<REAL, NT, REAL ? 8 : 4>(st, namps >> 1, op, tab + (op.first - sg.rot0));
                 } else if (op.kind == OP_TAB) {
-                    small_pass_tab<REAL, NT>(st, A.n, op, tab + (op.first - sg.rot0));
+                    if (op.stream >= 0) small_pass_tab_stream<REAL, NT>(st, op, tab + (op.first - sg.rot0), stream);
+                    else small_pass_tab<REAL, NT>(st, A.n, op, tab + (op.first - sg.rot0));
                 } else if (op.kind == OP_DIAG) {
                     if constexpr (!REAL) small_pass_diag<NT>(st, namps, op, tab + (op.first - sg.rot0));
                 } else {
                     small_pass_gate<REAL, NT>(st, namps, op);
                 }
-                if (!(A.dbg & 1)) __syncthreads();
+                if constexpr (LDS_STATE) {
+                    // the state is in LDS: the barrier only has to order LDS traffic
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                } else {
+                    __syncthreads();
+                }
             }
         }
         __syncthreads();

@@ -309,3 +309,20 @@ def test_streaming_path_20_qubits_against_c_oracle(SV):
     assert abs(e - e_ref) < 1e-10 * max(1.0, np.abs(hc).sum())
     assert np.abs(amps - psi_ref[idx.astype(np.int64)]).max() < 1e-12
     assert abs(n2 - 1.0) < 1e-11
+
+
+def test_index_streams_match_in_kernel_indices(SV):
+    """host-precomputed pair-index streams (index_streams = 1, default) against in-kernel index arithmetic (0)"""
+    from openvqe_amd import chem, fermion
+    mol = chem.molecule("H2O"); mol.rhf()
+    ham = mol.jw_hamiltonian()
+    gens = fermion.uccsd_generators(mol.nao, mol.n_elec // 2)
+    thetas = np.random.default_rng(3).uniform(-0.2, 0.2, (4, len(gens)))
+    with SV(14) as sv:
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, mol.hf_init())
+        out = {}
+        for level in (1, 0):
+            sv.set_option("index_streams", level)
+            out[level] = sv.energy_batch(thetas)
+    assert np.abs(out[1] - out[0]).max() < 1e-10
