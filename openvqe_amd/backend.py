@@ -229,20 +229,26 @@ class Statevector:
 
     # -- ADAPT ----------------------------------------------------------------------------------
     def pool_gradients(self, pool_ops, mode):
-        """Gradient screen over ``pool_ops`` on the resident state, with the stored Hamiltonian."""
-        offsets = np.zeros(len(pool_ops) + 1, np.int64)
-        xs, zs, cs = [], [], []
-        for k, op in enumerate(pool_ops):
-            px, pz, pc = pack_terms(self.nbqbits, op.terms)
-            xs.append(px)
-            zs.append(pz)
-            cs.append(pc)
-            offsets[k + 1] = offsets[k] + px.shape[0]
-        xs = np.concatenate(xs) if xs else np.zeros(0, np.uint64)
-        zs = np.concatenate(zs) if zs else np.zeros(0, np.uint64)
-        cs = np.concatenate(cs) if cs else np.zeros(0, np.complex128)
-        if xs.shape[0] == 0:
-            xs, zs, cs = np.zeros(1, np.uint64), np.zeros(1, np.uint64), np.zeros(1, np.complex128)
+        """Gradient screen over ``pool_ops`` on the resident state, with the stored Hamiltonian.
+        The packed form of the pool is cached (the pool is the same object in every ADAPT iteration)."""
+        cache = getattr(self, "_pool_cache", None)
+        if cache is not None and cache[0] is pool_ops and cache[1] == len(pool_ops):
+            offsets, xs, zs, cs = cache[2]
+        else:
+            offsets = np.zeros(len(pool_ops) + 1, np.int64)
+            xs, zs, cs = [], [], []
+            for k, op in enumerate(pool_ops):
+                px, pz, pc = pack_terms(self.nbqbits, op.terms)
+                xs.append(px)
+                zs.append(pz)
+                cs.append(pc)
+                offsets[k + 1] = offsets[k] + px.shape[0]
+            xs = np.concatenate(xs) if xs else np.zeros(0, np.uint64)
+            zs = np.concatenate(zs) if zs else np.zeros(0, np.uint64)
+            cs = np.concatenate(cs) if cs else np.zeros(0, np.complex128)
+            if xs.shape[0] == 0:
+                xs, zs, cs = np.zeros(1, np.uint64), np.zeros(1, np.uint64), np.zeros(1, np.complex128)
+            self._pool_cache = (pool_ops, len(pool_ops), (offsets, xs, zs, cs))
         out = np.zeros(len(pool_ops), np.float64)
         self._ck(self._L.ovqe_pool_gradients(self._h, len(pool_ops), offsets, xs, zs,
                                              np.ascontiguousarray(cs.real), np.ascontiguousarray(cs.imag),
