@@ -296,7 +296,7 @@ int ensure_rp(ovqe_handle h, size_t n) {
 
 // sum over [bra|P|ket] groups -> complex result on host
 int run_bilinear(ovqe_handle h, const amp_t *bra, const amp_t *ket, const std::vector<HGroup> &groups,
-                 const HGroup *d_groups, const HTerm *d_terms, double2 *out) {
+                 const HGroup *d_groups, const HTerm *d_terms, double2 *out, bool hermitian_expectation = false) {
     const int nb = reduce_blocks(h->namps);
     const int G = (int)groups.size();
     if (G == 0) {
@@ -304,7 +304,8 @@ int run_bilinear(ovqe_handle h, const amp_t *bra, const amp_t *ket, const std::v
         return OVQE_OK;
     }
     // chunk the group loop so that one launch streams at most ~64 GiB
-    const double bytes_per_group = 32.0 * (double)h->namps;
+    hermitian_expectation = hermitian_expectation && bra == ket && h->n_global == 0;
+    const double bytes_per_group = (hermitian_expectation ? 16.0 : 32.0) * (double)h->namps;
     int per_launch = (int)std::max(1.0, std::min((double)G, 6.4e10 / bytes_per_group));
     const int nchunks = (G + per_launch - 1) / per_launch;
     int rc = ensure(h, h->d_partials, (size_t)nchunks * nb * sizeof(double2));
@@ -313,8 +314,13 @@ int run_bilinear(ovqe_handle h, const amp_t *bra, const amp_t *ket, const std::v
     if (rc) return rc;
     for (int c = 0; c < nchunks; ++c) {
         const int g0 = c * per_launch, g1 = std::min(G, g0 + per_launch);
-        hipLaunchKernelGGL(k_bilinear, dim3(nb), dim3(256), 0, h->stream, bra, ket, h->namps, d_groups, g0, g1, d_terms,
-                           (double2 *)h->d_partials.p + (size_t)c * nb);
+        if (hermitian_expectation) {
+            hipLaunchKernelGGL(k_expect_pairs, dim3(nb), dim3(256), 0, h->stream, ket, h->namps, d_groups, g0, g1,
+                               d_terms, (double2 *)h->d_partials.p + (size_t)c * nb);
+        } else {
+            hipLaunchKernelGGL(k_bilinear, dim3(nb), dim3(256), 0, h->stream, bra, ket, h->namps, d_groups, g0, g1,
+                               d_terms, (double2 *)h->d_partials.p + (size_t)c * nb);
+        }
     }
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->stream, (const double2 *)h->d_partials.p,
                        (int64_t)nchunks * nb, (double2 *)h->d_result.p, 0);
@@ -1073,7 +1079,8 @@ int ovqe_bilinear(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64
     double2 res = make_double2(0.0, 0.0);
     if (!rc)
         rc = run_bilinear(h, bra_dev ? (const amp_t *)bra_dev : h->state, ket_dev ? (const amp_t *)ket_dev : h->state,
-                          groups, (const HGroup *)dg.p, (const HTerm *)dt.p, &res);
+                          groups, (const HGroup *)dg.p, (const HTerm *)dt.p, &res,
+                          /*hermitian_expectation=*/!bra_dev && !ket_dev && !coeff_im);
     if (dg.p) (void)hipFree(dg.p);
     if (dt.p) (void)hipFree(dt.p);
     out_re_im[0] = res.x;
@@ -1193,7 +1200,7 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
         if (rc) return rc;
         double2 res;
         rc = run_bilinear(h, h->state, h->state, h->ham.groups, (const HGroup *)h->ham.d_groups.p,
-                          (const HTerm *)h->ham.d_terms.p, &res);
+                          (const HTerm *)h->ham.d_terms.p, &res, true);
         if (rc) return rc;
         energies[b] = res.x + h->ham.constant;
     }

@@ -309,6 +309,52 @@ __global__ __launch_bounds__(256) void k_bilinear(const amp_t *__restrict__ bra,
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
+// <psi|H|psi> contribution of the groups [g0,g1) for a Hermitian sum (real coefficients before the i^ny fold):
+// the (i,j) and (j,i) terms of a group are complex conjugates, so each pair is visited once:
+//   E_g = 2 Re sum_{k} D(i) conj(a_i) a_j,  i = insert_zero(k, pivot), j = i ^ x   (x = 0: sum_i D(i) |a_i|^2)
+// -> every amplitude is read once per group (16 B) instead of twice.
+__global__ __launch_bounds__(256) void k_expect_pairs(const amp_t *__restrict__ st, uint64_t namps,
+                                                      const HGroup *__restrict__ groups, int g0, int g1,
+                                                      const HTerm *__restrict__ terms, double2 *__restrict__ partials) {
+    __shared__ double2 red[4];
+    double acc = 0.0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (int g = g0; g < g1; ++g) {
+        const HGroup gr = groups[g];
+        if (gr.x == 0) {
+            for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) {
+                const amp_t a = st[i];
+                const uint64_t gi = gr.jbase | i;
+                double d = 0.0;
+                for (int t = gr.t0; t < gr.t1; ++t) {
+                    const HTerm ht = terms[t];
+                    d += parity64(gi & ht.z) ? -ht.cr : ht.cr;
+                }
+                acc += d * (a.x * a.x + a.y * a.y);
+            }
+        } else {
+            const int pivot = 63 - __clzll(gr.x);
+            for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k < (namps >> 1); k += stride) {
+                const uint64_t i = insert_zero(k, pivot), j = i ^ gr.x;
+                const amp_t a = st[i], c = st[j];
+                const uint64_t gj = gr.jbase | j;
+                double dr = 0.0, di = 0.0;
+                for (int t = gr.t0; t < gr.t1; ++t) {
+                    const HTerm ht = terms[t];
+                    const bool neg = parity64(gj & ht.z);
+                    dr += neg ? -ht.cr : ht.cr;
+                    di += neg ? -ht.ci : ht.ci;
+                }
+                const double vx = a.x * c.x + a.y * c.y;  // conj(a_i) a_j
+                const double vy = a.x * c.y - a.y * c.x;
+                acc += 2.0 * (dr * vx - di * vy);
+            }
+        }
+    }
+    double2 t = block_sum<256>(make_double2(acc, 0.0), red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
 // out[slot] = sum of `count` complex partials (single block, fixed order)
 __global__ __launch_bounds__(256) void k_reduce(const double2 *__restrict__ partials, int64_t count,
                                                 double2 *__restrict__ out, int slot) {
