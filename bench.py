@@ -120,7 +120,8 @@ def main():
     backend = os.environ.get("OVQE_BENCH_BACKEND", "nccl")  # "gloo": functional test of the N>1 path on one GPU
     if os.environ.get("OVQE_BENCH_SINGLE_DEVICE"):
         local_rank = 0
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("OVQE_BENCH_FORCE_DIST"))  # force: exercise the RCCL path at N=1
+    if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
@@ -130,7 +131,7 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
 
     import __graft_entry__ as entry
-    if world > 1:
+    if use_dist:
         # one builder per node (the .so is shared in-tree); the others wait for it
         if local_rank == 0:
             entry.build()
@@ -155,7 +156,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -169,7 +170,7 @@ def main():
         kernel_ms += sv.last_batch_ms()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -249,7 +250,7 @@ def main():
                 "gpu_minus_cpu_energy": e_gpu0 - cpu["fused"]["energy0"],
             }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

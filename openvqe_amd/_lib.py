@@ -74,6 +74,16 @@ def lib():
     """Load libovqe_sv.so (built by ``__graft_entry__.build()``); raise loudly if it is absent."""
     global _lib
     if _lib is None:
+        # ONE HIP runtime per process: PyTorch bundles its own libamdhip64.so (soname libamdhip64.so.7, like the
+        # system one).  If torch is imported first, libovqe_sv binds to that already-loaded runtime; the other
+        # order would load two runtimes (torch looks its copy up by the unversioned file name) and device pointers
+        # could not be shared.  So when torch is installed it is imported before the library is opened.
+        import sys
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         if not os.path.exists(LIB_PATH):
             raise BackendError(
                 f"{LIB_PATH} is not built — run `python -c 'import __graft_entry__ as g; g.build()'`. "

@@ -95,6 +95,12 @@ int fail(ovqe_handle h, int code, const std::string &msg) {
     return code;
 }
 
+// every entry point runs on its handle's device, whatever the caller's current device is
+#define OVQE_ENTER(h)                        \
+    do {                                     \
+        if (h) (void)hipSetDevice((h)->device); \
+    } while (0)
+
 #define HIPC(h, call)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (call);                                                                         \
@@ -854,6 +860,7 @@ int ovqe_create_shard(int n_local, int n_global, uint64_t shard_index, int devic
 }
 
 int ovqe_destroy(ovqe_handle h) {
+    OVQE_ENTER(h);
     if (!h) return OVQE_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
@@ -874,6 +881,7 @@ int ovqe_destroy(ovqe_handle h) {
 }
 
 int ovqe_set_stream(ovqe_handle h, void *hip_stream) {
+    OVQE_ENTER(h);
     if (!h) return OVQE_ERR_INVALID;
     HIPC(h, hipStreamSynchronize(h->stream));
     h->stream = (hipStream_t)hip_stream;
@@ -881,6 +889,7 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream) {
 }
 
 int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
+    OVQE_ENTER(h);
     if (!h || !name) return OVQE_ERR_INVALID;
     const std::string k(name);
     if (k == "force_path") h->opt_force_path = (int)value;
@@ -912,12 +921,14 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
 }
 
 int ovqe_state_ptr(ovqe_handle h, void **dev_ptr) {
+    OVQE_ENTER(h);
     if (!h || !dev_ptr) return OVQE_ERR_INVALID;
     *dev_ptr = h->state;
     return OVQE_OK;
 }
 
 int ovqe_adopt_state(ovqe_handle h, void *dev_ptr) {
+    OVQE_ENTER(h);
     if (!h || !dev_ptr) return OVQE_ERR_INVALID;
     HIPC(h, hipStreamSynchronize(h->stream));
     if (h->own_state && h->state) (void)hipFree(h->state);
@@ -927,6 +938,7 @@ int ovqe_adopt_state(ovqe_handle h, void *dev_ptr) {
 }
 
 int ovqe_init_basis(ovqe_handle h, uint64_t index) {
+    OVQE_ENTER(h);
     if (!h) return OVQE_ERR_INVALID;
     const int ntot = h->n_local + h->n_global;
     if (ntot < 64 && (index >> ntot)) return fail(h, OVQE_ERR_INVALID, "basis index out of range");
@@ -937,6 +949,7 @@ int ovqe_init_basis(ovqe_handle h, uint64_t index) {
 }
 
 int ovqe_set_state(ovqe_handle h, const double *amps) {
+    OVQE_ENTER(h);
     if (!h || !amps) return OVQE_ERR_INVALID;
     HIPC(h, hipMemcpyAsync(h->state, amps, h->namps * sizeof(amp_t), hipMemcpyHostToDevice, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
@@ -944,6 +957,7 @@ int ovqe_set_state(ovqe_handle h, const double *amps) {
 }
 
 int ovqe_get_state(ovqe_handle h, double *amps) {
+    OVQE_ENTER(h);
     if (!h || !amps) return OVQE_ERR_INVALID;
     HIPC(h, hipMemcpyAsync(amps, h->state, h->namps * sizeof(amp_t), hipMemcpyDeviceToHost, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
@@ -951,6 +965,7 @@ int ovqe_get_state(ovqe_handle h, double *amps) {
 }
 
 int ovqe_get_amplitudes(ovqe_handle h, int64_t count, const uint64_t *idx, double *amps) {
+    OVQE_ENTER(h);
     if (!h || count < 0 || (count && (!idx || !amps))) return OVQE_ERR_INVALID;
     if (count == 0) return OVQE_OK;
     for (int64_t i = 0; i < count; ++i)
@@ -974,6 +989,7 @@ int ovqe_get_amplitudes(ovqe_handle h, int64_t count, const uint64_t *idx, doubl
 }
 
 int ovqe_randomize(ovqe_handle h, uint64_t seed, double norm2_total, double *scale_out) {
+    OVQE_ENTER(h);
     if (!h) return OVQE_ERR_INVALID;
     const int nb = reduce_blocks(h->namps);
     int rc = ensure(h, h->d_partials, (size_t)nb * sizeof(double2));
@@ -1013,6 +1029,7 @@ int ovqe_norm2(ovqe_handle h, double *out) {
 
 // ---- unit operations ----------------------------------------------------------------------------
 int ovqe_apply_pauli_rotations(ovqe_handle h, int64_t R, const uint64_t *x, const uint64_t *z, const double *phi) {
+    OVQE_ENTER(h);
     if (!h || R < 0 || (R && (!x || !z || !phi))) return OVQE_ERR_INVALID;
     if (R == 0) return OVQE_OK;
     const uint64_t lmask = local_mask(h);
@@ -1041,10 +1058,12 @@ int ovqe_apply_pauli_rotations(ovqe_handle h, int64_t R, const uint64_t *x, cons
 }
 
 int ovqe_apply_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi) {
+    OVQE_ENTER(h);
     return ovqe_apply_pauli_rotations(h, 1, &x, &z, &phi);
 }
 
 int ovqe_apply_gate(ovqe_handle h, int opcode, int b0, int b1, double angle) {
+    OVQE_ENTER(h);
     if (!h) return OVQE_ERR_INVALID;
     if (b0 < 0 || b0 >= h->n_local) return fail(h, OVQE_ERR_INVALID, "gate bit out of (local) range");
     const uint64_t bit = 1ull << b0;
@@ -1068,6 +1087,7 @@ int ovqe_apply_gate(ovqe_handle h, int opcode, int b0, int b1, double angle) {
 
 int ovqe_bilinear(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64_t T, const uint64_t *x,
                   const uint64_t *z, const double *coeff_re, const double *coeff_im, double *out_re_im) {
+    OVQE_ENTER(h);
     if (!h || T < 0 || !out_re_im || (T && (!x || !z || !coeff_re))) return OVQE_ERR_INVALID;
     std::vector<HGroup> groups;
     std::vector<HTerm> terms;
@@ -1090,6 +1110,7 @@ int ovqe_bilinear(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64
 
 int ovqe_expectation(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff,
                      double constant, double *out) {
+    OVQE_ENTER(h);
     if (!out) return OVQE_ERR_INVALID;
     double res[2] = {0.0, 0.0};
     int rc = ovqe_bilinear(h, nullptr, nullptr, T, x, z, coeff, nullptr, res);
@@ -1101,6 +1122,7 @@ int ovqe_expectation(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t
 // ---- compiled evaluation ------------------------------------------------------------------------
 int ovqe_set_hamiltonian(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff,
                          double constant) {
+    OVQE_ENTER(h);
     if (!h || T < 0 || (T && (!x || !z || !coeff))) return OVQE_ERR_INVALID;
     h->ham.set = false;
     int rc = build_groups(h, T, x, z, coeff, nullptr, false, h->ham.groups, h->ham.terms);
@@ -1116,6 +1138,7 @@ int ovqe_set_hamiltonian(ovqe_handle h, int64_t T, const uint64_t *x, const uint
 
 int ovqe_set_program(ovqe_handle h, int64_t R, const uint64_t *x, const uint64_t *z, const double *coeff,
                      const double *phi0, const int32_t *pidx, int32_t K, uint64_t hf_index) {
+    OVQE_ENTER(h);
     if (!h || R < 0 || K < 0 || (R && (!x || !z || !coeff || !pidx))) return OVQE_ERR_INVALID;
     const int ntot = h->n_local + h->n_global;
     const uint64_t allmask = ntot >= 64 ? ~0ull : ((1ull << ntot) - 1ull);
@@ -1137,6 +1160,7 @@ int ovqe_set_program(ovqe_handle h, int64_t R, const uint64_t *x, const uint64_t
 int ovqe_set_gate_program(ovqe_handle h, int64_t G, const int32_t *opcode, const int32_t *b0, const int32_t *b1,
                           const double *ascale, const double *aconst, const int32_t *pidx, int32_t K,
                           uint64_t hf_index) {
+    OVQE_ENTER(h);
     if (!h || G < 0 || K < 0 || (G && (!opcode || !b0 || !b1 || !ascale || !aconst || !pidx))) return OVQE_ERR_INVALID;
     if (h->n_global) return fail(h, OVQE_ERR_INVALID, "gate programs are single-device");
     if (hf_index >> h->n_local) return fail(h, OVQE_ERR_INVALID, "hf_index out of range");
@@ -1181,6 +1205,7 @@ int ovqe_set_gate_program(ovqe_handle h, int64_t G, const int32_t *opcode, const
 }
 
 int ovqe_prepare_state(ovqe_handle h, const double *theta, int32_t K) {
+    OVQE_ENTER(h);
     if (!h) return OVQE_ERR_INVALID;
     int rc = check_theta(h, theta, K);
     if (rc) return rc;
@@ -1188,6 +1213,7 @@ int ovqe_prepare_state(ovqe_handle h, const double *theta, int32_t K) {
 }
 
 int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, double *energies) {
+    OVQE_ENTER(h);
     if (!h || B < 0 || (B && !energies)) return OVQE_ERR_INVALID;
     int rc = check_theta(h, theta, K);
     if (rc) return rc;
@@ -1211,12 +1237,14 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
 }
 
 int ovqe_energy(ovqe_handle h, const double *theta, int32_t K, double *energy) {
+    OVQE_ENTER(h);
     return ovqe_energy_batch(h, 1, theta, K, energy);
 }
 
 // ---- ADAPT --------------------------------------------------------------------------------------
 int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, const uint64_t *x, const uint64_t *z,
                         const double *coeff_re, const double *coeff_im, int mode, double *grads) {
+    OVQE_ENTER(h);
     if (!h || n_ops < 0 || !offsets || (n_ops && !grads)) return OVQE_ERR_INVALID;
     if (mode != OVQE_GRAD_FERMIONIC && mode != OVQE_GRAD_QUBIT) return fail(h, OVQE_ERR_INVALID, "unknown gradient mode");
     if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
@@ -1289,6 +1317,7 @@ int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, co
 
 int ovqe_apply_exp_pauli_sum(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff_re,
                              const double *coeff_im, double theta) {
+    OVQE_ENTER(h);
     if (!h || T < 0 || (T && (!x || !z || !coeff_re))) return OVQE_ERR_INVALID;
     if (T == 0 || theta == 0.0) return OVQE_OK;
     std::vector<HGroup> groups;
@@ -1338,6 +1367,7 @@ int ovqe_apply_exp_pauli_sum(ovqe_handle h, int64_t T, const uint64_t *x, const 
 
 // ---- measurement support ------------------------------------------------------------------------
 int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, int warmup, int reps, double *avg_ms) {
+    OVQE_ENTER(h);
     if (!h || !avg_ms || reps <= 0 || warmup < 0) return OVQE_ERR_INVALID;
     if (x & ~local_mask(h)) return fail(h, OVQE_ERR_INVALID, "x mask touches global (rank) bits");
     int rc = ensure_rp(h, 1);
@@ -1362,6 +1392,7 @@ int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, 
 }
 
 int ovqe_last_batch_ms(ovqe_handle h, double *ms) {
+    OVQE_ENTER(h);
     if (!h || !ms) return OVQE_ERR_INVALID;
     *ms = h->last_batch_ms;
     return OVQE_OK;

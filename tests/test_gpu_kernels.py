@@ -326,3 +326,34 @@ def test_index_streams_match_in_kernel_indices(SV):
             sv.set_option("index_streams", level)
             out[level] = sv.energy_batch(thetas)
     assert np.abs(out[1] - out[0]).max() < 1e-10
+
+
+def test_sharded_statevector_single_rank_hip_engine(gpu_lib):
+    """openvqe_amd.distributed.ShardedStatevector on its product engine (torch tensor adopted by the C ABI handle)
+    at world size 1: same rotations / expectation as the plain handle and the oracle."""
+    import torch
+    from openvqe_amd.distributed import ShardedStatevector
+    n = 12
+    rng = np.random.default_rng(1212)
+    R, T = 30, 40
+    xs = [int(v) for v in rng.integers(0, 1 << n, R)]
+    zs = [int(v) for v in rng.integers(0, 1 << n, R)]
+    xs[4] = 0
+    xs[9] = xs[8]
+    phis = rng.uniform(-1, 1, R)
+    hx = [int(v) for v in rng.integers(0, 1 << n, T)]
+    hz = [int(v) for v in rng.integers(0, 1 << n, T)]
+    hc = rng.normal(size=T)
+    hf = int(rng.integers(0, 1 << n))
+    sv = ShardedStatevector(n, device=0)
+    e = sv.energy(hx, hz, hc, -0.5, xs, zs, phis, hf)
+    got = sv.gather_state()
+    psi = np.zeros(1 << n, complex)
+    psi[hf] = 1
+    for x, z, p in zip(xs, zs, phis):
+        psi = masks.rotate(psi, x, z, p)
+    assert np.abs(got - psi).max() < AMP_TOL
+    assert abs(e - masks.expectation(psi, hx, hz, hc, -0.5)) < 1e-11 * max(1.0, np.abs(hc).sum())
+    assert abs(sv.norm2() - 1.0) < 1e-12
+    assert sv.engine.tensor.is_cuda and sv.engine.tensor.dtype == torch.complex128
+    sv.engine.sv.close()
