@@ -50,3 +50,22 @@ def spin_complement_gsd(n_elec, orbital_number, transform="JW"):
     # they simply carry no Pauli terms here and rank with gradient 0.
     pool = [fermion.psum_to_hamiltonian(n, _jw_sum(n, terms), tol=1e-13) for terms in singles + doubles]
     return len(pool), pool
+
+
+def singlet_upccgsd(n_orb, transform="JW", perm=0):
+    """-> (pool_size, cluster_ops_sp): spin-adapted generalised singles + paired doubles, the list repeated
+    ``perm`` extra times (k-UpCCGSD) — enumeration of ref:openvqe/common_files/generator_excitations.py:403-466
+    (pool size 36 for H2/6-31G with perm = 2, ref:tests/test_main_ucc.py:15)."""
+    if transform != "JW":
+        raise NotImplementedError("only the Jordan-Wigner mapping is restated")
+    n = 2 * n_orb
+    singles, doubles = [], []
+    for p in range(0, n, 2):
+        for q in range(0, p, 2):
+            singles.append([(1, _cc(q, p)), (-1, _cc(p, q)), (1, _cc(q + 1, p + 1)), (-1, _cc(p + 1, q + 1))])
+    import itertools
+    for p, q in itertools.combinations(range(0, n, 2), 2):
+        doubles.append([(1.0, _cccc(q, p, q + 1, p + 1)), (-1.0, _cccc(p + 1, q + 1, p, q))])
+    pool = [fermion.psum_to_hamiltonian(n, _jw_sum(n, terms), tol=1e-13) for terms in singles + doubles]
+    pool = pool + pool * perm
+    return len(pool), pool

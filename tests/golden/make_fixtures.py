@@ -125,6 +125,20 @@ def make_k3_k5():
     out["h4_sto3g_nuclear_repulsion"] = float(re.search(r"Nuclear repulsion =\s+([0-9.]+)", run).group(1))
     out["h4_sto3g_orbital_energies"] = [float(v) for v in
                                         re.search(r"Orbital energies =\s+\[([^\]]+)\]", run).group(1).split()]
+    # K6: notebooks/demo_puccgsd.ipynb (H2/6-31G, k-UpCCGSD with k = 2 -> pool 36, 18 parameters)
+    run = "\n".join(notebook_stdout(os.path.join(REF, "notebooks/demo_puccgsd.ipynb")))
+    it = _dict_after(run, "iterations are:")
+    res = _dict_after(run, "results are:")
+    out["h2_631g_upccgsd"] = {
+        "pool_size": int(re.search(r"Pool size:\s+(\d+)", run).group(1)),
+        "CNOT1": res["CNOT1"], "CNOT2": res["CNOT2"], "len_op1": res["len_op1"], "len_op2": res["len_op2"],
+        "minimum_energy_result1_guess": it["minimum_energy_result1_guess"][0],
+        "theta_optimized_result1": it["theta_optimized_result1"][0],
+        "theta0": 0.01,
+        # E(theta0) followed by the 18 forward-difference evaluations E(theta0 + 1.49e-8 e_k) of scipy's BFGS
+        "energies_1_first19": res["energies_1"][:19],
+        "n_function_evaluations_1": len(res["energies_1"]),
+    }
     json.dump(out, open(os.path.join(HERE, "k3_k5_notebook_traces.json"), "w"), indent=1)
     return out
 
