@@ -357,3 +357,62 @@ def test_sharded_statevector_single_rank_hip_engine(gpu_lib):
     assert abs(sv.norm2() - 1.0) < 1e-12
     assert sv.engine.tensor.is_cuda and sv.engine.tensor.dtype == torch.complex128
     sv.engine.sv.close()
+
+
+def test_real_gate_program_uses_real_kernel_and_matches_oracle(SV):
+    """X / H / CNOT / RY only: every rotation entry has an odd number of Y, so the fused kernel runs in real mode"""
+    n = 7
+    rng = np.random.default_rng(707)
+    H = random_hamiltonian(rng, n, 40)
+    K = 5
+    gates = []
+    for _ in range(80):
+        name = str(rng.choice(["X", "H", "RY", "CNOT"]))
+        if name == "CNOT":
+            c, t = rng.choice(n, 2, replace=False).tolist()
+            gates.append((name, [c, t], 0.0, 0.0, -1))
+        elif name == "RY":
+            gates.append((name, [int(rng.integers(0, n))], float(rng.choice([1.0, -1.0, -2.0])), float(rng.uniform(-1, 1)),
+                          int(rng.integers(-1, K))))
+        else:
+            gates.append((name, [int(rng.integers(0, n))], 0.0, 0.0, -1))
+    theta = rng.uniform(-1, 1, K)
+    hf = 0b1011000
+    psi = dense.basis_state(n, hf)
+    for name, qs, sc, co, p in gates:
+        psi = dense.apply_gate(psi, n, name, qs, co + (sc * theta[p] if p >= 0 else 0.0))
+    assert np.abs(psi.imag).max() < 1e-15
+    e_ref = dense.expectation(H, psi)
+    with SV(n) as sv:
+        sv.set_hamiltonian(H)
+        sv.set_gate_program(gates, K, hf)
+        for real_mode in (1, 0):
+            sv.set_option("real_mode", real_mode)
+            assert abs(sv.energy(theta) - e_ref) < 1e-11 * 40
+
+
+@pytest.mark.parametrize("n", [15, 16])
+def test_batched_path_above_lds_capacity(SV, n):
+    """n = 15, 16: batches >= 32 run the fused kernel with per-workgroup global state slices; single evaluations take
+    the streaming kernels — both must agree with each other and with the mask oracle"""
+    from openvqe_amd import fermion
+    rng = np.random.default_rng(n)
+    gens = fermion.uccsd_generators(n // 2, 2)[:: max(1, n // 3)] if n % 2 == 0 else \
+        [g for g in random_generators(rng, n, 6)]
+    ham = random_hamiltonian(rng, n, 60)
+    hf = int(rng.integers(0, 1 << n))
+    thetas = rng.uniform(-0.3, 0.3, (40, len(gens)))
+    xs, zs, cs = ham.packed()
+    with SV(n) as sv:
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, hf)
+        batch = sv.energy_batch(thetas)        # B = 40 >= 32: fused kernel
+        single = np.array([sv.energy(t) for t in thetas[:3]])   # streaming kernels
+    assert np.abs(batch[:3] - single).max() < 1e-10 * max(1.0, np.abs(cs).sum())
+    psi = np.zeros(1 << n, complex)
+    psi[hf] = 1
+    for g, th in zip(gens, thetas[0]):
+        for t in g.terms:
+            x, z = masks.pack_pauli(n, t.op, t.qbits)
+            psi = masks.rotate(psi, x, z, th * t.coeff)
+    assert abs(batch[0] - masks.expectation(psi, xs, zs, cs.real, ham.constant_coeff)) < 1e-10 * max(1.0, np.abs(cs).sum())
