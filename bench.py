@@ -72,6 +72,36 @@ def roofline_leg(device, n, reps=20, warmup=3):
     return res
 
 
+def extra_workloads_leg(device):
+    """SURVEY §8d M2 side figures (not `value`): single-evaluation latency, one finite-difference gradient
+    (B = K+1) and a large batch for H2 (4 qubits), LiH (12) and H2O (14), all STO-3G UCCSD from the in-repo front-end."""
+    from openvqe_amd import chem, fermion
+    from openvqe_amd.backend import Statevector
+    out = []
+    for name in ("H2-STO3G-WSSVQE", "LIH", "H2O"):
+        mol = chem.molecule(name)
+        mol.rhf()
+        ham = mol.jw_hamiltonian()
+        gens = fermion.uccsd_generators(mol.nao, mol.n_elec // 2)
+        K = len(gens)
+        rng = np.random.default_rng(K)
+        with Statevector(ham.nbqbits, device=device) as sv:
+            sv.set_hamiltonian(ham)
+            sv.set_ucc_program(gens, mol.hf_init())
+            row = {"molecule": name, "qubits": ham.nbqbits, "generators": K,
+                   "rotations": sum(len(g.terms) for g in gens), "hamiltonian_terms": len(ham.terms) + 1}
+            for label, B, reps in (("single", 1, 20), ("fd_gradient", K + 1, 10), ("batch4096", 4096, 3)):
+                th = rng.uniform(-0.1, 0.1, (B, K))
+                sv.energy_batch(th)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    sv.energy_batch(th)
+                dt = (time.perf_counter() - t0) / reps
+                row[label] = {"B": B, "ms": 1e3 * dt, "evals_per_s": B / dt}
+            out.append(row)
+    return out
+
+
 def pmc_traffic_per_launch():
     """HBM bytes per launch of the pair-sweep kernel from the newest committed PMC summary (profiles/*/pmc_summary.csv,
     produced by tools/profile_bench.sh with separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).
@@ -133,6 +163,7 @@ def main():
     ap.add_argument("--roofline-qubits", type=int, default=30)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the H2 / LiH / H2O latency and small-batch side figures")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -258,6 +289,8 @@ def main():
                 "worst_string": worst,
                 "per_string": rows,
             }
+        if not args.no_extra:
+            out["extra_workloads"] = extra_workloads_leg(local_rank)
         if not args.no_cpu and world == 1:
             cpu, cores = cpu_baseline_leg(ham, gens, hf, thetas[0], args.cpu_seconds)
             e_gpu0 = energy_check(ham, gens, hf, thetas[0, 0], local_rank)
