@@ -69,7 +69,8 @@ int ovqe_create_shard(int n_local, int n_global, uint64_t shard_index, int devic
 int ovqe_destroy(ovqe_handle h);
 /* run this handle's kernels on a caller-owned hipStream_t (NULL = default stream) */
 int ovqe_set_stream(ovqe_handle h, void *hip_stream);
-/* tuning knobs: "force_path" (0 auto, 1 fused small-register kernel, 2 streaming kernels),
+/* tuning knobs: "force_path" (0 auto, 1 fused small-register kernel, 2 streaming kernels, 3 support-compacted
+ * kernel), "sparse" (1: allow the support-compacted kernel when the program has a small reachable support),
  * "small_max_qubits", "small_batch_max_qubits", "unroll", "real_mode" (1: allow the real-amplitude
  * specialisation of the fused kernel when every rotation string has an odd number of Y),
  * "table_fusion" (1: commuting same-x runs become single sparse pair rotations in the fused kernel) */
@@ -136,6 +137,9 @@ int ovqe_energy(ovqe_handle h, const double *theta, int32_t K, double *energy);
 /* B parameter vectors (row-major B x K) in one launch — one finite-difference gradient of
  * scipy.optimize.minimize(jac=None) (ref:openvqe/ucc_family/get_energy_ucc.py:158-175) is B = K+1 */
 int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, double *energies);
+/* same with theta (B x K doubles) and energies (B doubles) RESIDENT ON THE DEVICE: nothing crosses PCIe
+ * (fused kernels, n <= 16; e.g. theta batches produced on the GPU, or uploaded once and re-used) */
+int ovqe_energy_batch_device(ovqe_handle h, int64_t B, const void *theta_dev, int32_t K, void *energies_dev);
 /* run the program and leave U(theta)|hf> in the handle's state buffer
  * (prepare_state_ansatz + get_statevector, ref:openvqe/adapt/fermionic_adapt_vqe.py:273-328) */
 int ovqe_prepare_state(ovqe_handle h, const double *theta, int32_t K);

@@ -56,6 +56,7 @@ SIGNATURES = {
     "ovqe_set_gate_program": (_int, [_H, _i64, _i32p, _i32p, _i32p, _f64p, _f64p, _i32p, ctypes.c_int32, _u64]),
     "ovqe_energy": (_int, [_H, _f64p, ctypes.c_int32, ctypes.POINTER(_dbl)]),
     "ovqe_energy_batch": (_int, [_H, _i64, _f64p, ctypes.c_int32, _f64p]),
+    "ovqe_energy_batch_device": (_int, [_H, _i64, _vp, ctypes.c_int32, _vp]),
     "ovqe_prepare_state": (_int, [_H, _f64p, ctypes.c_int32]),
     "ovqe_pool_gradients": (_int, [_H, _i64, _i64p, _u64p, _u64p, _f64p, _OptF64, _int, _f64p]),
     "ovqe_apply_exp_pauli_sum": (_int, [_H, _i64, _u64p, _u64p, _f64p, _OptF64, _dbl]),

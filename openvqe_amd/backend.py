@@ -218,6 +218,12 @@ class Statevector:
                                            self._K, out))
         return out
 
+    def energy_batch_device(self, n_batch, theta_ptr, energies_ptr):
+        """B evaluations with theta (B x K float64, row-major) and energies (B float64) resident on the device —
+        e.g. ``tensor.data_ptr()`` of torch CUDA tensors; returns when the energies are written."""
+        self._ck(self._L.ovqe_energy_batch_device(self._h, int(n_batch), ctypes.c_void_p(theta_ptr), self._K,
+                                                  ctypes.c_void_p(energies_ptr)))
+
     def prepare_state(self, theta):
         theta = np.ascontiguousarray(theta, np.float64).reshape(-1)[: self._K]
         self._ck(self._L.ovqe_prepare_state(self._h, theta if self._K else np.zeros(1), self._K))

@@ -14,6 +14,9 @@
 
 #include "sv_kernels.hpp"
 #include "sv_small.hpp"
+#include "sv_sparse.hpp"
+#include <unordered_map>
+#include <unordered_set>
 
 using namespace ovqe;
 
@@ -68,11 +71,19 @@ struct ovqe_sv {
     int cs_capacity = 512;
     // batched evaluation workspace
     DevBuf d_theta, d_energies, d_workspace;
+    // support-compacted program (sv_sparse.hpp): built lazily for the current (program, Hamiltonian)
+    bool sp_tried = false, sp_valid = false;
+    int sp_m = 0, sp_nops = 0, sp_nent = 0;
+    DevBuf d_sp_ops, d_sp_pairs, d_sp_entries;
+    int opt_sparse = 1;           // allow the support-compacted path
+    int opt_sparse_spw = 0;       // evaluations per wave (0 = automatic)
     // pair-index-space expectation tables of the fused kernel, built per (thread bits, real mode)
     DevBuf d_egroups, d_eterms, d_echunks, d_eflat;
     int exp_lbits = -1, exp_real = -1, exp_ngroups = 0, exp_nchunks = 0, exp_nflat = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_batch_ms = 0.f;
+    const double *cur_theta = nullptr;  // device pointers of the batch being evaluated
+    double *cur_energies = nullptr;
     // options
     int opt_force_path = 0;       // 0 auto, 1 small kernel, 2 streaming kernels
     int opt_small_max = 14;       // always-small up to this many qubits
@@ -458,6 +469,7 @@ bool try_table_op(ovqe_handle h, const SmallOp &op, SmallOp &out, std::vector<Sm
 
 int rebuild_small_program(ovqe_handle h) {
     const int cap = h->cs_capacity;
+    h->sp_tried = false;
     h->sops.clear();
     h->srots.clear();
     h->idx_stream.clear();
@@ -564,11 +576,11 @@ int launch_small(ovqe_handle h, const SmallArgs &A, int grid, size_t smem) {
         attr_done = true;
     }
     hipLaunchKernelGGL((k_small_vqe<REAL, LDS, NT, LBITS>), dim3(grid), dim3(NT), smem, h->stream, A,
-                       (const double *)h->d_theta.p, (const SmallOp *)h->d_ops.p, (const SmallRot *)h->d_rots.p,
+                       h->cur_theta, (const SmallOp *)h->d_ops.p, (const SmallRot *)h->d_rots.p,
                        (const SmallSeg *)h->d_segs.p, (const ExpGroup *)h->d_egroups.p, (const ExpChunk *)h->d_echunks.p,
                        (const ExpTerm *)h->d_eterms.p, (const FlatItem *)h->d_eflat.p, (const uint16_t *)h->d_stream.p,
                        h->d_workspace.p,
-                       (double *)h->d_energies.p);
+                       h->cur_energies);
     HIPC(h, hipGetLastError());
     return OVQE_OK;
 }
@@ -730,7 +742,7 @@ int build_exp_tables(ovqe_handle h, int lbits, bool real) {
 }
 
 // B evaluations with the fused kernel; energies -> host
-int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies) {
+int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies, bool on_device = false) {
     const int n = h->n_local;
     bool real = h->opt_real_mode != 0;
     for (const SmallRot &sr : h->rots) real = real && (sr.ny & 1);
@@ -748,14 +760,21 @@ int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies) {
     int max_slices = (int)std::max<size_t>(1, std::min<size_t>(512, ((size_t)512 << 20) / state_bytes));
     if (lds_state) max_slices = 1024;
     const int grid = (int)std::min<int64_t>(B, max_slices);
-    rc = ensure(h, h->d_theta, (size_t)B * std::max(1, h->K) * sizeof(double));
-    if (rc) return rc;
-    rc = ensure(h, h->d_energies, (size_t)B * sizeof(double));
-    if (rc) return rc;
     rc = ensure(h, h->d_workspace, lds_state ? 256 : (size_t)grid * state_bytes);
     if (rc) return rc;
-    if (h->K > 0)
-        HIPC(h, hipMemcpyAsync(h->d_theta.p, theta, (size_t)B * h->K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->cur_theta = theta;
+    h->cur_energies = energies;
+    if (!on_device) {
+        rc = ensure(h, h->d_theta, (size_t)B * std::max(1, h->K) * sizeof(double));
+        if (rc) return rc;
+        rc = ensure(h, h->d_energies, (size_t)B * sizeof(double));
+        if (rc) return rc;
+        if (h->K > 0)
+            HIPC(h, hipMemcpyAsync(h->d_theta.p, theta, (size_t)B * h->K * sizeof(double), hipMemcpyHostToDevice,
+                                   h->stream));
+        h->cur_theta = (const double *)h->d_theta.p;
+        h->cur_energies = (double *)h->d_energies.p;
+    }
     SmallArgs A;
     A.n = n;
     A.K = h->K;
@@ -784,7 +803,159 @@ int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies) {
     }
     if (rc) return rc;
     HIPC(h, hipEventRecord(h->ev1, h->stream));
-    HIPC(h, hipMemcpyAsync(energies, h->d_energies.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (!on_device)
+        HIPC(h, hipMemcpyAsync(energies, h->cur_energies, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    HIPC(h, hipEventElapsedTime(&h->last_batch_ms, h->ev0, h->ev1));
+    return OVQE_OK;
+}
+
+// ---- support-compacted path (sv_sparse.hpp) -------------------------------------------------------------------
+// Propagate the reachable support of |hf> through the OP_TAB ops and restate program and Hamiltonian on compact
+// indices.  Returns with h->sp_valid = false when the structure is absent (then the dense kernels run).
+int build_sparse_program(ovqe_handle h) {
+    h->sp_tried = true;
+    h->sp_valid = false;
+    if (!h->opt_sparse || !h->opt_table_fusion || !h->opt_real_mode || h->n_global != 0 || h->n_local > 40) return OVQE_OK;
+    if (!h->prog_set || !h->ham.set || h->K <= 0) return OVQE_OK;
+    for (const SmallRot &sr : h->rots)
+        if (!(sr.ny & 1)) return OVQE_OK;  // real mode only
+    for (const SmallOp &op : h->sops)
+        if (op.kind != OP_TAB || op.count > 127) return OVQE_OK;
+    const int MAXM = 4096;
+    std::unordered_map<uint64_t, int> id;
+    std::vector<uint64_t> S;
+    auto get = [&](uint64_t a) {
+        auto it = id.find(a);
+        if (it != id.end()) return it->second;
+        const int k = (int)S.size();
+        id.emplace(a, k);
+        S.push_back(a);
+        return k;
+    };
+    get(h->hf);
+    std::vector<SpOp> ops;
+    std::vector<uint32_t> pairs;
+    for (const SmallOp &op : h->sops) {
+        const uint64_t x = op.x, pbit = 1ull << (63 - __builtin_clzll(x));
+        SpOp so;
+        so.first = (int32_t)pairs.size();
+        so.tab0 = op.first;
+        so.pad = 0;
+        const size_t s0 = S.size();
+        std::unordered_set<uint64_t> seen;
+        for (size_t k = 0; k < s0; ++k) {
+            const uint64_t a = S[k];
+            const uint64_t i0 = (a & pbit) ? (a ^ x) : a;
+            if (!seen.insert(i0).second) continue;
+            for (int p = 0; p < op.count; ++p) {
+                if ((i0 & x) != h->srots[op.first + p].z) continue;
+                const int ci = get(i0), cj = get(i0 ^ x);
+                if ((int)S.size() > MAXM) return OVQE_OK;
+                const uint32_t sgn = (__builtin_popcountll(i0 & (uint64_t)op.zc) & 1) ? 1u : 0u;
+                pairs.push_back((uint32_t)ci | ((uint32_t)cj << 12) | (sgn << 24) | ((uint32_t)p << 25));
+                break;
+            }
+        }
+        so.npairs = (int32_t)pairs.size() - so.first;
+        if (so.npairs > 0) ops.push_back(so);
+    }
+    const int m = (int)S.size();
+    // Hamiltonian restricted to the support (real mode: even-ny terms; pair counted once -> factor 2)
+    std::vector<SpEntry> entries;
+    for (const HGroup &g : h->ham.groups) {
+        const uint64_t x = g.x;
+        const uint64_t pbit = x ? 1ull << (63 - __builtin_clzll(x)) : 0;
+        for (int k = 0; k < m; ++k) {
+            const uint64_t a = S[k];
+            if (x && (a & pbit)) continue;
+            const uint64_t b = a ^ x;
+            int kb = k;
+            if (x) {
+                auto it = id.find(b);
+                if (it == id.end()) continue;
+                kb = it->second;
+            }
+            double d = 0.0;
+            for (int t = g.t0; t < g.t1; ++t) {
+                const HTerm &ht = h->ham.terms[t];
+                if (__builtin_popcountll(x & ht.z) & 1) continue;  // odd #Y: zero on a real state
+                d += (__builtin_popcountll(b & ht.z) & 1) ? -ht.cr : ht.cr;
+            }
+            if (d == 0.0) continue;
+            SpEntry e;
+            e.ij = (uint32_t)k | ((uint32_t)kb << 12);
+            e.pad = 0;
+            e.c = x ? 2.0 * d : d;
+            entries.push_back(e);
+            if (entries.size() > (size_t)16 << 20) return OVQE_OK;
+        }
+    }
+    int rc = upload(h, h->d_sp_ops, ops.data(), ops.size() * sizeof(SpOp));
+    if (!rc) rc = upload(h, h->d_sp_pairs, pairs.data(), pairs.size() * sizeof(uint32_t));
+    if (!rc) rc = upload(h, h->d_sp_entries, entries.data(), entries.size() * sizeof(SpEntry));
+    if (rc) return rc;
+    h->sp_m = m;
+    h->sp_nops = (int)ops.size();
+    h->sp_nent = (int)entries.size();
+    h->sp_valid = true;
+    return OVQE_OK;
+}
+
+template <int SPW>
+int launch_sparse(ovqe_handle h, const SparseArgs &A, int grid, size_t smem) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sparse_vqe<SPW>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_sparse_vqe<SPW>), dim3(grid), dim3(64), smem, h->stream, A, h->cur_theta,
+                       (const SmallRot *)h->d_rots.p, (const SpOp *)h->d_sp_ops.p, (const uint32_t *)h->d_sp_pairs.p,
+                       (const SpEntry *)h->d_sp_entries.p, h->cur_energies);
+    HIPC(h, hipGetLastError());
+    return OVQE_OK;
+}
+
+// on_device: theta / energies are device pointers (inputs already resident in HBM, results left there)
+int run_sparse(ovqe_handle h, int64_t B, const double *theta, double *energies, bool on_device = false) {
+    int rc = OVQE_OK;
+    const double *d_theta = theta;
+    double *d_energies = energies;
+    if (!on_device) {
+        rc = ensure(h, h->d_theta, (size_t)B * std::max(1, h->K) * sizeof(double));
+        if (!rc) rc = ensure(h, h->d_energies, (size_t)B * sizeof(double));
+        if (rc) return rc;
+        HIPC(h, hipMemcpyAsync(h->d_theta.p, theta, (size_t)B * h->K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        d_theta = (const double *)h->d_theta.p;
+        d_energies = (double *)h->d_energies.p;
+    }
+    h->cur_theta = d_theta;
+    h->cur_energies = d_energies;
+    SparseArgs A;
+    A.m = h->sp_m;
+    A.K = h->K;
+    A.nops = h->sp_nops;
+    A.ntab = (int)h->srots.size();
+    A.nent = h->sp_nent;
+    A.pad = 0;
+    A.B = B;
+    A.constant = h->ham.constant;
+    const size_t per_eval = (size_t)A.m * sizeof(double) + (size_t)A.ntab * sizeof(double2);
+    int spw = h->opt_sparse_spw;
+    if (spw != 1 && spw != 2 && spw != 4) spw = B >= 2048 ? 2 : 1;  // measured: 2 evaluations per wave is the sweet spot
+    while (spw > 1 && per_eval * spw > 64 * 1024) spw >>= 1;
+    if (per_eval * spw > 150 * 1024) return fail(h, OVQE_ERR_INVALID, "support too large for the compacted kernel");
+    const int64_t nwork = (B + spw - 1) / spw;
+    const int grid = (int)std::min<int64_t>(nwork, 256 * 32);
+    HIPC(h, hipEventRecord(h->ev0, h->stream));
+    if (spw == 4) rc = launch_sparse<4>(h, A, grid, per_eval * 4);
+    else if (spw == 2) rc = launch_sparse<2>(h, A, grid, per_eval * 2);
+    else rc = launch_sparse<1>(h, A, grid, per_eval);
+    if (rc) return rc;
+    HIPC(h, hipEventRecord(h->ev1, h->stream));
+    if (!on_device)
+        HIPC(h, hipMemcpyAsync(energies, h->cur_energies, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
     HIPC(h, hipEventElapsedTime(&h->last_batch_ms, h->ev0, h->ev1));
     return OVQE_OK;
@@ -869,7 +1040,7 @@ int ovqe_destroy(ovqe_handle h) {
         if (h->scratch[k]) (void)hipFree(h->scratch[k]);
     DevBuf *bufs[] = {&h->d_partials, &h->d_result, &h->d_rp, &h->ham.d_groups, &h->ham.d_terms, &h->d_ops,
                       &h->d_rots, &h->d_segs, &h->d_stream, &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups,
-                      &h->d_eterms, &h->d_echunks, &h->d_eflat};
+                      &h->d_eterms, &h->d_echunks, &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (h->h_rp) (void)hipHostFree(h->h_rp);
@@ -896,7 +1067,14 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "small_max_qubits") h->opt_small_max = (int)value;
     else if (k == "small_batch_max_qubits") h->opt_small_batch_max = (int)value;
     else if (k == "unroll") h->opt_unroll = (int)value;
-    else if (k == "real_mode") h->opt_real_mode = (int)value;
+    else if (k == "real_mode") {
+        h->opt_real_mode = (int)value;
+        h->sp_tried = false;
+    }
+    else if (k == "sparse") {
+        h->opt_sparse = (int)value;
+        h->sp_tried = false;
+    } else if (k == "sparse_spw") h->opt_sparse_spw = (int)value;
     else if (k == "index_streams") {
         h->opt_index_streams = (int)value;
         if (h->prog_set) return rebuild_small_program(h);
@@ -1133,6 +1311,7 @@ int ovqe_set_hamiltonian(ovqe_handle h, int64_t T, const uint64_t *x, const uint
     h->ham.constant = constant;
     h->ham.set = true;
     h->exp_lbits = -1;
+    h->sp_tried = false;
     return OVQE_OK;
 }
 
@@ -1219,6 +1398,14 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
     if (rc) return rc;
     if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
     if (B == 0) return OVQE_OK;
+    if (h->opt_force_path == 0 || h->opt_force_path == 3) {
+        if (!h->sp_tried) {
+            rc = build_sparse_program(h);
+            if (rc) return rc;
+        }
+        if (h->sp_valid) return run_sparse(h, B, theta, energies);
+        if (h->opt_force_path == 3) return fail(h, OVQE_ERR_STATE, "program has no compact support (sparse path forced)");
+    }
     if (use_small_path(h, B)) return run_small(h, B, theta, energies);
     HIPC(h, hipEventRecord(h->ev0, h->stream));
     for (int64_t b = 0; b < B; ++b) {
@@ -1234,6 +1421,27 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
     HIPC(h, hipStreamSynchronize(h->stream));
     HIPC(h, hipEventElapsedTime(&h->last_batch_ms, h->ev0, h->ev1));
     return OVQE_OK;
+}
+
+int ovqe_energy_batch_device(ovqe_handle h, int64_t B, const void *theta_dev, int32_t K, void *energies_dev) {
+    OVQE_ENTER(h);
+    if (!h || B < 0 || (B && (!theta_dev || !energies_dev))) return OVQE_ERR_INVALID;
+    if (!h->prog_set) return fail(h, OVQE_ERR_STATE, "no program set (ovqe_set_program / ovqe_set_gate_program)");
+    if (K != h->K || K <= 0) return fail(h, OVQE_ERR_INVALID, "K does not match the program's parameter count");
+    if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
+    if (B == 0) return OVQE_OK;
+    int rc;
+    if (h->opt_force_path == 0 || h->opt_force_path == 3) {
+        if (!h->sp_tried) {
+            rc = build_sparse_program(h);
+            if (rc) return rc;
+        }
+        if (h->sp_valid) return run_sparse(h, B, (const double *)theta_dev, (double *)energies_dev, true);
+        if (h->opt_force_path == 3) return fail(h, OVQE_ERR_STATE, "program has no compact support (sparse path forced)");
+    }
+    if (h->n_global == 0 && h->n_local <= 16 && h->opt_force_path != 2)
+        return run_small(h, B, (const double *)theta_dev, (double *)energies_dev, true);
+    return fail(h, OVQE_ERR_INVALID, "device-resident batches are served by the fused kernels (n <= 16) only");
 }
 
 int ovqe_energy(ovqe_handle h, const double *theta, int32_t K, double *energy) {

@@ -1,0 +1,104 @@
+// sv_sparse.hpp — support-compacted evaluation: E(theta) on the REACHABLE SUPPORT of the circuit.
+//
+// A fused OP_TAB pass (sv_small.hpp) never touches a pair whose rotation angle is structurally zero, so an
+// amplitude that is not reachable from |HF> through the active pairs of the program is exactly 0.0 for every
+// parameter vector.  The host propagates that support through the program once (ovqe_sv.hip,
+// build_sparse_program): S_0 = {hf}, S_k = S_{k-1} + partners of S_{k-1} under the active pairs of op k.  For a
+// particle-number / spin conserving ansatz on a Hartree-Fock determinant this is the CI space of the sector
+// (H2O/STO-3G: 441 of 16384 amplitudes); nothing about fermions is assumed — the analysis is on Pauli masks.
+//
+// When the support is small the whole evaluation is re-expressed on compact indices 0..m-1:
+//   * per op: the list of active pairs inside the support, (ci, cj, chain sign, pattern id);
+//   * <H>: the list of (ci, cj, coefficient) with H_{ij} != 0 inside the support — the quadratic form of the
+//     Hamiltonian restricted to S (coefficients D_g(i) summed on the host, real mode).
+// Results are identical to the dense kernels up to the summation order of <H> (skipped work is exact zeros).
+// One WAVE owns SPW evaluations: no workgroup barrier exists anywhere; LDS traffic of a wave is in order.
+#pragma once
+#include "sv_small.hpp"
+
+namespace ovqe {
+
+struct SpOp {
+    int32_t first;   // first pair
+    int32_t npairs;
+    int32_t tab0;    // first table entry of the op (pattern p -> tab0 + p)
+    int32_t pad;
+};
+
+// pair word: ci (12 bits) | cj (12 bits) << 12 | sign << 24 | pattern << 25
+struct SpEntry {
+    uint32_t ij;  // ci | cj << 12   (ci == cj: diagonal entry)
+    uint32_t pad;
+    double c;     // 2 * H_ij (off-diagonal, pair counted once) or H_ii
+};
+
+struct SparseArgs {
+    int m;        // support size
+    int K;
+    int nops;
+    int ntab;
+    int nent;
+    int pad;
+    int64_t B;
+    double constant;
+};
+
+template <int SPW>
+__global__ __launch_bounds__(64) void k_sparse_vqe(SparseArgs A, const double *__restrict__ theta,
+                                                   const SmallRot *__restrict__ tabrots,
+                                                   const SpOp *__restrict__ ops, const uint32_t *__restrict__ pairs,
+                                                   const SpEntry *__restrict__ entries,
+                                                   double *__restrict__ energies) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *st = reinterpret_cast<double *>(smem);                        // [SPW][m]
+    double2 *cs = reinterpret_cast<double2 *>(st + (size_t)SPW * A.m);    // [SPW][ntab]
+    const int lane = threadIdx.x;
+    const int64_t nwork = (A.B + SPW - 1) / SPW;
+    for (int64_t w = blockIdx.x; w < nwork; w += gridDim.x) {
+        const int64_t b0 = w * SPW;
+        // |HF> (compact index 0) and the cos/sin table of every active pattern, per evaluation
+        for (int i = lane; i < SPW * A.m; i += 64) st[i] = (i % A.m == 0) ? 1.0 : 0.0;
+        for (int r = lane; r < SPW * A.ntab; r += 64) {
+            const int s = r / A.ntab, e = r - s * A.ntab;
+            const int64_t b = b0 + s < A.B ? b0 + s : A.B - 1;
+            const SmallRot sr = tabrots[e];
+            double sn, c;
+            sincos(sr.coeff * theta[b * A.K + sr.pidx], &sn, &c);
+            cs[r] = make_double2(c, sn);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int o = 0; o < A.nops; ++o) {
+            const SpOp op = ops[o];
+            for (int e = lane; e < op.npairs * SPW; e += 64) {
+                const int s = SPW == 1 ? 0 : e / op.npairs, pe = SPW == 1 ? e : e - s * op.npairs;
+                const uint32_t pw = pairs[op.first + pe];
+                const uint32_t ci = pw & 0xfffu, cj = (pw >> 12) & 0xfffu;
+                const double2 t = cs[s * A.ntab + op.tab0 + (int)(pw >> 25)];
+                const double sn = (pw & (1u << 24)) ? -t.y : t.y;
+                double *base = st + (size_t)s * A.m;
+                const double u = base[ci], v = base[cj];
+                base[ci] = t.x * u + sn * v;
+                base[cj] = t.x * v - sn * u;
+            }
+            // pairs of one op are disjoint; the next op may touch them from other lanes of this wave
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        double acc[SPW];
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) acc[s] = 0.0;
+        for (int e = lane; e < A.nent; e += 64) {
+            const SpEntry en = entries[e];
+            const uint32_t ci = en.ij & 0xfffu, cj = (en.ij >> 12) & 0xfffu;
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) acc[s] += en.c * st[(size_t)s * A.m + ci] * st[(size_t)s * A.m + cj];
+        }
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            const double tot = wave_sum(acc[s]);
+            if (lane == 0 && b0 + s < A.B) energies[b0 + s] = tot + A.constant;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+}  // namespace ovqe

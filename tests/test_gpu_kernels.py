@@ -269,7 +269,9 @@ def test_real_mode_matches_complex_mode_and_oracle(SV, n, m, o):
     with SV(n) as sv:
         sv.set_hamiltonian(ham)
         sv.set_ucc_program(gens, hf)
-        for label, opts in (("real", {"force_path": 1, "real_mode": 1, "table_fusion": 1}),
+        for label, opts in (("sparse", {"force_path": 3, "real_mode": 1, "table_fusion": 1}),
+                            ("auto", {"force_path": 0, "real_mode": 1, "table_fusion": 1}),
+                            ("real", {"force_path": 1, "real_mode": 1, "table_fusion": 1}),
                             ("complex", {"force_path": 1, "real_mode": 0, "table_fusion": 1}),
                             ("real_seq", {"force_path": 1, "real_mode": 1, "table_fusion": 0}),
                             ("complex_seq", {"force_path": 1, "real_mode": 0, "table_fusion": 0}),
@@ -416,3 +418,42 @@ def test_batched_path_above_lds_capacity(SV, n):
             x, z = masks.pack_pauli(n, t.op, t.qbits)
             psi = masks.rotate(psi, x, z, th * t.coeff)
     assert abs(batch[0] - masks.expectation(psi, xs, zs, cs.real, ham.constant_coeff)) < 1e-10 * max(1.0, np.abs(cs).sum())
+
+
+def test_device_resident_batches_and_sparse_fallbacks(SV):
+    """ovqe_energy_batch_device (theta / energies as torch CUDA tensors) on the support-compacted and the dense fused
+    kernel; programs without a compact support (complex gates) must refuse force_path = 3 and fall back otherwise."""
+    import torch
+    from openvqe_amd import chem, fermion
+    from openvqe_amd._lib import BackendError
+    mol = chem.molecule("LIH"); mol.rhf()
+    ham = mol.jw_hamiltonian()
+    gens = fermion.uccsd_generators(mol.nao, mol.n_elec // 2)
+    B = 300
+    th = np.random.default_rng(5).uniform(-0.2, 0.2, (B, len(gens)))
+    td = torch.from_numpy(th).cuda()
+    with SV(12) as sv:
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, mol.hf_init())
+        sv.set_option("force_path", 2)
+        ref = sv.energy_batch(th[:6])                      # streaming kernels
+        out = {}
+        for path in (3, 1, 0):
+            sv.set_option("force_path", path)
+            ed = torch.zeros(B, dtype=torch.float64, device="cuda")
+            sv.energy_batch_device(B, td.data_ptr(), ed.data_ptr())
+            out[path] = ed.cpu().numpy()
+            assert np.abs(out[path][:6] - ref).max() < 1e-10
+            assert np.abs(sv.energy_batch(th) - out[path]).max() < 1e-12   # host-buffer entry point, same kernel
+        assert np.abs(out[3] - out[1]).max() < 1e-10 and np.array_equal(out[3], out[0])
+    with SV(5) as sv:
+        rng = np.random.default_rng(8)
+        sv.set_hamiltonian(random_hamiltonian(rng, 5, 20))
+        gates = [("H", [0], 0.0, 0.0, -1), ("RZ", [0], 1.0, 0.0, 0), ("CNOT", [0, 3], 0.0, 0.0, -1), ("RX", [3], 1.0, 0.1, 1)]
+        sv.set_gate_program(gates, 2, 0)
+        e_auto = sv.energy([0.3, -0.2])                     # falls back to the dense fused kernel
+        sv.set_option("force_path", 2)
+        assert abs(sv.energy([0.3, -0.2]) - e_auto) < 1e-12
+        sv.set_option("force_path", 3)
+        with pytest.raises(BackendError):
+            sv.energy([0.3, -0.2])
