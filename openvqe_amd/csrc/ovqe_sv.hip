@@ -321,7 +321,7 @@ int run_bilinear(ovqe_handle h, const amp_t *bra, const amp_t *ket, const std::v
         return OVQE_OK;
     }
     // chunk the group loop so that one launch streams at most ~64 GiB
-    hermitian_expectation = hermitian_expectation && bra == ket && h->n_global == 0;
+    hermitian_expectation = hermitian_expectation && bra == ket;  // x is local whenever bra == ket (same shard)
     const double bytes_per_group = (hermitian_expectation ? 16.0 : 32.0) * (double)h->namps;
     int per_launch = (int)std::max(1.0, std::min((double)G, 6.4e10 / bytes_per_group));
     const int nchunks = (G + per_launch - 1) / per_launch;
@@ -1274,11 +1274,14 @@ int ovqe_bilinear(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64
     DevBuf dg, dt;
     rc = upload(h, dg, groups.data(), groups.size() * sizeof(HGroup));
     if (!rc) rc = upload(h, dt, terms.data(), terms.size() * sizeof(HTerm));
+    bool real_coeffs = true;  // real coefficients: every term is Hermitian -> pair-trick kernel when bra == ket
+    if (coeff_im)
+        for (int64_t t = 0; t < T; ++t) real_coeffs = real_coeffs && coeff_im[t] == 0.0;
     double2 res = make_double2(0.0, 0.0);
     if (!rc)
         rc = run_bilinear(h, bra_dev ? (const amp_t *)bra_dev : h->state, ket_dev ? (const amp_t *)ket_dev : h->state,
                           groups, (const HGroup *)dg.p, (const HTerm *)dt.p, &res,
-                          /*hermitian_expectation=*/!bra_dev && !ket_dev && !coeff_im);
+                          /*hermitian_expectation=*/!bra_dev && !ket_dev && real_coeffs);
     if (dg.p) (void)hipFree(dg.p);
     if (dt.p) (void)hipFree(dt.p);
     out_re_im[0] = res.x;
