@@ -69,3 +69,37 @@ def singlet_upccgsd(n_orb, transform="JW", perm=0):
     pool = [fermion.psum_to_hamiltonian(n, _jw_sum(n, terms), tol=1e-13) for terms in singles + doubles]
     pool = pool + pool * perm
     return len(pool), pool
+
+
+# ---------------------------------------------------------------------------------------------- qubit pools
+def qubit_pool(kind, nbqbits, rng=None):
+    """Single-Pauli-string pools of qubit-ADAPT (ref:openvqe/common_files/qubit_pool.py:278-465, 1184-1268):
+    'YXXX' | 'XYXX' | 'XXYX' | 'XXXY' — "YX" on every pair (a, b) with a + b even, then the 4-letter string on every
+    quadruple with an even number of odd indices, each as Hamiltonian(n, [Term(-1.0, string, qubits)]);
+    'random' — position by position one of the four pools (the reference draws with an unseeded
+    np.random.randint; pass ``rng`` for a reproducible draw).  50 operators at 8 qubits
+    (ref:tests/test_main_qubit_adapt.py:14)."""
+    import itertools
+
+    from .operators import Hamiltonian, Term
+
+    def family(word):
+        out = []
+        for a, b in itertools.combinations(range(nbqbits), 2):
+            if (a + b) % 2 == 0:
+                out.append(Hamiltonian(nbqbits, [Term(-1.0, "YX", [a, b])], do_clean_up=False))
+        for q in itertools.combinations(range(nbqbits), 4):
+            if sum(k % 2 for k in q) % 2 == 0:
+                out.append(Hamiltonian(nbqbits, [Term(-1.0, word, list(q))], do_clean_up=False))
+        return out
+
+    if kind in ("YXXX", "XYXX", "XXYX", "XXXY"):
+        pool = family(kind)
+    elif kind == "random":
+        import numpy as np
+        rng = rng or np.random.default_rng()
+        fams = [family(w) for w in ("YXXX", "XYXX", "XXYX", "XXXY")]
+        pool = [fams[int(rng.integers(0, 4))][i] for i in range(len(fams[3]))]
+    else:
+        raise KeyError(kind)
+    return len(pool), pool

@@ -139,6 +139,17 @@ def make_k3_k5():
         "energies_1_first19": res["energies_1"][:19],
         "n_function_evaluations_1": len(res["energies_1"]),
     }
+    # K4: notebooks/demo_qubit_adapt.ipynb (H2/6-31G, random YXXX-family pool of 50): iteration 0 does not depend on the draw
+    run = "\n".join(notebook_stdout(os.path.join(REF, "notebooks/demo_qubit_adapt.ipynb")))
+    out["h2_631g_qubit_adapt_iter0"] = {
+        "pool_length": int(re.search(r"length of the pool (\d+)", run).group(1)),
+        "reference_energy_simulator": float(re.search(r"reference_energy from the simulator: ([-0-9.]+)", run).group(1)),
+        "reference_energy_analytical": float(re.search(r"reference_energy from the analytical calculations: ([-0-9.]+)", run).group(1)),
+        "sorted_gradients": eval(re.search(r"sorted_mylist_value of gradient_without_0 (\[.*?\])", run).group(1)),
+        "norm_8dp": float(re.search(r"Norm of <\[H,A\]> =\s+([0-9.]+)", run).group(1)),
+        "op_index": int(re.search(r"op_indices of iteration_0 \[(\d+)\]", run).group(1)),
+        "energy": float(re.search(r"Energy reached from the simulator: ([-0-9.]+)", run).group(1)),
+    }
     json.dump(out, open(os.path.join(HERE, "k3_k5_notebook_traces.json"), "w"), indent=1)
     return out
 
