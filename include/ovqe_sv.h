@@ -73,7 +73,13 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * kernel), "sparse" (1: allow the support-compacted kernel when the program has a small reachable support),
  * "small_max_qubits", "small_batch_max_qubits", "unroll", "real_mode" (1: allow the real-amplitude
  * specialisation of the fused kernel when every rotation string has an odd number of Y),
- * "table_fusion" (1: commuting same-x runs become single sparse pair rotations in the fused kernel) */
+ * "table_fusion" (1: commuting same-x runs become single sparse pair rotations in the fused kernel),
+ * "tile_bits" (streaming path: 0 = one sweep per op; 10..12 = LDS tiles of 2^bits amplitudes that take runs of
+ * consecutive ops per sweep, default 11), "tile_low" (lowest index bits always inside a tile, default 4),
+ * "clifford_frame" (read by the NEXT ovqe_set_gate_program: 0 = execute the literal gate list; 1 (default) = when
+ * the Clifford part of the list — X, H, CNOT, quarter-turn rotations — multiplies to the identity, run the
+ * algebraically identical sequence of Pauli rotations with conjugated strings instead; 2 = always, Clifford part
+ * appended literally) */
 int ovqe_set_option(ovqe_handle h, const char *name, int64_t value);
 /* device pointer to the 2^n_local amplitudes (for RCCL exchange by the host layer) */
 int ovqe_state_ptr(ovqe_handle h, void **dev_ptr);
@@ -163,6 +169,11 @@ int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, 
                              double *avg_ms);
 /* device time in ms of the most recent ovqe_energy_batch launch (HIP events) */
 int ovqe_last_batch_ms(ovqe_handle h, double *ms);
+/* shape of the compiled program (diagnostics / tests), up to `count` entries of:
+ *   [0] ops of the sequential program  [1] Pauli rotations  [2] literal X/H/CNOT ops  [3] streaming sweeps per
+ *   evaluation  [4] of those, LDS-tiled multi-op sweeps  [5] ops of the fused-kernel program
+ *   [6] support-compacted program: -1 not analysed yet, 0 none, else the size of the reachable support */
+int ovqe_program_info(ovqe_handle h, int64_t *info, int count);
 
 #ifdef __cplusplus
 }

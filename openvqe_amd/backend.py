@@ -233,6 +233,14 @@ class Statevector:
         self._ck(self._L.ovqe_last_batch_ms(self._h, ctypes.byref(out)))
         return out.value
 
+    def program_info(self):
+        """shape of the compiled program: ops, rotations, literal gates, sweeps per evaluation, tiled sweeps,
+        fused-kernel ops, support size (-1 = not analysed yet)"""
+        out = (ctypes.c_int64 * 7)()
+        self._ck(self._L.ovqe_program_info(self._h, out, 7))
+        keys = ("ops", "rotations", "literal_gates", "sweeps", "tiled_sweeps", "fused_ops", "support")
+        return dict(zip(keys, [int(v) for v in out]))
+
     # -- ADAPT ----------------------------------------------------------------------------------
     def pool_gradients(self, pool_ops, mode):
         """Gradient screen over ``pool_ops`` on the resident state, with the stored Hamiltonian.

@@ -15,6 +15,7 @@
 #include "sv_kernels.hpp"
 #include "sv_small.hpp"
 #include "sv_sparse.hpp"
+#include "sv_tile.hpp"
 #include <unordered_map>
 #include <unordered_set>
 
@@ -95,11 +96,22 @@ struct ovqe_sv {
     int opt_persist_blocks = 2048;
     int opt_small_threads = 0;    // 0: automatic; 256/512/1024: workgroup size of the fused kernel
     int opt_real_mode = 1;        // allow the real-amplitude specialisation of the fused kernel
+    // LDS-tiled multi-op sweeps of the streaming path (sv_tile.hpp)
+    int opt_tile_bits = 11;       // 0: one sweep per op; 10..12: tile size 2^bits amplitudes
+    double2 init_amp = make_double2(1.0, 0.0);  // amplitude of |hf> (global phase of a folded Clifford part)
+    int opt_clifford_frame = 1;   // gate programs: 0 literal, 1 Clifford-frame form when the frame closes, 2 forced
+    int opt_tile_low = 4;         // lowest index bits always inside the tile (contiguous 16 B << low chunks)
+    std::vector<TileSeg> tsegs;
+    std::vector<TileOp> tops;
+    std::vector<TileRot> trots;
+    std::vector<int32_t> plan;    // >= 0: tile segment; < 0: op (-1 - index) launched as its own sweep
+    DevBuf d_tops, d_trots;
 };
 
 namespace {
 
 int rebuild_small_program(ovqe_handle h);
+int build_tile_program(ovqe_handle h);
 
 int fail(ovqe_handle h, int code, const std::string &msg) {
     if (h) h->err = msg; else g_create_error = msg;
@@ -348,18 +360,153 @@ int run_bilinear(ovqe_handle h, const amp_t *bra, const amp_t *ket, const std::v
     return OVQE_OK;
 }
 
-int init_basis(ovqe_handle h, uint64_t index) {
+int init_basis(ovqe_handle h, uint64_t index, double2 one = make_double2(1.0, 0.0)) {
     const uint64_t lmask = local_mask(h);
     const int has = ((index & ~lmask) == h->base) ? 1 : 0;
     hipLaunchKernelGGL(k_init_basis, dim3(reduce_blocks(h->namps)), dim3(256), 0, h->stream, h->state, h->namps,
-                       index & lmask, has);
+                       index & lmask, has, one);
     HIPC(h, hipGetLastError());
     return OVQE_OK;
 }
 
+// ---- LDS-tiled multi-op sweeps (sv_tile.hpp) --------------------------------------------------------
+template <int M>
+int launch_tile(ovqe_handle h, const TileSeg &sg) {
+    constexpr int NT = 256;
+    const size_t smem = ((size_t)16 << M) + TILE_ROT_CAP * sizeof(RotLds);
+    const unsigned grid = (unsigned)(h->namps >> M);
+    const bool ntl = h->n_local >= 25;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sweep<M, NT, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sweep<M, NT, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done = true;
+    }
+    if (ntl) {
+        hipLaunchKernelGGL((k_tile_sweep<M, NT, true>), dim3(grid), dim3(NT), smem, h->stream, h->state, h->base, sg,
+                           (const TileOp *)h->d_tops.p, (const TileRot *)h->d_trots.p, (const RotParam *)h->d_rp.p);
+    } else {
+        hipLaunchKernelGGL((k_tile_sweep<M, NT, false>), dim3(grid), dim3(NT), smem, h->stream, h->state, h->base, sg,
+                           (const TileOp *)h->d_tops.p, (const TileRot *)h->d_trots.p, (const RotParam *)h->d_rp.p);
+    }
+    HIPC(h, hipGetLastError());
+    return OVQE_OK;
+}
+
+int launch_tile_segment(ovqe_handle h, const TileSeg &sg) {
+    switch (__builtin_popcountll(sg.smask)) {
+    case 10: return launch_tile<10>(h, sg);
+    case 11: return launch_tile<11>(h, sg);
+    case 12: return launch_tile<12>(h, sg);
+    }
+    return fail(h, OVQE_ERR_INVALID, "corrupt tile segment");
+}
+
+inline uint32_t extract_bits(uint64_t v, uint64_t mask) {  // pext
+    uint32_t r = 0;
+    int k = 0;
+    for (uint64_t mk = mask; mk; mk &= mk - 1ull, ++k)
+        if ((v >> __builtin_ctzll(mk)) & 1ull) r |= 1u << k;
+    return r;
+}
+
+// Greedy segmentation of the sequential program into tile sweeps: consecutive ops are taken while the union of
+// their mixing bits (x mask / gate target) and the mandatory low bits fits the tile; ops that do not fit, and
+// segments of a single op, keep their own full-bandwidth sweep.
+int build_tile_program(ovqe_handle h) {
+    h->tsegs.clear();
+    h->tops.clear();
+    h->trots.assign(h->rots.size(), TileRot{0, 0, 0});
+    h->plan.clear();
+    const int M = h->opt_tile_bits;
+    const int nops = (int)h->ops.size();
+    const bool tiled = M >= 10 && M <= 12 && h->n_local >= M + 2 && h->opt_tile_low >= 0 && h->opt_tile_low <= 8;
+    if (!tiled) {
+        for (int i = 0; i < nops; ++i) h->plan.push_back(-1 - i);
+        return OVQE_OK;
+    }
+    const uint64_t lowbits = (1ull << h->opt_tile_low) - 1ull;
+    auto need = [&](const SmallOp &op) -> uint64_t {
+        switch (op.kind) {
+        case OP_PAIR: return op.x;
+        case OP_DIAG: return 0ull;
+        case OP_CNOT: return 1ull << op.count;
+        default: return 1ull << op.pivot;
+        }
+    };
+    auto is_rot = [](const SmallOp &op) { return op.kind == OP_PAIR || op.kind == OP_DIAG; };
+    int i = 0;
+    while (i < nops) {
+        uint64_t S = lowbits;
+        int j = i, nrot = 0;
+        while (j < nops) {
+            const SmallOp &op = h->ops[j];
+            const uint64_t nb = S | need(op);
+            if (__builtin_popcountll(nb) > M) break;
+            if (is_rot(op) && nrot + op.count > TILE_ROT_CAP) break;
+            if (is_rot(op)) nrot += op.count;
+            S = nb;
+            ++j;
+        }
+        if (j - i < 2) {
+            h->plan.push_back(-1 - i);
+            ++i;
+            continue;
+        }
+        for (int b = 0; __builtin_popcountll(S) < M; ++b) S |= 1ull << b;  // fill with the lowest free bits
+        TileSeg sg = {};
+        sg.smask = S;
+        uint64_t lo = 0, mk = S;
+        for (int k = 0; k < 8; ++k) {  // log2(NT) = 8 thread bits
+            lo |= mk & (0ull - mk);
+            mk &= mk - 1ull;
+        }
+        sg.mask_lo = lo;
+        sg.mask_hi = S & ~lo;
+        sg.op0 = (int32_t)h->tops.size();
+        sg.rot0 = sg.rot1 = -1;
+        for (int o = i; o < j; ++o) {
+            const SmallOp &op = h->ops[o];
+            TileOp t = {};
+            t.kind = (int16_t)op.kind;
+            if (is_rot(op)) {
+                t.x = extract_bits(op.x, S);
+                t.pivot = (int16_t)(t.x ? 31 - __builtin_clz(t.x) : 0);
+                t.first = op.first;
+                t.count = op.count;
+                if (sg.rot0 < 0) sg.rot0 = op.first;
+                sg.rot1 = op.first + op.count;
+                for (int r = op.first; r < op.first + op.count; ++r) {
+                    h->trots[r].zin = extract_bits(h->rots[r].z, S);
+                    h->trots[r].zout = h->rots[r].z & ~S;
+                }
+            } else if (op.kind == OP_CNOT) {
+                const int cb = op.first, tbit = op.count;
+                t.x = extract_bits(1ull << tbit, S);
+                t.pivot = (int16_t)(31 - __builtin_clz(t.x));
+                t.first = ((S >> cb) & 1ull) ? (31 - __builtin_clz(extract_bits(1ull << cb, S))) : (-1 - cb);
+            } else {
+                t.x = extract_bits(1ull << op.pivot, S);
+                t.pivot = (int16_t)(31 - __builtin_clz(t.x));
+            }
+            h->tops.push_back(t);
+        }
+        if (sg.rot0 < 0) sg.rot0 = sg.rot1 = 0;
+        sg.op1 = (int32_t)h->tops.size();
+        h->plan.push_back((int32_t)h->tsegs.size());
+        h->tsegs.push_back(sg);
+        i = j;
+    }
+    int rc = upload(h, h->d_tops, h->tops.data(), h->tops.size() * sizeof(TileOp));
+    if (rc) return rc;
+    return upload(h, h->d_trots, h->trots.data(), h->trots.size() * sizeof(TileRot));
+}
+
 // run the compiled program with the streaming kernels (state left in h->state)
 int run_program_streaming(ovqe_handle h, const double *theta) {
-    int rc = init_basis(h, h->hf);
+    int rc = init_basis(h, h->hf, h->init_amp);
     if (rc) return rc;
     const size_t R = h->rots.size();
     rc = ensure_rp(h, std::max<size_t>(R, 1));
@@ -381,7 +528,13 @@ int run_program_streaming(ovqe_handle h, const double *theta) {
         }
     }
     if (R) HIPC(h, hipMemcpyAsync(h->d_rp.p, h->h_rp, R * sizeof(RotParam), hipMemcpyHostToDevice, h->stream));
-    for (const SmallOp &op : h->ops) {
+    for (const int32_t step : h->plan) {
+        if (step >= 0) {
+            rc = launch_tile_segment(h, h->tsegs[step]);
+            if (rc) return rc;
+            continue;
+        }
+        const SmallOp &op = h->ops[-1 - step];
         switch (op.kind) {
         case OP_PAIR:
         case OP_DIAG:
@@ -529,6 +682,8 @@ int rebuild_small_program(ovqe_handle h) {
 int finish_program(ovqe_handle h) {
     int rc = rebuild_small_program(h);
     if (rc) return rc;
+    rc = build_tile_program(h);
+    if (rc) return rc;
     h->prog_set = true;
     return OVQE_OK;
 }
@@ -557,6 +712,149 @@ void push_rotation(ovqe_handle h, uint64_t x, uint64_t z, double coeff, double p
     op.count = 1;
     op.pivot = x ? 63 - __builtin_clzll(x) : 0;
     h->ops.push_back(op);
+}
+
+// ---- gate programs ---------------------------------------------------------------------------------
+void push_gate(ovqe_handle h, int opcode, int b0, int b1) {
+    SmallOp op = {};
+    if (opcode == OVQE_GATE_CNOT) {
+        op.x = 1ull << b1;
+        op.kind = OP_CNOT;
+        op.first = b0;
+        op.count = b1;
+        op.pivot = b1;
+    } else {
+        op.x = 1ull << b0;
+        op.kind = opcode == OVQE_GATE_X ? OP_X : OP_H;
+        op.pivot = b0;
+    }
+    h->ops.push_back(op);
+}
+
+void push_literal_gate(ovqe_handle h, int opcode, int b0, int b1, double ascale, double aconst, int32_t pidx) {
+    const uint64_t bit = 1ull << b0;
+    switch (opcode) {
+    case OVQE_GATE_RX: push_rotation(h, bit, 0, 0.5 * ascale, 0.5 * aconst, pidx); break;
+    case OVQE_GATE_RY: push_rotation(h, bit, bit, 0.5 * ascale, 0.5 * aconst, pidx); break;
+    case OVQE_GATE_RZ: push_rotation(h, 0, bit, 0.5 * ascale, 0.5 * aconst, pidx); break;
+    default: push_gate(h, opcode, b0, b1);
+    }
+}
+
+// the literal gate list, one op per gate (consecutive rotations with equal x masks still share a sweep)
+int compile_gate_program_literal(ovqe_handle h, int64_t G, const int32_t *opcode, const int32_t *b0, const int32_t *b1,
+                                 const double *ascale, const double *aconst, const int32_t *pidx) {
+    h->prog_set = false;
+    h->ops.clear();
+    h->rots.clear();
+    h->init_amp = make_double2(1.0, 0.0);
+    for (int64_t g = 0; g < G; ++g) push_literal_gate(h, opcode[g], b0[g], b1[g], ascale[g], aconst[g], pidx[g]);
+    return finish_program(h);
+}
+
+// Clifford-frame compilation.  X, H, CNOT and the fixed quarter-turn rotations RX/RY/RZ(+-pi/2) of the reference's
+// templates (ref:openvqe/common_files/circuit.py:13-106) are Clifford gates: with C_<k the product of the Clifford
+// gates before rotation k,   U = C_total * prod_k exp(-i phi_k C_<k^dagger P_k C_<k),   and the conjugated generator
+// is again a Pauli string (Heisenberg picture; tracked as images of X_q, Z_q).  When C_total is the identity — every
+// QUCCSD template returns the frame to the identity: its Clifford part only routes the excitation — the literal gate
+// list is EXACTLY a sequence of Pauli rotations, which then take the fused same-x / commuting-run / real-mode /
+// support-compacted paths.  C_total = e^{i alpha}: the phase is read from one execution of the Clifford part alone
+// on |hf>; anything but alpha = 0 (or a frame that does not close) keeps the literal program.
+// clifford_frame = 2 (tests): always use the frame form and append the Clifford part literally.
+struct PauliRaw {  // i^k X^x Z^z
+    uint64_t x, z;
+    int k;
+};
+inline PauliRaw pauli_mul(const PauliRaw &a, const PauliRaw &b) {
+    return PauliRaw{a.x ^ b.x, a.z ^ b.z, (a.k + b.k + 2 * __builtin_popcountll(a.z & b.x)) & 3};
+}
+
+int compile_gate_program_frame(ovqe_handle h, int64_t G, const int32_t *opcode, const int32_t *b0, const int32_t *b1,
+                               const double *ascale, const double *aconst, const int32_t *pidx, bool *done) {
+    *done = false;
+    const int n = h->n_local;
+    std::vector<PauliRaw> ix(n), iz(n);
+    for (int q = 0; q < n; ++q) {
+        ix[q] = PauliRaw{1ull << q, 0, 0};
+        iz[q] = PauliRaw{0, 1ull << q, 0};
+    }
+    struct Emit { uint64_t x, z; double coeff, phi0; int32_t pidx; };
+    std::vector<Emit> emitted;
+    std::vector<int64_t> tail;  // gates folded into the frame (the Clifford part, original order)
+    for (int64_t g = 0; g < G; ++g) {
+        const int t = b0[g];
+        switch (opcode[g]) {
+        case OVQE_GATE_H: std::swap(ix[t], iz[t]); tail.push_back(g); continue;
+        case OVQE_GATE_X: iz[t].k = (iz[t].k + 2) & 3; tail.push_back(g); continue;
+        case OVQE_GATE_CNOT:
+            ix[t] = pauli_mul(ix[t], ix[b1[g]]);          // X_c -> X_c X_t
+            iz[b1[g]] = pauli_mul(iz[t], iz[b1[g]]);      // Z_t -> Z_c Z_t
+            tail.push_back(g);
+            continue;
+        default: break;
+        }
+        const double phi0 = 0.5 * aconst[g], coeff = 0.5 * ascale[g];
+        if (pidx[g] < 0 && std::fabs(std::fabs(phi0) - M_PI_4) < 1e-15) {
+            // quarter turn exp(-i s pi/4 P): Q -> i s P Q for the generators anticommuting with P
+            const int s = phi0 > 0 ? 1 : 3;  // i^1 = i, i^3 = -i
+            const PauliRaw X = ix[t], Z = iz[t];
+            if (opcode[g] == OVQE_GATE_RZ) {
+                ix[t] = pauli_mul(PauliRaw{0, 0, s}, pauli_mul(Z, X));
+            } else if (opcode[g] == OVQE_GATE_RX) {
+                iz[t] = pauli_mul(PauliRaw{0, 0, s}, pauli_mul(X, Z));
+            } else {  // RY: X -> s Z, Z -> -s X
+                ix[t] = pauli_mul(PauliRaw{0, 0, s == 1 ? 0 : 2}, Z);
+                iz[t] = pauli_mul(PauliRaw{0, 0, s == 1 ? 2 : 0}, X);
+            }
+            tail.push_back(g);
+            continue;
+        }
+        PauliRaw P;
+        if (opcode[g] == OVQE_GATE_RX) P = ix[t];
+        else if (opcode[g] == OVQE_GATE_RZ) P = iz[t];
+        else P = pauli_mul(PauliRaw{0, 0, 1}, pauli_mul(ix[t], iz[t]));  // Y = i X Z
+        const int rel = (P.k - __builtin_popcountll(P.x & P.z)) & 3;    // Hermitian string = i^{|x&z|} X^x Z^z
+        if (rel & 1) return fail(h, OVQE_ERR_INVALID, "internal: non-Hermitian conjugated generator");
+        const double sg = rel ? -1.0 : 1.0;
+        emitted.push_back(Emit{P.x, P.z, sg * coeff, sg * phi0, pidx[g]});
+    }
+    bool closed = true;
+    for (int q = 0; q < n && closed; ++q)
+        closed = ix[q].x == (1ull << q) && ix[q].z == 0 && ix[q].k == 0 && iz[q].x == 0 && iz[q].z == (1ull << q) &&
+                 iz[q].k == 0;
+    const bool forced = h->opt_clifford_frame == 2;
+    if (!closed && !forced) return OVQE_OK;
+    bool drop_tail = false;
+    double2 phase = make_double2(1.0, 0.0);
+    h->init_amp = phase;
+    if (closed && !forced) {
+        // global phase of the Clifford part: execute it alone on |hf>
+        h->prog_set = false;
+        h->ops.clear();
+        h->rots.clear();
+        for (const int64_t g : tail) push_literal_gate(h, opcode[g], b0[g], b1[g], ascale[g], aconst[g], pidx[g]);
+        if (!tail.empty()) {
+            int rc = build_tile_program(h);
+            if (rc) return rc;
+            std::vector<double> zero((size_t)std::max(h->K, 1), 0.0);
+            rc = run_program_streaming(h, zero.data());
+            if (rc) return rc;
+            double2 amp;
+            HIPC(h, hipMemcpy(&amp, h->state + h->hf, sizeof(double2), hipMemcpyDeviceToHost));
+            if (std::fabs(amp.x * amp.x + amp.y * amp.y - 1.0) > 1e-12) return OVQE_OK;  // cannot happen: literal
+            phase = amp;
+        }
+        drop_tail = true;
+    }
+    h->prog_set = false;
+    h->ops.clear();
+    h->rots.clear();
+    for (const Emit &e : emitted) push_rotation(h, e.x, e.z, e.coeff, e.phi0, e.pidx);
+    if (!drop_tail)
+        for (const int64_t g : tail) push_literal_gate(h, opcode[g], b0[g], b1[g], ascale[g], aconst[g], pidx[g]);
+    *done = true;
+    h->init_amp = phase;  // energies do not depend on it; ovqe_prepare_state reproduces the literal circuit's phase
+    return finish_program(h);
 }
 
 bool use_small_path(ovqe_handle h, int64_t B) {
@@ -1040,7 +1338,8 @@ int ovqe_destroy(ovqe_handle h) {
         if (h->scratch[k]) (void)hipFree(h->scratch[k]);
     DevBuf *bufs[] = {&h->d_partials, &h->d_result, &h->d_rp, &h->ham.d_groups, &h->ham.d_terms, &h->d_ops,
                       &h->d_rots, &h->d_segs, &h->d_stream, &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups,
-                      &h->d_eterms, &h->d_echunks, &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries};
+                      &h->d_eterms, &h->d_echunks, &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries,
+                      &h->d_tops, &h->d_trots};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (h->h_rp) (void)hipHostFree(h->h_rp);
@@ -1080,6 +1379,11 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
         if (h->prog_set) return rebuild_small_program(h);
     }
     else if (k == "rot_variant") h->opt_rot_variant = (int)value;
+    else if (k == "clifford_frame") h->opt_clifford_frame = (int)value;  // applies to the next ovqe_set_gate_program
+    else if (k == "tile_bits" || k == "tile_low") {
+        (k == "tile_bits" ? h->opt_tile_bits : h->opt_tile_low) = (int)value;
+        if (h->prog_set) return build_tile_program(h);
+    }
     else if (k == "persist_blocks") h->opt_persist_blocks = (int)value;
     else if (k == "small_threads") {
         h->opt_small_threads = (int)value;
@@ -1333,6 +1637,7 @@ int ovqe_set_program(ovqe_handle h, int64_t R, const uint64_t *x, const uint64_t
     h->prog_set = false;
     h->ops.clear();
     h->rots.clear();
+    h->init_amp = make_double2(1.0, 0.0);
     h->K = K;
     h->hf = hf_index;
     for (int64_t r = 0; r < R; ++r) push_rotation(h, x[r], z[r], coeff[r], phi0 ? phi0[r] : 0.0, pidx[r]);
@@ -1353,37 +1658,15 @@ int ovqe_set_gate_program(ovqe_handle h, int64_t G, const int32_t *opcode, const
         if (opcode[g] < 0 || opcode[g] > OVQE_GATE_CNOT) return fail(h, OVQE_ERR_INVALID, "unknown gate opcode");
         if (pidx[g] >= K) return fail(h, OVQE_ERR_INVALID, "parameter index >= K");
     }
-    h->prog_set = false;
-    h->ops.clear();
-    h->rots.clear();
     h->K = K;
     h->hf = hf_index;
-    for (int64_t g = 0; g < G; ++g) {
-        const uint64_t bit = 1ull << b0[g];
-        SmallOp op = {};
-        switch (opcode[g]) {
-        case OVQE_GATE_RX: push_rotation(h, bit, 0, 0.5 * ascale[g], 0.5 * aconst[g], pidx[g]); break;
-        case OVQE_GATE_RY: push_rotation(h, bit, bit, 0.5 * ascale[g], 0.5 * aconst[g], pidx[g]); break;
-        case OVQE_GATE_RZ: push_rotation(h, 0, bit, 0.5 * ascale[g], 0.5 * aconst[g], pidx[g]); break;
-        case OVQE_GATE_X:
-        case OVQE_GATE_H:
-            op.x = bit;
-            op.kind = opcode[g] == OVQE_GATE_X ? OP_X : OP_H;
-            op.first = 0;
-            op.count = 0;
-            op.pivot = b0[g];
-            h->ops.push_back(op);
-            break;
-        default:  // CNOT
-            op.x = 1ull << b1[g];
-            op.kind = OP_CNOT;
-            op.first = b0[g];
-            op.count = b1[g];
-            op.pivot = b1[g];
-            h->ops.push_back(op);
-        }
+    if (h->opt_clifford_frame) {
+        bool done = false;
+        int rc = compile_gate_program_frame(h, G, opcode, b0, b1, ascale, aconst, pidx, &done);
+        if (rc) return rc;
+        if (done) return OVQE_OK;
     }
-    return finish_program(h);
+    return compile_gate_program_literal(h, G, opcode, b0, b1, ascale, aconst, pidx);
 }
 
 int ovqe_prepare_state(ovqe_handle h, const double *theta, int32_t K) {
@@ -1599,6 +1882,17 @@ int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, 
     float ms = 0.f;
     HIPC(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *avg_ms = (double)ms / reps;
+    return OVQE_OK;
+}
+
+int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
+    if (!h || !info || count < 0) return OVQE_ERR_INVALID;
+    if (!h->prog_set) return fail(h, OVQE_ERR_STATE, "no program set");
+    int64_t v[7] = {(int64_t)h->ops.size(), (int64_t)h->rots.size(), 0, (int64_t)h->plan.size(),
+                    (int64_t)h->tsegs.size(), (int64_t)h->sops.size(),
+                    !h->sp_tried ? -1 : (h->sp_valid ? (int64_t)h->sp_m : 0)};
+    for (const SmallOp &op : h->ops) v[2] += (op.kind == OP_X || op.kind == OP_H || op.kind == OP_CNOT);
+    for (int i = 0; i < count && i < 7; ++i) info[i] = v[i];
     return OVQE_OK;
 }
 

@@ -437,10 +437,10 @@ __global__ __launch_bounds__(256) void k_pool_grad(const amp_t *__restrict__ sig
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_init_basis(amp_t *__restrict__ st, uint64_t namps, uint64_t local_index,
-                                                    int has_one) {
+                                                    int has_one, double2 one) {
     const uint64_t stride = (uint64_t)gridDim.x * 256u;
     for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) {
-        st[i] = make_double2((has_one && i == local_index) ? 1.0 : 0.0, 0.0);
+        st[i] = (has_one && i == local_index) ? one : make_double2(0.0, 0.0);
     }
 }
 

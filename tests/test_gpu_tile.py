@@ -1,0 +1,152 @@
+"""LDS-tiled multi-op sweeps of the streaming path (openvqe_amd/csrc/sv_tile.hpp): parity with the plain-C oracle
+and with the one-sweep-per-op kernels, through the C ABI."""
+import numpy as np
+import pytest
+
+from tests.util import quccsd_like_gates, random_generators, random_hamiltonian
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def SV(gpu_lib):
+    from openvqe_amd.backend import Statevector
+    return Statevector
+
+
+def _gate_arrays(n, gates):
+    from openvqe_amd.backend import GATE_OPCODES
+    return ([GATE_OPCODES[g[0]] for g in gates], [n - 1 - g[1][0] for g in gates],
+            [n - 1 - g[1][1] if len(g[1]) > 1 else 0 for g in gates], [g[2] for g in gates], [g[3] for g in gates],
+            [g[4] for g in gates])
+
+
+@pytest.mark.parametrize("n,tile_bits,tile_low", [(13, 11, 4), (14, 12, 4), (15, 10, 4), (16, 11, 4), (16, 12, 5),
+                                                  (17, 11, 6), (17, 10, 0), (18, 11, 4)])
+def test_tiled_gate_program_matches_c_oracle(SV, n, tile_bits, tile_low):
+    """QUCCSD templates (CNOT ladders, controls inside and outside the tile) + random literal gates"""
+    from oracle import cref
+    rng = np.random.default_rng(1000 * n + 10 * tile_bits + tile_low)
+    gates, K = quccsd_like_gates(rng, n, 4, 5, extra_random=25)
+    theta = rng.uniform(-1, 1, K)
+    H = random_hamiltonian(rng, n, 60)
+    hf = int(rng.integers(0, 1 << n))
+    hx, hz, hc = H.packed()
+    e_ref, psi_ref = cref.gate_energy(n, hf, *_gate_arrays(n, gates), theta, hx, hz, hc.real.copy(), H.constant_coeff)
+    idx = rng.integers(0, 1 << n, 4000).astype(np.uint64)
+    out = {}
+    with SV(n) as sv:
+        sv.set_option("force_path", 2)
+        sv.set_hamiltonian(H)
+        for bits in (0, tile_bits):
+            sv.set_option("tile_low", tile_low)
+            sv.set_option("tile_bits", bits)
+            sv.set_gate_program(gates, K, hf)
+            e = sv.energy(theta)
+            sv.prepare_state(theta)
+            out[bits] = (e, sv.get_amplitudes(idx), sv.norm2())
+    for bits, (e, amps, n2) in out.items():
+        assert abs(e - e_ref) < 1e-10 * max(1.0, np.abs(hc).sum()), bits
+        assert np.abs(amps - psi_ref[idx.astype(np.int64)]).max() < 1e-12, bits
+        assert abs(n2 - 1.0) < 1e-11
+    assert np.abs(out[0][1] - out[tile_bits][1]).max() < 1e-14
+
+
+@pytest.mark.parametrize("n,tile_bits", [(14, 11), (16, 10), (18, 12), (20, 11)])
+def test_tiled_rotation_program_matches_c_oracle(SV, n, tile_bits):
+    """Pauli-rotation programs: same-x runs, diagonal strings, z chains crossing the tile boundary, wide x masks that
+    keep their own sweep"""
+    from openvqe_amd import fermion
+    from openvqe_amd.backend import compile_ucc_program
+    from oracle import cref
+    rng = np.random.default_rng(77 * n + tile_bits)
+    gens = fermion.uccsd_generators(n // 2, 2)[::5][:25] + random_generators(rng, n, 10)
+    order = rng.permutation(len(gens))
+    gens = [gens[i] for i in order]
+    hf = fermion.hf_integer(n, 4)
+    H = random_hamiltonian(rng, n, 80)
+    theta = rng.uniform(-0.4, 0.4, len(gens))
+    rx, rz, rc, pidx, K = compile_ucc_program(n, gens)
+    hx, hz, hc = H.packed()
+    e_ref, psi_ref = cref.ucc_energy(n, hf, rx, rz, rc, pidx, theta, hx, hz, hc.real.copy(), H.constant_coeff, 0)
+    idx = rng.integers(0, 1 << n, 4000).astype(np.uint64)
+    with SV(n) as sv:
+        sv.set_option("force_path", 2)
+        sv.set_option("tile_bits", tile_bits)
+        sv.set_hamiltonian(H)
+        sv.set_ucc_program(gens, hf)
+        e = sv.energy(theta)
+        sv.prepare_state(theta)
+        amps = sv.get_amplitudes(idx)
+    assert abs(e - e_ref) < 1e-10 * max(1.0, np.abs(hc).sum())
+    assert np.abs(amps - psi_ref[idx.astype(np.int64)]).max() < 1e-12
+
+
+@pytest.mark.parametrize("n,ns,nd", [(4, 2, 1), (8, 4, 6), (12, 6, 10), (14, 6, 12), (16, 5, 8)])
+def test_quccsd_templates_compile_to_pauli_rotations(SV, n, ns, nd):
+    """Clifford-frame form of the reference's QUCCSD gate list: the frame closes after every template, so NO literal
+    gate is left, and state + energy equal the literal gate-by-gate execution (C oracle and clifford_frame = 0)"""
+    from oracle import cref
+    rng = np.random.default_rng(4242 + n)
+    gates, K = quccsd_like_gates(rng, n, ns, nd, disjoint_ladders=True)
+    theta = rng.uniform(-1, 1, K)
+    H = random_hamiltonian(rng, n, 50)
+    hf = int(rng.integers(0, 1 << n))
+    hx, hz, hc = H.packed()
+    e_ref, psi_ref = cref.gate_energy(n, hf, *_gate_arrays(n, gates), theta, hx, hz, hc.real.copy(), H.constant_coeff)
+    with SV(n) as sv:
+        sv.set_hamiltonian(H)
+        res = {}
+        for mode in (0, 1):
+            sv.set_option("clifford_frame", mode)
+            sv.set_gate_program(gates, K, hf)
+            info = sv.program_info()
+            e = sv.energy(theta)
+            eb = sv.energy_batch(np.stack([theta, 0.5 * theta, -theta]))
+            sv.prepare_state(theta)
+            res[mode] = (info, e, eb, sv.get_state())
+    info0, info1 = res[0][0], res[1][0]
+    assert info0["literal_gates"] > 0 and info1["literal_gates"] == 0, (info0, info1)
+    assert info1["rotations"] == 2 * ns + 8 * nd
+    scale = max(1.0, np.abs(hc).sum())
+    for mode in (0, 1):
+        assert abs(res[mode][1] - e_ref) < 1e-10 * scale
+        assert abs(res[mode][2][0] - e_ref) < 1e-10 * scale
+        assert np.abs(res[mode][3] - psi_ref).max() < 1e-12
+    assert np.abs(res[0][2] - res[1][2]).max() < 1e-10 * scale
+
+
+@pytest.mark.parametrize("n,seed", [(3, 0), (5, 1), (6, 2), (9, 3), (13, 4)])
+def test_forced_clifford_frame_on_random_circuits(SV, n, seed):
+    """the conjugation algebra (X, H, CNOT, RX/RY/RZ(+-pi/2) folded into the frame; every other rotation re-expressed
+    in it, the Clifford part appended literally) on random circuits, against the Kronecker / plain-C oracles"""
+    from oracle import cref
+    rng = np.random.default_rng(900 + seed)
+    K = 5
+    gates = []
+    for _ in range(80):
+        name = str(rng.choice(["X", "H", "RX", "RY", "RZ", "CNOT", "Q"]))
+        if name == "CNOT":
+            c, t = rng.choice(n, 2, replace=False).tolist()
+            gates.append((name, [c, t], 0.0, 0.0, -1))
+        elif name in ("X", "H"):
+            gates.append((name, [int(rng.integers(0, n))], 0.0, 0.0, -1))
+        elif name == "Q":  # quarter turns: folded
+            gates.append((str(rng.choice(["RX", "RY", "RZ"])), [int(rng.integers(0, n))], 0.0,
+                          float(rng.choice([np.pi / 2, -np.pi / 2])), -1))
+        else:
+            gates.append((name, [int(rng.integers(0, n))], float(rng.choice([1.0, -1.0, -2.0])),
+                          float(rng.uniform(-1, 1)), int(rng.integers(-1, K))))
+    theta = rng.uniform(-1, 1, K)
+    H = random_hamiltonian(rng, n, min(40, 4 ** n - 1))
+    hf = int(rng.integers(0, 1 << n))
+    hx, hz, hc = H.packed()
+    e_ref, psi_ref = cref.gate_energy(n, hf, *_gate_arrays(n, gates), theta, hx, hz, hc.real.copy(), H.constant_coeff)
+    with SV(n) as sv:
+        sv.set_hamiltonian(H)
+        for mode in (2, 1, 0):
+            sv.set_option("clifford_frame", mode)
+            sv.set_gate_program(gates, K, hf)
+            assert abs(sv.energy(theta) - e_ref) < 1e-10 * max(1.0, np.abs(hc).sum()), mode
+            sv.prepare_state(theta)
+            assert np.abs(sv.get_state() - psi_ref).max() < 1e-12, mode

@@ -163,3 +163,27 @@ def test_adapt_gradient_formulas_agree():
         em = dense.exact_exp_state(psi, [a], [-h])
         fd = (np.vdot(ep, hmat @ ep).real - np.vdot(em, hmat @ em).real) / (2 * h)
         assert abs(fd - gi) < 1e-7
+
+
+def test_c_gate_program_matches_dense_oracle():
+    """the plain-C gate-level evaluator (checker of the tiled GPU sweeps at n >= 14) against the Kronecker oracle
+    on the reference's QUCCSD templates (ref:openvqe/common_files/circuit.py:13-106) plus random literal gates"""
+    from openvqe_amd.backend import GATE_OPCODES
+    from tests.util import quccsd_like_gates
+    n = 7
+    rng = np.random.default_rng(31)
+    gates, K = quccsd_like_gates(rng, n, 3, 3, extra_random=12)
+    theta = rng.uniform(-1, 1, K)
+    H = random_hamiltonian(rng, n, 40)
+    hf = 0b1101000
+    psi = dense.basis_state(n, hf)
+    for name, qs, sc, co, p in gates:
+        psi = dense.apply_gate(psi, n, name, qs, co + (sc * theta[p] if p >= 0 else 0.0))
+    hx, hz, hc = H.packed()
+    opc = [GATE_OPCODES[g[0]] for g in gates]
+    b0 = [n - 1 - g[1][0] for g in gates]
+    b1 = [n - 1 - g[1][1] if len(g[1]) > 1 else 0 for g in gates]
+    e, psi_c = cref.gate_energy(n, hf, opc, b0, b1, [g[2] for g in gates], [g[3] for g in gates],
+                                [g[4] for g in gates], theta, hx, hz, hc.real.copy(), H.constant_coeff)
+    assert np.abs(psi_c - psi).max() < 1e-13
+    assert abs(e - dense.expectation(H, psi)) < 1e-11
