@@ -172,7 +172,9 @@ int ovqe_last_batch_ms(ovqe_handle h, double *ms);
 /* shape of the compiled program (diagnostics / tests), up to `count` entries of:
  *   [0] ops of the sequential program  [1] Pauli rotations  [2] literal X/H/CNOT ops  [3] streaming sweeps per
  *   evaluation  [4] of those, LDS-tiled multi-op sweeps  [5] ops of the fused-kernel program
- *   [6] support-compacted program: -1 not analysed yet, 0 none, else the size of the reachable support */
+ *   [6] support-compacted program: -1 not analysed yet, 0 none, else the size of the reachable support
+ *   [7] tile sweeps of the stored Hamiltonian's expectation (0 until first used / when not tiled)  [8] x-groups
+ *   that keep their own sweep  [9] (group, pattern) entries  [10] merged terms  [11] pair x term evaluations per tile */
 int ovqe_program_info(ovqe_handle h, int64_t *info, int count);
 
 #ifdef __cplusplus

@@ -236,9 +236,10 @@ class Statevector:
     def program_info(self):
         """shape of the compiled program: ops, rotations, literal gates, sweeps per evaluation, tiled sweeps,
         fused-kernel ops, support size (-1 = not analysed yet)"""
-        out = (ctypes.c_int64 * 7)()
-        self._ck(self._L.ovqe_program_info(self._h, out, 7))
-        keys = ("ops", "rotations", "literal_gates", "sweeps", "tiled_sweeps", "fused_ops", "support")
+        out = (ctypes.c_int64 * 12)()
+        self._ck(self._L.ovqe_program_info(self._h, out, 12))
+        keys = ("ops", "rotations", "literal_gates", "sweeps", "tiled_sweeps", "fused_ops", "support",
+                "h_tile_sweeps", "h_untiled_groups", "h_entries", "h_merged_terms", "h_pair_terms_per_tile")
         return dict(zip(keys, [int(v) for v in out]))
 
     # -- ADAPT ----------------------------------------------------------------------------------

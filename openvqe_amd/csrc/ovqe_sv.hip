@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -36,6 +37,12 @@ struct HamDev {  // grouped Pauli sum resident on the device
     DevBuf d_groups, d_terms;
     double constant = 0.0;
     bool set = false;
+    // tile cover of the x-groups (sv_tile.hpp k_tile_expect), built lazily for (tile_bits, tile_low)
+    int tile_bits = -1, tile_low = -1;
+    std::vector<ExSweep> tsweeps;
+    int n_rest = 0;  // groups that fit no tile keep their own sweep (k_expect_pairs)
+    int64_t tile_work = 0, tile_entries = 0, tile_terms = 0;  // pair x term evaluations per tile over all sweeps
+    DevBuf d_tchunks, d_tgroups, d_tterms, d_rest;
 };
 
 }  // namespace
@@ -66,6 +73,8 @@ struct ovqe_sv {
     std::vector<SmallRot> rots;
     std::vector<SmallOp> sops;   // fused-kernel program: ops with commuting runs turned into OP_TAB
     std::vector<SmallRot> srots; // its table entries (sequential rotations and OP_TAB patterns)
+    std::vector<int32_t> sop_src;  // source op (index into ops) of every fused-program op
+    std::vector<uint64_t> sop_zc;  // OP_TAB: the run's common z mask outside x, all 64 bits
     std::vector<SmallSeg> segs;
     DevBuf d_ops, d_rots, d_segs, d_stream;
     std::vector<uint16_t> idx_stream;  // precomputed (sign<<15 | index) streams of the OP_TAB ops
@@ -360,6 +369,232 @@ int run_bilinear(ovqe_handle h, const amp_t *bra, const amp_t *ket, const std::v
     return OVQE_OK;
 }
 
+inline uint32_t extract_bits(uint64_t v, uint64_t mask) {  // pext
+    uint32_t r = 0;
+    int k = 0;
+    for (uint64_t mk = mask; mk; mk &= mk - 1ull, ++k)
+        if ((v >> __builtin_ctzll(mk)) & 1ull) r |= 1u << k;
+    return r;
+}
+
+// ---- tiled expectation (sv_tile.hpp) -----------------------------------------------------------------------
+// Greedy cover of the x-groups by tile bit sets: a set starts from the mandatory low bits and grows by the bit that
+// brings the most still-uncovered groups within reach (groups that are nearly inside count more).
+int build_ham_tiles(ovqe_handle h) {
+    HamDev &H = h->ham;
+    const int M = h->opt_tile_bits, L = h->opt_tile_low;
+    H.tile_bits = M;
+    H.tile_low = L;
+    H.tsweeps.clear();
+    H.n_rest = 0;
+    const bool tiled = M >= 10 && M <= 12 && h->n_local >= M + 2 && L >= 0 && L <= 8 && H.groups.size() >= 3;
+    if (!tiled) return OVQE_OK;
+    const int G = (int)H.groups.size();
+    const uint64_t lowbits = (1ull << L) - 1ull;
+    std::vector<char> covered(G, 0);
+    std::vector<ExChunkT> chunks;
+    std::vector<ExEntryT> tgroups;
+    std::map<std::pair<uint64_t, uint64_t>, std::pair<double, double>> merged;
+    std::vector<ExTermT> tterms;
+    std::vector<HGroup> rest;
+    int remaining = 0;
+    for (int g = 0; g < G; ++g) {
+        if (__builtin_popcountll(H.groups[g].x | lowbits) > M) {
+            covered[g] = 2;
+            rest.push_back(H.groups[g]);
+        } else {
+            ++remaining;
+        }
+    }
+    const double wgt[8] = {1.0, 0.25, 0.0625, 0.015625, 0.00390625, 0.0009765625, 0.000244140625, 0.00006103515625};
+    while (remaining > 0) {
+        uint64_t S = lowbits;
+        while (__builtin_popcountll(S) < M) {
+            const int room = M - __builtin_popcountll(S);
+            double score[64] = {0.0};
+            bool any = false;
+            for (int g = 0; g < G; ++g) {
+                if (covered[g]) continue;
+                const uint64_t miss = H.groups[g].x & ~S;
+                const int nm = __builtin_popcountll(miss);
+                if (nm == 0 || nm > room) continue;
+                any = true;
+                for (uint64_t mk = miss; mk; mk &= mk - 1ull) score[__builtin_ctzll(mk)] += wgt[std::min(nm - 1, 7)];
+            }
+            if (!any) break;
+            int best = -1;
+            for (int b = 0; b < h->n_local; ++b)
+                if (!((S >> b) & 1ull) && (best < 0 || score[b] > score[best])) best = b;
+            S |= 1ull << best;
+        }
+        for (int b = 0; __builtin_popcountll(S) < M; ++b) S |= 1ull << b;
+        ExSweep sw = {};
+        sw.smask = S;
+        uint64_t lo = 0, mk = S;
+        for (int k = 0; k < TILE_EXPECT_LOG_NT; ++k) {  // thread bits
+            lo |= mk & (0ull - mk);
+            mk &= mk - 1ull;
+        }
+        sw.mask_lo = lo;
+        sw.mask_hi = S & ~lo;
+        sw.c0 = (int32_t)chunks.size();
+        ExChunkT ck = {(int32_t)tgroups.size(), (int32_t)tgroups.size(), (int32_t)tterms.size(), (int32_t)tterms.size()};
+        int took = 0;
+        for (int g = 0; g < G; ++g) {
+            if (covered[g] || (H.groups[g].x & ~S)) continue;
+            covered[g] = 1;
+            --remaining;
+            ++took;
+            const HGroup &gr = H.groups[g];
+            const uint32_t xl = extract_bits(gr.x, S);
+            const int w = __builtin_popcount(xl);
+            int xpos[16], np = 0;
+            for (uint32_t mk2 = xl; mk2; mk2 &= mk2 - 1u) xpos[np++] = __builtin_ctz(mk2);
+            const uint32_t npat = w ? (1u << (w - 1)) : 1u;
+            for (uint32_t e = 0; e < npat; ++e) {
+                uint32_t ibits = 0;
+                for (int f = 0; f + 1 < w; ++f)
+                    if ((e >> f) & 1u) ibits |= 1u << xpos[f];
+                const uint32_t jx = ibits ^ xl;  // the partner's bits on the x positions
+                // merge the terms that agree outside x: key = (z on the tile without x, z outside the tile)
+                merged.clear();
+                for (int t = gr.t0; t < gr.t1; ++t) {
+                    const HTerm &ht = H.terms[t];
+                    const uint32_t zin = extract_bits(ht.z, S);
+                    const double sg = (__builtin_popcount(jx & zin) & 1) ? -1.0 : 1.0;
+                    auto &slot = merged[std::make_pair((uint64_t)(zin & ~xl), ht.z & ~S)];
+                    slot.first += sg * ht.cr;
+                    slot.second += sg * ht.ci;
+                }
+                std::vector<ExTermT> mt;
+                bool real_only = true;
+                for (const auto &kv : merged) {
+                    if (kv.second.first == 0.0 && kv.second.second == 0.0) continue;  // exact cancellation
+                    ExTermT et = {};
+                    et.zin = (uint32_t)kv.first.first;
+                    et.zout = kv.first.second;
+                    et.cr = kv.second.first;
+                    et.ci = kv.second.second;
+                    if (et.ci != 0.0) real_only = false;
+                    mt.push_back(et);
+                }
+                if (mt.empty()) continue;
+                const int nk_total = 1 << (M - w);
+                for (size_t m0 = 0; m0 < mt.size(); m0 += TILE_TERM_CAP) {  // oversized lists are split (linear)
+                    const size_t m1 = std::min(mt.size(), m0 + TILE_TERM_CAP);
+                    if ((int)tterms.size() - ck.t0 + (int)(m1 - m0) > TILE_TERM_CAP) {
+                        ck.g1 = (int32_t)tgroups.size();
+                        ck.t1 = (int32_t)tterms.size();
+                        chunks.push_back(ck);
+                        ck = {ck.g1, ck.g1, ck.t1, ck.t1};
+                    }
+                    const int32_t t0 = (int32_t)tterms.size();
+                    tterms.insert(tterms.end(), mt.begin() + m0, mt.begin() + m1);
+                    for (int k0 = 0; k0 < nk_total; k0 += TILE_ENTRY_PAIRS) {
+                        ExEntryT en = {};
+                        en.x = xl;
+                        en.ibits = ibits;
+                        en.t0 = t0;
+                        en.t1 = (int32_t)tterms.size();
+                        en.k0 = k0;
+                        en.nk = std::min(TILE_ENTRY_PAIRS, nk_total - k0);
+                        en.real_only = real_only ? 1 : 0;
+                        tgroups.push_back(en);
+                    }
+                }
+            }
+        }
+        ck.g1 = (int32_t)tgroups.size();
+        ck.t1 = (int32_t)tterms.size();
+        if (ck.g1 > ck.g0) chunks.push_back(ck);
+        sw.c1 = (int32_t)chunks.size();
+        if (took == 0) return fail(h, OVQE_ERR_INVALID, "internal: tile cover made no progress");
+        H.tsweeps.push_back(sw);
+    }
+    H.n_rest = (int)rest.size();
+    H.tile_work = 0;
+    for (const ExEntryT &en : tgroups) H.tile_work += (int64_t)en.nk * (en.t1 - en.t0);
+    H.tile_entries = (int64_t)tgroups.size();
+    H.tile_terms = (int64_t)tterms.size();
+    int rc = upload(h, H.d_tchunks, chunks.data(), chunks.size() * sizeof(ExChunkT));
+    if (rc) return rc;
+    rc = upload(h, H.d_tgroups, tgroups.data(), tgroups.size() * sizeof(ExEntryT));
+    if (rc) return rc;
+    rc = upload(h, H.d_tterms, tterms.data(), tterms.size() * sizeof(ExTermT));
+    if (rc) return rc;
+    return upload(h, H.d_rest, rest.data(), rest.size() * sizeof(HGroup));
+}
+
+template <int M>
+int launch_tile_expect(ovqe_handle h, const ExSweep &sw, double2 *partials, int accumulate) {
+    constexpr int NT = 1 << TILE_EXPECT_LOG_NT;
+    const size_t smem = ((size_t)16 << M) + TILE_TERM_CAP * sizeof(ExTermLds) + (NT / 64) * sizeof(double2);
+    const unsigned grid = (unsigned)(h->namps >> M);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_expect<M, NT, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_expect<M, NT, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done = true;
+    }
+    const HamDev &H = h->ham;
+    if (h->n_local >= 25) {
+        hipLaunchKernelGGL((k_tile_expect<M, NT, true>), dim3(grid), dim3(NT), smem, h->stream, h->state, h->base, sw,
+                           (const ExChunkT *)H.d_tchunks.p, (const ExEntryT *)H.d_tgroups.p,
+                           (const ExTermT *)H.d_tterms.p, partials, accumulate);
+    } else {
+        hipLaunchKernelGGL((k_tile_expect<M, NT, false>), dim3(grid), dim3(NT), smem, h->stream, h->state, h->base, sw,
+                           (const ExChunkT *)H.d_tchunks.p, (const ExEntryT *)H.d_tgroups.p,
+                           (const ExTermT *)H.d_tterms.p, partials, accumulate);
+    }
+    HIPC(h, hipGetLastError());
+    return OVQE_OK;
+}
+
+// <state|H|state> of the stored Hamiltonian through the tile cover; *used = false when there is no cover
+int run_expectation_tiled(ovqe_handle h, double2 *out, bool *used) {
+    HamDev &H = h->ham;
+    *used = false;
+    if (H.tile_bits != h->opt_tile_bits || H.tile_low != h->opt_tile_low) {
+        int rc = build_ham_tiles(h);
+        if (rc) return rc;
+    }
+    if (H.tsweeps.empty()) return OVQE_OK;
+    const int M = H.tile_bits;
+    const int64_t ntiles = (int64_t)(h->namps >> M);
+    const int nb = reduce_blocks(h->namps);
+    int rc = ensure(h, h->d_partials, (size_t)(ntiles + nb) * sizeof(double2));
+    if (rc) return rc;
+    rc = ensure(h, h->d_result, 64 * sizeof(double2));
+    if (rc) return rc;
+    double2 *partials = (double2 *)h->d_partials.p;
+    int acc = 0;
+    for (const ExSweep &sw : H.tsweeps) {
+        switch (M) {
+        case 10: rc = launch_tile_expect<10>(h, sw, partials, acc); break;
+        case 11: rc = launch_tile_expect<11>(h, sw, partials, acc); break;
+        default: rc = launch_tile_expect<12>(h, sw, partials, acc); break;
+        }
+        if (rc) return rc;
+        acc = 1;
+    }
+    int64_t count = ntiles;
+    if (H.n_rest) {
+        hipLaunchKernelGGL(k_expect_pairs, dim3(nb), dim3(256), 0, h->stream, h->state, h->namps,
+                           (const HGroup *)H.d_rest.p, 0, H.n_rest, (const HTerm *)H.d_terms.p, partials + ntiles);
+        count += nb;
+    }
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->stream, (const double2 *)partials, count,
+                       (double2 *)h->d_result.p, 0);
+    HIPC(h, hipGetLastError());
+    HIPC(h, hipMemcpyAsync(h->h_result, h->d_result.p, sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    *out = h->h_result[0];
+    *used = true;
+    return OVQE_OK;
+}
+
 int init_basis(ovqe_handle h, uint64_t index, double2 one = make_double2(1.0, 0.0)) {
     const uint64_t lmask = local_mask(h);
     const int has = ((index & ~lmask) == h->base) ? 1 : 0;
@@ -404,24 +639,18 @@ int launch_tile_segment(ovqe_handle h, const TileSeg &sg) {
     return fail(h, OVQE_ERR_INVALID, "corrupt tile segment");
 }
 
-inline uint32_t extract_bits(uint64_t v, uint64_t mask) {  // pext
-    uint32_t r = 0;
-    int k = 0;
-    for (uint64_t mk = mask; mk; mk &= mk - 1ull, ++k)
-        if ((v >> __builtin_ctzll(mk)) & 1ull) r |= 1u << k;
-    return r;
-}
-
-// Greedy segmentation of the sequential program into tile sweeps: consecutive ops are taken while the union of
+// Greedy segmentation of the (table-fused) program into tile sweeps: consecutive ops are taken while the union of
 // their mixing bits (x mask / gate target) and the mandatory low bits fits the tile; ops that do not fit, and
-// segments of a single op, keep their own full-bandwidth sweep.
+// segments of a single op, keep their own full-bandwidth sweep.  Commuting runs enter a tile in their OP_TAB form
+// (one rotation per active pair pattern, see try_table_op): inside a fused sweep the arithmetic, not HBM, is the
+// cost, and the table form does 1/64 of it for a JW double excitation.
 int build_tile_program(ovqe_handle h) {
     h->tsegs.clear();
     h->tops.clear();
-    h->trots.assign(h->rots.size(), TileRot{0, 0, 0});
+    h->trots.assign(h->srots.size(), TileRot{0, 0, 0});
     h->plan.clear();
     const int M = h->opt_tile_bits;
-    const int nops = (int)h->ops.size();
+    const int nops = (int)h->sops.size();
     const bool tiled = M >= 10 && M <= 12 && h->n_local >= M + 2 && h->opt_tile_low >= 0 && h->opt_tile_low <= 8;
     if (!tiled) {
         for (int i = 0; i < nops; ++i) h->plan.push_back(-1 - i);
@@ -430,19 +659,20 @@ int build_tile_program(ovqe_handle h) {
     const uint64_t lowbits = (1ull << h->opt_tile_low) - 1ull;
     auto need = [&](const SmallOp &op) -> uint64_t {
         switch (op.kind) {
-        case OP_PAIR: return op.x;
+        case OP_PAIR:
+        case OP_TAB: return op.x;
         case OP_DIAG: return 0ull;
         case OP_CNOT: return 1ull << op.count;
         default: return 1ull << op.pivot;
         }
     };
-    auto is_rot = [](const SmallOp &op) { return op.kind == OP_PAIR || op.kind == OP_DIAG; };
+    auto is_rot = [](const SmallOp &op) { return op.kind == OP_PAIR || op.kind == OP_DIAG || op.kind == OP_TAB; };
     int i = 0;
     while (i < nops) {
         uint64_t S = lowbits;
         int j = i, nrot = 0;
         while (j < nops) {
-            const SmallOp &op = h->ops[j];
+            const SmallOp &op = h->sops[j];
             const uint64_t nb = S | need(op);
             if (__builtin_popcountll(nb) > M) break;
             if (is_rot(op) && nrot + op.count > TILE_ROT_CAP) break;
@@ -468,7 +698,7 @@ int build_tile_program(ovqe_handle h) {
         sg.op0 = (int32_t)h->tops.size();
         sg.rot0 = sg.rot1 = -1;
         for (int o = i; o < j; ++o) {
-            const SmallOp &op = h->ops[o];
+            const SmallOp &op = h->sops[o];
             TileOp t = {};
             t.kind = (int16_t)op.kind;
             if (is_rot(op)) {
@@ -478,9 +708,13 @@ int build_tile_program(ovqe_handle h) {
                 t.count = op.count;
                 if (sg.rot0 < 0) sg.rot0 = op.first;
                 sg.rot1 = op.first + op.count;
+                const uint64_t zc = op.kind == OP_TAB ? h->sop_zc[o] : 0ull;
+                t.zc = extract_bits(zc, S);
                 for (int r = op.first; r < op.first + op.count; ++r) {
-                    h->trots[r].zin = extract_bits(h->rots[r].z, S);
-                    h->trots[r].zout = h->rots[r].z & ~S;
+                    // OP_TAB entries: z = the pattern's bits (inside x, hence inside the tile); the run's common z
+                    // part outside the tile is a per-tile sign of every entry
+                    h->trots[r].zin = extract_bits(h->srots[r].z, S);
+                    h->trots[r].zout = op.kind == OP_TAB ? (zc & ~S) : (h->srots[r].z & ~S);
                 }
             } else if (op.kind == OP_CNOT) {
                 const int cb = op.first, tbit = op.count;
@@ -504,42 +738,49 @@ int build_tile_program(ovqe_handle h) {
     return upload(h, h->d_trots, h->trots.data(), h->trots.size() * sizeof(TileRot));
 }
 
-// run the compiled program with the streaming kernels (state left in h->state)
+inline RotParam resolve_rot(const SmallRot &sr, const double *theta) {
+    const double phi = sr.phi0 + (sr.pidx >= 0 ? sr.coeff * theta[sr.pidx] : 0.0);
+    RotParam rp;
+    rp.z = sr.z;
+    rp.c = std::cos(phi);
+    const double s = std::sin(phi);
+    rp.s = (sr.ny & 2) ? -s : s;
+    rp.odd = sr.ny & 1;
+    rp.pad = 0;
+    return rp;
+}
+
+// run the compiled program with the streaming kernels (state left in h->state).
+// Angle table: [0, S) the entries of the table-fused program (tile sweeps, sequential runs), [S, S+R) the original
+// rotations (commuting runs that keep their own sweep run in their sequential form).
 int run_program_streaming(ovqe_handle h, const double *theta) {
     int rc = init_basis(h, h->hf, h->init_amp);
     if (rc) return rc;
-    const size_t R = h->rots.size();
-    rc = ensure_rp(h, std::max<size_t>(R, 1));
+    const size_t S = h->srots.size(), R = h->rots.size();
+    rc = ensure_rp(h, std::max<size_t>(S + R, 1));
     if (rc) return rc;
-    // every op of a fused run shares x; the table needs x per rotation for the ny fold
-    for (const SmallOp &op : h->ops) {
-        if (op.kind != OP_PAIR && op.kind != OP_DIAG) continue;
-        for (int r = op.first; r < op.first + op.count; ++r) {
-            const SmallRot &sr = h->rots[r];
-            const double phi = sr.phi0 + (sr.pidx >= 0 ? sr.coeff * theta[sr.pidx] : 0.0);
-            RotParam rp;
-            rp.z = sr.z;
-            rp.c = std::cos(phi);
-            const double s = std::sin(phi);
-            rp.s = (sr.ny & 2) ? -s : s;
-            rp.odd = sr.ny & 1;
-            rp.pad = 0;
-            h->h_rp[r] = rp;
-        }
-    }
-    if (R) HIPC(h, hipMemcpyAsync(h->d_rp.p, h->h_rp, R * sizeof(RotParam), hipMemcpyHostToDevice, h->stream));
+    for (size_t r = 0; r < S; ++r) h->h_rp[r] = resolve_rot(h->srots[r], theta);
+    for (size_t r = 0; r < R; ++r) h->h_rp[S + r] = resolve_rot(h->rots[r], theta);
+    if (S + R)
+        HIPC(h, hipMemcpyAsync(h->d_rp.p, h->h_rp, (S + R) * sizeof(RotParam), hipMemcpyHostToDevice, h->stream));
+    const RotParam *d_rp = (const RotParam *)h->d_rp.p;
     for (const int32_t step : h->plan) {
         if (step >= 0) {
             rc = launch_tile_segment(h, h->tsegs[step]);
             if (rc) return rc;
             continue;
         }
-        const SmallOp &op = h->ops[-1 - step];
+        const SmallOp &op = h->sops[-1 - step];
         switch (op.kind) {
         case OP_PAIR:
         case OP_DIAG:
-            rc = launch_rot_run(h, op.kind == OP_PAIR ? op.x : 0ull, (const RotParam *)h->d_rp.p + op.first, op.count);
+            rc = launch_rot_run(h, op.kind == OP_PAIR ? op.x : 0ull, d_rp + op.first, op.count);
             break;
+        case OP_TAB: {
+            const SmallOp &src = h->ops[h->sop_src[-1 - step]];
+            rc = launch_rot_run(h, src.x, d_rp + S + src.first, src.count);
+            break;
+        }
         case OP_X: rc = launch_gate(h, 0, op.pivot, 0); break;
         case OP_H: rc = launch_gate(h, 1, op.pivot, 0); break;
         case OP_CNOT: rc = launch_gate(h, 2, op.first, op.count); break;
@@ -625,12 +866,20 @@ int rebuild_small_program(ovqe_handle h) {
     h->sp_tried = false;
     h->sops.clear();
     h->srots.clear();
+    h->sop_src.clear();
+    h->sop_zc.clear();
     h->idx_stream.clear();
-    for (const SmallOp &op : h->ops) {
+    auto push_sop = [&](const SmallOp &op, int src, uint64_t zc) {
+        h->sops.push_back(op);
+        h->sop_src.push_back(src);
+        h->sop_zc.push_back(zc);
+    };
+    for (int oi = 0; oi < (int)h->ops.size(); ++oi) {
+        const SmallOp &op = h->ops[oi];
         if (op.kind == OP_PAIR || op.kind == OP_DIAG) {
             SmallOp t;
             if (h->opt_table_fusion && try_table_op(h, op, t, h->srots)) {
-                if (t.count > 0) h->sops.push_back(t);  // count == 0: the run is the identity
+                if (t.count > 0) push_sop(t, oi, h->rots[op.first].z & ~op.x);  // count == 0: the run is the identity
                 continue;
             }
             for (int o = 0; o < op.count; o += cap) {  // split runs longer than the LDS table
@@ -638,10 +887,10 @@ int rebuild_small_program(ovqe_handle h) {
                 p.first = (int32_t)h->srots.size();
                 p.count = std::min(cap, op.count - o);
                 for (int r = 0; r < p.count; ++r) h->srots.push_back(h->rots[op.first + o + r]);
-                h->sops.push_back(p);
+                push_sop(p, oi, 0);
             }
         } else {
-            h->sops.push_back(op);
+            push_sop(op, oi, 0);
         }
     }
     h->segs.clear();
@@ -834,7 +1083,7 @@ int compile_gate_program_frame(ovqe_handle h, int64_t G, const int32_t *opcode, 
         h->rots.clear();
         for (const int64_t g : tail) push_literal_gate(h, opcode[g], b0[g], b1[g], ascale[g], aconst[g], pidx[g]);
         if (!tail.empty()) {
-            int rc = build_tile_program(h);
+            int rc = finish_program(h);
             if (rc) return rc;
             std::vector<double> zero((size_t)std::max(h->K, 1), 0.0);
             rc = run_program_streaming(h, zero.data());
@@ -1339,7 +1588,7 @@ int ovqe_destroy(ovqe_handle h) {
     DevBuf *bufs[] = {&h->d_partials, &h->d_result, &h->d_rp, &h->ham.d_groups, &h->ham.d_terms, &h->d_ops,
                       &h->d_rots, &h->d_segs, &h->d_stream, &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups,
                       &h->d_eterms, &h->d_echunks, &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries,
-                      &h->d_tops, &h->d_trots};
+                      &h->d_tops, &h->d_trots, &h->ham.d_tchunks, &h->ham.d_tgroups, &h->ham.d_tterms, &h->ham.d_rest};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (h->h_rp) (void)hipHostFree(h->h_rp);
@@ -1376,7 +1625,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     } else if (k == "sparse_spw") h->opt_sparse_spw = (int)value;
     else if (k == "index_streams") {
         h->opt_index_streams = (int)value;
-        if (h->prog_set) return rebuild_small_program(h);
+        if (h->prog_set) return finish_program(h);
     }
     else if (k == "rot_variant") h->opt_rot_variant = (int)value;
     else if (k == "clifford_frame") h->opt_clifford_frame = (int)value;  // applies to the next ovqe_set_gate_program
@@ -1393,7 +1642,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
         if (h->opt_table_fusion != (int)value && h->prog_set) {
             h->opt_table_fusion = (int)value;
             h->exp_lbits = -1;
-            return rebuild_small_program(h);
+            return finish_program(h);
         }
         h->opt_table_fusion = (int)value;
         h->exp_lbits = -1;
@@ -1617,6 +1866,7 @@ int ovqe_set_hamiltonian(ovqe_handle h, int64_t T, const uint64_t *x, const uint
     if (rc) return rc;
     h->ham.constant = constant;
     h->ham.set = true;
+    h->ham.tile_bits = -1;  // tile cover rebuilt on first use
     h->exp_lbits = -1;
     h->sp_tried = false;
     return OVQE_OK;
@@ -1698,8 +1948,12 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
         rc = run_program_streaming(h, theta + b * (int64_t)K);
         if (rc) return rc;
         double2 res;
-        rc = run_bilinear(h, h->state, h->state, h->ham.groups, (const HGroup *)h->ham.d_groups.p,
-                          (const HTerm *)h->ham.d_terms.p, &res, true);
+        bool tiled = false;
+        rc = run_expectation_tiled(h, &res, &tiled);
+        if (rc) return rc;
+        if (!tiled)
+            rc = run_bilinear(h, h->state, h->state, h->ham.groups, (const HGroup *)h->ham.d_groups.p,
+                              (const HTerm *)h->ham.d_terms.p, &res, true);
         if (rc) return rc;
         energies[b] = res.x + h->ham.constant;
     }
@@ -1888,11 +2142,13 @@ int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, 
 int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
     if (!h || !info || count < 0) return OVQE_ERR_INVALID;
     if (!h->prog_set) return fail(h, OVQE_ERR_STATE, "no program set");
-    int64_t v[7] = {(int64_t)h->ops.size(), (int64_t)h->rots.size(), 0, (int64_t)h->plan.size(),
-                    (int64_t)h->tsegs.size(), (int64_t)h->sops.size(),
-                    !h->sp_tried ? -1 : (h->sp_valid ? (int64_t)h->sp_m : 0)};
+    int64_t v[12] = {(int64_t)h->ops.size(), (int64_t)h->rots.size(), 0, (int64_t)h->plan.size(),
+                     (int64_t)h->tsegs.size(), (int64_t)h->sops.size(),
+                     !h->sp_tried ? -1 : (h->sp_valid ? (int64_t)h->sp_m : 0),
+                     (int64_t)h->ham.tsweeps.size(), (int64_t)h->ham.n_rest, h->ham.tile_entries, h->ham.tile_terms,
+                     h->ham.tile_work};
     for (const SmallOp &op : h->ops) v[2] += (op.kind == OP_X || op.kind == OP_H || op.kind == OP_CNOT);
-    for (int i = 0; i < count && i < 7; ++i) info[i] = v[i];
+    for (int i = 0; i < count && i < 12; ++i) info[i] = v[i];
     return OVQE_OK;
 }
 

@@ -31,7 +31,8 @@ struct TileOp {
     int16_t pivot;   // local pivot / target bit
     int32_t first;   // OP_PAIR / OP_DIAG: first rotation (absolute);  OP_CNOT: local control bit, or
                      // -1 - (global bit) when the control lies outside the tile
-    int32_t count;   // rotations of the run
+    int32_t count;   // rotations of the run / active patterns (OP_TAB)
+    uint32_t zc;     // OP_TAB: the run's z mask outside x, on the tile bits
 };
 
 struct TileRot {     // static part of a rotation inside its segment
@@ -100,7 +101,11 @@ __global__ __launch_bounds__(NT) void k_tile_sweep(amp_t *__restrict__ st, uint6
         op.first = top.first;
         op.count = top.count;
         op.pivot = top.pivot;
-        if (op.kind == OP_PAIR) {
+        if (op.kind == OP_TAB) {
+            op.zc = top.zc;
+            op.fixmask = top.x;
+            small_pass_tab<false, NT>(tile, M, op, tab + (op.first - seg.rot0));
+        } else if (op.kind == OP_PAIR) {
             small_pass_pair<false, NT, U>(tile, NEL >> 1, op, tab + (op.first - seg.rot0));
         } else if (op.kind == OP_DIAG) {
             small_pass_diag<NT>(tile, NEL, op, tab + (op.first - seg.rot0));
@@ -125,6 +130,169 @@ __global__ __launch_bounds__(NT) void k_tile_sweep(amp_t *__restrict__ st, uint6
         const v2d t = {a.x, a.y};
         const uint64_t g = tb | glow | spread_bits((uint32_t)j, seg.mask_hi);
         if (NTL) __builtin_nontemporal_store(t, &p[g]); else p[g] = t;
+    }
+}
+
+// ---- <psi|H|psi> on tiles --------------------------------------------------------------------------------
+// The x-groups of a Hermitian Pauli sum are covered by tile bit sets: every group whose x mask lies inside the sweep's
+// set S is evaluated from the LDS copy of the tile (E_g = 2 Re sum_pairs D(j) conj(a_i) a_j, the pair trick of
+// k_expect_pairs), so the state is read ONCE per sweep instead of once per x-group (JW Hamiltonians: weight-2/-4
+// masks; ~25 groups per sweep at 24 qubits).
+// Work items are (group, pattern) ENTRIES: for a fixed pattern of the pair's bits on the x positions, the x part of
+// every z mask is a constant sign, so terms that agree outside x merge on the host — the 8 strings of a JW double
+// excitation become ONE coefficient on 2 of the 8 patterns, XX/YY number-operator families halve — and patterns whose
+// coefficients cancel exactly are never visited.  One wave owns an entry (<= 256 pairs); z bits outside the tile
+// are per-tile signs, folded into the coefficients while a chunk of the term table is staged in LDS.
+constexpr int TILE_TERM_CAP = 512;
+constexpr int TILE_ENTRY_PAIRS = 256;
+constexpr int TILE_EXPECT_LOG_NT = 8;   // threads per workgroup of k_tile_expect (256 measured faster than 1024)
+
+struct ExSweep {
+    uint64_t smask, mask_lo, mask_hi;
+    int32_t c0, c1;   // chunk range
+};
+struct ExChunkT {
+    int32_t g0, g1, t0, t1;  // entries, terms
+};
+struct ExEntryT {
+    uint32_t x;       // tile-local x mask (0: diagonal group)
+    uint32_t ibits;   // the pattern: bits of i on the non-pivot x positions (pivot bit of i is 0)
+    int32_t t0, t1;   // merged terms (absolute)
+    int32_t k0, nk;   // free-index range [k0, k0 + nk), nk <= TILE_ENTRY_PAIRS
+    int32_t real_only;  // every ci == 0
+    int32_t pad;
+};
+struct ExTermT {
+    uint64_t zout;    // z outside the tile
+    uint32_t zin;     // z on the tile bits, x positions cleared
+    uint32_t pad;
+    double cr, ci;    // i^ny and the pattern's sign folded
+};
+struct ExTermLds {
+    double cr, ci;
+    uint32_t zin, pad;
+};
+
+template <int M, int NT, bool NTL>
+__global__ __launch_bounds__(NT) void k_tile_expect(const amp_t *__restrict__ st, uint64_t base, ExSweep sw,
+                                                    const ExChunkT *__restrict__ chunks,
+                                                    const ExEntryT *__restrict__ entries,
+                                                    const ExTermT *__restrict__ terms, double2 *__restrict__ partials,
+                                                    int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t NEL = 1u << M;
+    constexpr int TRIPS = NEL / NT;
+    constexpr int PP = TILE_ENTRY_PAIRS / 64;  // pairs per lane
+    double2 *tile = reinterpret_cast<double2 *>(smem);
+    ExTermLds *lt = reinterpret_cast<ExTermLds *>(smem + (size_t)NEL * sizeof(double2));
+    double2 *red = reinterpret_cast<double2 *>(lt + TILE_TERM_CAP);
+    const v2d *p = reinterpret_cast<const v2d *>(st);
+
+    uint64_t tb = blockIdx.x;
+    for (uint64_t mk = sw.smask; mk; mk &= mk - 1ull) tb = insert_zero(tb, __ffsll((long long)mk) - 1);
+    const uint64_t glow = spread_bits(threadIdx.x, sw.mask_lo);
+    const uint64_t gbase = base | tb;
+    {
+        v2d reg[TRIPS];
+#pragma unroll
+        for (int j = 0; j < TRIPS; ++j) {
+            const uint64_t g = tb | glow | spread_bits((uint32_t)j, sw.mask_hi);
+            reg[j] = NTL ? __builtin_nontemporal_load(&p[g]) : p[g];
+        }
+#pragma unroll
+        for (int j = 0; j < TRIPS; ++j) tile[threadIdx.x + j * NT] = make_double2(reg[j].x, reg[j].y);
+    }
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u;
+    double acc = 0.0;
+    for (int ch = sw.c0; ch < sw.c1; ++ch) {
+        const ExChunkT ck = chunks[ch];
+        __syncthreads();  // tile visible / previous chunk's term table no longer read
+        for (int t = ck.t0 + (int)threadIdx.x; t < ck.t1; t += NT) {
+            const ExTermT et = terms[t];
+            const bool neg = parity64(gbase & et.zout);
+            ExTermLds l;
+            l.cr = neg ? -et.cr : et.cr;
+            l.ci = neg ? -et.ci : et.ci;
+            l.zin = et.zin;
+            l.pad = 0;
+            lt[t - ck.t0] = l;
+        }
+        __syncthreads();
+        for (int g = ck.g0 + wave; g < ck.g1; g += NT / 64) {
+            const ExEntryT en = entries[g];
+            const ExTermLds *gt = lt + (en.t0 - ck.t0);
+            const int nt = en.t1 - en.t0;
+            double part = 0.0;
+            if (nt <= 2) {
+                // the common case after merging (a JW double excitation leaves ONE coefficient per active pattern):
+                // the pair set-up is the cost, so no unrolling over dead lanes — one pair per lane per trip
+                const ExTermLds l0 = gt[0];
+                ExTermLds l1 = gt[nt - 1];
+                if (nt == 1) {
+                    l1.cr = 0.0;
+                    l1.ci = 0.0;
+                }
+                const uint32_t dlane = deposit_index((uint32_t)en.k0 + lane, en.x) | en.ibits;
+                const uint32_t d64 = deposit_index(64u, en.x);  // k -> k + 64 never carries into lane bits
+                uint32_t i = dlane;
+                for (uint32_t k = lane; k < (uint32_t)en.nk; k += 64u) {
+                    const uint32_t j = i ^ en.x;
+                    const double2 a = tile[i], c = tile[j];
+                    const double wx = a.x * c.x + a.y * c.y, wy = a.x * c.y - a.y * c.x;
+                    const bool n0 = __popc(j & l0.zin) & 1, n1 = __popc(j & l1.zin) & 1;
+                    const double dr = (n0 ? -l0.cr : l0.cr) + (n1 ? -l1.cr : l1.cr);
+                    const double di = (n0 ? -l0.ci : l0.ci) + (n1 ? -l1.ci : l1.ci);
+                    part += dr * wx - di * wy;
+                    i = (((i | en.x) + d64) & ~en.x) | en.ibits;  // next free index, x positions skipped
+                }
+            } else {
+            double vx[PP], vy[PP], dr[PP], di[PP];
+            uint32_t jj[PP];
+#pragma unroll
+            for (int m = 0; m < PP; ++m) {
+                const uint32_t k = (uint32_t)en.k0 + lane + 64u * m;
+                const bool live = lane + 64u * m < (uint32_t)en.nk;
+                const uint32_t i = deposit_index(k, en.x) | en.ibits;
+                jj[m] = i ^ en.x;
+                const double2 a = tile[i & (NEL - 1u)], c = tile[jj[m] & (NEL - 1u)];
+                vx[m] = live ? a.x * c.x + a.y * c.y : 0.0;  // conj(a_i) a_j   (x = 0: |a_i|^2)
+                vy[m] = live ? a.x * c.y - a.y * c.x : 0.0;
+                dr[m] = 0.0;
+                di[m] = 0.0;
+            }
+            if (en.real_only) {
+                for (int t = 0; t < nt; ++t) {
+                    const ExTermLds l = gt[t];
+#pragma unroll
+                    for (int m = 0; m < PP; ++m) dr[m] += (__popc(jj[m] & l.zin) & 1) ? -l.cr : l.cr;
+                }
+            } else {
+                for (int t = 0; t < nt; ++t) {
+                    const ExTermLds l = gt[t];
+#pragma unroll
+                    for (int m = 0; m < PP; ++m) {
+                        const bool neg = __popc(jj[m] & l.zin) & 1;
+                        dr[m] += neg ? -l.cr : l.cr;
+                        di[m] += neg ? -l.ci : l.ci;
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < PP; ++m) part += dr[m] * vx[m] - di[m] * vy[m];
+            }
+            acc += en.x ? 2.0 * part : part;
+        }
+    }
+    __syncthreads();
+    const double2 t = block_sum<NT>(make_double2(acc, 0.0), red);
+    if (threadIdx.x == 0) {
+        if (accumulate) {
+            const double2 o = partials[blockIdx.x];
+            partials[blockIdx.x] = make_double2(o.x + t.x, o.y);
+        } else {
+            partials[blockIdx.x] = t;
+        }
     }
 }
 

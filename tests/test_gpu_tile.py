@@ -150,3 +150,33 @@ def test_forced_clifford_frame_on_random_circuits(SV, n, seed):
             assert abs(sv.energy(theta) - e_ref) < 1e-10 * max(1.0, np.abs(hc).sum()), mode
             sv.prepare_state(theta)
             assert np.abs(sv.get_state() - psi_ref).max() < 1e-12, mode
+
+
+@pytest.mark.parametrize("m,o,tile_bits,tile_low", [(7, 3, 11, 4), (8, 3, 10, 4), (8, 2, 12, 3), (9, 4, 11, 5)])
+def test_tiled_expectation_of_jw_hamiltonian(SV, m, o, tile_bits, tile_low):
+    """<psi|H|psi> through the tile cover of the x-groups (weight-0/2/4 masks of a JW two-body Hamiltonian, z chains
+    crossing the tiles) against the one-sweep-per-group kernel and the plain-C oracle"""
+    from openvqe_amd import fermion
+    from openvqe_amd.backend import compile_ucc_program
+    from oracle import cref
+    n = 2 * m
+    ham, gens, hf = fermion.synthetic_molecule(m, o, seed=100 + n)
+    gens = gens[::3]
+    rng = np.random.default_rng(n)
+    theta = rng.uniform(-0.3, 0.3, len(gens))
+    rx, rz, rc, pidx, K = compile_ucc_program(n, gens)
+    hx, hz, hc = ham.packed()
+    e_ref, _ = cref.ucc_energy(n, hf, rx, rz, rc, pidx, theta, hx, hz, hc.real.copy(), ham.constant_coeff, 0)
+    es = {}
+    with SV(n) as sv:
+        sv.set_option("force_path", 2)
+        sv.set_option("tile_low", tile_low)
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, hf)
+        for bits in (0, tile_bits):
+            sv.set_option("tile_bits", bits)
+            es[bits] = sv.energy(theta)
+    scale = max(1.0, np.abs(hc).sum())
+    assert abs(es[0] - e_ref) < 1e-10 * scale
+    assert abs(es[tile_bits] - e_ref) < 1e-10 * scale
+    assert abs(es[tile_bits] - es[0]) < 1e-11 * scale

@@ -28,3 +28,4 @@ with Statevector(n) as sv:
         print(f"prepare {t1*1e3:.1f} ms ({32*2**n*len(gens)/t1/1e9:.0f} GB/s per fused sweep; {32*2**n*R/t1/1e9:.0f} GB/s per rotation)  "
               f"expectation ~{t2*1e3:.1f} ms ({16*2**n*G/t2/1e9:.0f} GB/s algorithmic)  energy {t3*1e3:.1f} ms  "
               f"B_eval={(32*2**n*R+16*2**n*G)/1e9:.0f} GB -> {(32*2**n*R+16*2**n*G)/t3/1e9:.0f} GB/s  E={e2:.10f}", flush=True)
+    print(sv.program_info(), flush=True)
