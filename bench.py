@@ -99,6 +99,77 @@ def extra_workloads_leg(device):
                 dt = (time.perf_counter() - t0) / reps
                 row[label] = {"B": B, "ms": 1e3 * dt, "evals_per_s": B / dt}
             out.append(row)
+    out.extend(gate_and_midsize_workloads(device))
+    return out
+
+
+def _quccsd_gates(m, o, stride=1):
+    """literal gate list of the reference's fermionic QUCCSD templates (ref:openvqe/common_files/circuit.py:13-106)
+    on the UCCSD excitations of m spatial orbitals / o occupied, every `stride`-th excitation"""
+    from openvqe_amd import fermion
+    from openvqe_amd.common_files.circuit import efficient_fermionic_ansatz
+    from openvqe_amd.qat_compat import AffineParam, Program, lower_circuit
+    singles, doubles = fermion.uccsd_excitations(m, o)
+    exci = ([[i, a] for i, a in singles] + [[i, j, a, b] for i, j, a, b in doubles])[::stride]
+    prog = Program()
+    reg = prog.qalloc(2 * m)
+    efficient_fermionic_ansatz(reg, prog, exci, [AffineParam(k) for k in range(len(exci))])
+    _, kind, gates = lower_circuit(prog.to_circ())
+    assert kind == "gates"
+    return gates, len(exci), fermion.hf_integer(2 * m, 2 * o)
+
+
+def gate_and_midsize_workloads(device):
+    """configs[3]-type side figures: the QUCCSD gate list at H2O size (literal execution vs Clifford-frame form) and
+    24-qubit state preparation (QUCCSD gate list; UCCSD Pauli-rotation program) on the streaming kernels with
+    LDS-tiled multi-op sweeps, against one sweep per op."""
+    from openvqe_amd import chem, fermion
+    from openvqe_amd.backend import Statevector
+    out = []
+    mol = chem.molecule("H2O")
+    mol.rhf()
+    ham = mol.jw_hamiltonian()
+    gates, K, hf = _quccsd_gates(mol.nao, mol.n_elec // 2)
+    rng = np.random.default_rng(5)
+    row = {"workload": "H2O/STO-3G QUCCSD gate list", "qubits": ham.nbqbits, "literal_gates": len(gates), "parameters": K}
+    with Statevector(ham.nbqbits, device=device) as sv:
+        sv.set_hamiltonian(ham)
+        th_all = rng.uniform(-0.1, 0.1, (4096, K))
+        for label, mode, B in (("literal", 0, 64), ("clifford_frame", 1, 4096)):
+            sv.set_option("clifford_frame", mode)
+            sv.set_gate_program(gates, K, hf)
+            th = th_all[:B]
+            e0 = sv.energy_batch(th[:4])
+            sv.energy_batch(th)
+            t0 = time.perf_counter()
+            sv.energy_batch(th)
+            dt = time.perf_counter() - t0
+            row[label] = {"B": B, "evals_per_s": B / dt, "program": sv.program_info(), "E0": float(e0[0])}
+    out.append(row)
+    m, o, stride = 12, 5, 5
+    n = 2 * m
+    gates, K, hf = _quccsd_gates(m, o, stride)
+    gens = fermion.uccsd_generators(m, o)[::stride]
+    theta = rng.uniform(-0.1, 0.1, K)
+    row = {"workload": "24-qubit state preparation (every 5th UCCSD excitation of 10e/12o)", "qubits": n,
+           "excitations": K, "literal_gates": len(gates), "pauli_rotations": sum(len(g.terms) for g in gens)}
+    with Statevector(n, device=device) as sv:
+        for label, setter, frame, bits in (
+                ("quccsd_literal_one_sweep_per_gate", lambda: sv.set_gate_program(gates, K, hf), 0, 0),
+                ("quccsd_literal_tiled", lambda: sv.set_gate_program(gates, K, hf), 0, -1),
+                ("quccsd_clifford_frame_tiled", lambda: sv.set_gate_program(gates, K, hf), 1, -1),
+                ("uccsd_one_sweep_per_run", lambda: sv.set_ucc_program(gens, hf), 1, 0),
+                ("uccsd_tiled", lambda: sv.set_ucc_program(gens, hf), 1, -1)):
+            sv.set_option("clifford_frame", frame)
+            sv.set_option("tile_bits", bits)
+            setter()
+            sv.prepare_state(theta)
+            t0 = time.perf_counter()
+            sv.prepare_state(theta)
+            dt = time.perf_counter() - t0
+            info = sv.program_info()
+            row[label] = {"ms": 1e3 * dt, "sweeps": info["sweeps"], "tiled_sweeps": info["tiled_sweeps"]}
+    out.append(row)
     return out
 
 
@@ -112,7 +183,9 @@ def pmc_traffic_per_launch():
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.csv"))):
         fetch = write = nf = nw = 0.0
         for row in csv.DictReader(open(path)):
-            if "k_rot_pairs" not in row["kernel"]:
+            # the 30-qubit sweeps are the non-temporal instances (NTL = true); cached instances belong to the
+            # mid-size side workloads of the same run
+            if "k_rot_pairs_v<" not in row["kernel"] or ", true, false>" not in row["kernel"]:
                 continue
             n = float(row["dispatches"])
             if row["counter"] == "FETCH_SIZE":

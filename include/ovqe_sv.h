@@ -75,7 +75,7 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * specialisation of the fused kernel when every rotation string has an odd number of Y),
  * "table_fusion" (1: commuting same-x runs become single sparse pair rotations in the fused kernel),
  * "tile_bits" (streaming path: 0 = one sweep per op; 10..12 = LDS tiles of 2^bits amplitudes that take runs of
- * consecutive ops per sweep, default 11), "tile_low" (lowest index bits always inside a tile, default 4),
+ * consecutive ops per sweep; default -1 = automatic: 12 for n >= 25, else 11), "tile_low" (lowest index bits always inside a tile, default 4),
  * "clifford_frame" (read by the NEXT ovqe_set_gate_program: 0 = execute the literal gate list; 1 (default) = when
  * the Clifford part of the list — X, H, CNOT, quarter-turn rotations — multiplies to the identity, run the
  * algebraically identical sequence of Pauli rotations with conjugated strings instead; 2 = always, Clifford part

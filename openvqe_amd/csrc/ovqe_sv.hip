@@ -106,7 +106,8 @@ struct ovqe_sv {
     int opt_small_threads = 0;    // 0: automatic; 256/512/1024: workgroup size of the fused kernel
     int opt_real_mode = 1;        // allow the real-amplitude specialisation of the fused kernel
     // LDS-tiled multi-op sweeps of the streaming path (sv_tile.hpp)
-    int opt_tile_bits = 11;       // 0: one sweep per op; 10..12: tile size 2^bits amplitudes
+    int opt_tile_bits = -1;       // -1: automatic (12 when the state streams from HBM, n >= 25; else 11);
+                                  // 0: one sweep per op; 10..12: tile size 2^bits amplitudes
     double2 init_amp = make_double2(1.0, 0.0);  // amplitude of |hf> (global phase of a folded Clifford part)
     int opt_clifford_frame = 1;   // gate programs: 0 literal, 1 Clifford-frame form when the frame closes, 2 forced
     int opt_tile_low = 4;         // lowest index bits always inside the tile (contiguous 16 B << low chunks)
@@ -369,6 +370,8 @@ int run_bilinear(ovqe_handle h, const amp_t *bra, const amp_t *ket, const std::v
     return OVQE_OK;
 }
 
+inline int tile_bits(ovqe_handle h) { return h->opt_tile_bits >= 0 ? h->opt_tile_bits : (h->n_local >= 25 ? 12 : 11); }
+
 inline uint32_t extract_bits(uint64_t v, uint64_t mask) {  // pext
     uint32_t r = 0;
     int k = 0;
@@ -382,7 +385,7 @@ inline uint32_t extract_bits(uint64_t v, uint64_t mask) {  // pext
 // brings the most still-uncovered groups within reach (groups that are nearly inside count more).
 int build_ham_tiles(ovqe_handle h) {
     HamDev &H = h->ham;
-    const int M = h->opt_tile_bits, L = h->opt_tile_low;
+    const int M = tile_bits(h), L = h->opt_tile_low;
     H.tile_bits = M;
     H.tile_low = L;
     H.tsweeps.clear();
@@ -556,7 +559,7 @@ int launch_tile_expect(ovqe_handle h, const ExSweep &sw, double2 *partials, int 
 int run_expectation_tiled(ovqe_handle h, double2 *out, bool *used) {
     HamDev &H = h->ham;
     *used = false;
-    if (H.tile_bits != h->opt_tile_bits || H.tile_low != h->opt_tile_low) {
+    if (H.tile_bits != tile_bits(h) || H.tile_low != h->opt_tile_low) {
         int rc = build_ham_tiles(h);
         if (rc) return rc;
     }
@@ -649,7 +652,7 @@ int build_tile_program(ovqe_handle h) {
     h->tops.clear();
     h->trots.assign(h->srots.size(), TileRot{0, 0, 0});
     h->plan.clear();
-    const int M = h->opt_tile_bits;
+    const int M = tile_bits(h);
     const int nops = (int)h->sops.size();
     const bool tiled = M >= 10 && M <= 12 && h->n_local >= M + 2 && h->opt_tile_low >= 0 && h->opt_tile_low <= 8;
     if (!tiled) {

@@ -69,3 +69,72 @@ def test_30_qubit_rotation_sampled_parity_and_properties(gpu_lib):
         combo = sv.bilinear(xs, zs, cs).real
         assert abs(combo - float(np.dot(cs[1:], singles))) < 1e-10
         assert all(abs(v) <= 1.0 + 1e-12 for v in singles)
+
+
+def _sparse_rotate(psi, x, z, phi):
+    """exp(-i phi P) on a dict {index: amplitude}: (P psi)_i = i^ny (-1)^{|(i^x)&z|} psi_{i^x}  (oracle/masks.py formula)"""
+    ph = (1j) ** (bin(x & z).count("1") % 4)
+    out = {}
+    c, s = np.cos(phi), np.sin(phi)
+    for j, a in psi.items():
+        out[j] = out.get(j, 0.0) + c * a
+        i = j ^ x
+        sign = -1.0 if bin(j & z).count("1") & 1 else 1.0   # (i^x) = j
+        out[i] = out.get(i, 0.0) - 1j * s * ph * sign * a
+    return out
+
+
+def test_30_qubit_tiled_program_and_expectation_against_sparse_oracle(gpu_lib):
+    """a UCC-type program from |hf> at 30 qubits (JW doubles and singles with long z chains, a wide string that keeps
+    its own sweep, a diagonal string): LDS-tiled sweeps + tiled <H> (non-temporal paths) against a host simulation of
+    the few non-zero amplitudes, and against the one-sweep-per-op kernels"""
+    from openvqe_amd import fermion
+    from openvqe_amd.backend import Statevector
+    from openvqe_amd.operators import Hamiltonian, Term
+    n = N
+    rng = np.random.default_rng(3030)
+    gens = [fermion._excitation_generator(n, [a], [i]) for i, a in ((0, 28), (3, 17))]
+    gens += [fermion._excitation_generator(n, [b, a], [i, j]) for i, j, a, b in
+             ((0, 1, 26, 29), (2, 3, 12, 13), (1, 2, 20, 27), (0, 3, 8, 9), (4, 5, 28, 29), (0, 1, 6, 7))]
+    gens.insert(3, Hamiltonian(n, [Term(0.7, "XYZXZZYXXY", [0, 3, 5, 8, 11, 14, 19, 22, 25, 29])], do_clean_up=False))
+    gens.insert(5, Hamiltonian(n, [Term(-0.4, "ZZZ", [1, 15, 29])], do_clean_up=False))
+    hf = fermion.hf_integer(n, 6)
+    theta = rng.uniform(-0.6, 0.6, len(gens))
+    terms = [Term(0.5, "Z", [0]), Term(-0.25, "ZZ", [2, 29]), Term(0.3, "XZZX", [0, 1, 2, 3]),
+             Term(0.3, "YZZY", [0, 1, 2, 3]), Term(0.11, "XXYY", [2, 3, 12, 13]), Term(-0.11, "YYXX", [2, 3, 12, 13]),
+             Term(0.2, "XX", [28, 29]), Term(0.2, "YY", [28, 29]), Term(0.05, "XZX", [4, 17, 28]),
+             Term(0.4, "X" * 14, list(range(0, 28, 2)))]
+    H = Hamiltonian(n, terms, 0.125)
+    psi = {hf: 1.0 + 0j}
+    for g, th in zip(gens, theta):
+        for t in g.terms:
+            x, z = pack_string(n, t.op, t.qbits)
+            psi = _sparse_rotate(psi, x, z, th * t.coeff)
+    e_ref = H.constant_coeff
+    for t in H.terms:
+        x, z = pack_string(n, t.op, t.qbits)
+        ph = (1j) ** (bin(x & z).count("1") % 4)
+        e_ref += (t.coeff * sum(np.conj(psi.get(j ^ x, 0.0)) * ph * (-1.0 if bin(j & z).count("1") & 1 else 1.0) * a
+                                for j, a in psi.items())).real
+    support = np.array(sorted(psi), np.uint64)
+    want = np.array([psi[int(i)] for i in support])
+    extra = rng.integers(0, 1 << n, 2000).astype(np.uint64)
+    with Statevector(n) as sv:
+        sv.set_option("force_path", 2)
+        sv.set_hamiltonian(H)
+        res = {}
+        for bits in (11, 0):
+            sv.set_option("tile_bits", bits)
+            sv.set_ucc_program(gens, hf)
+            info = sv.program_info()
+            e = sv.energy(theta)
+            sv.prepare_state(theta)
+            res[bits] = (e, sv.get_amplitudes(support), sv.get_amplitudes(extra), sv.norm2(), info, sv.program_info())
+    assert res[11][4]["tiled_sweeps"] >= 1 and res[0][4]["tiled_sweeps"] == 0
+    assert res[11][5]["h_tile_sweeps"] >= 1 and res[11][5]["h_untiled_groups"] == 1
+    for bits, (e, amps, others, n2, _, _) in res.items():
+        assert abs(e - e_ref) < 1e-12, bits
+        assert np.abs(amps - want).max() < 1e-14, bits
+        assert abs(n2 - 1.0) < 1e-12
+        mask = ~np.isin(extra, support)
+        assert np.all(others[mask] == 0.0)
