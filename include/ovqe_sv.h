@@ -163,6 +163,16 @@ int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, co
 int ovqe_apply_exp_pauli_sum(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff_re,
                              const double *coeff_im, double theta);
 
+/* ---- lowest eigenpair of the stored Hamiltonian (Lanczos on the device, two-pass: tridiagonal matrix, then the Ritz
+ * vector by the same recurrence; random start vector from `seed`, so every symmetry sector is reached — the global
+ * minimum over the whole register, like column 0 of the reference's dense np.linalg.eigh,
+ * ref:openvqe/adapt/fermionic_adapt_vqe.py:474 / qubit_adapt_vqe.py:424-426, which is O(8^n) and infeasible at the
+ * H2O size).  Stops when the Lanczos residual estimate < tol * max(1, |lambda|) or after max_iter steps.  The
+ * normalised eigenvector is left in the handle's state buffer (ovqe_get_state); *energy includes the constant,
+ * *residual = |H y - lambda y| measured afterwards, *iterations = Lanczos steps taken. */
+int ovqe_ground_state(ovqe_handle h, double tol, int max_iter, uint64_t seed, double *energy, double *residual,
+                      int *iterations);
+
 /* ---- measurement support (bench.py): average device time in ms of `reps` back-to-back launches of
  * one Pauli-rotation sweep, bracketed by HIP events on the handle's stream */
 int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, int warmup, int reps,

@@ -12,7 +12,6 @@ reference's).  Differences are confined to WHERE the arithmetic runs:
 """
 import numpy as np
 import scipy.optimize
-import scipy.sparse.linalg
 from numpy import binary_repr
 
 from ..backend import GRAD_FERMIONIC, Statevector
@@ -126,11 +125,17 @@ def fun_fidelity(circ, eigenvalues, eigenvectors, nbqbits):
 
 
 def _ground_space(hamiltonian_sp):
-    """dense eigh like the reference (line 474) while it is feasible, sparse Lanczos above"""
+    """dense eigh like the reference (fermionic_adapt_vqe.py:474) while it is feasible (its cost is O(8^n): 4 GiB and
+    hours at the H2O size); above, the lowest eigenpair by Lanczos ON THE DEVICE (ovqe_ground_state: random start
+    vector, i.e. the minimum over the whole register like eigh's column 0) — returned in eigh's (values, vectors) shape"""
     if hamiltonian_sp.nbqbits <= _DENSE_EIGH_MAX_QUBITS:
         return np.linalg.eigh(hamiltonian_sp.get_matrix())
-    vals, vecs = scipy.sparse.linalg.eigsh(hamiltonian_sp.get_matrix(sparse=True), k=1, which="SA")
-    return vals, vecs
+    sv = _screen_backend(hamiltonian_sp.nbqbits)
+    if getattr(sv, "_ham_token", None) is not hamiltonian_sp:
+        sv.set_hamiltonian(hamiltonian_sp)
+        sv._ham_token = hamiltonian_sp
+    energy, _, _ = sv.ground_state(tol=1e-10)
+    return np.array([energy]), sv.get_state().reshape(-1, 1)
 
 
 def fermionic_adapt_vqe(hamiltonian_sparse, cluster_ops_sparse, reference_ket, hamiltonian_sp, cluster_ops_sp,

@@ -233,6 +233,14 @@ class Statevector:
         self._ck(self._L.ovqe_last_batch_ms(self._h, ctypes.byref(out)))
         return out.value
 
+    def ground_state(self, tol=1e-10, max_iter=3000, seed=20250227):
+        """lowest eigenpair of the stored Hamiltonian by device-side Lanczos; the eigenvector is left in the
+        state buffer (``get_state``).  -> (energy, residual |H y - E y|, iterations)"""
+        e, r, it = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        self._ck(self._L.ovqe_ground_state(self._h, float(tol), int(max_iter), int(seed), ctypes.byref(e),
+                                           ctypes.byref(r), ctypes.byref(it)))
+        return e.value, r.value, it.value
+
     def program_info(self):
         """shape of the compiled program: ops, rotations, literal gates, sweeps per evaluation, tiled sweeps,
         fused-kernel ops, support size (-1 = not analysed yet)"""

@@ -2116,6 +2116,182 @@ int ovqe_apply_exp_pauli_sum(ovqe_handle h, int64_t T, const uint64_t *x, const 
     return rc;
 }
 
+// ---- ground state of the stored Hamiltonian: Lanczos on the device -------------------------------------------
+namespace {
+
+// lowest eigenpair of the symmetric tridiagonal matrix (a[0..m), b[0..m-1)): bisection on the Sturm count, then
+// inverse iteration with a shift just below the eigenvalue (T - mu is positive definite: LDL^T without pivoting)
+void tridiag_lowest(const std::vector<double> &a, const std::vector<double> &b, int m, double *lam,
+                    std::vector<double> &s) {
+    double lo = 1e300, hi = -1e300;
+    for (int i = 0; i < m; ++i) {
+        const double r = (i > 0 ? std::fabs(b[i - 1]) : 0.0) + (i < m - 1 ? std::fabs(b[i]) : 0.0);
+        lo = std::min(lo, a[i] - r);
+        hi = std::max(hi, a[i] + r);
+    }
+    const double scale = std::max({std::fabs(lo), std::fabs(hi), 1e-300});
+    auto below = [&](double x) {  // number of eigenvalues < x
+        int c = 0;
+        double d = 1.0;
+        for (int i = 0; i < m; ++i) {
+            d = a[i] - x - (i > 0 ? b[i - 1] * b[i - 1] / d : 0.0);
+            if (std::fabs(d) < 1e-300) d = -1e-300;
+            if (d < 0.0) ++c;
+        }
+        return c;
+    };
+    for (int it = 0; it < 300 && hi - lo > 4e-16 * scale; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (below(mid) >= 1) hi = mid; else lo = mid;
+    }
+    *lam = 0.5 * (lo + hi);
+    const double mu = *lam - 1e-9 * scale;
+    std::vector<double> d(m), l(std::max(m - 1, 0));
+    d[0] = a[0] - mu;
+    for (int i = 0; i + 1 < m; ++i) {
+        l[i] = b[i] / d[i];
+        d[i + 1] = a[i + 1] - mu - l[i] * b[i];
+    }
+    s.assign(m, 1.0 / std::sqrt((double)m));
+    for (int it = 0; it < 6; ++it) {
+        for (int i = 1; i < m; ++i) s[i] -= l[i - 1] * s[i - 1];
+        for (int i = 0; i < m; ++i) s[i] /= d[i];
+        for (int i = m - 2; i >= 0; --i) s[i] -= l[i] * s[i + 1];
+        double nrm = 0.0;
+        for (int i = 0; i < m; ++i) nrm += s[i] * s[i];
+        nrm = 1.0 / std::sqrt(nrm);
+        for (int i = 0; i < m; ++i) s[i] *= nrm;
+    }
+}
+
+struct Lanczos {
+    ovqe_handle h;
+    int nb;
+    int reduce_to_host(double2 *out) {
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->stream, (const double2 *)h->d_partials.p, (int64_t)nb,
+                           (double2 *)h->d_result.p, 0);
+        HIPC(h, hipGetLastError());
+        HIPC(h, hipMemcpyAsync(h->h_result, h->d_result.p, sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+        HIPC(h, hipStreamSynchronize(h->stream));
+        *out = h->h_result[0];
+        return OVQE_OK;
+    }
+    void apply_h(amp_t *out, const amp_t *in) {
+        hipLaunchKernelGGL(k_apply_sum, dim3(nb), dim3(256), 0, h->stream, out, in, (amp_t *)nullptr, h->namps, h->base,
+                           (const HGroup *)h->ham.d_groups.p, (int)h->ham.groups.size(), (const HTerm *)h->ham.d_terms.p,
+                           1.0, 0.0, 0.0, 0.0);
+    }
+    int dot(const amp_t *a, const amp_t *b, double2 *out) {
+        hipLaunchKernelGGL(k_dot, dim3(nb), dim3(256), 0, h->stream, a, b, h->namps, (double2 *)h->d_partials.p);
+        return reduce_to_host(out);
+    }
+    int update(amp_t *w, const amp_t *v, const amp_t *vprev, double alpha, double beta, double *norm) {
+        hipLaunchKernelGGL(k_lanczos_update, dim3(nb), dim3(256), 0, h->stream, w, v, vprev, alpha, beta, h->namps,
+                           (double2 *)h->d_partials.p);
+        double2 r;
+        int rc = reduce_to_host(&r);
+        *norm = std::sqrt(r.x);
+        return rc;
+    }
+    int start(amp_t *v, uint64_t seed) {
+        hipLaunchKernelGGL(k_randomize, dim3(nb), dim3(256), 0, h->stream, v, h->namps, h->base, seed, 1.0,
+                           (double2 *)h->d_partials.p);
+        double2 r;
+        int rc = reduce_to_host(&r);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_scale, dim3(nb), dim3(256), 0, h->stream, v, h->namps, 1.0 / std::sqrt(r.x));
+        return OVQE_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" int ovqe_ground_state(ovqe_handle h, double tol, int max_iter, uint64_t seed, double *energy,
+                                 double *residual, int *iterations) {
+    OVQE_ENTER(h);
+    if (!h || !energy || max_iter < 1 || !(tol > 0.0)) return OVQE_ERR_INVALID;
+    if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
+    if (h->n_global) return fail(h, OVQE_ERR_INVALID, "ovqe_ground_state is single-device");
+    int rc = ensure_scratch(h, 0);
+    if (!rc) rc = ensure_scratch(h, 1);
+    Lanczos L{h, reduce_blocks(h->namps)};
+    if (!rc) rc = ensure(h, h->d_partials, (size_t)L.nb * sizeof(double2));
+    if (!rc) rc = ensure(h, h->d_result, 64 * sizeof(double2));
+    if (rc) return rc;
+    max_iter = (int)std::min<uint64_t>((uint64_t)max_iter, h->namps);
+    amp_t *tmp = nullptr;
+    if (hipMalloc((void **)&tmp, h->namps * sizeof(amp_t)) != hipSuccess) return fail(h, OVQE_ERR_ALLOC, "hipMalloc Lanczos vector");
+    std::vector<double> alpha, beta, s;
+    double lam = 0.0, est = 0.0;
+    int m = 0;
+    auto recurrence = [&](bool accumulate) -> int {
+        amp_t *A = h->scratch[0], *B = h->scratch[1], *C = tmp;  // v_{j-1}, v_j, w
+        int r = L.start(B, seed);
+        if (r) return r;
+        if (accumulate)
+            hipLaunchKernelGGL(k_axpy_real, dim3(L.nb), dim3(256), 0, h->stream, h->state, (const amp_t *)B, s[0], h->namps, 1);
+        const int steps = accumulate ? m - 1 : max_iter;
+        for (int j = 0; j < steps; ++j) {
+            L.apply_h(C, B);
+            double bj;
+            if (accumulate) {
+                r = L.update(C, B, j ? A : nullptr, alpha[j], j ? beta[j - 1] : 0.0, &bj);
+                if (r) return r;
+                bj = beta[j];
+            } else {
+                double2 d;
+                r = L.dot(B, C, &d);
+                if (r) return r;
+                alpha.push_back(d.x);
+                r = L.update(C, B, j ? A : nullptr, d.x, j ? beta[j - 1] : 0.0, &bj);
+                if (r) return r;
+                m = j + 1;
+                const bool last = j + 1 == steps || bj < 1e-13 * std::max(1.0, std::fabs(d.x));
+                if (last || (j >= 4 && j % 5 == 4)) {
+                    tridiag_lowest(alpha, beta, m, &lam, s);
+                    est = std::fabs(bj * s[m - 1]);
+                    if (last || est < tol * std::max(1.0, std::fabs(lam))) return OVQE_OK;
+                }
+                beta.push_back(bj);
+            }
+            hipLaunchKernelGGL(k_scale, dim3(L.nb), dim3(256), 0, h->stream, C, h->namps, 1.0 / bj);
+            amp_t *t = A;
+            A = B;
+            B = C;
+            C = t;
+            if (accumulate)
+                hipLaunchKernelGGL(k_axpy_real, dim3(L.nb), dim3(256), 0, h->stream, h->state, (const amp_t *)B, s[j + 1],
+                                   h->namps, 0);
+        }
+        return OVQE_OK;
+    };
+    rc = recurrence(false);       // pass 1: the tridiagonal matrix
+    if (!rc) rc = recurrence(true);  // pass 2: the Ritz vector, same recurrence
+    double true_res = 0.0;
+    if (!rc) {
+        // normalise, Rayleigh quotient and true residual |H y - lambda y|
+        double2 d;
+        rc = L.dot(h->state, h->state, &d);
+        if (!rc) {
+            hipLaunchKernelGGL(k_scale, dim3(L.nb), dim3(256), 0, h->stream, h->state, h->namps, 1.0 / std::sqrt(d.x));
+            L.apply_h(tmp, h->state);
+            rc = L.dot(h->state, tmp, &d);
+        }
+        if (!rc) {
+            lam = d.x;
+            rc = L.update(tmp, h->state, nullptr, lam, 0.0, &true_res);
+        }
+    }
+    if (!rc && hipGetLastError() != hipSuccess) rc = fail(h, OVQE_ERR_HIP, "ground_state: launch failed");
+    (void)hipFree(tmp);
+    if (rc) return rc;
+    *energy = lam + h->ham.constant;
+    if (residual) *residual = true_res;
+    if (iterations) *iterations = m;
+    (void)est;
+    return OVQE_OK;
+}
+
 // ---- measurement support ------------------------------------------------------------------------
 int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, int warmup, int reps, double *avg_ms) {
     OVQE_ENTER(h);

@@ -497,6 +497,59 @@ __global__ __launch_bounds__(256) void k_norm2(const amp_t *__restrict__ st, uin
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
+// ---- Lanczos support (ovqe_ground_state) ---------------------------------------------------------------
+// partials[b] = sum_i conj(a_i) b_i over the block's grid-stride slice
+__global__ __launch_bounds__(256) void k_dot(const amp_t *__restrict__ a, const amp_t *__restrict__ b, uint64_t namps,
+                                             double2 *__restrict__ partials) {
+    __shared__ double2 red[4];
+    double2 acc = make_double2(0.0, 0.0);
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) {
+        const amp_t u = a[i], v = b[i];
+        acc.x += u.x * v.x + u.y * v.y;
+        acc.y += u.x * v.y - u.y * v.x;
+    }
+    const double2 t = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// w <- w - alpha v - beta vprev ;  partials[b] = sum |w_i|^2   (vprev may be null)
+__global__ __launch_bounds__(256) void k_lanczos_update(amp_t *__restrict__ w, const amp_t *__restrict__ v,
+                                                        const amp_t *__restrict__ vprev, double alpha, double beta,
+                                                        uint64_t namps, double2 *__restrict__ partials) {
+    __shared__ double2 red[4];
+    double acc = 0.0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) {
+        amp_t r = w[i];
+        const amp_t a = v[i];
+        r.x -= alpha * a.x;
+        r.y -= alpha * a.y;
+        if (vprev) {
+            const amp_t b = vprev[i];
+            r.x -= beta * b.x;
+            r.y -= beta * b.y;
+        }
+        w[i] = r;
+        acc += r.x * r.x + r.y * r.y;
+    }
+    const double2 t = block_sum<256>(make_double2(acc, 0.0), red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// y <- (init ? 0 : y) + s * v
+__global__ __launch_bounds__(256) void k_axpy_real(amp_t *__restrict__ y, const amp_t *__restrict__ v, double s,
+                                                   uint64_t namps, int init) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) {
+        const amp_t a = v[i];
+        amp_t r = init ? make_double2(0.0, 0.0) : y[i];
+        r.x += s * a.x;
+        r.y += s * a.y;
+        y[i] = r;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gather(const amp_t *__restrict__ st, int64_t count,
                                                 const uint64_t *__restrict__ idx, amp_t *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

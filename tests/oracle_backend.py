@@ -73,6 +73,17 @@ class OracleStatevector:
         assert np.abs(cs.imag).max(initial=0) < 1e-12
         self._ham = (xs, zs, cs.real, complex(hamiltonian.constant_coeff or 0).real)
 
+    def ground_state(self, tol=1e-10, max_iter=3000, seed=0):
+        """checker of ovqe_ground_state: matrix-free scipy Lanczos (ARPACK) on the bit-mask oracle's H|v>"""
+        import scipy.sparse.linalg as sla
+        xs, zs, cs, const = self._ham
+        op = sla.LinearOperator((self.psi.size,) * 2, dtype=complex,
+                                matvec=lambda v: masks.apply_pauli_sum(np.asarray(v, complex).ravel(), xs, zs, cs))
+        vals, vecs = sla.eigsh(op, k=1, which="SA", tol=tol)
+        self.psi = vecs[:, 0] / np.linalg.norm(vecs[:, 0])
+        res = np.linalg.norm(masks.apply_pauli_sum(self.psi, xs, zs, cs) - vals[0] * self.psi)
+        return float(vals[0] + const), float(res), 0
+
     def set_rotation_program(self, xs, zs, coeffs, pidx, n_params, hf_init, phi0=None):
         phi0 = np.zeros(len(xs)) if phi0 is None else np.asarray(phi0)
         self._prog = ("rot", np.asarray(xs), np.asarray(zs), np.asarray(coeffs), phi0, np.asarray(pidx), int(hf_init))

@@ -164,3 +164,21 @@ def test_adapt_screen_on_synthetic_8_qubits(gpu_lib):
     assert np.abs(ranks["hip"][0] - ranks["oracle"][0]).max() < 1e-12
     assert ranks["hip"][1] == ranks["oracle"][1]
     assert ranks["hip"][2] == ranks["oracle"][2]
+
+
+def test_fermionic_adapt_fidelity_with_device_ground_state(h2, monkeypatch):
+    """the fidelity column of fermionic ADAPT when the exact ground vector comes from ovqe_ground_state (the path taken
+    above 12 qubits) instead of the reference's dense eigh: identical to 1e-9"""
+    import openvqe_amd.adapt.fermionic_adapt_vqe as fa
+    ham, hf, e0 = h2
+    pool = fermion.uccsd_pool_antihermitian(2, 1)
+    args = dict(n_max_grads=1, fci=e0, optimizer="COBYLA", tolerance=1e-6, type_conver="norm",
+                threshold_needed=1e-2, max_external_iterations=10)
+    out = {}
+    for label, limit in (("eigh", 12), ("lanczos", 2)):
+        with engine("hip"):
+            monkeypatch.setattr(fa, "_DENSE_EIGH_MAX_QUBITS", limit)
+            out[label] = fa.fermionic_adapt_vqe(None, None, None, ham, pool, hf, **args)
+    assert out["eigh"][1]["indices"] == out["lanczos"][1]["indices"]
+    assert np.abs(np.array(out["eigh"][0]["fidelity"]) - np.array(out["lanczos"][0]["fidelity"])).max() < 1e-9
+    assert out["lanczos"][0]["fidelity"][-1] > 0.9

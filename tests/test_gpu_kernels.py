@@ -457,3 +457,46 @@ def test_device_resident_batches_and_sparse_fallbacks(SV):
         sv.set_option("force_path", 3)
         with pytest.raises(BackendError):
             sv.energy([0.3, -0.2])
+
+
+@pytest.mark.parametrize("n,kind", [(1, "random"), (4, "random"), (8, "molecule"), (10, "random"), (12, "molecule"),
+                                    (14, "molecule")])
+def test_ground_state_lanczos(SV, n, kind):
+    """ovqe_ground_state (device Lanczos, the stand-in for the reference's dense eigh of fermionic_adapt_vqe.py:474)
+    against numpy's dense eigh (n <= 10) / the oracle engine's matrix-free ARPACK run above"""
+    from openvqe_amd import fermion
+    from tests.oracle_backend import OracleStatevector
+    rng = np.random.default_rng(4000 + n)
+    if kind == "molecule":
+        H, _, _ = fermion.synthetic_molecule(n // 2, max(1, n // 4), seed=n)
+    else:
+        H = random_hamiltonian(rng, n, min(30, 4 ** n - 1))
+    with SV(n) as sv:
+        sv.set_hamiltonian(H)
+        e, res, its = sv.ground_state(tol=1e-11)
+        vec = sv.get_state()
+        e_state = sv.expectation(H)
+    assert abs(np.linalg.norm(vec) - 1.0) < 1e-12
+    assert abs(e_state - e) < 1e-9
+    if n <= 10:
+        w, v = np.linalg.eigh(H.get_matrix())
+        e_ref = w[0]
+        ground = v[:, np.abs(w - w[0]) < 1e-9]          # the ground SPACE (degenerate levels)
+        overlap = np.linalg.norm(ground.conj().T @ vec) ** 2
+    elif n <= 12:
+        o = OracleStatevector(n)
+        o.set_hamiltonian(H)
+        e_ref, _, _ = o.ground_state(tol=1e-12)
+        overlap = None
+    else:  # an eigenpair by its residual; lowest: not above the Hartree-Fock-like basis-state energies
+        e_ref, overlap = e, None
+        with SV(n) as sv:
+            sv.set_hamiltonian(H)
+            for idx in (0, (1 << n) - 1, int(rng.integers(0, 1 << n))):
+                sv.init_basis(idx)
+                assert sv.expectation(H) >= e - 1e-9
+    scale = max(1.0, sum(abs(t.coeff) for t in H.terms))
+    assert abs(e - e_ref) < 1e-9 * scale, (e, e_ref, its)
+    assert res < 1e-6 * scale
+    if overlap is not None:
+        assert abs(overlap - 1.0) < 1e-8, overlap

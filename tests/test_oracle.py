@@ -187,3 +187,16 @@ def test_c_gate_program_matches_dense_oracle():
                                 [g[4] for g in gates], theta, hx, hz, hc.real.copy(), H.constant_coeff)
     assert np.abs(psi_c - psi).max() < 1e-13
     assert abs(e - dense.expectation(H, psi)) < 1e-11
+
+
+def test_oracle_engine_ground_state_matches_dense_eigh():
+    """the checker of ovqe_ground_state (matrix-free ARPACK on the bit-mask oracle) against numpy's dense eigh"""
+    from tests.oracle_backend import OracleStatevector
+    n = 6
+    H = random_hamiltonian(np.random.default_rng(66), n, 40)
+    o = OracleStatevector(n)
+    o.set_hamiltonian(H)
+    e, res, _ = o.ground_state(tol=1e-12)
+    w, v = np.linalg.eigh(H.get_matrix())
+    assert abs(e - w[0]) < 1e-10 and res < 1e-8
+    assert abs(abs(np.vdot(v[:, 0], o.get_state())) - 1.0) < 1e-8
