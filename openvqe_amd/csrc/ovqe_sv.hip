@@ -31,6 +31,14 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+struct TilePlan {  // segmentation of an op list into LDS-tiled sweeps (sv_tile.hpp)
+    std::vector<TileSeg> tsegs;
+    std::vector<TileOp> tops;
+    std::vector<TileRot> trots;
+    std::vector<int32_t> plan;  // >= 0: tile segment; < 0: op (-1 - index) launched as its own sweep
+    DevBuf d_tops, d_trots;
+};
+
 struct HamDev {  // grouped Pauli sum resident on the device
     std::vector<HGroup> groups;
     std::vector<HTerm> terms;
@@ -65,6 +73,9 @@ struct ovqe_sv {
     double2 *h_result = nullptr;  // pinned, small
 
     HamDev ham;
+    HamDev ham_adhoc;             // last Hermitian sum evaluated by ovqe_expectation / ovqe_bilinear on the own state
+    std::vector<uint64_t> adhoc_x, adhoc_z;
+    std::vector<double> adhoc_c;
     // compiled program
     bool prog_set = false;
     int32_t K = 0;
@@ -111,11 +122,8 @@ struct ovqe_sv {
     double2 init_amp = make_double2(1.0, 0.0);  // amplitude of |hf> (global phase of a folded Clifford part)
     int opt_clifford_frame = 1;   // gate programs: 0 literal, 1 Clifford-frame form when the frame closes, 2 forced
     int opt_tile_low = 4;         // lowest index bits always inside the tile (contiguous 16 B << low chunks)
-    std::vector<TileSeg> tsegs;
-    std::vector<TileOp> tops;
-    std::vector<TileRot> trots;
-    std::vector<int32_t> plan;    // >= 0: tile segment; < 0: op (-1 - index) launched as its own sweep
-    DevBuf d_tops, d_trots;
+    TilePlan tp;                  // of the stored program
+    TilePlan tp_adhoc;            // of the rotation list of the current ovqe_apply_pauli_rotations call
 };
 
 namespace {
@@ -383,8 +391,7 @@ inline uint32_t extract_bits(uint64_t v, uint64_t mask) {  // pext
 // ---- tiled expectation (sv_tile.hpp) -----------------------------------------------------------------------
 // Greedy cover of the x-groups by tile bit sets: a set starts from the mandatory low bits and grows by the bit that
 // brings the most still-uncovered groups within reach (groups that are nearly inside count more).
-int build_ham_tiles(ovqe_handle h) {
-    HamDev &H = h->ham;
+int build_ham_tiles(ovqe_handle h, HamDev &H) {
     const int M = tile_bits(h), L = h->opt_tile_low;
     H.tile_bits = M;
     H.tile_low = L;
@@ -529,7 +536,7 @@ int build_ham_tiles(ovqe_handle h) {
 }
 
 template <int M>
-int launch_tile_expect(ovqe_handle h, const ExSweep &sw, double2 *partials, int accumulate) {
+int launch_tile_expect(ovqe_handle h, const HamDev &H, const ExSweep &sw, double2 *partials, int accumulate) {
     constexpr int NT = 1 << TILE_EXPECT_LOG_NT;
     const size_t smem = ((size_t)16 << M) + TILE_TERM_CAP * sizeof(ExTermLds) + (NT / 64) * sizeof(double2);
     const unsigned grid = (unsigned)(h->namps >> M);
@@ -541,7 +548,6 @@ int launch_tile_expect(ovqe_handle h, const ExSweep &sw, double2 *partials, int 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done = true;
     }
-    const HamDev &H = h->ham;
     if (h->n_local >= 25) {
         hipLaunchKernelGGL((k_tile_expect<M, NT, true>), dim3(grid), dim3(NT), smem, h->stream, h->state, h->base, sw,
                            (const ExChunkT *)H.d_tchunks.p, (const ExEntryT *)H.d_tgroups.p,
@@ -556,11 +562,10 @@ int launch_tile_expect(ovqe_handle h, const ExSweep &sw, double2 *partials, int 
 }
 
 // <state|H|state> of the stored Hamiltonian through the tile cover; *used = false when there is no cover
-int run_expectation_tiled(ovqe_handle h, double2 *out, bool *used) {
-    HamDev &H = h->ham;
+int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used) {
     *used = false;
     if (H.tile_bits != tile_bits(h) || H.tile_low != h->opt_tile_low) {
-        int rc = build_ham_tiles(h);
+        int rc = build_ham_tiles(h, H);
         if (rc) return rc;
     }
     if (H.tsweeps.empty()) return OVQE_OK;
@@ -575,9 +580,9 @@ int run_expectation_tiled(ovqe_handle h, double2 *out, bool *used) {
     int acc = 0;
     for (const ExSweep &sw : H.tsweeps) {
         switch (M) {
-        case 10: rc = launch_tile_expect<10>(h, sw, partials, acc); break;
-        case 11: rc = launch_tile_expect<11>(h, sw, partials, acc); break;
-        default: rc = launch_tile_expect<12>(h, sw, partials, acc); break;
+        case 10: rc = launch_tile_expect<10>(h, H, sw, partials, acc); break;
+        case 11: rc = launch_tile_expect<11>(h, H, sw, partials, acc); break;
+        default: rc = launch_tile_expect<12>(h, H, sw, partials, acc); break;
         }
         if (rc) return rc;
         acc = 1;
@@ -609,7 +614,7 @@ int init_basis(ovqe_handle h, uint64_t index, double2 one = make_double2(1.0, 0.
 
 // ---- LDS-tiled multi-op sweeps (sv_tile.hpp) --------------------------------------------------------
 template <int M>
-int launch_tile(ovqe_handle h, const TileSeg &sg) {
+int launch_tile(ovqe_handle h, const TilePlan &tp, const TileSeg &sg) {
     constexpr int NT = 256;
     const size_t smem = ((size_t)16 << M) + TILE_ROT_CAP * sizeof(RotLds);
     const unsigned grid = (unsigned)(h->namps >> M);
@@ -624,20 +629,20 @@ int launch_tile(ovqe_handle h, const TileSeg &sg) {
     }
     if (ntl) {
         hipLaunchKernelGGL((k_tile_sweep<M, NT, true>), dim3(grid), dim3(NT), smem, h->stream, h->state, h->base, sg,
-                           (const TileOp *)h->d_tops.p, (const TileRot *)h->d_trots.p, (const RotParam *)h->d_rp.p);
+                           (const TileOp *)tp.d_tops.p, (const TileRot *)tp.d_trots.p, (const RotParam *)h->d_rp.p);
     } else {
         hipLaunchKernelGGL((k_tile_sweep<M, NT, false>), dim3(grid), dim3(NT), smem, h->stream, h->state, h->base, sg,
-                           (const TileOp *)h->d_tops.p, (const TileRot *)h->d_trots.p, (const RotParam *)h->d_rp.p);
+                           (const TileOp *)tp.d_tops.p, (const TileRot *)tp.d_trots.p, (const RotParam *)h->d_rp.p);
     }
     HIPC(h, hipGetLastError());
     return OVQE_OK;
 }
 
-int launch_tile_segment(ovqe_handle h, const TileSeg &sg) {
+int launch_tile_segment(ovqe_handle h, const TilePlan &tp, const TileSeg &sg) {
     switch (__builtin_popcountll(sg.smask)) {
-    case 10: return launch_tile<10>(h, sg);
-    case 11: return launch_tile<11>(h, sg);
-    case 12: return launch_tile<12>(h, sg);
+    case 10: return launch_tile<10>(h, tp, sg);
+    case 11: return launch_tile<11>(h, tp, sg);
+    case 12: return launch_tile<12>(h, tp, sg);
     }
     return fail(h, OVQE_ERR_INVALID, "corrupt tile segment");
 }
@@ -647,16 +652,17 @@ int launch_tile_segment(ovqe_handle h, const TileSeg &sg) {
 // segments of a single op, keep their own full-bandwidth sweep.  Commuting runs enter a tile in their OP_TAB form
 // (one rotation per active pair pattern, see try_table_op): inside a fused sweep the arithmetic, not HBM, is the
 // cost, and the table form does 1/64 of it for a JW double excitation.
-int build_tile_program(ovqe_handle h) {
-    h->tsegs.clear();
-    h->tops.clear();
-    h->trots.assign(h->srots.size(), TileRot{0, 0, 0});
-    h->plan.clear();
+int build_tile_plan(ovqe_handle h, const std::vector<SmallOp> &sops, const std::vector<SmallRot> &srots,
+                    const std::vector<uint64_t> &sop_zc, TilePlan &tp) {
+    tp.tsegs.clear();
+    tp.tops.clear();
+    tp.trots.assign(srots.size(), TileRot{0, 0, 0});
+    tp.plan.clear();
     const int M = tile_bits(h);
-    const int nops = (int)h->sops.size();
+    const int nops = (int)sops.size();
     const bool tiled = M >= 10 && M <= 12 && h->n_local >= M + 2 && h->opt_tile_low >= 0 && h->opt_tile_low <= 8;
     if (!tiled) {
-        for (int i = 0; i < nops; ++i) h->plan.push_back(-1 - i);
+        for (int i = 0; i < nops; ++i) tp.plan.push_back(-1 - i);
         return OVQE_OK;
     }
     const uint64_t lowbits = (1ull << h->opt_tile_low) - 1ull;
@@ -675,7 +681,7 @@ int build_tile_program(ovqe_handle h) {
         uint64_t S = lowbits;
         int j = i, nrot = 0;
         while (j < nops) {
-            const SmallOp &op = h->sops[j];
+            const SmallOp &op = sops[j];
             const uint64_t nb = S | need(op);
             if (__builtin_popcountll(nb) > M) break;
             if (is_rot(op) && nrot + op.count > TILE_ROT_CAP) break;
@@ -684,7 +690,7 @@ int build_tile_program(ovqe_handle h) {
             ++j;
         }
         if (j - i < 2) {
-            h->plan.push_back(-1 - i);
+            tp.plan.push_back(-1 - i);
             ++i;
             continue;
         }
@@ -698,10 +704,10 @@ int build_tile_program(ovqe_handle h) {
         }
         sg.mask_lo = lo;
         sg.mask_hi = S & ~lo;
-        sg.op0 = (int32_t)h->tops.size();
+        sg.op0 = (int32_t)tp.tops.size();
         sg.rot0 = sg.rot1 = -1;
         for (int o = i; o < j; ++o) {
-            const SmallOp &op = h->sops[o];
+            const SmallOp &op = sops[o];
             TileOp t = {};
             t.kind = (int16_t)op.kind;
             if (is_rot(op)) {
@@ -711,13 +717,13 @@ int build_tile_program(ovqe_handle h) {
                 t.count = op.count;
                 if (sg.rot0 < 0) sg.rot0 = op.first;
                 sg.rot1 = op.first + op.count;
-                const uint64_t zc = op.kind == OP_TAB ? h->sop_zc[o] : 0ull;
+                const uint64_t zc = op.kind == OP_TAB ? sop_zc[o] : 0ull;
                 t.zc = extract_bits(zc, S);
                 for (int r = op.first; r < op.first + op.count; ++r) {
                     // OP_TAB entries: z = the pattern's bits (inside x, hence inside the tile); the run's common z
                     // part outside the tile is a per-tile sign of every entry
-                    h->trots[r].zin = extract_bits(h->srots[r].z, S);
-                    h->trots[r].zout = op.kind == OP_TAB ? (zc & ~S) : (h->srots[r].z & ~S);
+                    tp.trots[r].zin = extract_bits(srots[r].z, S);
+                    tp.trots[r].zout = op.kind == OP_TAB ? (zc & ~S) : (srots[r].z & ~S);
                 }
             } else if (op.kind == OP_CNOT) {
                 const int cb = op.first, tbit = op.count;
@@ -728,18 +734,20 @@ int build_tile_program(ovqe_handle h) {
                 t.x = extract_bits(1ull << op.pivot, S);
                 t.pivot = (int16_t)(31 - __builtin_clz(t.x));
             }
-            h->tops.push_back(t);
+            tp.tops.push_back(t);
         }
         if (sg.rot0 < 0) sg.rot0 = sg.rot1 = 0;
-        sg.op1 = (int32_t)h->tops.size();
-        h->plan.push_back((int32_t)h->tsegs.size());
-        h->tsegs.push_back(sg);
+        sg.op1 = (int32_t)tp.tops.size();
+        tp.plan.push_back((int32_t)tp.tsegs.size());
+        tp.tsegs.push_back(sg);
         i = j;
     }
-    int rc = upload(h, h->d_tops, h->tops.data(), h->tops.size() * sizeof(TileOp));
+    int rc = upload(h, tp.d_tops, tp.tops.data(), tp.tops.size() * sizeof(TileOp));
     if (rc) return rc;
-    return upload(h, h->d_trots, h->trots.data(), h->trots.size() * sizeof(TileRot));
+    return upload(h, tp.d_trots, tp.trots.data(), tp.trots.size() * sizeof(TileRot));
 }
+
+int build_tile_program(ovqe_handle h) { return build_tile_plan(h, h->sops, h->srots, h->sop_zc, h->tp); }
 
 inline RotParam resolve_rot(const SmallRot &sr, const double *theta) {
     const double phi = sr.phi0 + (sr.pidx >= 0 ? sr.coeff * theta[sr.pidx] : 0.0);
@@ -767,9 +775,9 @@ int run_program_streaming(ovqe_handle h, const double *theta) {
     if (S + R)
         HIPC(h, hipMemcpyAsync(h->d_rp.p, h->h_rp, (S + R) * sizeof(RotParam), hipMemcpyHostToDevice, h->stream));
     const RotParam *d_rp = (const RotParam *)h->d_rp.p;
-    for (const int32_t step : h->plan) {
+    for (const int32_t step : h->tp.plan) {
         if (step >= 0) {
-            rc = launch_tile_segment(h, h->tsegs[step]);
+            rc = launch_tile_segment(h, h->tp, h->tp.tsegs[step]);
             if (rc) return rc;
             continue;
         }
@@ -1591,7 +1599,9 @@ int ovqe_destroy(ovqe_handle h) {
     DevBuf *bufs[] = {&h->d_partials, &h->d_result, &h->d_rp, &h->ham.d_groups, &h->ham.d_terms, &h->d_ops,
                       &h->d_rots, &h->d_segs, &h->d_stream, &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups,
                       &h->d_eterms, &h->d_echunks, &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries,
-                      &h->d_tops, &h->d_trots, &h->ham.d_tchunks, &h->ham.d_tgroups, &h->ham.d_tterms, &h->ham.d_rest};
+                      &h->tp.d_tops, &h->tp.d_trots, &h->tp_adhoc.d_tops, &h->tp_adhoc.d_trots, &h->ham.d_tchunks, &h->ham.d_tgroups, &h->ham.d_tterms, &h->ham.d_rest,
+                      &h->ham_adhoc.d_groups, &h->ham_adhoc.d_terms, &h->ham_adhoc.d_tchunks, &h->ham_adhoc.d_tgroups,
+                      &h->ham_adhoc.d_tterms, &h->ham_adhoc.d_rest};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (h->h_rp) (void)hipHostFree(h->h_rp);
@@ -1779,13 +1789,39 @@ int ovqe_apply_pauli_rotations(ovqe_handle h, int64_t R, const uint64_t *x, cons
     if (rc) return rc;
     for (int64_t r = 0; r < R; ++r) h->h_rp[r] = make_rot(x[r], z[r], phi[r]);
     HIPC(h, hipMemcpyAsync(h->d_rp.p, h->h_rp, (size_t)R * sizeof(RotParam), hipMemcpyHostToDevice, h->stream));
-    int64_t r0 = 0;
-    while (r0 < R) {
+    // same-x runs, then LDS-tiled multi-run sweeps where consecutive runs fit a tile (sharded registers: the local
+    // sweeps between two exchanges arrive here as one list)
+    std::vector<SmallOp> ops;
+    std::vector<SmallRot> rots((size_t)R);
+    for (int64_t r0 = 0; r0 < R;) {
         int64_t r1 = r0 + 1;
         while (r1 < R && x[r1] == x[r0]) ++r1;
-        rc = launch_rot_run(h, x[r0], (const RotParam *)h->d_rp.p + r0, (int)(r1 - r0));
-        if (rc) return rc;
+        SmallOp op = {};
+        op.x = x[r0];
+        op.kind = x[r0] ? OP_PAIR : OP_DIAG;
+        op.first = (int32_t)r0;
+        op.count = (int32_t)(r1 - r0);
+        op.pivot = x[r0] ? 63 - __builtin_clzll(x[r0]) : 0;
+        ops.push_back(op);
+        for (int64_t r = r0; r < r1; ++r) rots[(size_t)r].z = z[r];
         r0 = r1;
+    }
+    TilePlan &tp = h->tp_adhoc;
+    if (ops.size() >= 2 && R < (1ll << 30)) {
+        rc = build_tile_plan(h, ops, rots, std::vector<uint64_t>(ops.size(), 0), tp);
+        if (rc) return rc;
+    } else {
+        tp.plan.assign(ops.size(), 0);
+        for (size_t i = 0; i < ops.size(); ++i) tp.plan[i] = -1 - (int32_t)i;
+    }
+    for (const int32_t step : tp.plan) {
+        if (step >= 0) {
+            rc = launch_tile_segment(h, tp, tp.tsegs[step]);
+        } else {
+            const SmallOp &op = ops[-1 - step];
+            rc = launch_rot_run(h, op.x, (const RotParam *)h->d_rp.p + op.first, op.count);
+        }
+        if (rc) return rc;
     }
     HIPC(h, hipStreamSynchronize(h->stream));
     return OVQE_OK;
@@ -1823,6 +1859,39 @@ int ovqe_bilinear(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64
                   const uint64_t *z, const double *coeff_re, const double *coeff_im, double *out_re_im) {
     OVQE_ENTER(h);
     if (!h || T < 0 || !out_re_im || (T && (!x || !z || !coeff_re))) return OVQE_ERR_INVALID;
+    bool real_coeffs = true;  // real coefficients: every term is Hermitian -> pair-trick kernels when bra == ket
+    if (coeff_im)
+        for (int64_t t = 0; t < T; ++t) real_coeffs = real_coeffs && coeff_im[t] == 0.0;
+    if (!bra_dev && !ket_dev && real_coeffs && T > 0) {
+        // <state|H|state> of a Hermitian sum: kept (with its tile cover) until a different sum arrives — a sharded
+        // register evaluates the same local term list once per energy
+        HamDev &H = h->ham_adhoc;
+        const bool same = H.set && (int64_t)h->adhoc_x.size() == T &&
+                          std::equal(x, x + T, h->adhoc_x.begin()) && std::equal(z, z + T, h->adhoc_z.begin()) &&
+                          std::equal(coeff_re, coeff_re + T, h->adhoc_c.begin());
+        if (!same) {
+            H.set = false;
+            int rc = build_groups(h, T, x, z, coeff_re, nullptr, false, H.groups, H.terms);
+            if (rc) return rc;
+            rc = upload(h, H.d_groups, H.groups.data(), H.groups.size() * sizeof(HGroup));
+            if (!rc) rc = upload(h, H.d_terms, H.terms.data(), H.terms.size() * sizeof(HTerm));
+            if (rc) return rc;
+            h->adhoc_x.assign(x, x + T);
+            h->adhoc_z.assign(z, z + T);
+            h->adhoc_c.assign(coeff_re, coeff_re + T);
+            H.tile_bits = -1;
+            H.set = true;
+        }
+        double2 res = make_double2(0.0, 0.0);
+        bool tiled = false;
+        int rc = run_expectation_tiled(h, H, &res, &tiled);
+        if (!rc && !tiled)
+            rc = run_bilinear(h, h->state, h->state, H.groups, (const HGroup *)H.d_groups.p, (const HTerm *)H.d_terms.p,
+                              &res, true);
+        out_re_im[0] = res.x;
+        out_re_im[1] = res.y;
+        return rc;
+    }
     std::vector<HGroup> groups;
     std::vector<HTerm> terms;
     int rc = build_groups(h, T, x, z, coeff_re, coeff_im, /*allow_global_x=*/ket_dev != nullptr, groups, terms);
@@ -1830,14 +1899,10 @@ int ovqe_bilinear(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64
     DevBuf dg, dt;
     rc = upload(h, dg, groups.data(), groups.size() * sizeof(HGroup));
     if (!rc) rc = upload(h, dt, terms.data(), terms.size() * sizeof(HTerm));
-    bool real_coeffs = true;  // real coefficients: every term is Hermitian -> pair-trick kernel when bra == ket
-    if (coeff_im)
-        for (int64_t t = 0; t < T; ++t) real_coeffs = real_coeffs && coeff_im[t] == 0.0;
     double2 res = make_double2(0.0, 0.0);
     if (!rc)
         rc = run_bilinear(h, bra_dev ? (const amp_t *)bra_dev : h->state, ket_dev ? (const amp_t *)ket_dev : h->state,
-                          groups, (const HGroup *)dg.p, (const HTerm *)dt.p, &res,
-                          /*hermitian_expectation=*/!bra_dev && !ket_dev && real_coeffs);
+                          groups, (const HGroup *)dg.p, (const HTerm *)dt.p, &res, false);
     if (dg.p) (void)hipFree(dg.p);
     if (dt.p) (void)hipFree(dt.p);
     out_re_im[0] = res.x;
@@ -1952,7 +2017,7 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
         if (rc) return rc;
         double2 res;
         bool tiled = false;
-        rc = run_expectation_tiled(h, &res, &tiled);
+        rc = run_expectation_tiled(h, h->ham, &res, &tiled);
         if (rc) return rc;
         if (!tiled)
             rc = run_bilinear(h, h->state, h->state, h->ham.groups, (const HGroup *)h->ham.d_groups.p,
@@ -2321,8 +2386,8 @@ int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, 
 int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
     if (!h || !info || count < 0) return OVQE_ERR_INVALID;
     if (!h->prog_set) return fail(h, OVQE_ERR_STATE, "no program set");
-    int64_t v[12] = {(int64_t)h->ops.size(), (int64_t)h->rots.size(), 0, (int64_t)h->plan.size(),
-                     (int64_t)h->tsegs.size(), (int64_t)h->sops.size(),
+    int64_t v[12] = {(int64_t)h->ops.size(), (int64_t)h->rots.size(), 0, (int64_t)h->tp.plan.size(),
+                     (int64_t)h->tp.tsegs.size(), (int64_t)h->sops.size(),
                      !h->sp_tried ? -1 : (h->sp_valid ? (int64_t)h->sp_m : 0),
                      (int64_t)h->ham.tsweeps.size(), (int64_t)h->ham.n_rest, h->ham.tile_entries, h->ham.tile_terms,
                      h->ham.tile_work};

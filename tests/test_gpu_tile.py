@@ -180,3 +180,72 @@ def test_tiled_expectation_of_jw_hamiltonian(SV, m, o, tile_bits, tile_low):
     assert abs(es[0] - e_ref) < 1e-10 * scale
     assert abs(es[tile_bits] - e_ref) < 1e-10 * scale
     assert abs(es[tile_bits] - es[0]) < 1e-11 * scale
+
+
+@pytest.mark.parametrize("n,g", [(14, 0), (16, 0), (15, 1), (16, 2)])
+def test_tiled_rotation_lists_incl_shard_handles(SV, n, g):
+    """ovqe_apply_pauli_rotations on a random state: lists of low-weight strings (several same-x runs per tile sweep)
+    mixed with wide ones, on a plain handle and on shard handles (z on rank bits = per-shard sign)"""
+    from oracle import masks
+    from tests.util import random_state
+    rng = np.random.default_rng(1234 + 10 * n + g)
+    nl = n - g
+    psi = random_state(rng, n)
+    xs, zs, phis = [], [], []
+    ref = psi.copy()
+    for k in range(36):
+        if k % 9 == 8:
+            x = int(rng.integers(0, 1 << nl))                      # wide: keeps its own sweep
+        else:
+            bits = rng.choice(nl, int(rng.choice([1, 2, 4])), replace=False)
+            x = int(sum(1 << int(b) for b in bits))
+            if rng.random() < 0.15:
+                x = 0                                              # diagonal string
+        z = int(rng.integers(0, 1 << n))
+        phi = float(rng.uniform(-1, 1))
+        reps = 1 + int(rng.integers(0, 3))
+        for _ in range(reps):                                      # same-x run with different z
+            xs.append(x); zs.append(z ^ int(rng.integers(0, 1 << n))); phis.append(phi)
+            ref = masks.rotate(ref, xs[-1], zs[-1], phis[-1])
+    shards = [SV(nl, n_global=g, shard_index=s) for s in range(1 << g)]
+    try:
+        for s, sv in enumerate(shards):
+            sv.set_state(psi[s << nl:(s + 1) << nl])
+            sv.apply_pauli_rotations(xs, zs, phis)
+        got = np.concatenate([sv.get_state() for sv in shards])
+    finally:
+        for sv in shards:
+            sv.close()
+    assert np.abs(got - ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("n,g", [(14, 0), (16, 0), (15, 1)])
+def test_tiled_adhoc_expectation_incl_shard_handles(SV, n, g):
+    """ovqe_expectation / ovqe_bilinear on the handle's own state (Hermitian sum, local x): tile cover, cached between
+    calls, z on rank bits as per-shard signs; against the bit-mask oracle on a random state"""
+    from openvqe_amd import fermion
+    from oracle import masks
+    from tests.util import random_state
+    rng = np.random.default_rng(99 + n + g)
+    nl = n - g
+    psi = random_state(rng, n)
+    ham, _, _ = fermion.synthetic_molecule(nl // 2, 2, seed=n)          # JW strings on the local qubits ...
+    xs, zs, cs = ham.packed()
+    cs = cs.real.copy()
+    xs = xs.astype(np.uint64)
+    zs = (zs ^ (rng.integers(0, 1 << g, len(zs)).astype(np.uint64) << np.uint64(nl))) if g else zs   # ... z also on rank bits
+    want = masks.expectation(psi, xs, zs, cs)
+    shards = [SV(nl, n_global=g, shard_index=s) for s in range(1 << g)]
+    try:
+        got = []
+        for rep in range(2):                                               # second call: cached cover
+            tot = 0.0
+            for s, sv in enumerate(shards):
+                sv.set_state(psi[s << nl:(s + 1) << nl])
+                tot += sv.bilinear(xs, zs, cs).real
+            got.append(tot)
+    finally:
+        for sv in shards:
+            sv.close()
+    scale = np.abs(cs).sum()
+    assert abs(got[0] - want) < 1e-11 * scale and got[0] == got[1]
