@@ -615,7 +615,7 @@ int init_basis(ovqe_handle h, uint64_t index, double2 one = make_double2(1.0, 0.
 // ---- LDS-tiled multi-op sweeps (sv_tile.hpp) --------------------------------------------------------
 template <int M>
 int launch_tile(ovqe_handle h, const TilePlan &tp, const TileSeg &sg) {
-    constexpr int NT = 256;
+    constexpr int NT = 1 << TILE_SWEEP_LOG_NT;
     const size_t smem = ((size_t)16 << M) + TILE_ROT_CAP * sizeof(RotLds);
     const unsigned grid = (unsigned)(h->namps >> M);
     const bool ntl = h->n_local >= 25;
@@ -698,7 +698,7 @@ int build_tile_plan(ovqe_handle h, const std::vector<SmallOp> &sops, const std::
         TileSeg sg = {};
         sg.smask = S;
         uint64_t lo = 0, mk = S;
-        for (int k = 0; k < 8; ++k) {  // log2(NT) = 8 thread bits
+        for (int k = 0; k < TILE_SWEEP_LOG_NT; ++k) {  // thread bits
             lo |= mk & (0ull - mk);
             mk &= mk - 1ull;
         }

@@ -16,6 +16,7 @@
 namespace ovqe {
 
 constexpr int TILE_ROT_CAP = 256;  // rotation entries staged in LDS per segment
+constexpr int TILE_SWEEP_LOG_NT = 9;  // threads per workgroup of k_tile_sweep
 
 struct TileSeg {       // one HBM sweep
     uint64_t smask;    // the tile's index bits (|smask| = M)
