@@ -396,7 +396,7 @@ def main():
                 "worst_string": worst,
                 "per_string": rows,
             }
-        if not args.no_extra:
+        if not args.no_extra and world == 1:  # side figures belong to the single-GPU line; N > 1 ranks only wait
             out["extra_workloads"] = extra_workloads_leg(local_rank)
         if not args.no_cpu and world == 1:
             cpu, cores = cpu_baseline_leg(ham, gens, hf, thetas_host[0], args.cpu_seconds)
