@@ -163,6 +163,14 @@ int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, co
 int ovqe_apply_exp_pauli_sum(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff_re,
                              const double *coeff_im, double theta);
 
+/* ---- E(theta) and its EXACT gradient dE/dtheta[K] by the adjoint (reverse-mode) method: psi = U(theta)|hf>,
+ * lambda = H psi, then one backward pass over the program that un-applies every rotation from both states and reads
+ * dE/dtheta_p = sum_{r: pidx_r = p} 2 c_r Im <lambda_r|P_r|psi_r> on the way — about three circuit executions for
+ * ALL K derivatives, where the reference's BFGS (jac=None, ref:openvqe/ucc_family/get_energy_ucc.py:158-175) spends K+1
+ * evaluations on forward differences (opt-in, because exact derivatives change the
+ * optimiser's iterates at the 1e-8 level).  Streaming kernels, any n; the state buffer is left in |hf>. */
+int ovqe_energy_gradient(ovqe_handle h, const double *theta, int32_t K, double *energy, double *grad);
+
 /* ---- lowest eigenpair of the stored Hamiltonian (Lanczos on the device, two-pass: tridiagonal matrix, then the Ritz
  * vector by the same recurrence; random start vector from `seed`, so every symmetry sector is reached — the global
  * minimum over the whole register, like column 0 of the reference's dense np.linalg.eigh,

@@ -233,6 +233,17 @@ class Statevector:
         self._ck(self._L.ovqe_last_batch_ms(self._h, ctypes.byref(out)))
         return out.value
 
+    def energy_gradient(self, theta):
+        """E(theta) and the exact gradient dE/dtheta by the adjoint method (one forward + one backward pass over the
+        program for all K derivatives) -> (energy, grad[K])"""
+        theta = np.ascontiguousarray(theta, np.float64).reshape(-1)[: self._K]
+        if theta.shape[0] != self._K:
+            raise ValueError(f"expected {self._K} parameters")
+        e = ctypes.c_double()
+        grad = np.zeros(max(self._K, 1), np.float64)
+        self._ck(self._L.ovqe_energy_gradient(self._h, theta if self._K else np.zeros(1), self._K, ctypes.byref(e), grad))
+        return e.value, grad[: self._K]
+
     def ground_state(self, tol=1e-10, max_iter=3000, seed=20250227):
         """lowest eigenpair of the stored Hamiltonian by device-side Lanczos; the eigenvector is left in the
         state buffer (``get_state``).  -> (energy, residual |H y - E y|, iterations)"""

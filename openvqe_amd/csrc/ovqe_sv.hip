@@ -303,14 +303,15 @@ int launch_rot_run(ovqe_handle h, uint64_t x, const RotParam *d_rp, int nrot) {
     return OVQE_OK;
 }
 
-int launch_gate(ovqe_handle h, int kind, int b0, int b1) {
+int launch_gate(ovqe_handle h, int kind, int b0, int b1, amp_t *st = nullptr) {
+    if (!st) st = h->state;
     const uint64_t nwork = kind == 2 ? (h->namps >> 2) : (h->namps >> 1);
     if (nwork == 0) return fail(h, OVQE_ERR_INVALID, "register too small for this gate");
     if (nwork >= 1024) {
-        hipLaunchKernelGGL(k_gate<4>, dim3((unsigned)((nwork + 1023) / 1024)), dim3(256), 0, h->stream, h->state, nwork,
+        hipLaunchKernelGGL(k_gate<4>, dim3((unsigned)((nwork + 1023) / 1024)), dim3(256), 0, h->stream, st, nwork,
                            kind, b0, b1);
     } else {
-        hipLaunchKernelGGL(k_gate<1>, dim3((unsigned)((nwork + 255) / 256)), dim3(256), 0, h->stream, h->state, nwork,
+        hipLaunchKernelGGL(k_gate<1>, dim3((unsigned)((nwork + 255) / 256)), dim3(256), 0, h->stream, st, nwork,
                            kind, b0, b1);
     }
     HIPC(h, hipGetLastError());
@@ -2354,6 +2355,78 @@ extern "C" int ovqe_ground_state(ovqe_handle h, double tol, int max_iter, uint64
     if (residual) *residual = true_res;
     if (iterations) *iterations = m;
     (void)est;
+    return OVQE_OK;
+}
+
+// ---- exact gradient by the adjoint method -------------------------------------------------------------------
+extern "C" int ovqe_energy_gradient(ovqe_handle h, const double *theta, int32_t K, double *energy, double *grad) {
+    OVQE_ENTER(h);
+    if (!h || !energy || !grad) return OVQE_ERR_INVALID;
+    int rc = check_theta(h, theta, K);
+    if (rc) return rc;
+    if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
+    if (h->n_global) return fail(h, OVQE_ERR_INVALID, "ovqe_energy_gradient is single-device");
+    rc = run_program_streaming(h, theta);  // psi = U(theta)|hf>; angle table: original rotations at offset S
+    if (!rc) rc = ensure_scratch(h, 0);
+    Lanczos L{h, reduce_blocks(h->namps)};
+    const int nb = L.nb;
+    if (!rc) rc = ensure(h, h->d_partials, (size_t)std::max(nb, ADJ_MAX_ROT * nb) * sizeof(double2));
+    if (!rc) rc = ensure(h, h->d_result, 64 * sizeof(double2));
+    const size_t R = h->rots.size(), S = h->srots.size();
+    DevBuf d_w;
+    if (!rc) rc = ensure(h, d_w, std::max<size_t>(R, 1) * sizeof(double));
+    if (rc) return rc;
+    amp_t *lam = h->scratch[0];
+    L.apply_h(lam, h->state);
+    double2 e;
+    rc = L.dot(h->state, lam, &e);
+    const RotParam *d_rp = (const RotParam *)h->d_rp.p + S;
+    double *partials = (double *)h->d_partials.p;
+    for (int oi = (int)h->ops.size() - 1; oi >= 0 && !rc; --oi) {
+        const SmallOp &op = h->ops[oi];
+        switch (op.kind) {
+        case OP_PAIR:
+        case OP_DIAG:
+            for (int hi = op.count; hi > 0; hi -= ADJ_MAX_ROT) {  // chunks from the end of the run backwards
+                const int lo = std::max(0, hi - ADJ_MAX_ROT), cnt = hi - lo;
+                if (op.kind == OP_PAIR)
+                    hipLaunchKernelGGL(k_adjoint_pairs, dim3(nb), dim3(256), 0, h->stream, h->state, lam, h->namps >> 1,
+                                       op.pivot, op.x, h->base, d_rp + op.first + lo, cnt, partials);
+                else
+                    hipLaunchKernelGGL(k_adjoint_diag, dim3(nb), dim3(256), 0, h->stream, h->state, lam, h->namps,
+                                       h->base, d_rp + op.first + lo, cnt, partials);
+                hipLaunchKernelGGL(k_reduce_rows, dim3(cnt), dim3(256), 0, h->stream, (const double *)partials, nb,
+                                   (double *)d_w.p + op.first + lo);
+            }
+            break;
+        case OP_X:
+            rc = launch_gate(h, 0, op.pivot, 0);
+            if (!rc) rc = launch_gate(h, 0, op.pivot, 0, lam);
+            break;
+        case OP_H:
+            rc = launch_gate(h, 1, op.pivot, 0);
+            if (!rc) rc = launch_gate(h, 1, op.pivot, 0, lam);
+            break;
+        case OP_CNOT:
+            rc = launch_gate(h, 2, op.first, op.count);
+            if (!rc) rc = launch_gate(h, 2, op.first, op.count, lam);
+            break;
+        default: rc = fail(h, OVQE_ERR_INVALID, "corrupt program");
+        }
+    }
+    std::vector<double> w(R, 0.0);
+    if (!rc && hipGetLastError() != hipSuccess) rc = fail(h, OVQE_ERR_HIP, "energy_gradient: launch failed");
+    if (!rc && R && hipMemcpyAsync(w.data(), d_w.p, R * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+        rc = fail(h, OVQE_ERR_HIP, "energy_gradient: copy failed");
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, OVQE_ERR_HIP, "energy_gradient: sync failed");
+    if (d_w.p) (void)hipFree(d_w.p);
+    if (rc) return rc;
+    for (int32_t p = 0; p < K; ++p) grad[p] = 0.0;
+    for (size_t r = 0; r < R; ++r) {
+        const SmallRot &sr = h->rots[r];
+        if (sr.pidx >= 0) grad[sr.pidx] += 2.0 * sr.coeff * ((sr.ny & 2) ? -w[r] : w[r]);
+    }
+    *energy = e.x + h->ham.constant;
     return OVQE_OK;
 }
 

@@ -497,6 +497,99 @@ __global__ __launch_bounds__(256) void k_norm2(const amp_t *__restrict__ st, uin
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
+// ---- adjoint (reverse-mode) gradient of E(theta) = <psi(theta)|H|psi(theta)>  (ovqe_energy_gradient) ----------
+// Backward pass over one same-x run, rotations in REVERSE order.  psi holds U_r...U_1|hf>, lam holds
+// U_{r+1}^+...U_R^+ H|psi_R>; for every rotation r of the run the kernel accumulates
+//   w_r = sum_pairs  Re/Im [ s_i conj(lam_i) psi_j + s_j conj(lam_j) psi_i ]      (Re for odd ny, Im for even)
+// (dE/dtheta_p = sum_r 2 coeff_r kappa_r w_r, kappa = -1 if ny & 2; assembled on the host) and then un-rotates both
+// states, psi <- U_r^+ psi, lam <- U_r^+ lam.  One read + one write of BOTH states per run.
+constexpr int ADJ_MAX_ROT = 16;
+
+__global__ __launch_bounds__(256) void k_adjoint_pairs(amp_t *__restrict__ psi, amp_t *__restrict__ lam,
+                                                       uint64_t npairs, int pivot, uint64_t x, uint64_t base,
+                                                       const RotParam *__restrict__ rp, int nrot,
+                                                       double *__restrict__ partials /* [nrot][gridDim.x] */) {
+    __shared__ double2 red[4];
+    double w[ADJ_MAX_ROT];
+#pragma unroll
+    for (int r = 0; r < ADJ_MAX_ROT; ++r) w[r] = 0.0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k < npairs; k += stride) {
+        const uint64_t i = insert_zero(k, pivot), j = i ^ x;
+        amp_t u = psi[i], v = psi[j], lu = lam[i], lv = lam[j];
+#pragma unroll
+        for (int q = 0; q < ADJ_MAX_ROT; ++q) {
+            const int r = nrot - 1 - q;
+            if (r < 0) break;
+            RotParam rr = rp[r];
+            const int pi = parity64((base | i) & rr.z);
+            const int pj = pi ^ rr.odd;
+            const double si = pj ? -1.0 : 1.0, sj = pi ? -1.0 : 1.0;
+            // t = s_i conj(lam_i) psi_j + s_j conj(lam_j) psi_i
+            const double tr = si * (lu.x * v.x + lu.y * v.y) + sj * (lv.x * u.x + lv.y * u.y);
+            const double ti = si * (lu.x * v.y - lu.y * v.x) + sj * (lv.x * u.y - lv.y * u.x);
+            w[q] += rr.odd ? tr : ti;
+            rr.s = -rr.s;  // U^+ = exp(+i phi P)
+            rot_pair(u, v, rr, base | i);
+            rot_pair(lu, lv, rr, base | i);
+        }
+        psi[i] = u;
+        psi[j] = v;
+        lam[i] = lu;
+        lam[j] = lv;
+    }
+#pragma unroll
+    for (int q = 0; q < ADJ_MAX_ROT; ++q) {
+        if (q >= nrot) break;
+        const double2 t = block_sum<256>(make_double2(w[q], 0.0), red);
+        if (threadIdx.x == 0) partials[(size_t)(nrot - 1 - q) * gridDim.x + blockIdx.x] = t.x;
+    }
+}
+
+// diagonal run (x = 0, P = Z^z): w_r = sum_i Im[ s_i conj(lam_i) psi_i ]; un-rotation a <- (c + i s sigma) a
+__global__ __launch_bounds__(256) void k_adjoint_diag(amp_t *__restrict__ psi, amp_t *__restrict__ lam, uint64_t namps,
+                                                      uint64_t base, const RotParam *__restrict__ rp, int nrot,
+                                                      double *__restrict__ partials) {
+    __shared__ double2 red[4];
+    double w[ADJ_MAX_ROT];
+#pragma unroll
+    for (int r = 0; r < ADJ_MAX_ROT; ++r) w[r] = 0.0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) {
+        amp_t a = psi[i], l = lam[i];
+#pragma unroll
+        for (int q = 0; q < ADJ_MAX_ROT; ++q) {
+            const int r = nrot - 1 - q;
+            if (r < 0) break;
+            const RotParam rr = rp[r];
+            const double sg = parity64((base | i) & rr.z) ? -1.0 : 1.0;
+            w[q] += sg * (l.x * a.y - l.y * a.x);
+            const double s = -sg * rr.s;  // forward: (c - i s sg) a
+            a = make_double2(rr.c * a.x + s * a.y, rr.c * a.y - s * a.x);
+            l = make_double2(rr.c * l.x + s * l.y, rr.c * l.y - s * l.x);
+        }
+        psi[i] = a;
+        lam[i] = l;
+    }
+#pragma unroll
+    for (int q = 0; q < ADJ_MAX_ROT; ++q) {
+        if (q >= nrot) break;
+        const double2 t = block_sum<256>(make_double2(w[q], 0.0), red);
+        if (threadIdx.x == 0) partials[(size_t)(nrot - 1 - q) * gridDim.x + blockIdx.x] = t.x;
+    }
+}
+
+// out[row] = sum of the row's `count` partials (one block per row, fixed order)
+__global__ __launch_bounds__(256) void k_reduce_rows(const double *__restrict__ partials, int count,
+                                                     double *__restrict__ out) {
+    __shared__ double2 red[4];
+    double acc = 0.0;
+    const double *row = partials + (size_t)blockIdx.x * count;
+    for (int i = threadIdx.x; i < count; i += 256) acc += row[i];
+    const double2 t = block_sum<256>(make_double2(acc, 0.0), red);
+    if (threadIdx.x == 0) out[blockIdx.x] = t.x;
+}
+
 // ---- Lanczos support (ovqe_ground_state) ---------------------------------------------------------------
 // partials[b] = sum_i conj(a_i) b_i over the block's grid-stride slice
 __global__ __launch_bounds__(256) void k_dot(const amp_t *__restrict__ a, const amp_t *__restrict__ b, uint64_t namps,

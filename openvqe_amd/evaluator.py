@@ -52,6 +52,11 @@ class _Evaluator:
         self._activate()
         return self.sv.energy_batch(np.asarray(thetas, dtype=np.float64)[:, : self.n_params])
 
+    def energy_gradient(self, theta):
+        """(E, dE/dtheta) by the adjoint method on the device (ovqe_energy_gradient)"""
+        self._activate()
+        return self.sv.energy_gradient(np.asarray(theta, dtype=np.float64)[: self.n_params])
+
     def state(self, theta):
         self._activate()
         self.sv.prepare_state(np.asarray(theta, dtype=np.float64))

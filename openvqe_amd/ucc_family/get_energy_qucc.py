@@ -25,6 +25,9 @@ def _excitation_indices(cluster_ops):
 
 
 class EnergyUCC:
+    #: opt-in: exact Jacobian by the adjoint method (ovqe_energy_gradient) instead of scipy's forward differences
+    adjoint_gradient = False
+
     def __init__(self):
         self._cache = None
 
@@ -78,10 +81,18 @@ class EnergyUCC:
         print("method= ", method)
         energies1, energies2 = [], []
         runs = []
+        jac = None
+        if self.adjoint_gradient:
+            ev = self._evaluator(hamiltonian_sp, cluster_ops, hf_init_sp)
+
+            def jac(theta):
+                g = np.zeros(len(theta))
+                g[: ev.n_params] = ev.energy_gradient(np.asarray(theta, dtype=float))[1]
+                return g
         for x0, sink in ((theta_current1, energies1), (theta_current2, energies2)):
             runs.append(scipy.optimize.minimize(
                 lambda theta, sink=sink: self.action_quccsd(theta, hamiltonian_sp, cluster_ops, hf_init_sp, sink),
-                x0=x0, method=method, tol=tolerance, options={"maxiter": 50000, "disp": True}))
+                x0=x0, jac=jac, method=method, tol=tolerance, options={"maxiter": 50000, "disp": True}))
         opt_result1, opt_result2 = runs
         theta_optimized_result1 = [opt_result1.x[si] for si in range(len(theta_current1))]
         theta_optimized_result2 = [opt_result2.x[si] for si in range(len(theta_current2))]

@@ -13,6 +13,9 @@ class EnergyUCC:
     #: opt-in: supply scipy with a forward-difference Jacobian computed by ONE batched device call
     #: (same step as scipy's jac=None path, so the iterates coincide)
     batched_gradient = False
+    #: opt-in: exact Jacobian by the adjoint method (ovqe_energy_gradient): about three circuit executions for all K
+    #: derivatives; iterates differ from the reference's forward-difference path at the 1e-8 level
+    adjoint_gradient = False
 
     def __init__(self):
         self._cache = {}
@@ -47,7 +50,15 @@ class EnergyUCC:
     def _minimize(self, hamiltonian_sp, ops, hf_init_sp, x0, energies, method, tolerance):
         fun = lambda theta: self.ucc_action(theta, hamiltonian_sp, ops, hf_init_sp, energies)  # noqa: E731
         jac = None
-        if self.batched_gradient:
+        if self.adjoint_gradient:
+            n_params = min(len(ops), len(x0))
+            ev = self._evaluator(hamiltonian_sp, ops, hf_init_sp, n_params)
+
+            def jac(theta):
+                g = np.zeros(len(theta))
+                g[:n_params] = ev.energy_gradient(np.asarray(theta, dtype=float))[1]
+                return g
+        elif self.batched_gradient:
             n_params = min(len(ops), len(x0))
             ev = self._evaluator(hamiltonian_sp, ops, hf_init_sp, n_params)
             eps = np.sqrt(np.finfo(float).eps)

@@ -73,6 +73,16 @@ class OracleStatevector:
         assert np.abs(cs.imag).max(initial=0) < 1e-12
         self._ham = (xs, zs, cs.real, complex(hamiltonian.constant_coeff or 0).real)
 
+    def energy_gradient(self, theta):
+        """checker of ovqe_energy_gradient: central differences of the oracle energy"""
+        theta = np.asarray(theta, float)
+        g = np.zeros(len(theta))
+        for k in range(len(theta)):
+            tp, tm = theta.copy(), theta.copy()
+            tp[k] += 1e-5; tm[k] -= 1e-5
+            g[k] = (self.energy(tp) - self.energy(tm)) / 2e-5
+        return self.energy(theta), g
+
     def ground_state(self, tol=1e-10, max_iter=3000, seed=0):
         """checker of ovqe_ground_state: matrix-free scipy Lanczos (ARPACK) on the bit-mask oracle's H|v>"""
         import scipy.sparse.linalg as sla

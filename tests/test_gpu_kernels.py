@@ -500,3 +500,72 @@ def test_ground_state_lanczos(SV, n, kind):
     assert res < 1e-6 * scale
     if overlap is not None:
         assert abs(overlap - 1.0) < 1e-8, overlap
+
+
+def _fd_gradient(fun, theta, step=1e-5):
+    g = np.zeros_like(theta)
+    for k in range(len(theta)):
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += step; tm[k] -= step
+        g[k] = (fun(tp) - fun(tm)) / (2 * step)
+    return g
+
+
+@pytest.mark.parametrize("n,k", [(2, 3), (5, 6), (8, 8), (11, 10), (13, 6), (15, 5)])
+def test_adjoint_gradient_of_ucc_programs(SV, n, k):
+    """ovqe_energy_gradient (adjoint method: one backward pass) against central differences of the ORACLE energy;
+    parameters shared by several rotations, diagonal strings, repeated parameters"""
+    from oracle import cref
+    from openvqe_amd.backend import compile_ucc_program
+    rng = np.random.default_rng(7100 + n)
+    H = random_hamiltonian(rng, n, min(40, 4 ** n - 1))
+    gens = random_generators(rng, n, k)
+    hf = int(rng.integers(0, 1 << n))
+    theta = rng.uniform(-0.5, 0.5, k)
+    rx, rz, rc, pidx, K = compile_ucc_program(n, gens)
+    hx, hz, hc = H.packed()
+
+    def e_oracle(th):
+        return cref.ucc_energy(n, hf, rx, rz, rc, pidx, th, hx, hz, hc.real.copy(), H.constant_coeff, 0)[0]
+
+    g_ref = _fd_gradient(e_oracle, theta)
+    with SV(n) as sv:
+        sv.set_hamiltonian(H)
+        sv.set_ucc_program(gens, hf)
+        e, g = sv.energy_gradient(theta)
+        e2 = sv.energy(theta)
+    scale = max(1.0, np.abs(hc).sum())
+    assert abs(e - e_oracle(theta)) < 1e-10 * scale and abs(e - e2) < 1e-10 * scale
+    assert np.abs(g - g_ref).max() < 2e-8 * scale, (g, g_ref)
+
+
+@pytest.mark.parametrize("frame", [0, 1])
+def test_adjoint_gradient_of_gate_programs(SV, frame):
+    """literal gate list (X / H / CNOT un-applied on both states, RX / RY / RZ as rotations) and its Clifford-frame
+    form give the same exact gradient; checked against central differences of the plain-C gate-level oracle"""
+    from oracle import cref
+    from openvqe_amd.backend import GATE_OPCODES
+    from tests.util import quccsd_like_gates
+    n = 8
+    rng = np.random.default_rng(8200)
+    gates, K = quccsd_like_gates(rng, n, 3, 4, extra_random=0 if frame else 10, disjoint_ladders=True)
+    theta = rng.uniform(-0.7, 0.7, K)
+    H = random_hamiltonian(rng, n, 50)
+    hf = 0b11010010
+    hx, hz, hc = H.packed()
+    arrs = ([GATE_OPCODES[g[0]] for g in gates], [n - 1 - g[1][0] for g in gates],
+            [n - 1 - g[1][1] if len(g[1]) > 1 else 0 for g in gates], [g[2] for g in gates], [g[3] for g in gates],
+            [g[4] for g in gates])
+
+    def e_oracle(th):
+        return cref.gate_energy(n, hf, *arrs, th, hx, hz, hc.real.copy(), H.constant_coeff)[0]
+
+    g_ref = _fd_gradient(e_oracle, theta)
+    with SV(n) as sv:
+        sv.set_option("clifford_frame", frame)
+        sv.set_hamiltonian(H)
+        sv.set_gate_program(gates, K, hf)
+        e, g = sv.energy_gradient(theta)
+    scale = max(1.0, np.abs(hc).sum())
+    assert abs(e - e_oracle(theta)) < 1e-10 * scale
+    assert np.abs(g - g_ref).max() < 2e-8 * scale
