@@ -224,6 +224,19 @@ def cpu_baseline_leg(ham, gens, hf, thetas, budget_s=12.0):
             if dt > budget_s / 2:
                 break
         out[label] = {"evals_per_s": cnt / dt, "evals": cnt, "seconds": dt, "threads": cores, "energy0": float(e[0])}
+    # the fused CPU sweep beside the GPU's single-Pauli-string sweep (26 qubits = 1 GiB, OpenMP over the cores)
+    from openvqe_amd.operators import pack_string
+    nq = 26
+    psi = np.zeros(1 << nq, np.complex128)
+    psi[0] = 1.0
+    x, z = pack_string(nq, "XXXY", [0, 9, 17, nq - 1])
+    L.orc_pauli_rotation(psi, nq, int(x), int(z), 0.1)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        L.orc_pauli_rotation(psi, nq, int(x), int(z), 0.1)
+    dt = (time.perf_counter() - t0) / reps
+    out["sweep_26q"] = {"ms": 1e3 * dt, "GBs": 32.0 * (1 << nq) / dt / 1e9, "threads": cores}
     return out, cores
 
 
@@ -412,6 +425,7 @@ def main():
                           f"(CNOT staircase gate by gate, observable term by term) on the same cores: "
                           f"{cpu['gate_level']['evals_per_s']:.2f} evals/s over {cpu['gate_level']['evals']} evaluations",
                 "gate_level_evals_per_s": cpu["gate_level"]["evals_per_s"],
+                "single_string_sweep_26_qubits": cpu["sweep_26q"],
                 "gpu_minus_cpu_energy": e_gpu0 - cpu["fused"]["energy0"],
             }
         print(json.dumps(out))
