@@ -536,11 +536,18 @@ int build_ham_tiles(ovqe_handle h, HamDev &H) {
     return upload(h, H.d_rest, rest.data(), rest.size() * sizeof(HGroup));
 }
 
+inline int expect_ysplit(ovqe_handle h, int M) {  // workgroups per tile: fill the chip when there are few tiles
+    const uint64_t tiles = h->namps >> M;
+    int y = 1;
+    while (y < 8 && tiles * y < 1024) y *= 2;
+    return y;
+}
+
 template <int M>
 int launch_tile_expect(ovqe_handle h, const HamDev &H, const ExSweep &sw, double2 *partials, int accumulate) {
     constexpr int NT = 1 << TILE_EXPECT_LOG_NT;
     const size_t smem = ((size_t)16 << M) + TILE_TERM_CAP * sizeof(ExTermLds) + (NT / 64) * sizeof(double2);
-    const unsigned grid = (unsigned)(h->namps >> M);
+    const dim3 grid((unsigned)(h->namps >> M), (unsigned)expect_ysplit(h, M));
     static bool attr_done = false;
     if (!attr_done) {
         HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_expect<M, NT, true>),
@@ -550,11 +557,11 @@ int launch_tile_expect(ovqe_handle h, const HamDev &H, const ExSweep &sw, double
         attr_done = true;
     }
     if (h->n_local >= 25) {
-        hipLaunchKernelGGL((k_tile_expect<M, NT, true>), dim3(grid), dim3(NT), smem, h->stream, h->state, h->base, sw,
+        hipLaunchKernelGGL((k_tile_expect<M, NT, true>), grid, dim3(NT), smem, h->stream, h->state, h->base, sw,
                            (const ExChunkT *)H.d_tchunks.p, (const ExEntryT *)H.d_tgroups.p,
                            (const ExTermT *)H.d_tterms.p, partials, accumulate);
     } else {
-        hipLaunchKernelGGL((k_tile_expect<M, NT, false>), dim3(grid), dim3(NT), smem, h->stream, h->state, h->base, sw,
+        hipLaunchKernelGGL((k_tile_expect<M, NT, false>), grid, dim3(NT), smem, h->stream, h->state, h->base, sw,
                            (const ExChunkT *)H.d_tchunks.p, (const ExEntryT *)H.d_tgroups.p,
                            (const ExTermT *)H.d_tterms.p, partials, accumulate);
     }
@@ -571,7 +578,7 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used) {
     }
     if (H.tsweeps.empty()) return OVQE_OK;
     const int M = H.tile_bits;
-    const int64_t ntiles = (int64_t)(h->namps >> M);
+    const int64_t ntiles = (int64_t)(h->namps >> M) * expect_ysplit(h, M);  // partial sums: one per workgroup
     const int nb = reduce_blocks(h->namps);
     int rc = ensure(h, h->d_partials, (size_t)(ntiles + nb) * sizeof(double2));
     if (rc) return rc;
@@ -2008,7 +2015,9 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
             rc = build_sparse_program(h);
             if (rc) return rc;
         }
-        if (h->sp_valid) return run_sparse(h, B, theta, energies);
+        // one wave owns an evaluation on the compact support: unbeatable for batches, but a lone evaluation of a
+        // register beyond the LDS kernels is quicker on the whole chip (streaming + tiled sweeps)
+        if (h->sp_valid && (h->opt_force_path == 3 || h->n_local <= 14 || B >= 16)) return run_sparse(h, B, theta, energies);
         if (h->opt_force_path == 3) return fail(h, OVQE_ERR_STATE, "program has no compact support (sparse path forced)");
     }
     if (use_small_path(h, B)) return run_small(h, B, theta, energies);

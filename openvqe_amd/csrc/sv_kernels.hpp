@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void k_adjoint_pairs(amp_t *__restrict__ psi, 
 #pragma unroll
         for (int q = 0; q < ADJ_MAX_ROT; ++q) {
             const int r = nrot - 1 - q;
-            if (r < 0) break;
+            if (r < 0) continue;
             RotParam rr = rp[r];
             const int pi = parity64((base | i) & rr.z);
             const int pj = pi ^ rr.odd;
@@ -540,9 +540,10 @@ __global__ __launch_bounds__(256) void k_adjoint_pairs(amp_t *__restrict__ psi, 
     }
 #pragma unroll
     for (int q = 0; q < ADJ_MAX_ROT; ++q) {
-        if (q >= nrot) break;
-        const double2 t = block_sum<256>(make_double2(w[q], 0.0), red);
-        if (threadIdx.x == 0) partials[(size_t)(nrot - 1 - q) * gridDim.x + blockIdx.x] = t.x;
+        if (q < nrot) {  // nrot is uniform: every thread takes the same path through the barriers of block_sum
+            const double2 t = block_sum<256>(make_double2(w[q], 0.0), red);
+            if (threadIdx.x == 0) partials[(size_t)(nrot - 1 - q) * gridDim.x + blockIdx.x] = t.x;
+        }
     }
 }
 
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(256) void k_adjoint_diag(amp_t *__restrict__ psi, a
 #pragma unroll
         for (int q = 0; q < ADJ_MAX_ROT; ++q) {
             const int r = nrot - 1 - q;
-            if (r < 0) break;
+            if (r < 0) continue;
             const RotParam rr = rp[r];
             const double sg = parity64((base | i) & rr.z) ? -1.0 : 1.0;
             w[q] += sg * (l.x * a.y - l.y * a.x);
@@ -573,9 +574,10 @@ __global__ __launch_bounds__(256) void k_adjoint_diag(amp_t *__restrict__ psi, a
     }
 #pragma unroll
     for (int q = 0; q < ADJ_MAX_ROT; ++q) {
-        if (q >= nrot) break;
-        const double2 t = block_sum<256>(make_double2(w[q], 0.0), red);
-        if (threadIdx.x == 0) partials[(size_t)(nrot - 1 - q) * gridDim.x + blockIdx.x] = t.x;
+        if (q < nrot) {  // nrot is uniform: every thread takes the same path through the barriers of block_sum
+            const double2 t = block_sum<256>(make_double2(w[q], 0.0), red);
+            if (threadIdx.x == 0) partials[(size_t)(nrot - 1 - q) * gridDim.x + blockIdx.x] = t.x;
+        }
     }
 }
 

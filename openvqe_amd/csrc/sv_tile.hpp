@@ -220,7 +220,8 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const amp_t *__restrict__ st
             lt[t - ck.t0] = l;
         }
         __syncthreads();
-        for (int g = ck.g0 + wave; g < ck.g1; g += NT / 64) {
+        // small registers have fewer tiles than the chip has CUs: gridDim.y workgroups share a tile's entries
+        for (int g = ck.g0 + wave + (NT / 64) * (int)blockIdx.y; g < ck.g1; g += (NT / 64) * (int)gridDim.y) {
             const ExEntryT en = entries[g];
             const ExTermLds *gt = lt + (en.t0 - ck.t0);
             const int nt = en.t1 - en.t0;
@@ -288,11 +289,12 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const amp_t *__restrict__ st
     __syncthreads();
     const double2 t = block_sum<NT>(make_double2(acc, 0.0), red);
     if (threadIdx.x == 0) {
+        const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
         if (accumulate) {
-            const double2 o = partials[blockIdx.x];
-            partials[blockIdx.x] = make_double2(o.x + t.x, o.y);
+            const double2 o = partials[slot];
+            partials[slot] = make_double2(o.x + t.x, o.y);
         } else {
-            partials[blockIdx.x] = t;
+            partials[slot] = t;
         }
     }
 }
