@@ -76,6 +76,10 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * "table_fusion" (1: commuting same-x runs become single sparse pair rotations in the fused kernel),
  * "tile_bits" (streaming path: 0 = one sweep per op; 10..12 = LDS tiles of 2^bits amplitudes that take runs of
  * consecutive ops per sweep; default -1 = automatic: 12 for n >= 25, else 11), "tile_low" (lowest index bits always inside a tile, default 4),
+ * "real_stream" (1, default: a program
+ * whose rotation strings all have an odd number of Y — every UCC / ADAPT generator, the QUCCSD templates in frame form —
+ * keeps the amplitudes real; streaming energies (n >= 15) then store the state as 2^n doubles: half the HBM bytes per
+ * sweep, one more mixing bit per LDS tile; ovqe_prepare_state always delivers the complex state),
  * "clifford_frame" (read by the NEXT ovqe_set_gate_program: 0 = execute the literal gate list; 1 (default) = when
  * the Clifford part of the list — X, H, CNOT, quarter-turn rotations — multiplies to the identity, run the
  * algebraically identical sequence of Pauli rotations with conjugated strings instead; 2 = always, Clifford part
@@ -192,7 +196,8 @@ int ovqe_last_batch_ms(ovqe_handle h, double *ms);
  *   evaluation  [4] of those, LDS-tiled multi-op sweeps  [5] ops of the fused-kernel program
  *   [6] support-compacted program: -1 not analysed yet, 0 none, else the size of the reachable support
  *   [7] tile sweeps of the stored Hamiltonian's expectation (0 until first used / when not tiled)  [8] x-groups
- *   that keep their own sweep  [9] (group, pattern) entries  [10] merged terms  [11] pair x term evaluations per tile */
+ *   that keep their own sweep  [9] (group, pattern) entries  [10] merged terms  [11] pair x term evaluations per tile
+ *   [12] 1 when streaming energies of this program keep the state as 2^n real amplitudes */
 int ovqe_program_info(ovqe_handle h, int64_t *info, int count);
 
 #ifdef __cplusplus

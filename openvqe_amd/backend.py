@@ -255,10 +255,11 @@ class Statevector:
     def program_info(self):
         """shape of the compiled program: ops, rotations, literal gates, sweeps per evaluation, tiled sweeps,
         fused-kernel ops, support size (-1 = not analysed yet)"""
-        out = (ctypes.c_int64 * 12)()
-        self._ck(self._L.ovqe_program_info(self._h, out, 12))
+        out = (ctypes.c_int64 * 13)()
+        self._ck(self._L.ovqe_program_info(self._h, out, 13))
         keys = ("ops", "rotations", "literal_gates", "sweeps", "tiled_sweeps", "fused_ops", "support",
-                "h_tile_sweeps", "h_untiled_groups", "h_entries", "h_merged_terms", "h_pair_terms_per_tile")
+                "h_tile_sweeps", "h_untiled_groups", "h_entries", "h_merged_terms", "h_pair_terms_per_tile",
+                "real_stream")
         return dict(zip(keys, [int(v) for v in out]))
 
     # -- ADAPT ----------------------------------------------------------------------------------

@@ -47,6 +47,8 @@ struct HamDev {  // grouped Pauli sum resident on the device
     bool set = false;
     // tile cover of the x-groups (sv_tile.hpp k_tile_expect), built lazily for (tile_bits, tile_low)
     int tile_bits = -1, tile_low = -1;
+    bool tile_real = false;       // cover built for a real-amplitude state (masks in pair-index space, M + 1 bits)
+    int version = 0;              // ham_real: the version of the stored Hamiltonian it was copied from
     std::vector<ExSweep> tsweeps;
     int n_rest = 0;  // groups that fit no tile keep their own sweep (k_expect_pairs)
     int64_t tile_work = 0, tile_entries = 0, tile_terms = 0;  // pair x term evaluations per tile over all sweeps
@@ -123,6 +125,11 @@ struct ovqe_sv {
     int opt_clifford_frame = 1;   // gate programs: 0 literal, 1 Clifford-frame form when the frame closes, 2 forced
     int opt_tile_low = 4;         // lowest index bits always inside the tile (contiguous 16 B << low chunks)
     TilePlan tp;                  // of the stored program
+    TilePlan tp_real;             // same program on a real-amplitude state (built on first use)
+    bool tp_real_built = false;
+    bool prog_real_ok = false;    // every rotation has an odd number of Y and there is no diagonal run
+    int opt_real_stream = 1;      // streaming energies of such programs keep the state as 2^n doubles
+    HamDev ham_real;              // tile cover of the stored Hamiltonian for the real-amplitude state
     TilePlan tp_adhoc;            // of the rotation list of the current ovqe_apply_pauli_rotations call
 };
 
@@ -379,7 +386,15 @@ int run_bilinear(ovqe_handle h, const amp_t *bra, const amp_t *ket, const std::v
     return OVQE_OK;
 }
 
-inline int tile_bits(ovqe_handle h) { return h->opt_tile_bits >= 0 ? h->opt_tile_bits : (h->n_local >= 25 ? 12 : 11); }
+inline int tile_bits(ovqe_handle h, bool real = false) {
+    const int m = h->opt_tile_bits >= 0 ? h->opt_tile_bits : (h->n_local >= 25 ? 12 : 11);
+    return (real && m >= 10) ? m + 1 : m;  // the same LDS bytes hold twice the real amplitudes
+}
+inline bool tile_ok(ovqe_handle h, bool real) {
+    const int m = tile_bits(h, real);
+    return m >= (real ? 11 : 10) && m <= (real ? 13 : 12) && h->n_local >= m + 2 && h->opt_tile_low >= (real ? 1 : 0) &&
+           h->opt_tile_low <= 8;
+}
 
 inline uint32_t extract_bits(uint64_t v, uint64_t mask) {  // pext
     uint32_t r = 0;
@@ -392,13 +407,14 @@ inline uint32_t extract_bits(uint64_t v, uint64_t mask) {  // pext
 // ---- tiled expectation (sv_tile.hpp) -----------------------------------------------------------------------
 // Greedy cover of the x-groups by tile bit sets: a set starts from the mandatory low bits and grows by the bit that
 // brings the most still-uncovered groups within reach (groups that are nearly inside count more).
-int build_ham_tiles(ovqe_handle h, HamDev &H) {
-    const int M = tile_bits(h), L = h->opt_tile_low;
+int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
+    const int M = tile_bits(h, real), L = h->opt_tile_low;
     H.tile_bits = M;
     H.tile_low = L;
+    H.tile_real = real;
     H.tsweeps.clear();
     H.n_rest = 0;
-    const bool tiled = M >= 10 && M <= 12 && h->n_local >= M + 2 && L >= 0 && L <= 8 && H.groups.size() >= 3;
+    const bool tiled = tile_ok(h, real) && H.groups.size() >= 3;
     if (!tiled) return OVQE_OK;
     const int G = (int)H.groups.size();
     const uint64_t lowbits = (1ull << L) - 1ull;
@@ -440,14 +456,14 @@ int build_ham_tiles(ovqe_handle h, HamDev &H) {
         }
         for (int b = 0; __builtin_popcountll(S) < M; ++b) S |= 1ull << b;
         ExSweep sw = {};
-        sw.smask = S;
-        uint64_t lo = 0, mk = S;
+        sw.smask = real ? S >> 1 : S;  // real state: masks in the index space of amplitude pairs (sv_tile.hpp)
+        uint64_t lo = 0, mk = sw.smask;
         for (int k = 0; k < TILE_EXPECT_LOG_NT; ++k) {  // thread bits
             lo |= mk & (0ull - mk);
             mk &= mk - 1ull;
         }
         sw.mask_lo = lo;
-        sw.mask_hi = S & ~lo;
+        sw.mask_hi = sw.smask & ~lo;
         sw.c0 = (int32_t)chunks.size();
         ExChunkT ck = {(int32_t)tgroups.size(), (int32_t)tgroups.size(), (int32_t)tterms.size(), (int32_t)tterms.size()};
         int took = 0;
@@ -471,6 +487,7 @@ int build_ham_tiles(ovqe_handle h, HamDev &H) {
                 merged.clear();
                 for (int t = gr.t0; t < gr.t1; ++t) {
                     const HTerm &ht = H.terms[t];
+                    if (real && ht.ci != 0.0) continue;  // imaginary folded coefficient: <P> = 0 on a real state
                     const uint32_t zin = extract_bits(ht.z, S);
                     const double sg = (__builtin_popcount(jx & zin) & 1) ? -1.0 : 1.0;
                     auto &slot = merged[std::make_pair((uint64_t)(zin & ~xl), ht.z & ~S)];
@@ -543,25 +560,25 @@ inline int expect_ysplit(ovqe_handle h, int M) {  // workgroups per tile: fill t
     return y;
 }
 
-template <int M>
+template <int M, bool REAL>
 int launch_tile_expect(ovqe_handle h, const HamDev &H, const ExSweep &sw, double2 *partials, int accumulate) {
     constexpr int NT = 1 << TILE_EXPECT_LOG_NT;
-    const size_t smem = ((size_t)16 << M) + TILE_TERM_CAP * sizeof(ExTermLds) + (NT / 64) * sizeof(double2);
+    const size_t smem = ((size_t)(REAL ? 8 : 16) << M) + TILE_TERM_CAP * sizeof(ExTermLds) + (NT / 64) * sizeof(double2);
     const dim3 grid((unsigned)(h->namps >> M), (unsigned)expect_ysplit(h, M));
     static bool attr_done = false;
     if (!attr_done) {
-        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_expect<M, NT, true>),
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_expect<M, NT, true, REAL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_expect<M, NT, false>),
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_expect<M, NT, false, REAL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done = true;
     }
     if (h->n_local >= 25) {
-        hipLaunchKernelGGL((k_tile_expect<M, NT, true>), grid, dim3(NT), smem, h->stream, h->state, h->base, sw,
+        hipLaunchKernelGGL((k_tile_expect<M, NT, true, REAL>), grid, dim3(NT), smem, h->stream, (const void *)h->state, h->base, sw,
                            (const ExChunkT *)H.d_tchunks.p, (const ExEntryT *)H.d_tgroups.p,
                            (const ExTermT *)H.d_tterms.p, partials, accumulate);
     } else {
-        hipLaunchKernelGGL((k_tile_expect<M, NT, false>), grid, dim3(NT), smem, h->stream, h->state, h->base, sw,
+        hipLaunchKernelGGL((k_tile_expect<M, NT, false, REAL>), grid, dim3(NT), smem, h->stream, (const void *)h->state, h->base, sw,
                            (const ExChunkT *)H.d_tchunks.p, (const ExEntryT *)H.d_tgroups.p,
                            (const ExTermT *)H.d_tterms.p, partials, accumulate);
     }
@@ -570,15 +587,16 @@ int launch_tile_expect(ovqe_handle h, const HamDev &H, const ExSweep &sw, double
 }
 
 // <state|H|state> of the stored Hamiltonian through the tile cover; *used = false when there is no cover
-int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used) {
+int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bool real = false) {
     *used = false;
-    if (H.tile_bits != tile_bits(h) || H.tile_low != h->opt_tile_low) {
-        int rc = build_ham_tiles(h, H);
+    if (H.tile_bits != tile_bits(h, real) || H.tile_low != h->opt_tile_low || H.tile_real != real) {
+        int rc = build_ham_tiles(h, H, real);
         if (rc) return rc;
     }
-    if (H.tsweeps.empty()) return OVQE_OK;
+    if (H.tsweeps.empty() && !(real && H.n_rest)) return OVQE_OK;
     const int M = H.tile_bits;
-    const int64_t ntiles = (int64_t)(h->namps >> M) * expect_ysplit(h, M);  // partial sums: one per workgroup
+    // partial sums: one per workgroup of the tile sweeps (none when every group keeps its own sweep)
+    const int64_t ntiles = H.tsweeps.empty() ? 0 : (int64_t)(h->namps >> M) * expect_ysplit(h, M);
     const int nb = reduce_blocks(h->namps);
     int rc = ensure(h, h->d_partials, (size_t)(ntiles + nb) * sizeof(double2));
     if (rc) return rc;
@@ -587,18 +605,30 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used) {
     double2 *partials = (double2 *)h->d_partials.p;
     int acc = 0;
     for (const ExSweep &sw : H.tsweeps) {
-        switch (M) {
-        case 10: rc = launch_tile_expect<10>(h, H, sw, partials, acc); break;
-        case 11: rc = launch_tile_expect<11>(h, H, sw, partials, acc); break;
-        default: rc = launch_tile_expect<12>(h, H, sw, partials, acc); break;
+        if (real) {
+            switch (M) {
+            case 11: rc = launch_tile_expect<11, true>(h, H, sw, partials, acc); break;
+            case 12: rc = launch_tile_expect<12, true>(h, H, sw, partials, acc); break;
+            default: rc = launch_tile_expect<13, true>(h, H, sw, partials, acc); break;
+            }
+        } else {
+            switch (M) {
+            case 10: rc = launch_tile_expect<10, false>(h, H, sw, partials, acc); break;
+            case 11: rc = launch_tile_expect<11, false>(h, H, sw, partials, acc); break;
+            default: rc = launch_tile_expect<12, false>(h, H, sw, partials, acc); break;
+            }
         }
         if (rc) return rc;
         acc = 1;
     }
     int64_t count = ntiles;
     if (H.n_rest) {
-        hipLaunchKernelGGL(k_expect_pairs, dim3(nb), dim3(256), 0, h->stream, h->state, h->namps,
-                           (const HGroup *)H.d_rest.p, 0, H.n_rest, (const HTerm *)H.d_terms.p, partials + ntiles);
+        if (real)
+            hipLaunchKernelGGL(k_expect_pairs_real, dim3(nb), dim3(256), 0, h->stream, (const double *)h->state, h->namps,
+                               (const HGroup *)H.d_rest.p, 0, H.n_rest, (const HTerm *)H.d_terms.p, partials + ntiles);
+        else
+            hipLaunchKernelGGL(k_expect_pairs, dim3(nb), dim3(256), 0, h->stream, h->state, h->namps,
+                               (const HGroup *)H.d_rest.p, 0, H.n_rest, (const HTerm *)H.d_terms.p, partials + ntiles);
         count += nb;
     }
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->stream, (const double2 *)partials, count,
@@ -621,36 +651,48 @@ int init_basis(ovqe_handle h, uint64_t index, double2 one = make_double2(1.0, 0.
 }
 
 // ---- LDS-tiled multi-op sweeps (sv_tile.hpp) --------------------------------------------------------
-template <int M>
+template <int M, bool REAL>
 int launch_tile(ovqe_handle h, const TilePlan &tp, const TileSeg &sg) {
     constexpr int NT = 1 << TILE_SWEEP_LOG_NT;
-    const size_t smem = ((size_t)16 << M) + TILE_ROT_CAP * sizeof(RotLds);
+    const size_t smem = ((size_t)(REAL ? 8 : 16) << M) + TILE_ROT_CAP * sizeof(RotLds);
     const unsigned grid = (unsigned)(h->namps >> M);
     const bool ntl = h->n_local >= 25;
     static bool attr_done = false;
     if (!attr_done) {
-        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sweep<M, NT, true>),
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sweep<M, NT, true, REAL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sweep<M, NT, false>),
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sweep<M, NT, false, REAL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done = true;
     }
     if (ntl) {
-        hipLaunchKernelGGL((k_tile_sweep<M, NT, true>), dim3(grid), dim3(NT), smem, h->stream, h->state, h->base, sg,
-                           (const TileOp *)tp.d_tops.p, (const TileRot *)tp.d_trots.p, (const RotParam *)h->d_rp.p);
+        hipLaunchKernelGGL((k_tile_sweep<M, NT, true, REAL>), dim3(grid), dim3(NT), smem, h->stream, (void *)h->state,
+                           h->base, sg, (const TileOp *)tp.d_tops.p, (const TileRot *)tp.d_trots.p,
+                           (const RotParam *)h->d_rp.p);
     } else {
-        hipLaunchKernelGGL((k_tile_sweep<M, NT, false>), dim3(grid), dim3(NT), smem, h->stream, h->state, h->base, sg,
-                           (const TileOp *)tp.d_tops.p, (const TileRot *)tp.d_trots.p, (const RotParam *)h->d_rp.p);
+        hipLaunchKernelGGL((k_tile_sweep<M, NT, false, REAL>), dim3(grid), dim3(NT), smem, h->stream, (void *)h->state,
+                           h->base, sg, (const TileOp *)tp.d_tops.p, (const TileRot *)tp.d_trots.p,
+                           (const RotParam *)h->d_rp.p);
     }
     HIPC(h, hipGetLastError());
     return OVQE_OK;
 }
 
-int launch_tile_segment(ovqe_handle h, const TilePlan &tp, const TileSeg &sg) {
-    switch (__builtin_popcountll(sg.smask)) {
-    case 10: return launch_tile<10>(h, tp, sg);
-    case 11: return launch_tile<11>(h, tp, sg);
-    case 12: return launch_tile<12>(h, tp, sg);
+// tile sizes: complex 2^10..2^12 amplitudes; real 2^11..2^13 (the segment's masks then hold one bit less, sv_tile.hpp)
+int launch_tile_segment(ovqe_handle h, const TilePlan &tp, const TileSeg &sg, bool real = false) {
+    const int bits = __builtin_popcountll(sg.smask) + (real ? 1 : 0);
+    if (real) {
+        switch (bits) {
+        case 11: return launch_tile<11, true>(h, tp, sg);
+        case 12: return launch_tile<12, true>(h, tp, sg);
+        case 13: return launch_tile<13, true>(h, tp, sg);
+        }
+    } else {
+        switch (bits) {
+        case 10: return launch_tile<10, false>(h, tp, sg);
+        case 11: return launch_tile<11, false>(h, tp, sg);
+        case 12: return launch_tile<12, false>(h, tp, sg);
+        }
     }
     return fail(h, OVQE_ERR_INVALID, "corrupt tile segment");
 }
@@ -661,14 +703,14 @@ int launch_tile_segment(ovqe_handle h, const TilePlan &tp, const TileSeg &sg) {
 // (one rotation per active pair pattern, see try_table_op): inside a fused sweep the arithmetic, not HBM, is the
 // cost, and the table form does 1/64 of it for a JW double excitation.
 int build_tile_plan(ovqe_handle h, const std::vector<SmallOp> &sops, const std::vector<SmallRot> &srots,
-                    const std::vector<uint64_t> &sop_zc, TilePlan &tp) {
+                    const std::vector<uint64_t> &sop_zc, TilePlan &tp, bool real = false) {
     tp.tsegs.clear();
     tp.tops.clear();
     tp.trots.assign(srots.size(), TileRot{0, 0, 0});
     tp.plan.clear();
-    const int M = tile_bits(h);
+    const int M = tile_bits(h, real);
     const int nops = (int)sops.size();
-    const bool tiled = M >= 10 && M <= 12 && h->n_local >= M + 2 && h->opt_tile_low >= 0 && h->opt_tile_low <= 8;
+    const bool tiled = tile_ok(h, real);
     if (!tiled) {
         for (int i = 0; i < nops; ++i) tp.plan.push_back(-1 - i);
         return OVQE_OK;
@@ -704,14 +746,14 @@ int build_tile_plan(ovqe_handle h, const std::vector<SmallOp> &sops, const std::
         }
         for (int b = 0; __builtin_popcountll(S) < M; ++b) S |= 1ull << b;  // fill with the lowest free bits
         TileSeg sg = {};
-        sg.smask = S;
-        uint64_t lo = 0, mk = S;
+        sg.smask = real ? S >> 1 : S;  // real state: masks in the index space of amplitude pairs
+        uint64_t lo = 0, mk = sg.smask;
         for (int k = 0; k < TILE_SWEEP_LOG_NT; ++k) {  // thread bits
             lo |= mk & (0ull - mk);
             mk &= mk - 1ull;
         }
         sg.mask_lo = lo;
-        sg.mask_hi = S & ~lo;
+        sg.mask_hi = sg.smask & ~lo;
         sg.op0 = (int32_t)tp.tops.size();
         sg.rot0 = sg.rot1 = -1;
         for (int o = i; o < j; ++o) {
@@ -772,8 +814,19 @@ inline RotParam resolve_rot(const SmallRot &sr, const double *theta) {
 // run the compiled program with the streaming kernels (state left in h->state).
 // Angle table: [0, S) the entries of the table-fused program (tile sweeps, sequential runs), [S, S+R) the original
 // rotations (commuting runs that keep their own sweep run in their sequential form).
-int run_program_streaming(ovqe_handle h, const double *theta) {
-    int rc = init_basis(h, h->hf, h->init_amp);
+int run_program_streaming(ovqe_handle h, const double *theta, bool real = false) {
+    int rc = OVQE_OK;
+    if (real) {
+        if (!h->tp_real_built) {
+            rc = build_tile_plan(h, h->sops, h->srots, h->sop_zc, h->tp_real, true);
+            if (rc) return rc;
+            h->tp_real_built = true;
+        }
+        hipLaunchKernelGGL(k_init_basis_real, dim3(reduce_blocks(h->namps)), dim3(256), 0, h->stream, (double *)h->state,
+                           h->namps, h->hf);
+    } else {
+        rc = init_basis(h, h->hf, h->init_amp);
+    }
     if (rc) return rc;
     const size_t S = h->srots.size(), R = h->rots.size();
     rc = ensure_rp(h, std::max<size_t>(S + R, 1));
@@ -783,13 +836,34 @@ int run_program_streaming(ovqe_handle h, const double *theta) {
     if (S + R)
         HIPC(h, hipMemcpyAsync(h->d_rp.p, h->h_rp, (S + R) * sizeof(RotParam), hipMemcpyHostToDevice, h->stream));
     const RotParam *d_rp = (const RotParam *)h->d_rp.p;
-    for (const int32_t step : h->tp.plan) {
+    const TilePlan &tp = real ? h->tp_real : h->tp;
+    const int nbr = reduce_blocks(h->namps);
+    for (const int32_t step : tp.plan) {
         if (step >= 0) {
-            rc = launch_tile_segment(h, h->tp, h->tp.tsegs[step]);
+            rc = launch_tile_segment(h, tp, tp.tsegs[step], real);
             if (rc) return rc;
             continue;
         }
         const SmallOp &op = h->sops[-1 - step];
+        if (real) {  // one-op sweeps on the real state
+            double *st = (double *)h->state;
+            if (op.kind == OP_PAIR) {
+                hipLaunchKernelGGL(k_rot_pairs_real, dim3(nbr), dim3(256), 0, h->stream, st, h->namps >> 1, op.pivot, op.x,
+                                   h->base, d_rp + op.first, op.count);
+            } else if (op.kind == OP_TAB) {
+                const SmallOp &src = h->ops[h->sop_src[-1 - step]];
+                hipLaunchKernelGGL(k_rot_pairs_real, dim3(nbr), dim3(256), 0, h->stream, st, h->namps >> 1, src.pivot, src.x,
+                                   h->base, d_rp + S + src.first, src.count);
+            } else if (op.kind == OP_X || op.kind == OP_H) {
+                hipLaunchKernelGGL(k_gate_real, dim3(nbr), dim3(256), 0, h->stream, st, h->namps >> 1,
+                                   op.kind == OP_X ? 0 : 1, op.pivot, 0);
+            } else if (op.kind == OP_CNOT) {
+                hipLaunchKernelGGL(k_gate_real, dim3(nbr), dim3(256), 0, h->stream, st, h->namps >> 2, 2, op.first, op.count);
+            } else {
+                return fail(h, OVQE_ERR_INVALID, "internal: complex op in a real program");
+            }
+            continue;
+        }
         switch (op.kind) {
         case OP_PAIR:
         case OP_DIAG:
@@ -952,6 +1026,10 @@ int finish_program(ovqe_handle h) {
     if (rc) return rc;
     rc = build_tile_program(h);
     if (rc) return rc;
+    h->tp_real_built = false;
+    h->prog_real_ok = !h->ops.empty();
+    for (const SmallOp &op : h->ops) h->prog_real_ok = h->prog_real_ok && op.kind != OP_DIAG;
+    for (const SmallRot &sr : h->rots) h->prog_real_ok = h->prog_real_ok && (sr.ny & 1);
     h->prog_set = true;
     return OVQE_OK;
 }
@@ -1609,7 +1687,9 @@ int ovqe_destroy(ovqe_handle h) {
                       &h->d_eterms, &h->d_echunks, &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries,
                       &h->tp.d_tops, &h->tp.d_trots, &h->tp_adhoc.d_tops, &h->tp_adhoc.d_trots, &h->ham.d_tchunks, &h->ham.d_tgroups, &h->ham.d_tterms, &h->ham.d_rest,
                       &h->ham_adhoc.d_groups, &h->ham_adhoc.d_terms, &h->ham_adhoc.d_tchunks, &h->ham_adhoc.d_tgroups,
-                      &h->ham_adhoc.d_tterms, &h->ham_adhoc.d_rest};
+                      &h->ham_adhoc.d_tterms, &h->ham_adhoc.d_rest, &h->tp_real.d_tops, &h->tp_real.d_trots,
+                      &h->ham_real.d_terms, &h->ham_real.d_tchunks, &h->ham_real.d_tgroups, &h->ham_real.d_tterms,
+                      &h->ham_real.d_rest};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (h->h_rp) (void)hipHostFree(h->h_rp);
@@ -1649,6 +1729,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
         if (h->prog_set) return finish_program(h);
     }
     else if (k == "rot_variant") h->opt_rot_variant = (int)value;
+    else if (k == "real_stream") h->opt_real_stream = (int)value;
     else if (k == "clifford_frame") h->opt_clifford_frame = (int)value;  // applies to the next ovqe_set_gate_program
     else if (k == "tile_bits" || k == "tile_low") {
         (k == "tile_bits" ? h->opt_tile_bits : h->opt_tile_low) = (int)value;
@@ -1943,6 +2024,7 @@ int ovqe_set_hamiltonian(ovqe_handle h, int64_t T, const uint64_t *x, const uint
     h->ham.constant = constant;
     h->ham.set = true;
     h->ham.tile_bits = -1;  // tile cover rebuilt on first use
+    h->ham.version++;
     h->exp_lbits = -1;
     h->sp_tried = false;
     return OVQE_OK;
@@ -2023,12 +2105,25 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
     if (use_small_path(h, B)) return run_small(h, B, theta, energies);
     HIPC(h, hipEventRecord(h->ev0, h->stream));
     for (int64_t b = 0; b < B; ++b) {
-        rc = run_program_streaming(h, theta + b * (int64_t)K);
+        // programs that keep the amplitudes real stream 8 bytes per amplitude (state left as 2^n doubles)
+        const bool real = h->opt_real_stream && h->prog_real_ok && h->n_global == 0 && tile_ok(h, true) &&
+                          h->ham.groups.size() >= 3;
+        if (real && h->ham_real.version != h->ham.version) {
+            HamDev &R = h->ham_real;
+            R.groups = h->ham.groups;
+            R.terms = h->ham.terms;
+            rc = upload(h, R.d_terms, R.terms.data(), R.terms.size() * sizeof(HTerm));
+            if (rc) return rc;
+            R.tile_bits = -1;
+            R.version = h->ham.version;
+        }
+        rc = run_program_streaming(h, theta + b * (int64_t)K, real);
         if (rc) return rc;
         double2 res;
         bool tiled = false;
-        rc = run_expectation_tiled(h, h->ham, &res, &tiled);
+        rc = run_expectation_tiled(h, real ? h->ham_real : h->ham, &res, &tiled, real);
         if (rc) return rc;
+        if (real && !tiled) return fail(h, OVQE_ERR_INVALID, "internal: real-amplitude path without a tile cover");
         if (!tiled)
             rc = run_bilinear(h, h->state, h->state, h->ham.groups, (const HGroup *)h->ham.d_groups.p,
                               (const HTerm *)h->ham.d_terms.p, &res, true);
@@ -2468,13 +2563,14 @@ int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, 
 int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
     if (!h || !info || count < 0) return OVQE_ERR_INVALID;
     if (!h->prog_set) return fail(h, OVQE_ERR_STATE, "no program set");
-    int64_t v[12] = {(int64_t)h->ops.size(), (int64_t)h->rots.size(), 0, (int64_t)h->tp.plan.size(),
+    int64_t v[13] = {(int64_t)h->ops.size(), (int64_t)h->rots.size(), 0, (int64_t)h->tp.plan.size(),
                      (int64_t)h->tp.tsegs.size(), (int64_t)h->sops.size(),
                      !h->sp_tried ? -1 : (h->sp_valid ? (int64_t)h->sp_m : 0),
                      (int64_t)h->ham.tsweeps.size(), (int64_t)h->ham.n_rest, h->ham.tile_entries, h->ham.tile_terms,
-                     h->ham.tile_work};
+                     h->ham.tile_work,
+                     (h->opt_real_stream && h->prog_real_ok && h->n_global == 0 && tile_ok(h, true)) ? 1 : 0};
     for (const SmallOp &op : h->ops) v[2] += (op.kind == OP_X || op.kind == OP_H || op.kind == OP_CNOT);
-    for (int i = 0; i < count && i < 12; ++i) info[i] = v[i];
+    for (int i = 0; i < count && i < 13; ++i) info[i] = v[i];
     return OVQE_OK;
 }
 

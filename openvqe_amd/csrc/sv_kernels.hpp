@@ -497,6 +497,96 @@ __global__ __launch_bounds__(256) void k_norm2(const amp_t *__restrict__ st, uin
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
+// ---- real-amplitude state (2^n doubles): one-op sweeps for what does not fit a tile ----------------------------
+// run of odd-ny rotations sharing x: u' = c u + s_i v, v' = c v + s_j u
+__global__ __launch_bounds__(256) void k_rot_pairs_real(double *__restrict__ st, uint64_t npairs, int pivot, uint64_t x,
+                                                        uint64_t base, const RotParam *__restrict__ rp, int nrot) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k < npairs; k += stride) {
+        const uint64_t i = insert_zero(k, pivot), j = i ^ x;
+        double u = st[i], v = st[j];
+        for (int r = 0; r < nrot; ++r) {
+            const RotParam rr = rp[r];
+            const int pi = parity64((base | i) & rr.z);
+            const double si = (pi ^ 1) ? -rr.s : rr.s, sj = pi ? -rr.s : rr.s;  // odd ny: pj = pi ^ 1
+            const double nu = rr.c * u + si * v, nv = rr.c * v + sj * u;
+            u = nu;
+            v = nv;
+        }
+        st[i] = u;
+        st[j] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gate_real(double *__restrict__ st, uint64_t nwork, int kind, int b0, int b1) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k < nwork; k += stride) {
+        uint64_t i, j;
+        if (kind == 2) {
+            const int lo = b0 < b1 ? b0 : b1, hi = b0 < b1 ? b1 : b0;
+            i = insert_zero(insert_zero(k, lo), hi) | (1ull << b0);
+            j = i | (1ull << b1);
+        } else {
+            i = insert_zero(k, b0);
+            j = i | (1ull << b0);
+        }
+        const double a = st[i], b = st[j];
+        if (kind == 1) {
+            const double r = 0.70710678118654752440;
+            st[i] = (a + b) * r;
+            st[j] = (a - b) * r;
+        } else {
+            st[i] = b;
+            st[j] = a;
+        }
+    }
+}
+
+// pair-trick expectation of the groups [g0, g1) on a real state (terms with an imaginary folded coefficient vanish)
+__global__ __launch_bounds__(256) void k_expect_pairs_real(const double *__restrict__ st, uint64_t namps,
+                                                           const HGroup *__restrict__ groups, int g0, int g1,
+                                                           const HTerm *__restrict__ terms,
+                                                           double2 *__restrict__ partials) {
+    __shared__ double2 red[4];
+    double acc = 0.0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (int g = g0; g < g1; ++g) {
+        const HGroup gr = groups[g];
+        const bool diag = gr.x == 0;
+        const int pivot = diag ? 0 : 63 - __clzll(gr.x);
+        const uint64_t cnt = diag ? namps : (namps >> 1);
+        for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k < cnt; k += stride) {
+            const uint64_t i = diag ? k : insert_zero(k, pivot), j = i ^ gr.x;
+            const uint64_t gj = gr.jbase | j;
+            double d = 0.0;
+            for (int t = gr.t0; t < gr.t1; ++t) {
+                const HTerm ht = terms[t];
+                d += parity64(gj & ht.z) ? -ht.cr : ht.cr;
+            }
+            acc += (diag ? 1.0 : 2.0) * d * st[i] * st[j];
+        }
+    }
+    const double2 t = block_sum<256>(make_double2(acc, 0.0), red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void k_init_basis_real(double *__restrict__ st, uint64_t namps, uint64_t index) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) st[i] = i == index ? 1.0 : 0.0;
+}
+
+// in-place widening real -> complex of the amplitudes [lo, hi): complex[i] = one * real[i].  Called for the index
+// ranges [2^k, 2^(k+1)) from the top down (the complex image of a range lies beyond the reals still to be read), then [0,1).
+__global__ __launch_bounds__(256) void k_widen(void *__restrict__ st, uint64_t lo, uint64_t hi, double2 one) {
+    const double *re = reinterpret_cast<const double *>(st);
+    amp_t *cx = reinterpret_cast<amp_t *>(st);
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = lo + (uint64_t)blockIdx.x * 256u + threadIdx.x; i < hi; i += stride) {
+        const double a = re[i];
+        cx[i] = make_double2(a * one.x, a * one.y);
+    }
+}
+
 // ---- adjoint (reverse-mode) gradient of E(theta) = <psi(theta)|H|psi(theta)>  (ovqe_energy_gradient) ----------
 // Backward pass over one same-x run, rotations in REVERSE order.  psi holds U_r...U_1|hf>, lam holds
 // U_{r+1}^+...U_R^+ H|psi_R>; for every rotation r of the run the kernel accumulates

@@ -54,23 +54,30 @@ __device__ __forceinline__ uint64_t spread_bits(uint32_t v, uint64_t mask) {
     return r;
 }
 
-template <int M, int NT, bool NTL>
-__global__ __launch_bounds__(NT) void k_tile_sweep(amp_t *__restrict__ st, uint64_t base, TileSeg seg,
+// REAL = true: the state is stored as 2^n doubles (a program whose rotations all have an odd number of Y, starting from
+// a basis state, keeps the amplitudes real): the same code moves 16-byte elements = PAIRS of amplitudes, i.e. the
+// segment's masks live in the index space of the pairs (amplitude index >> 1, bit 0 always inside the tile), and the
+// tile holds 2^M doubles — twice the amplitudes per LDS byte, so one more mixing bit per sweep at half the HBM bytes.
+template <int M, int NT, bool NTL, bool REAL>
+__global__ __launch_bounds__(NT) void k_tile_sweep(void *__restrict__ st, uint64_t base, TileSeg seg,
                                                    const TileOp *__restrict__ ops, const TileRot *__restrict__ trot,
                                                    const RotParam *__restrict__ rp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr uint32_t NEL = 1u << M;
-    constexpr int TRIPS = NEL / NT;
+    typedef typename Amp<REAL>::T amp;
+    constexpr uint32_t NEL = 1u << M;                 // amplitudes per tile
+    constexpr uint32_t NELV = REAL ? NEL / 2 : NEL;   // 16-byte elements per tile
+    constexpr int TRIPS = NELV / NT;
     constexpr int U = (NEL / 2 / NT) >= 4 ? 4 : ((NEL / 2 / NT) >= 2 ? 2 : 1);
-    double2 *tile = reinterpret_cast<double2 *>(smem);
-    RotLds *tab = reinterpret_cast<RotLds *>(smem + (size_t)NEL * sizeof(double2));
+    amp *tile = reinterpret_cast<amp *>(smem);
+    double2 *tilev = reinterpret_cast<double2 *>(smem);
+    RotLds *tab = reinterpret_cast<RotLds *>(smem + (size_t)NELV * sizeof(double2));
     v2d *p = reinterpret_cast<v2d *>(st);
 
     // tile base: the block index spread over the index bits NOT in the tile
     uint64_t tb = blockIdx.x;
     for (uint64_t mk = seg.smask; mk; mk &= mk - 1ull) tb = insert_zero(tb, __ffsll((long long)mk) - 1);
     const uint64_t glow = spread_bits(threadIdx.x, seg.mask_lo);
-    const uint64_t gbase = base | tb;
+    const uint64_t gbase = base | (REAL ? tb << 1 : tb);
 
     v2d reg[TRIPS];
 #pragma unroll
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(NT) void k_tile_sweep(amp_t *__restrict__ st, uint6
         tab[r - seg.rot0] = rl;
     }
 #pragma unroll
-    for (int j = 0; j < TRIPS; ++j) tile[threadIdx.x + j * NT] = make_double2(reg[j].x, reg[j].y);
+    for (int j = 0; j < TRIPS; ++j) tilev[threadIdx.x + j * NT] = make_double2(reg[j].x, reg[j].y);
     __syncthreads();
 
     for (int o = seg.op0; o < seg.op1; ++o) {
@@ -105,29 +112,29 @@ __global__ __launch_bounds__(NT) void k_tile_sweep(amp_t *__restrict__ st, uint6
         if (op.kind == OP_TAB) {
             op.zc = top.zc;
             op.fixmask = top.x;
-            small_pass_tab<false, NT>(tile, M, op, tab + (op.first - seg.rot0));
+            small_pass_tab<REAL, NT>(tile, M, op, tab + (op.first - seg.rot0));
         } else if (op.kind == OP_PAIR) {
-            small_pass_pair<false, NT, U>(tile, NEL >> 1, op, tab + (op.first - seg.rot0));
+            small_pass_pair<REAL, NT, U>(tile, NEL >> 1, op, tab + (op.first - seg.rot0));
         } else if (op.kind == OP_DIAG) {
-            small_pass_diag<NT>(tile, NEL, op, tab + (op.first - seg.rot0));
+            if constexpr (!REAL) small_pass_diag<NT>(tile, NEL, op, tab + (op.first - seg.rot0));
         } else if (op.kind == OP_CNOT) {
             if (top.first >= 0) {
                 op.first = top.first;   // local control
                 op.count = top.pivot;   // local target
-                small_pass_gate<false, NT>(tile, NEL, op);
+                small_pass_gate<REAL, NT>(tile, NEL, op);
             } else if ((gbase >> (-1 - top.first)) & 1ull) {
                 op.kind = OP_X;         // control bit is set on the whole tile
-                small_pass_gate<false, NT>(tile, NEL, op);
+                small_pass_gate<REAL, NT>(tile, NEL, op);
             }
         } else {
-            small_pass_gate<false, NT>(tile, NEL, op);
+            small_pass_gate<REAL, NT>(tile, NEL, op);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 
 #pragma unroll
     for (int j = 0; j < TRIPS; ++j) {
-        const double2 a = tile[threadIdx.x + j * NT];
+        const double2 a = tilev[threadIdx.x + j * NT];
         const v2d t = {a.x, a.y};
         const uint64_t g = tb | glow | spread_bits((uint32_t)j, seg.mask_hi);
         if (NTL) __builtin_nontemporal_store(t, &p[g]); else p[g] = t;
@@ -174,25 +181,28 @@ struct ExTermLds {
     uint32_t zin, pad;
 };
 
-template <int M, int NT, bool NTL>
-__global__ __launch_bounds__(NT) void k_tile_expect(const amp_t *__restrict__ st, uint64_t base, ExSweep sw,
+template <int M, int NT, bool NTL, bool REAL>
+__global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st, uint64_t base, ExSweep sw,
                                                     const ExChunkT *__restrict__ chunks,
                                                     const ExEntryT *__restrict__ entries,
                                                     const ExTermT *__restrict__ terms, double2 *__restrict__ partials,
                                                     int accumulate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename Amp<REAL>::T amp;
     constexpr uint32_t NEL = 1u << M;
-    constexpr int TRIPS = NEL / NT;
+    constexpr uint32_t NELV = REAL ? NEL / 2 : NEL;  // 16-byte elements (REAL: pairs of amplitudes, see k_tile_sweep)
+    constexpr int TRIPS = NELV / NT;
     constexpr int PP = TILE_ENTRY_PAIRS / 64;  // pairs per lane
-    double2 *tile = reinterpret_cast<double2 *>(smem);
-    ExTermLds *lt = reinterpret_cast<ExTermLds *>(smem + (size_t)NEL * sizeof(double2));
+    const amp *tile = reinterpret_cast<const amp *>(smem);
+    double2 *tilev = reinterpret_cast<double2 *>(smem);
+    ExTermLds *lt = reinterpret_cast<ExTermLds *>(smem + (size_t)NELV * sizeof(double2));
     double2 *red = reinterpret_cast<double2 *>(lt + TILE_TERM_CAP);
     const v2d *p = reinterpret_cast<const v2d *>(st);
 
     uint64_t tb = blockIdx.x;
     for (uint64_t mk = sw.smask; mk; mk &= mk - 1ull) tb = insert_zero(tb, __ffsll((long long)mk) - 1);
     const uint64_t glow = spread_bits(threadIdx.x, sw.mask_lo);
-    const uint64_t gbase = base | tb;
+    const uint64_t gbase = base | (REAL ? tb << 1 : tb);
     {
         v2d reg[TRIPS];
 #pragma unroll
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const amp_t *__restrict__ st
             reg[j] = NTL ? __builtin_nontemporal_load(&p[g]) : p[g];
         }
 #pragma unroll
-        for (int j = 0; j < TRIPS; ++j) tile[threadIdx.x + j * NT] = make_double2(reg[j].x, reg[j].y);
+        for (int j = 0; j < TRIPS; ++j) tilev[threadIdx.x + j * NT] = make_double2(reg[j].x, reg[j].y);
     }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t lane = threadIdx.x & 63u;
@@ -240,12 +250,16 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const amp_t *__restrict__ st
                 uint32_t i = dlane;
                 for (uint32_t k = lane; k < (uint32_t)en.nk; k += 64u) {
                     const uint32_t j = i ^ en.x;
-                    const double2 a = tile[i], c = tile[j];
-                    const double wx = a.x * c.x + a.y * c.y, wy = a.x * c.y - a.y * c.x;
+                    const amp a = tile[i], c = tile[j];
                     const bool n0 = __popc(j & l0.zin) & 1, n1 = __popc(j & l1.zin) & 1;
                     const double dr = (n0 ? -l0.cr : l0.cr) + (n1 ? -l1.cr : l1.cr);
-                    const double di = (n0 ? -l0.ci : l0.ci) + (n1 ? -l1.ci : l1.ci);
-                    part += dr * wx - di * wy;
+                    if constexpr (REAL) {
+                        part += dr * (a * c);
+                    } else {
+                        const double wx = a.x * c.x + a.y * c.y, wy = a.x * c.y - a.y * c.x;
+                        const double di = (n0 ? -l0.ci : l0.ci) + (n1 ? -l1.ci : l1.ci);
+                        part += dr * wx - di * wy;
+                    }
                     i = (((i | en.x) + d64) & ~en.x) | en.ibits;  // next free index, x positions skipped
                 }
             } else {
@@ -257,13 +271,18 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const amp_t *__restrict__ st
                 const bool live = lane + 64u * m < (uint32_t)en.nk;
                 const uint32_t i = deposit_index(k, en.x) | en.ibits;
                 jj[m] = i ^ en.x;
-                const double2 a = tile[i & (NEL - 1u)], c = tile[jj[m] & (NEL - 1u)];
-                vx[m] = live ? a.x * c.x + a.y * c.y : 0.0;  // conj(a_i) a_j   (x = 0: |a_i|^2)
-                vy[m] = live ? a.x * c.y - a.y * c.x : 0.0;
+                const amp a = tile[i & (NEL - 1u)], c = tile[jj[m] & (NEL - 1u)];
+                if constexpr (REAL) {
+                    vx[m] = live ? a * c : 0.0;
+                    vy[m] = 0.0;
+                } else {
+                    vx[m] = live ? a.x * c.x + a.y * c.y : 0.0;  // conj(a_i) a_j   (x = 0: |a_i|^2)
+                    vy[m] = live ? a.x * c.y - a.y * c.x : 0.0;
+                }
                 dr[m] = 0.0;
                 di[m] = 0.0;
             }
-            if (en.real_only) {
+            if (REAL || en.real_only) {
                 for (int t = 0; t < nt; ++t) {
                     const ExTermLds l = gt[t];
 #pragma unroll

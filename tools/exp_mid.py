@@ -5,6 +5,7 @@ import numpy as np
 from openvqe_amd import fermion
 from openvqe_amd.backend import Statevector
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
+if "--cache" in sys.argv: args = [a for a in args if a != sys.argv[sys.argv.index("--cache") + 1]]
 m, o = (int(args[0]), int(args[1])) if len(args) > 1 else (12, 5)
 cache = sys.argv[sys.argv.index("--cache") + 1] if "--cache" in sys.argv else None
 reps = 1 if "--once" in sys.argv else 2
@@ -19,7 +20,9 @@ n = 2 * m
 R = sum(len(g.terms) for g in gens); G = len(set(ham.packed()[0].tolist()))
 print(f"n={n} build {time.time()-t:.1f}s terms={len(ham.terms)} groups={G} gens={len(gens)} rots={R}", flush=True)
 theta = np.random.default_rng(1).uniform(-0.1, 0.1, len(gens))
+opts = [a[6:].split("=") for a in sys.argv if a.startswith("--opt=")]
 with Statevector(n) as sv:
+    for k, v in opts: sv.set_option(k, int(v))
     t = time.time(); sv.set_hamiltonian(ham); sv.set_ucc_program(gens, hf); print(f"upload {time.time()-t:.2f}s", flush=True)
     for rep in range(reps):
         t = time.time(); sv.prepare_state(theta); t1 = time.time() - t
