@@ -2563,12 +2563,13 @@ int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, 
 int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
     if (!h || !info || count < 0) return OVQE_ERR_INVALID;
     if (!h->prog_set) return fail(h, OVQE_ERR_STATE, "no program set");
+    const bool real_on = h->opt_real_stream && h->prog_real_ok && h->n_global == 0 && tile_ok(h, true);
+    const HamDev &HI = (real_on && h->ham_real.version == h->ham.version) ? h->ham_real : h->ham;  // the cover in use
     int64_t v[13] = {(int64_t)h->ops.size(), (int64_t)h->rots.size(), 0, (int64_t)h->tp.plan.size(),
                      (int64_t)h->tp.tsegs.size(), (int64_t)h->sops.size(),
                      !h->sp_tried ? -1 : (h->sp_valid ? (int64_t)h->sp_m : 0),
-                     (int64_t)h->ham.tsweeps.size(), (int64_t)h->ham.n_rest, h->ham.tile_entries, h->ham.tile_terms,
-                     h->ham.tile_work,
-                     (h->opt_real_stream && h->prog_real_ok && h->n_global == 0 && tile_ok(h, true)) ? 1 : 0};
+                     (int64_t)HI.tsweeps.size(), (int64_t)HI.n_rest, HI.tile_entries, HI.tile_terms, HI.tile_work,
+                     real_on ? 1 : 0};
     for (const SmallOp &op : h->ops) v[2] += (op.kind == OP_X || op.kind == OP_H || op.kind == OP_CNOT);
     for (int i = 0; i < count && i < 13; ++i) info[i] = v[i];
     return OVQE_OK;

@@ -84,8 +84,10 @@ def _sparse_rotate(psi, x, z, phi):
     return out
 
 
-def test_30_qubit_tiled_program_and_expectation_against_sparse_oracle(gpu_lib):
-    """a UCC-type program from |hf> at 30 qubits (JW doubles and singles with long z chains, a wide string that keeps
+@pytest.mark.parametrize("real", [False, True])
+def test_30_qubit_tiled_program_and_expectation_against_sparse_oracle(gpu_lib, real):
+    """(real = True: every string has an odd number of Y, so streaming energies keep 2^30 REAL amplitudes, 8 GiB)
+    a UCC-type program from |hf> at 30 qubits (JW doubles and singles with long z chains, a wide string that keeps
     its own sweep, a diagonal string): LDS-tiled sweeps + tiled <H> (non-temporal paths) against a host simulation of
     the few non-zero amplitudes, and against the one-sweep-per-op kernels"""
     from openvqe_amd import fermion
@@ -96,8 +98,10 @@ def test_30_qubit_tiled_program_and_expectation_against_sparse_oracle(gpu_lib):
     gens = [fermion._excitation_generator(n, [a], [i]) for i, a in ((0, 28), (3, 17))]
     gens += [fermion._excitation_generator(n, [b, a], [i, j]) for i, j, a, b in
              ((0, 1, 26, 29), (2, 3, 12, 13), (1, 2, 20, 27), (0, 3, 8, 9), (4, 5, 28, 29), (0, 1, 6, 7))]
-    gens.insert(3, Hamiltonian(n, [Term(0.7, "XYZXZZYXXY", [0, 3, 5, 8, 11, 14, 19, 22, 25, 29])], do_clean_up=False))
-    gens.insert(5, Hamiltonian(n, [Term(-0.4, "ZZZ", [1, 15, 29])], do_clean_up=False))
+    wide = "XYZXZZXXXX" if real else "XYZXZZYXXY"
+    gens.insert(3, Hamiltonian(n, [Term(0.7, wide, [0, 3, 5, 8, 11, 14, 19, 22, 25, 29])], do_clean_up=False))
+    if not real:
+        gens.insert(5, Hamiltonian(n, [Term(-0.4, "ZZZ", [1, 15, 29])], do_clean_up=False))
     hf = fermion.hf_integer(n, 6)
     theta = rng.uniform(-0.6, 0.6, len(gens))
     terms = [Term(0.5, "Z", [0]), Term(-0.25, "ZZ", [2, 29]), Term(0.3, "XZZX", [0, 1, 2, 3]),
@@ -131,6 +135,7 @@ def test_30_qubit_tiled_program_and_expectation_against_sparse_oracle(gpu_lib):
             sv.prepare_state(theta)
             res[bits] = (e, sv.get_amplitudes(support), sv.get_amplitudes(extra), sv.norm2(), info, sv.program_info())
     assert res[11][4]["tiled_sweeps"] >= 1 and res[0][4]["tiled_sweeps"] == 0
+    assert res[11][4]["real_stream"] == (1 if real else 0)
     assert res[11][5]["h_tile_sweeps"] >= 1 and res[11][5]["h_untiled_groups"] == 1
     for bits, (e, amps, others, n2, _, _) in res.items():
         assert abs(e - e_ref) < 1e-12, bits
