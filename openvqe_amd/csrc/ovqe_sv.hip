@@ -2565,8 +2565,9 @@ int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
     if (!h->prog_set) return fail(h, OVQE_ERR_STATE, "no program set");
     const bool real_on = h->opt_real_stream && h->prog_real_ok && h->n_global == 0 && tile_ok(h, true);
     const HamDev &HI = (real_on && h->ham_real.version == h->ham.version) ? h->ham_real : h->ham;  // the cover in use
-    int64_t v[13] = {(int64_t)h->ops.size(), (int64_t)h->rots.size(), 0, (int64_t)h->tp.plan.size(),
-                     (int64_t)h->tp.tsegs.size(), (int64_t)h->sops.size(),
+    const TilePlan &TP = (real_on && h->tp_real_built) ? h->tp_real : h->tp;  // the plan the energies use
+    int64_t v[13] = {(int64_t)h->ops.size(), (int64_t)h->rots.size(), 0, (int64_t)TP.plan.size(),
+                     (int64_t)TP.tsegs.size(), (int64_t)h->sops.size(),
                      !h->sp_tried ? -1 : (h->sp_valid ? (int64_t)h->sp_m : 0),
                      (int64_t)HI.tsweeps.size(), (int64_t)HI.n_rest, HI.tile_entries, HI.tile_terms, HI.tile_work,
                      real_on ? 1 : 0};
