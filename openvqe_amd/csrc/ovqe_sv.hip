@@ -52,7 +52,7 @@ struct HamDev {  // grouped Pauli sum resident on the device
     std::vector<ExSweep> tsweeps;
     int n_rest = 0;  // groups that fit no tile keep their own sweep (k_expect_pairs)
     int64_t tile_work = 0, tile_entries = 0, tile_terms = 0;  // pair x term evaluations per tile over all sweeps
-    DevBuf d_tchunks, d_tgroups, d_tterms, d_rest;
+    DevBuf d_tchunks, d_tgroups, d_tterms, d_tflats, d_titems, d_rest;
 };
 
 }  // namespace
@@ -414,6 +414,7 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
     H.tile_real = real;
     H.tsweeps.clear();
     H.n_rest = 0;
+    H.tile_work = 0;
     const bool tiled = tile_ok(h, real) && H.groups.size() >= 3;
     if (!tiled) return OVQE_OK;
     const int G = (int)H.groups.size();
@@ -423,6 +424,8 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
     std::vector<ExEntryT> tgroups;
     std::map<std::pair<uint64_t, uint64_t>, std::pair<double, double>> merged;
     std::vector<ExTermT> tterms;
+    std::vector<ExFlatT> tflats;
+    std::vector<ExItemT> titems;
     std::vector<HGroup> rest;
     int remaining = 0;
     for (int g = 0; g < G; ++g) {
@@ -465,6 +468,7 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
         sw.mask_lo = lo;
         sw.mask_hi = sw.smask & ~lo;
         sw.c0 = (int32_t)chunks.size();
+        sw.i0 = (int32_t)titems.size();
         ExChunkT ck = {(int32_t)tgroups.size(), (int32_t)tgroups.size(), (int32_t)tterms.size(), (int32_t)tterms.size()};
         int took = 0;
         for (int g = 0; g < G; ++g) {
@@ -508,6 +512,33 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
                 }
                 if (mt.empty()) continue;
                 const int nk_total = 1 << (M - w);
+                if (mt.size() <= 2 && nk_total >= 2) {  // one lane per TILE_ITEM_PAIRS pairs (sv_tile.hpp)
+                    ExFlatT fe = {};
+                    fe.x = xl;
+                    fe.ibits = ibits;
+                    fe.zin0 = mt[0].zin;
+                    fe.zout0 = mt[0].zout;
+                    fe.c0r = mt[0].cr;
+                    fe.c0i = mt[0].ci;
+                    if (mt.size() == 2) {
+                        fe.zin1 = mt[1].zin;
+                        fe.zout1 = mt[1].zout;
+                        fe.c1r = mt[1].cr;
+                        fe.c1i = mt[1].ci;
+                    }
+                    for (int k0 = 0; k0 < nk_total; k0 += TILE_ITEM_PAIRS) {
+                        uint32_t istart = (uint32_t)k0;  // deposit k0 over the positions outside x, ascending
+                        for (int f = 0; f < w; ++f) {
+                            const uint32_t low = (1u << xpos[f]) - 1u;
+                            istart = ((istart & ~low) << 1) | (istart & low);
+                        }
+                        titems.push_back(ExItemT{(uint32_t)tflats.size(), istart | ibits,
+                                                 (uint32_t)std::min(TILE_ITEM_PAIRS, nk_total - k0), 0u});
+                    }
+                    tflats.push_back(fe);
+                    H.tile_work += (int64_t)nk_total * (int64_t)mt.size();
+                    continue;
+                }
                 for (size_t m0 = 0; m0 < mt.size(); m0 += TILE_TERM_CAP) {  // oversized lists are split (linear)
                     const size_t m1 = std::min(mt.size(), m0 + TILE_TERM_CAP);
                     if ((int)tterms.size() - ck.t0 + (int)(m1 - m0) > TILE_TERM_CAP) {
@@ -536,19 +567,23 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
         ck.t1 = (int32_t)tterms.size();
         if (ck.g1 > ck.g0) chunks.push_back(ck);
         sw.c1 = (int32_t)chunks.size();
+        sw.i1 = (int32_t)titems.size();
         if (took == 0) return fail(h, OVQE_ERR_INVALID, "internal: tile cover made no progress");
         H.tsweeps.push_back(sw);
     }
     H.n_rest = (int)rest.size();
-    H.tile_work = 0;
     for (const ExEntryT &en : tgroups) H.tile_work += (int64_t)en.nk * (en.t1 - en.t0);
-    H.tile_entries = (int64_t)tgroups.size();
+    H.tile_entries = (int64_t)(tgroups.size() + tflats.size());
     H.tile_terms = (int64_t)tterms.size();
     int rc = upload(h, H.d_tchunks, chunks.data(), chunks.size() * sizeof(ExChunkT));
     if (rc) return rc;
     rc = upload(h, H.d_tgroups, tgroups.data(), tgroups.size() * sizeof(ExEntryT));
     if (rc) return rc;
     rc = upload(h, H.d_tterms, tterms.data(), tterms.size() * sizeof(ExTermT));
+    if (rc) return rc;
+    rc = upload(h, H.d_tflats, tflats.data(), tflats.size() * sizeof(ExFlatT));
+    if (rc) return rc;
+    rc = upload(h, H.d_titems, titems.data(), titems.size() * sizeof(ExItemT));
     if (rc) return rc;
     return upload(h, H.d_rest, rest.data(), rest.size() * sizeof(HGroup));
 }
@@ -576,11 +611,13 @@ int launch_tile_expect(ovqe_handle h, const HamDev &H, const ExSweep &sw, double
     if (h->n_local >= 25) {
         hipLaunchKernelGGL((k_tile_expect<M, NT, true, REAL>), grid, dim3(NT), smem, h->stream, (const void *)h->state, h->base, sw,
                            (const ExChunkT *)H.d_tchunks.p, (const ExEntryT *)H.d_tgroups.p,
-                           (const ExTermT *)H.d_tterms.p, partials, accumulate);
+                           (const ExTermT *)H.d_tterms.p, (const ExFlatT *)H.d_tflats.p, (const ExItemT *)H.d_titems.p, partials,
+                           accumulate);
     } else {
         hipLaunchKernelGGL((k_tile_expect<M, NT, false, REAL>), grid, dim3(NT), smem, h->stream, (const void *)h->state, h->base, sw,
                            (const ExChunkT *)H.d_tchunks.p, (const ExEntryT *)H.d_tgroups.p,
-                           (const ExTermT *)H.d_tterms.p, partials, accumulate);
+                           (const ExTermT *)H.d_tterms.p, (const ExFlatT *)H.d_tflats.p, (const ExItemT *)H.d_titems.p, partials,
+                           accumulate);
     }
     HIPC(h, hipGetLastError());
     return OVQE_OK;
@@ -1685,7 +1722,8 @@ int ovqe_destroy(ovqe_handle h) {
     DevBuf *bufs[] = {&h->d_partials, &h->d_result, &h->d_rp, &h->ham.d_groups, &h->ham.d_terms, &h->d_ops,
                       &h->d_rots, &h->d_segs, &h->d_stream, &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups,
                       &h->d_eterms, &h->d_echunks, &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries,
-                      &h->tp.d_tops, &h->tp.d_trots, &h->tp_adhoc.d_tops, &h->tp_adhoc.d_trots, &h->ham.d_tchunks, &h->ham.d_tgroups, &h->ham.d_tterms, &h->ham.d_rest,
+                      &h->tp.d_tops, &h->tp.d_trots, &h->tp_adhoc.d_tops, &h->tp_adhoc.d_trots, &h->ham.d_tchunks, &h->ham.d_tgroups, &h->ham.d_tterms, &h->ham.d_tflats, &h->ham.d_titems, &h->ham.d_rest,
+                      &h->ham_adhoc.d_tflats, &h->ham_adhoc.d_titems, &h->ham_real.d_tflats, &h->ham_real.d_titems,
                       &h->ham_adhoc.d_groups, &h->ham_adhoc.d_terms, &h->ham_adhoc.d_tchunks, &h->ham_adhoc.d_tgroups,
                       &h->ham_adhoc.d_tterms, &h->ham_adhoc.d_rest, &h->tp_real.d_tops, &h->tp_real.d_trots,
                       &h->ham_real.d_terms, &h->ham_real.d_tchunks, &h->ham_real.d_tgroups, &h->ham_real.d_tterms,

@@ -42,6 +42,18 @@ struct TileRot {     // static part of a rotation inside its segment
     uint32_t pad;
 };
 
+// LDS bank swizzle of a tile.  The pairs of a (group, pattern) entry / of a rotation share their low index bits whenever
+// the x mask sits on the low qubits, i.e. every lane of the wave would hit the SAME bank (measured: LDS bank-conflict
+// cycles = 95 % of the busy cycles of k_tile_expect).  The 16-byte element v is therefore kept at v ^ ((v >> 3) & 7):
+// elements that agree in their low bits but differ above spread over the 8 element slots of a 128-byte LDS row, and
+// consecutive elements stay conflict-free.  For a real tile the 16-byte element is a PAIR of amplitudes: amplitude e
+// lives at e ^ (((e >> 4) & 7) << 1).
+template <bool REAL>
+__device__ __forceinline__ uint32_t tile_swz(uint32_t e) {
+    return REAL ? e ^ (((e >> 4) & 7u) << 1) : e ^ ((e >> 3) & 7u);
+}
+__device__ __forceinline__ uint32_t tile_swz_v(uint32_t v) { return v ^ ((v >> 3) & 7u); }
+
 // pdep(v, mask): spread the low bits of v over the set bits of mask (ascending); mask is wave-uniform
 __device__ __forceinline__ uint64_t spread_bits(uint32_t v, uint64_t mask) {
     uint64_t r = 0;
@@ -153,11 +165,29 @@ __global__ __launch_bounds__(NT) void k_tile_sweep(void *__restrict__ st, uint64
 // are per-tile signs, folded into the coefficients while a chunk of the term table is staged in LDS.
 constexpr int TILE_TERM_CAP = 512;
 constexpr int TILE_ENTRY_PAIRS = 256;
-constexpr int TILE_EXPECT_LOG_NT = 8;   // threads per workgroup of k_tile_expect (256 measured faster than 1024)
+constexpr int TILE_EXPECT_LOG_NT = 9;   // threads per workgroup of k_tile_expect (256 measured faster than 1024)
 
 struct ExSweep {
     uint64_t smask, mask_lo, mask_hi;
-    int32_t c0, c1;   // chunk range
+    int32_t c0, c1;   // chunk range (entries with more than two merged terms: one wave per entry)
+    int32_t i0, i1;   // flat items (entries with one or two merged terms: one LANE per 64 pairs)
+};
+// A (group, pattern) entry with at most two merged terms — nearly all of them: a JW double excitation leaves ONE
+// coefficient per active pattern — costs more in per-entry set-up than in arithmetic when a whole wave serves it.
+// Such entries are cut into items of TILE_ITEM_PAIRS pairs and every LANE walks its own item (incremental index,
+// x positions skipped): the set-up is paid per lane, 64 items side by side, all of equal length.
+constexpr int TILE_ITEM_PAIRS = 64;
+struct ExFlatT {
+    uint32_t x, ibits;      // tile-local x mask / pattern bits
+    uint32_t zin0, zin1;    // the terms' z on the tile bits (x positions cleared)
+    uint64_t zout0, zout1;  // ... and outside the tile
+    double c0r, c0i, c1r, c1i;
+};
+struct ExItemT {
+    uint32_t entry;   // index into the flat entries
+    uint32_t istart;  // tile-local index of the item's first pair (pattern bits included)
+    uint32_t count;   // pairs (<= TILE_ITEM_PAIRS, even)
+    uint32_t pad;
 };
 struct ExChunkT {
     int32_t g0, g1, t0, t1;  // entries, terms
@@ -185,7 +215,9 @@ template <int M, int NT, bool NTL, bool REAL>
 __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st, uint64_t base, ExSweep sw,
                                                     const ExChunkT *__restrict__ chunks,
                                                     const ExEntryT *__restrict__ entries,
-                                                    const ExTermT *__restrict__ terms, double2 *__restrict__ partials,
+                                                    const ExTermT *__restrict__ terms,
+                                                    const ExFlatT *__restrict__ flats,
+                                                    const ExItemT *__restrict__ items, double2 *__restrict__ partials,
                                                     int accumulate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Amp<REAL>::T amp;
@@ -211,14 +243,43 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
             reg[j] = NTL ? __builtin_nontemporal_load(&p[g]) : p[g];
         }
 #pragma unroll
-        for (int j = 0; j < TRIPS; ++j) tilev[threadIdx.x + j * NT] = make_double2(reg[j].x, reg[j].y);
+        for (int j = 0; j < TRIPS; ++j) tilev[tile_swz_v(threadIdx.x + j * NT)] = make_double2(reg[j].x, reg[j].y);
     }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t lane = threadIdx.x & 63u;
     double acc = 0.0;
+    __syncthreads();  // tile visible
+    for (int t = sw.i0 + (int)threadIdx.x + NT * (int)blockIdx.y; t < sw.i1; t += NT * (int)gridDim.y) {
+        const ExItemT it = items[t];
+        const ExFlatT fe = flats[it.entry];
+        const bool s0 = parity64(gbase & fe.zout0), s1 = parity64(gbase & fe.zout1);
+        const double c0r = s0 ? -fe.c0r : fe.c0r, c1r = s1 ? -fe.c1r : fe.c1r;
+        const double c0i = s0 ? -fe.c0i : fe.c0i, c1i = s1 ? -fe.c1i : fe.c1i;
+        const uint32_t x = fe.x, keep = ~fe.x;
+        uint32_t i = it.istart;
+        double part = 0.0;
+        for (uint32_t c = 0; c < it.count; c += 2) {
+            const uint32_t i0 = i, j0 = i0 ^ x;
+            const uint32_t i1 = ((((i0 | x) + 1u) & keep) | fe.ibits) & (NEL - 1u), j1 = i1 ^ x;
+            i = ((((i1 | x) + 1u) & keep) | fe.ibits) & (NEL - 1u);
+            const amp a0 = tile[tile_swz<REAL>(i0)], b0 = tile[tile_swz<REAL>(j0)];
+            const amp a1 = tile[tile_swz<REAL>(i1)], b1 = tile[tile_swz<REAL>(j1)];
+            const bool n00 = __popc(j0 & fe.zin0) & 1, n01 = __popc(j0 & fe.zin1) & 1;
+            const bool n10 = __popc(j1 & fe.zin0) & 1, n11 = __popc(j1 & fe.zin1) & 1;
+            const double d0 = (n00 ? -c0r : c0r) + (n01 ? -c1r : c1r), d1 = (n10 ? -c0r : c0r) + (n11 ? -c1r : c1r);
+            if constexpr (REAL) {
+                part += d0 * (a0 * b0) + d1 * (a1 * b1);
+            } else {
+                const double e0 = (n00 ? -c0i : c0i) + (n01 ? -c1i : c1i), e1 = (n10 ? -c0i : c0i) + (n11 ? -c1i : c1i);
+                part += d0 * (a0.x * b0.x + a0.y * b0.y) - e0 * (a0.x * b0.y - a0.y * b0.x);
+                part += d1 * (a1.x * b1.x + a1.y * b1.y) - e1 * (a1.x * b1.y - a1.y * b1.x);
+            }
+        }
+        acc += x ? 2.0 * part : part;
+    }
     for (int ch = sw.c0; ch < sw.c1; ++ch) {
         const ExChunkT ck = chunks[ch];
-        __syncthreads();  // tile visible / previous chunk's term table no longer read
+        __syncthreads();  // previous chunk's term table no longer read
         for (int t = ck.t0 + (int)threadIdx.x; t < ck.t1; t += NT) {
             const ExTermT et = terms[t];
             const bool neg = parity64(gbase & et.zout);
@@ -248,19 +309,35 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
                 const uint32_t dlane = deposit_index((uint32_t)en.k0 + lane, en.x) | en.ibits;
                 const uint32_t d64 = deposit_index(64u, en.x);  // k -> k + 64 never carries into lane bits
                 uint32_t i = dlane;
-                for (uint32_t k = lane; k < (uint32_t)en.nk; k += 64u) {
-                    const uint32_t j = i ^ en.x;
-                    const amp a = tile[i], c = tile[j];
-                    const bool n0 = __popc(j & l0.zin) & 1, n1 = __popc(j & l1.zin) & 1;
-                    const double dr = (n0 ? -l0.cr : l0.cr) + (n1 ? -l1.cr : l1.cr);
-                    if constexpr (REAL) {
-                        part += dr * (a * c);
-                    } else {
-                        const double wx = a.x * c.x + a.y * c.y, wy = a.x * c.y - a.y * c.x;
-                        const double di = (n0 ? -l0.ci : l0.ci) + (n1 ? -l1.ci : l1.ci);
-                        part += dr * wx - di * wy;
+                // four trips at a time: the eight LDS reads are issued before the first result is needed
+                for (uint32_t k = lane; k < (uint32_t)en.nk; k += 256u) {
+                    uint32_t ii[4];
+                    amp a[4], c[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        ii[q] = i;
+                        i = (((i | en.x) + d64) & ~en.x) | en.ibits;  // next free index, x positions skipped
                     }
-                    i = (((i | en.x) + d64) & ~en.x) | en.ibits;  // next free index, x positions skipped
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        a[q] = tile[tile_swz<REAL>(ii[q] & (NEL - 1u))];
+                        c[q] = tile[tile_swz<REAL>((ii[q] ^ en.x) & (NEL - 1u))];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t j = ii[q] ^ en.x;
+                        const bool n0 = __popc(j & l0.zin) & 1, n1 = __popc(j & l1.zin) & 1;
+                        const double dr = (n0 ? -l0.cr : l0.cr) + (n1 ? -l1.cr : l1.cr);
+                        double v;
+                        if constexpr (REAL) {
+                            v = dr * (a[q] * c[q]);
+                        } else {
+                            const double wx = a[q].x * c[q].x + a[q].y * c[q].y, wy = a[q].x * c[q].y - a[q].y * c[q].x;
+                            const double di = (n0 ? -l0.ci : l0.ci) + (n1 ? -l1.ci : l1.ci);
+                            v = dr * wx - di * wy;
+                        }
+                        part += (k + 64u * q < (uint32_t)en.nk) ? v : 0.0;
+                    }
                 }
             } else {
             double vx[PP], vy[PP], dr[PP], di[PP];
@@ -271,7 +348,7 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
                 const bool live = lane + 64u * m < (uint32_t)en.nk;
                 const uint32_t i = deposit_index(k, en.x) | en.ibits;
                 jj[m] = i ^ en.x;
-                const amp a = tile[i & (NEL - 1u)], c = tile[jj[m] & (NEL - 1u)];
+                const amp a = tile[tile_swz<REAL>(i & (NEL - 1u))], c = tile[tile_swz<REAL>(jj[m] & (NEL - 1u))];
                 if constexpr (REAL) {
                     vx[m] = live ? a * c : 0.0;
                     vy[m] = 0.0;
