@@ -417,19 +417,29 @@ __global__ __launch_bounds__(256) void k_pool_grad(const amp_t *__restrict__ sig
     __shared__ double2 red[4];
     const int64_t op = blockIdx.x;
     double2 acc = make_double2(0.0, 0.0);
-    for (int64_t t = offsets[op]; t < offsets[op + 1]; ++t) {
+    const int64_t t1 = offsets[op + 1];
+    for (int64_t t = offsets[op]; t < t1;) {
+        // consecutive strings with one x mask (the 2 / 8 JW strings of a fermionic excitation) share the pass over the
+        // pairs: D(j) = sum_t (+-)(cr + i ci), one read of sigma_i and psi_j for the whole run
         const uint64_t x = xs[t];
-        const HTerm ht = terms[t];
+        int64_t te = t + 1;
+        while (te < t1 && xs[te] == x) ++te;
         for (uint64_t i = threadIdx.x; i < namps; i += 256) {
             const uint64_t jl = i ^ x;
             const amp_t b = sig[i], k = psi[jl];
-            const bool neg = parity64((base | jl) & ht.z);
-            const double cr = neg ? -ht.cr : ht.cr, ci = neg ? -ht.ci : ht.ci;
+            double cr = 0.0, ci = 0.0;
+            for (int64_t u = t; u < te; ++u) {
+                const HTerm ht = terms[u];
+                const bool neg = parity64((base | jl) & ht.z);
+                cr += neg ? -ht.cr : ht.cr;
+                ci += neg ? -ht.ci : ht.ci;
+            }
             const double vx = b.x * k.x + b.y * k.y;
             const double vy = b.x * k.y - b.y * k.x;
             acc.x += cr * vx - ci * vy;
             acc.y += cr * vy + ci * vx;
         }
+        t = te;
     }
     double2 t = block_sum<256>(acc, red);
     if (threadIdx.x == 0) out[op] = t;
