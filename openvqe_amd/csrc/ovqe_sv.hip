@@ -53,6 +53,7 @@ struct HamDev {  // grouped Pauli sum resident on the device
     int n_rest = 0;  // groups that fit no tile keep their own sweep (k_expect_pairs)
     int64_t tile_work = 0, tile_entries = 0, tile_terms = 0;  // pair x term evaluations per tile over all sweeps
     DevBuf d_tchunks, d_tgroups, d_tterms, d_tflats, d_titems, d_rest;
+    DevBuf d_achunks, d_agroups, d_aterms;  // operator-application form of the cover (k_tile_apply), complex covers only
 };
 
 }  // namespace
@@ -426,6 +427,9 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
     std::vector<ExTermT> tterms;
     std::vector<ExFlatT> tflats;
     std::vector<ExItemT> titems;
+    std::vector<ExChunkT> achunks;
+    std::vector<ExAGroupT> agroups;
+    std::vector<ExTermT> aterms;
     std::vector<HGroup> rest;
     int remaining = 0;
     for (int g = 0; g < G; ++g) {
@@ -471,6 +475,8 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
         sw.i0 = (int32_t)titems.size();
         ExChunkT ck = {(int32_t)tgroups.size(), (int32_t)tgroups.size(), (int32_t)tterms.size(), (int32_t)tterms.size()};
         int took = 0;
+        sw.a0 = (int32_t)achunks.size();
+        ExChunkT ak = {(int32_t)agroups.size(), (int32_t)agroups.size(), (int32_t)aterms.size(), (int32_t)aterms.size()};
         for (int g = 0; g < G; ++g) {
             if (covered[g] || (H.groups[g].x & ~S)) continue;
             covered[g] = 1;
@@ -478,6 +484,30 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
             ++took;
             const HGroup &gr = H.groups[g];
             const uint32_t xl = extract_bits(gr.x, S);
+            if (!real) {  // operator-application form: the group's raw terms, split when they exceed a chunk
+                for (int t0 = gr.t0; t0 < gr.t1; t0 += TILE_TERM_CAP) {
+                    const int t1 = std::min(gr.t1, t0 + TILE_TERM_CAP);
+                    if ((int)aterms.size() - ak.t0 + (t1 - t0) > TILE_TERM_CAP ||
+                        (int)agroups.size() - ak.g0 + 1 > TILE_APPLY_GROUPS) {
+                        ak.g1 = (int32_t)agroups.size();
+                        ak.t1 = (int32_t)aterms.size();
+                        achunks.push_back(ak);
+                        ak = {ak.g1, ak.g1, ak.t1, ak.t1};
+                    }
+                    ExAGroupT ag = {xl, (int32_t)aterms.size(), 0, 0};
+                    for (int t = t0; t < t1; ++t) {
+                        const HTerm &ht = H.terms[t];
+                        ExTermT et = {};
+                        et.zin = extract_bits(ht.z, S);
+                        et.zout = ht.z & ~S;
+                        et.cr = ht.cr;
+                        et.ci = ht.ci;
+                        aterms.push_back(et);
+                    }
+                    ag.t1 = (int32_t)aterms.size();
+                    agroups.push_back(ag);
+                }
+            }
             const int w = __builtin_popcount(xl);
             int xpos[16], np = 0;
             for (uint32_t mk2 = xl; mk2; mk2 &= mk2 - 1u) xpos[np++] = __builtin_ctz(mk2);
@@ -568,6 +598,10 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
         if (ck.g1 > ck.g0) chunks.push_back(ck);
         sw.c1 = (int32_t)chunks.size();
         sw.i1 = (int32_t)titems.size();
+        ak.g1 = (int32_t)agroups.size();
+        ak.t1 = (int32_t)aterms.size();
+        if (ak.g1 > ak.g0) achunks.push_back(ak);
+        sw.a1 = (int32_t)achunks.size();
         if (took == 0) return fail(h, OVQE_ERR_INVALID, "internal: tile cover made no progress");
         H.tsweeps.push_back(sw);
     }
@@ -584,6 +618,10 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
     rc = upload(h, H.d_tflats, tflats.data(), tflats.size() * sizeof(ExFlatT));
     if (rc) return rc;
     rc = upload(h, H.d_titems, titems.data(), titems.size() * sizeof(ExItemT));
+    if (rc) return rc;
+    rc = upload(h, H.d_achunks, achunks.data(), achunks.size() * sizeof(ExChunkT));
+    if (!rc) rc = upload(h, H.d_agroups, agroups.data(), agroups.size() * sizeof(ExAGroupT));
+    if (!rc) rc = upload(h, H.d_aterms, aterms.data(), aterms.size() * sizeof(ExTermT));
     if (rc) return rc;
     return upload(h, H.d_rest, rest.data(), rest.size() * sizeof(HGroup));
 }
@@ -675,6 +713,62 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bo
     HIPC(h, hipStreamSynchronize(h->stream));
     *out = h->h_result[0];
     *used = true;
+    return OVQE_OK;
+}
+
+// out = ident * in + H in for the stored Hamiltonian: tile sweeps when the cover holds every group, else the gather
+// kernel.  in / out: complex states of this handle's size, out != in.
+template <int M>
+int launch_tile_apply(ovqe_handle h, const HamDev &H, const ExSweep &sw, const amp_t *in, amp_t *out, int first,
+                      double ident) {
+    constexpr int NT = 1 << TILE_EXPECT_LOG_NT;  // the sweeps' thread / trip masks are laid out for this group size
+    const size_t smem = ((size_t)16 << M) + TILE_TERM_CAP * sizeof(ExTermLds) + TILE_APPLY_GROUPS * sizeof(ExAGroupT);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_apply<M, NT, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_apply<M, NT, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)(h->namps >> M);
+    if (h->n_local >= 25) {
+        hipLaunchKernelGGL((k_tile_apply<M, NT, true>), dim3(grid), dim3(NT), smem, h->stream, in, out, h->base, sw,
+                           (const ExChunkT *)H.d_achunks.p, (const ExAGroupT *)H.d_agroups.p,
+                           (const ExTermT *)H.d_aterms.p, first, ident);
+    } else {
+        hipLaunchKernelGGL((k_tile_apply<M, NT, false>), dim3(grid), dim3(NT), smem, h->stream, in, out, h->base, sw,
+                           (const ExChunkT *)H.d_achunks.p, (const ExAGroupT *)H.d_agroups.p,
+                           (const ExTermT *)H.d_aterms.p, first, ident);
+    }
+    HIPC(h, hipGetLastError());
+    return OVQE_OK;
+}
+
+int apply_hamiltonian(ovqe_handle h, amp_t *out, const amp_t *in, double ident) {
+    HamDev &H = h->ham;
+    if (H.tile_bits != tile_bits(h, false) || H.tile_low != h->opt_tile_low || H.tile_real) {
+        int rc = build_ham_tiles(h, H, false);
+        if (rc) return rc;
+    }
+    if (H.tsweeps.empty() || H.n_rest) {
+        hipLaunchKernelGGL(k_apply_sum, dim3(reduce_blocks(h->namps)), dim3(256), 0, h->stream, out, in, (amp_t *)nullptr,
+                           h->namps, h->base, (const HGroup *)H.d_groups.p, (int)H.groups.size(),
+                           (const HTerm *)H.d_terms.p, 1.0, 0.0, ident, 0.0);
+        HIPC(h, hipGetLastError());
+        return OVQE_OK;
+    }
+    int first = 1;
+    for (const ExSweep &sw : H.tsweeps) {
+        int rc;
+        switch (H.tile_bits) {
+        case 10: rc = launch_tile_apply<10>(h, H, sw, in, out, first, ident); break;
+        case 11: rc = launch_tile_apply<11>(h, H, sw, in, out, first, ident); break;
+        default: rc = launch_tile_apply<12>(h, H, sw, in, out, first, ident); break;
+        }
+        if (rc) return rc;
+        first = 0;
+    }
     return OVQE_OK;
 }
 
@@ -1722,7 +1816,8 @@ int ovqe_destroy(ovqe_handle h) {
     DevBuf *bufs[] = {&h->d_partials, &h->d_result, &h->d_rp, &h->ham.d_groups, &h->ham.d_terms, &h->d_ops,
                       &h->d_rots, &h->d_segs, &h->d_stream, &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups,
                       &h->d_eterms, &h->d_echunks, &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries,
-                      &h->tp.d_tops, &h->tp.d_trots, &h->tp_adhoc.d_tops, &h->tp_adhoc.d_trots, &h->ham.d_tchunks, &h->ham.d_tgroups, &h->ham.d_tterms, &h->ham.d_tflats, &h->ham.d_titems, &h->ham.d_rest,
+                      &h->tp.d_tops, &h->tp.d_trots, &h->tp_adhoc.d_tops, &h->tp_adhoc.d_trots, &h->ham.d_achunks, &h->ham.d_agroups, &h->ham.d_aterms, &h->ham_adhoc.d_achunks, &h->ham_adhoc.d_agroups,
+                      &h->ham_adhoc.d_aterms, &h->ham.d_tchunks, &h->ham.d_tgroups, &h->ham.d_tterms, &h->ham.d_tflats, &h->ham.d_titems, &h->ham.d_rest,
                       &h->ham_adhoc.d_tflats, &h->ham_adhoc.d_titems, &h->ham_real.d_tflats, &h->ham_real.d_titems,
                       &h->ham_adhoc.d_groups, &h->ham_adhoc.d_terms, &h->ham_adhoc.d_tchunks, &h->ham_adhoc.d_tgroups,
                       &h->ham_adhoc.d_tterms, &h->ham_adhoc.d_rest, &h->tp_real.d_tops, &h->tp_real.d_trots,
@@ -2217,10 +2312,8 @@ int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, co
     amp_t *sig = h->scratch[0];
     const int nb = reduce_blocks(h->namps);
     // sigma = H psi (constant included)
-    hipLaunchKernelGGL(k_apply_sum, dim3(nb), dim3(256), 0, h->stream, sig, (const amp_t *)h->state, (amp_t *)nullptr,
-                       h->namps, h->base, (const HGroup *)h->ham.d_groups.p, (int)h->ham.groups.size(),
-                       (const HTerm *)h->ham.d_terms.p, 1.0, 0.0, h->ham.constant, 0.0);
-    HIPC(h, hipGetLastError());
+    rc = apply_hamiltonian(h, sig, h->state, h->ham.constant);
+    if (rc) return rc;
     std::vector<double2> vals(n_ops);
     if (h->n_local <= 22) {
         // one block per pool operator, terms in caller order with i^ny folded
@@ -2384,11 +2477,7 @@ struct Lanczos {
         *out = h->h_result[0];
         return OVQE_OK;
     }
-    void apply_h(amp_t *out, const amp_t *in) {
-        hipLaunchKernelGGL(k_apply_sum, dim3(nb), dim3(256), 0, h->stream, out, in, (amp_t *)nullptr, h->namps, h->base,
-                           (const HGroup *)h->ham.d_groups.p, (int)h->ham.groups.size(), (const HTerm *)h->ham.d_terms.p,
-                           1.0, 0.0, 0.0, 0.0);
-    }
+    void apply_h(amp_t *out, const amp_t *in) { (void)apply_hamiltonian(h, out, in, 0.0); }
     int dot(const amp_t *a, const amp_t *b, double2 *out) {
         hipLaunchKernelGGL(k_dot, dim3(nb), dim3(256), 0, h->stream, a, b, h->namps, (double2 *)h->d_partials.p);
         return reduce_to_host(out);
@@ -2511,8 +2600,10 @@ extern "C" int ovqe_energy_gradient(ovqe_handle h, const double *theta, int32_t 
     rc = run_program_streaming(h, theta);  // psi = U(theta)|hf>; angle table: original rotations at offset S
     if (!rc) rc = ensure_scratch(h, 0);
     Lanczos L{h, reduce_blocks(h->namps)};
-    const int nb = L.nb;
-    if (!rc) rc = ensure(h, h->d_partials, (size_t)std::max(nb, ADJ_MAX_ROT * nb) * sizeof(double2));
+    // backward sweeps: one pair per thread while that stays below 65536 workgroups (a grid-stride loop of dependent
+    // load -> rotate -> store trips exposes the memory latency of both states), partial sums per workgroup and rotation
+    const int nb = (int)std::min<uint64_t>(65536, std::max<uint64_t>(1, (h->namps / 2 + 255) / 256));
+    if (!rc) rc = ensure(h, h->d_partials, (size_t)std::max(L.nb, ADJ_MAX_ROT * nb) * sizeof(double2));
     if (!rc) rc = ensure(h, h->d_result, 64 * sizeof(double2));
     const size_t R = h->rots.size(), S = h->srots.size();
     DevBuf d_w;

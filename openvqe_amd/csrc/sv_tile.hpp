@@ -171,6 +171,12 @@ struct ExSweep {
     uint64_t smask, mask_lo, mask_hi;
     int32_t c0, c1;   // chunk range (entries with more than two merged terms: one wave per entry)
     int32_t i0, i1;   // flat items (entries with one or two merged terms: one LANE per 64 pairs)
+    int32_t a0, a1;   // chunk range of the operator-application form (k_tile_apply)
+};
+struct ExAGroupT {    // x-group of the sweep with its raw terms (k_tile_apply)
+    uint32_t x;       // tile-local x mask
+    int32_t t0, t1;   // terms (absolute, in the apply term table)
+    int32_t pad;
 };
 // A (group, pattern) entry with at most two merged terms — nearly all of them: a JW double excitation leaves ONE
 // coefficient per active pattern — costs more in per-entry set-up than in arithmetic when a whole wave serves it.
@@ -392,6 +398,103 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
         } else {
             partials[slot] = t;
         }
+    }
+}
+
+// ---- out = ident * in + H in on tiles ------------------------------------------------------------------------
+// Same cover as k_tile_expect, operator-application form (sigma = H psi of the ADAPT screens and of the adjoint
+// gradient, the Lanczos matrix-vector product): a thread OWNS its output amplitudes (registers), walks the sweep's
+// x-groups and adds D_g(j) in_j, j = e ^ x, from the LDS copy of the input tile — no atomics, fixed summation order.
+// The output is accumulated across the sweeps (first sweep: out = ident * in + ..., later: out += ...), so a sweep
+// moves 48 bytes per amplitude where the gather kernel k_apply_sum re-reads the input once per x-group.  VALU-bound
+// (every term of every group is evaluated for every amplitude): about twice as fast as the gather kernel at 24 qubits.
+constexpr int TILE_APPLY_GROUPS = 128;  // x-groups of a chunk staged in LDS
+
+template <int M, int NT, bool NTL>
+__global__ __launch_bounds__(NT) void k_tile_apply(const amp_t *__restrict__ in, amp_t *__restrict__ out, uint64_t base,
+                                                   ExSweep sw, const ExChunkT *__restrict__ chunks,
+                                                   const ExAGroupT *__restrict__ groups,
+                                                   const ExTermT *__restrict__ terms, int first, double ident) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t NEL = 1u << M;
+    constexpr int TRIPS = NEL / NT;
+    double2 *tile = reinterpret_cast<double2 *>(smem);
+    ExTermLds *lt = reinterpret_cast<ExTermLds *>(smem + (size_t)NEL * sizeof(double2));
+    ExAGroupT *lg = reinterpret_cast<ExAGroupT *>(lt + TILE_TERM_CAP);
+    const v2d *p = reinterpret_cast<const v2d *>(in);
+    v2d *q = reinterpret_cast<v2d *>(out);
+
+    uint64_t tb = blockIdx.x;
+    for (uint64_t mk = sw.smask; mk; mk &= mk - 1ull) tb = insert_zero(tb, __ffsll((long long)mk) - 1);
+    const uint64_t glow = spread_bits(threadIdx.x, sw.mask_lo);
+    const uint64_t gbase = base | tb;
+    double2 self[TRIPS], acc[TRIPS];
+#pragma unroll
+    for (int j = 0; j < TRIPS; ++j) {
+        const uint64_t g = tb | glow | spread_bits((uint32_t)j, sw.mask_hi);
+        const v2d r = NTL ? __builtin_nontemporal_load(&p[g]) : p[g];
+        self[j] = make_double2(r.x, r.y);
+        acc[j] = make_double2(0.0, 0.0);
+        tile[tile_swz_v(threadIdx.x + j * NT)] = self[j];
+    }
+    for (int ch = sw.a0; ch < sw.a1; ++ch) {
+        const ExChunkT ck = chunks[ch];
+        __syncthreads();
+        for (int t = ck.t0 + (int)threadIdx.x; t < ck.t1; t += NT) {
+            const ExTermT et = terms[t];
+            const bool neg = parity64(gbase & et.zout);
+            ExTermLds l;
+            l.cr = neg ? -et.cr : et.cr;
+            l.ci = neg ? -et.ci : et.ci;
+            l.zin = et.zin;
+            l.pad = 0;
+            lt[t - ck.t0] = l;
+        }
+        for (int g = ck.g0 + (int)threadIdx.x; g < ck.g1; g += NT) lg[g - ck.g0] = groups[g];
+        __syncthreads();
+        for (int g = ck.g0; g < ck.g1; ++g) {
+            const ExAGroupT gr = lg[g - ck.g0];
+            const uint32_t xl = __builtin_amdgcn_readfirstlane(gr.x);
+            const int t0 = __builtin_amdgcn_readfirstlane(gr.t0) - ck.t0, t1 = __builtin_amdgcn_readfirstlane(gr.t1) - ck.t0;
+            uint32_t je[TRIPS];
+            double2 k[TRIPS];
+            double dr[TRIPS], di[TRIPS];
+#pragma unroll
+            for (int j = 0; j < TRIPS; ++j) {
+                je[j] = (threadIdx.x + j * NT) ^ xl;
+                k[j] = tile[tile_swz_v(je[j])];
+                dr[j] = 0.0;
+                di[j] = 0.0;
+            }
+            for (int t = t0; t < t1; ++t) {
+                const ExTermLds l = lt[t];
+#pragma unroll
+                for (int j = 0; j < TRIPS; ++j) {
+                    const bool neg = __popc(je[j] & l.zin) & 1;
+                    dr[j] += neg ? -l.cr : l.cr;
+                    di[j] += neg ? -l.ci : l.ci;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TRIPS; ++j) {
+                acc[j].x += dr[j] * k[j].x - di[j] * k[j].y;
+                acc[j].y += dr[j] * k[j].y + di[j] * k[j].x;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TRIPS; ++j) {
+        const uint64_t g = tb | glow | spread_bits((uint32_t)j, sw.mask_hi);
+        v2d r;
+        if (first) {
+            r.x = ident * self[j].x + acc[j].x;
+            r.y = ident * self[j].y + acc[j].y;
+        } else {
+            const v2d o = q[g];
+            r.x = o.x + acc[j].x;
+            r.y = o.y + acc[j].y;
+        }
+        q[g] = r;
     }
 }
 
