@@ -53,29 +53,34 @@ __global__ __launch_bounds__(64) void k_sparse_vqe(SparseArgs A, const double *_
     double *st = reinterpret_cast<double *>(smem);                        // [SPW][m]
     double2 *cs = reinterpret_cast<double2 *>(st + (size_t)SPW * A.m);    // [SPW][ntab]
     const int lane = threadIdx.x;
+    // the wave's lanes are split evenly over its SPW evaluations (no index division in the inner loops)
+    constexpr int LPS = 64 / SPW;
+    const int s = lane / LPS, l = lane % LPS;
+    double *base = st + (size_t)s * A.m;
+    const double2 *csb = cs + (size_t)s * A.ntab;
     const int64_t nwork = (A.B + SPW - 1) / SPW;
     for (int64_t w = blockIdx.x; w < nwork; w += gridDim.x) {
         const int64_t b0 = w * SPW;
         // |HF> (compact index 0) and the cos/sin table of every active pattern, per evaluation
         for (int i = lane; i < SPW * A.m; i += 64) st[i] = (i % A.m == 0) ? 1.0 : 0.0;
-        for (int r = lane; r < SPW * A.ntab; r += 64) {
-            const int s = r / A.ntab, e = r - s * A.ntab;
+        {
             const int64_t b = b0 + s < A.B ? b0 + s : A.B - 1;
-            const SmallRot sr = tabrots[e];
-            double sn, c;
-            sincos(sr.coeff * theta[b * A.K + sr.pidx], &sn, &c);
-            cs[r] = make_double2(c, sn);
+            const double *th = theta + b * A.K;
+            for (int e = l; e < A.ntab; e += LPS) {
+                const SmallRot sr = tabrots[e];
+                double sn, c;
+                sincos(sr.coeff * th[sr.pidx], &sn, &c);
+                cs[(size_t)s * A.ntab + e] = make_double2(c, sn);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (int o = 0; o < A.nops; ++o) {
             const SpOp op = ops[o];
-            for (int e = lane; e < op.npairs * SPW; e += 64) {
-                const int s = SPW == 1 ? 0 : e / op.npairs, pe = SPW == 1 ? e : e - s * op.npairs;
+            for (int pe = l; pe < op.npairs; pe += LPS) {
                 const uint32_t pw = pairs[op.first + pe];
                 const uint32_t ci = pw & 0xfffu, cj = (pw >> 12) & 0xfffu;
-                const double2 t = cs[s * A.ntab + op.tab0 + (int)(pw >> 25)];
+                const double2 t = csb[op.tab0 + (int)(pw >> 25)];
                 const double sn = (pw & (1u << 24)) ? -t.y : t.y;
-                double *base = st + (size_t)s * A.m;
                 const double u = base[ci], v = base[cj];
                 base[ci] = t.x * u + sn * v;
                 base[cj] = t.x * v - sn * u;
@@ -86,6 +91,7 @@ __global__ __launch_bounds__(64) void k_sparse_vqe(SparseArgs A, const double *_
         double acc[SPW];
 #pragma unroll
         for (int s = 0; s < SPW; ++s) acc[s] = 0.0;
+#pragma unroll 4  // four entries in flight: the loop is bound by the latency of its loads, not by issue
         for (int e = lane; e < A.nent; e += 64) {
             const SpEntry en = entries[e];
             const uint32_t ci = en.ij & 0xfffu, cj = (en.ij >> 12) & 0xfffu;
