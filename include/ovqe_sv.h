@@ -197,7 +197,8 @@ int ovqe_last_batch_ms(ovqe_handle h, double *ms);
  *   [6] support-compacted program: -1 not analysed yet, 0 none, else the size of the reachable support
  *   [7] tile sweeps of the stored Hamiltonian's expectation (0 until first used / when not tiled)  [8] x-groups
  *   that keep their own sweep  [9] (group, pattern) entries  [10] merged terms  [11] pair x term evaluations per tile
- *   [12] 1 when streaming energies of this program keep the state as 2^n real amplitudes */
+ *   [12] 1 when streaming energies of this program keep the state as 2^n real amplitudes
+ *   [13..15] support-compacted program: ops, active pairs per evaluation, entries of the restricted Hamiltonian */
 int ovqe_program_info(ovqe_handle h, int64_t *info, int count);
 
 #ifdef __cplusplus

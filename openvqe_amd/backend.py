@@ -255,11 +255,11 @@ class Statevector:
     def program_info(self):
         """shape of the compiled program: ops, rotations, literal gates, sweeps per evaluation, tiled sweeps,
         fused-kernel ops, support size (-1 = not analysed yet)"""
-        out = (ctypes.c_int64 * 13)()
-        self._ck(self._L.ovqe_program_info(self._h, out, 13))
+        out = (ctypes.c_int64 * 16)()
+        self._ck(self._L.ovqe_program_info(self._h, out, 16))
         keys = ("ops", "rotations", "literal_gates", "sweeps", "tiled_sweeps", "fused_ops", "support",
                 "h_tile_sweeps", "h_untiled_groups", "h_entries", "h_merged_terms", "h_pair_terms_per_tile",
-                "real_stream")
+                "real_stream", "sp_ops", "sp_pairs", "sp_h_entries")
         return dict(zip(keys, [int(v) for v in out]))
 
     # -- ADAPT ----------------------------------------------------------------------------------

@@ -98,6 +98,7 @@ struct ovqe_sv {
     // support-compacted program (sv_sparse.hpp): built lazily for the current (program, Hamiltonian)
     bool sp_tried = false, sp_valid = false;
     int sp_m = 0, sp_nops = 0, sp_nent = 0;
+    int64_t sp_npairs = 0;
     DevBuf d_sp_ops, d_sp_pairs, d_sp_entries;
     int opt_sparse = 1;           // allow the support-compacted path
     int opt_sparse_spw = 0;       // evaluations per wave (0 = automatic)
@@ -1673,6 +1674,7 @@ int build_sparse_program(ovqe_handle h) {
     h->sp_m = m;
     h->sp_nops = (int)ops.size();
     h->sp_nent = (int)entries.size();
+    h->sp_npairs = (int64_t)pairs.size();
     h->sp_valid = true;
     return OVQE_OK;
 }
@@ -2695,13 +2697,14 @@ int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
     const bool real_on = h->opt_real_stream && h->prog_real_ok && h->n_global == 0 && tile_ok(h, true);
     const HamDev &HI = (real_on && h->ham_real.version == h->ham.version) ? h->ham_real : h->ham;  // the cover in use
     const TilePlan &TP = (real_on && h->tp_real_built) ? h->tp_real : h->tp;  // the plan the energies use
-    int64_t v[13] = {(int64_t)h->ops.size(), (int64_t)h->rots.size(), 0, (int64_t)TP.plan.size(),
+    int64_t v[16] = {(int64_t)h->ops.size(), (int64_t)h->rots.size(), 0, (int64_t)TP.plan.size(),
                      (int64_t)TP.tsegs.size(), (int64_t)h->sops.size(),
                      !h->sp_tried ? -1 : (h->sp_valid ? (int64_t)h->sp_m : 0),
                      (int64_t)HI.tsweeps.size(), (int64_t)HI.n_rest, HI.tile_entries, HI.tile_terms, HI.tile_work,
-                     real_on ? 1 : 0};
+                     real_on ? 1 : 0, h->sp_valid ? (int64_t)h->sp_nops : 0, h->sp_valid ? (int64_t)h->sp_npairs : 0,
+                     h->sp_valid ? (int64_t)h->sp_nent : 0};
     for (const SmallOp &op : h->ops) v[2] += (op.kind == OP_X || op.kind == OP_H || op.kind == OP_CNOT);
-    for (int i = 0; i < count && i < 13; ++i) info[i] = v[i];
+    for (int i = 0; i < count && i < 16; ++i) info[i] = v[i];
     return OVQE_OK;
 }
 

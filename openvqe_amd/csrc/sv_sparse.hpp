@@ -85,8 +85,9 @@ __global__ __launch_bounds__(64) void k_sparse_vqe(SparseArgs A, const double *_
                 base[ci] = t.x * u + sn * v;
                 base[cj] = t.x * v - sn * u;
             }
-            // pairs of one op are disjoint; the next op may touch them from other lanes of this wave
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // pairs of one op are disjoint; the next op may touch them from other lanes of this wave: the LDS unit
+            // executes a wave's DS instructions in issue order, so only the COMPILER must not reorder across ops
+            asm volatile("" ::: "memory");
         }
         double acc[SPW];
 #pragma unroll

@@ -10,6 +10,8 @@ th = torch.from_numpy(np.random.default_rng(1).uniform(-0.1, 0.1, (B, K))).cuda(
 out = torch.empty(B, dtype=torch.float64, device="cuda")
 with Statevector(ham.nbqbits) as sv:
     sv.set_hamiltonian(ham); sv.set_ucc_program(gens, hf)
+    sv.energy_batch_device(B, th.data_ptr(), out.data_ptr())
+    print(sv.program_info(), flush=True)
     for spw in (1, 2, 4, 2):
         sv.set_option("sparse_spw", spw)
         sv.energy_batch_device(B, th.data_ptr(), out.data_ptr()); torch.cuda.synchronize()
