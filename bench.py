@@ -428,10 +428,18 @@ def main():
                 "single_string_sweep_26_qubits": cpu["sweep_26q"],
                 "gpu_minus_cpu_energy": e_gpu0 - cpu["fused"]["energy0"],
             }
-        print(json.dumps(out))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to the C-level stdout buffer; drain it so that the JSON line is the LAST line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def energy_check(ham, gens, hf, theta, device):
