@@ -142,7 +142,9 @@ int ovqe_set_gate_program(ovqe_handle h, int64_t G, const int32_t *opcode, const
                           const double *ascale, const double *aconst, const int32_t *pidx, int32_t K,
                           uint64_t hf_index);
 /* E(theta): one call == one ucc_action / action_quccsd evaluation
- * (ref:openvqe/ucc_family/get_energy_ucc.py:8-50, get_energy_qucc.py:11-56) */
+ * (ref:openvqe/ucc_family/get_energy_ucc.py:8-50, get_energy_qucc.py:11-56).  The content of the state buffer after an
+ * energy call is unspecified (the fused kernels never touch it, the streaming path may hold real amplitudes there):
+ * use ovqe_prepare_state to obtain U(theta)|hf>. */
 int ovqe_energy(ovqe_handle h, const double *theta, int32_t K, double *energy);
 /* B parameter vectors (row-major B x K) in one launch — one finite-difference gradient of
  * scipy.optimize.minimize(jac=None) (ref:openvqe/ucc_family/get_energy_ucc.py:158-175) is B = K+1 */
