@@ -1815,16 +1815,13 @@ int ovqe_destroy(ovqe_handle h) {
     if (h->own_state && h->state) (void)hipFree(h->state);
     for (int k = 0; k < 2; ++k)
         if (h->scratch[k]) (void)hipFree(h->scratch[k]);
-    DevBuf *bufs[] = {&h->d_partials, &h->d_result, &h->d_rp, &h->ham.d_groups, &h->ham.d_terms, &h->d_ops,
-                      &h->d_rots, &h->d_segs, &h->d_stream, &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups,
-                      &h->d_eterms, &h->d_echunks, &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries,
-                      &h->tp.d_tops, &h->tp.d_trots, &h->tp_adhoc.d_tops, &h->tp_adhoc.d_trots, &h->ham.d_achunks, &h->ham.d_agroups, &h->ham.d_aterms, &h->ham_adhoc.d_achunks, &h->ham_adhoc.d_agroups,
-                      &h->ham_adhoc.d_aterms, &h->ham.d_tchunks, &h->ham.d_tgroups, &h->ham.d_tterms, &h->ham.d_tflats, &h->ham.d_titems, &h->ham.d_rest,
-                      &h->ham_adhoc.d_tflats, &h->ham_adhoc.d_titems, &h->ham_real.d_tflats, &h->ham_real.d_titems,
-                      &h->ham_adhoc.d_groups, &h->ham_adhoc.d_terms, &h->ham_adhoc.d_tchunks, &h->ham_adhoc.d_tgroups,
-                      &h->ham_adhoc.d_tterms, &h->ham_adhoc.d_rest, &h->tp_real.d_tops, &h->tp_real.d_trots,
-                      &h->ham_real.d_terms, &h->ham_real.d_tchunks, &h->ham_real.d_tgroups, &h->ham_real.d_tterms,
-                      &h->ham_real.d_rest};
+    std::vector<DevBuf *> bufs = {&h->d_partials, &h->d_result, &h->d_rp, &h->d_ops, &h->d_rots, &h->d_segs, &h->d_stream,
+                                  &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups, &h->d_eterms, &h->d_echunks,
+                                  &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries};
+    for (TilePlan *tp : {&h->tp, &h->tp_adhoc, &h->tp_real}) bufs.insert(bufs.end(), {&tp->d_tops, &tp->d_trots});
+    for (HamDev *H : {&h->ham, &h->ham_adhoc, &h->ham_real})
+        bufs.insert(bufs.end(), {&H->d_groups, &H->d_terms, &H->d_tchunks, &H->d_tgroups, &H->d_tterms, &H->d_tflats,
+                                 &H->d_titems, &H->d_rest, &H->d_achunks, &H->d_agroups, &H->d_aterms});
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (h->h_rp) (void)hipHostFree(h->h_rp);
