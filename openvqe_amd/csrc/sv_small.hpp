@@ -147,8 +147,10 @@ __device__ __forceinline__ uint32_t deposit_index(uint32_t k, uint32_t fixmask) 
     return k;
 }
 
-template <bool REAL, int NT, int U, typename A>
-__device__ __forceinline__ void small_pass_pair(A *st, uint32_t npairs, const SmallOp &op, const RotLds *tab) {
+// ``st`` is a pointer to the amplitudes or any view with operator[] (the tile kernels pass a bank-swizzled view)
+template <bool REAL, int NT, int U, typename V>
+__device__ __forceinline__ void small_pass_pair(V st, uint32_t npairs, const SmallOp &op, const RotLds *tab) {
+    typedef typename Amp<REAL>::T A;
     const uint32_t x = (uint32_t)op.x;
     const int pivot = op.pivot;
     for (uint32_t k0 = threadIdx.x; k0 < npairs; k0 += NT * U) {
@@ -198,8 +200,8 @@ __device__ __forceinline__ void small_pass_pair(A *st, uint32_t npairs, const Sm
 }
 
 // x == 0 runs are complex phases: only reachable in complex mode
-template <int NT>
-__device__ __forceinline__ void small_pass_diag(double2 *st, uint32_t namps, const SmallOp &op, const RotLds *tab) {
+template <int NT, typename V>
+__device__ __forceinline__ void small_pass_diag(V st, uint32_t namps, const SmallOp &op, const RotLds *tab) {
     for (uint32_t i = threadIdx.x; i < namps; i += NT) {
         double2 a = st[i];
         for (int r = 0; r < op.count; ++r) {
@@ -236,8 +238,9 @@ __device__ __forceinline__ void small_pass_tab_stream(A *st, const SmallOp &op, 
     }
 }
 
-template <bool REAL, int NT, typename A>
-__device__ __forceinline__ void small_pass_tab(A *st, int n, const SmallOp &op, const RotLds *tab) {
+template <bool REAL, int NT, typename V>
+__device__ __forceinline__ void small_pass_tab(V st, int n, const SmallOp &op, const RotLds *tab) {
+    typedef typename Amp<REAL>::T A;
     const uint32_t nk = 1u << (n - __popc(op.fixmask));
     const uint32_t x = (uint32_t)op.x;
     for (int p = 0; p < op.count; ++p) {
@@ -258,8 +261,9 @@ __device__ __forceinline__ void small_pass_tab(A *st, int n, const SmallOp &op, 
     }
 }
 
-template <bool REAL, int NT, typename A>
-__device__ __forceinline__ void small_pass_gate(A *st, uint32_t namps, const SmallOp &op) {
+template <bool REAL, int NT, typename V>
+__device__ __forceinline__ void small_pass_gate(V st, uint32_t namps, const SmallOp &op) {
+    typedef typename Amp<REAL>::T A;
     if (op.kind == OP_CNOT) {
         const int cb = op.first, tb = op.count;
         const int lo = cb < tb ? cb : tb, hi = cb < tb ? tb : cb;

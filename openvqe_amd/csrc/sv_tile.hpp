@@ -53,6 +53,11 @@ __device__ __forceinline__ uint32_t tile_swz(uint32_t e) {
     return REAL ? e ^ (((e >> 4) & 7u) << 1) : e ^ ((e >> 3) & 7u);
 }
 __device__ __forceinline__ uint32_t tile_swz_v(uint32_t v) { return v ^ ((v >> 3) & 7u); }
+template <bool REAL>
+struct TileView {  // what the passes of sv_small.hpp index instead of the raw LDS pointer
+    typename Amp<REAL>::T *p;
+    __device__ __forceinline__ typename Amp<REAL>::T &operator[](uint32_t e) const { return p[tile_swz<REAL>(e)]; }
+};
 
 // pdep(v, mask): spread the low bits of v over the set bits of mask (ascending); mask is wave-uniform
 __device__ __forceinline__ uint64_t spread_bits(uint32_t v, uint64_t mask) {
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(NT) void k_tile_sweep(void *__restrict__ st, uint64
     constexpr uint32_t NELV = REAL ? NEL / 2 : NEL;   // 16-byte elements per tile
     constexpr int TRIPS = NELV / NT;
     constexpr int U = (NEL / 2 / NT) >= 4 ? 4 : ((NEL / 2 / NT) >= 2 ? 2 : 1);
-    amp *tile = reinterpret_cast<amp *>(smem);
+    const TileView<REAL> tile{reinterpret_cast<amp *>(smem)};  // bank-swizzled (see tile_swz)
     double2 *tilev = reinterpret_cast<double2 *>(smem);
     RotLds *tab = reinterpret_cast<RotLds *>(smem + (size_t)NELV * sizeof(double2));
     v2d *p = reinterpret_cast<v2d *>(st);
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(NT) void k_tile_sweep(void *__restrict__ st, uint64
         tab[r - seg.rot0] = rl;
     }
 #pragma unroll
-    for (int j = 0; j < TRIPS; ++j) tilev[threadIdx.x + j * NT] = make_double2(reg[j].x, reg[j].y);
+    for (int j = 0; j < TRIPS; ++j) tilev[tile_swz_v(threadIdx.x + j * NT)] = make_double2(reg[j].x, reg[j].y);
     __syncthreads();
 
     for (int o = seg.op0; o < seg.op1; ++o) {
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(NT) void k_tile_sweep(void *__restrict__ st, uint64
 
 #pragma unroll
     for (int j = 0; j < TRIPS; ++j) {
-        const double2 a = tilev[threadIdx.x + j * NT];
+        const double2 a = tilev[tile_swz_v(threadIdx.x + j * NT)];
         const v2d t = {a.x, a.y};
         const uint64_t g = tb | glow | spread_bits((uint32_t)j, seg.mask_hi);
         if (NTL) __builtin_nontemporal_store(t, &p[g]); else p[g] = t;
