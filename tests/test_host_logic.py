@@ -184,6 +184,34 @@ def test_energy_ucc_get_energies(oracle_engine, h2, capsys):
                         "energies2_substracted_from_FCI", "energies_1", "energies_2"}
 
 
+def test_gradient_options_of_the_ucc_mirrors(oracle_engine, h2):
+    """host logic of the opt-in Jacobians (batched forward differences / adjoint): both reach the minimum of the plain
+    jac=None run with fewer objective calls; the QUCCSD mirror likewise (engine = oracle, whose energy_gradient is a
+    central difference)"""
+    from openvqe_amd.ucc_family.get_energy_qucc import EnergyUCC as EnergyQUCC
+    from openvqe_amd.ucc_family.get_energy_ucc import EnergyUCC
+    ham, hf, e0 = h2
+    gens = fermion.uccsd_generators(2, 1)
+    runs = {}
+    for flag in (None, "batched_gradient", "adjoint_gradient"):
+        ucc = EnergyUCC()
+        if flag:
+            setattr(ucc, flag, True)
+        sink = []
+        runs[flag] = (ucc._minimize(ham, gens, hf, [0.0] * 3, sink, "BFGS", 1e-4), len(sink))
+    for flag in ("batched_gradient", "adjoint_gradient"):
+        assert abs(runs[flag][0].fun - runs[None][0].fun) < 1e-8
+        assert runs[flag][1] < runs[None][1]
+    ops = _qucc_cluster_ops()
+    out = {}
+    for flag in (False, True):
+        q = EnergyQUCC()
+        q.adjoint_gradient = flag
+        out[flag] = q.get_energies(ham, ops, hf, [0.01] * len(ops), [0.0] * len(ops), e0)
+    assert abs(out[True][0]["minimum_energy_result1_guess"][0] - out[False][0]["minimum_energy_result1_guess"][0]) < 1e-7
+    assert len(out[True][1]["energies_1"]) < len(out[False][1]["energies_1"])
+
+
 def test_energy_ucc_matches_reference_module(oracle_engine, h2):
     ham, hf, e0 = h2
     ref = reference_module("openvqe.ucc_family.get_energy_ucc")
