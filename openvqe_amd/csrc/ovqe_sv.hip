@@ -74,6 +74,12 @@ struct ovqe_sv {
     RotParam *h_rp = nullptr;  // pinned
     size_t h_rp_cap = 0;
     double2 *h_result = nullptr;  // pinned, small
+    // small batches (the one-evaluation-per-call loops of scipy's optimisers): parameters and energies travel through one
+    // pinned, device-mapped buffer that the fused kernels read / write directly — launch + sync instead of two copies,
+    // two event records and their completion round trips
+    double *h_io = nullptr;
+    double *d_io = nullptr;       // device alias of h_io
+    static constexpr size_t IO_DOUBLES = 8192;
 
     HamDev ham;
     HamDev ham_adhoc;             // last Hermitian sum evaluated by ovqe_expectation / ovqe_bilinear on the own state
@@ -1518,6 +1524,25 @@ int build_exp_tables(ovqe_handle h, int lbits, bool real) {
 }
 
 // B evaluations with the fused kernel; energies -> host
+// host <-> device traffic of a small batch through the mapped buffer: [theta B x K][energies B]
+bool mapped_io(ovqe_handle h, int64_t B) {
+    if ((size_t)B * (size_t)(h->K + 1) > ovqe_sv::IO_DOUBLES || B > 64) return false;
+    if (!h->h_io) {
+        if (hipHostMalloc((void **)&h->h_io, ovqe_sv::IO_DOUBLES * sizeof(double), hipHostMallocMapped) != hipSuccess) {
+            h->h_io = nullptr;
+            (void)hipGetLastError();
+            return false;
+        }
+        if (hipHostGetDevicePointer((void **)&h->d_io, h->h_io, 0) != hipSuccess) {
+            (void)hipHostFree(h->h_io);
+            h->h_io = nullptr;
+            (void)hipGetLastError();
+            return false;
+        }
+    }
+    return true;
+}
+
 int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies, bool on_device = false) {
     const int n = h->n_local;
     bool real = h->opt_real_mode != 0;
@@ -1540,7 +1565,12 @@ int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies, b
     if (rc) return rc;
     h->cur_theta = theta;
     h->cur_energies = energies;
-    if (!on_device) {
+    const bool zero_copy = !on_device && mapped_io(h, B);
+    if (zero_copy) {
+        if (h->K > 0) std::memcpy(h->h_io, theta, (size_t)B * h->K * sizeof(double));
+        h->cur_theta = h->d_io;
+        h->cur_energies = h->d_io + (size_t)B * h->K;
+    } else if (!on_device) {
         rc = ensure(h, h->d_theta, (size_t)B * std::max(1, h->K) * sizeof(double));
         if (rc) return rc;
         rc = ensure(h, h->d_energies, (size_t)B * sizeof(double));
@@ -1563,7 +1593,7 @@ int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies, b
     A.constant = h->ham.constant;
     A.hf = h->hf;
     const size_t smem = (lds_state ? state_bytes : 0) + (size_t)h->cs_capacity * sizeof(RotLds) + SMALL_OPS_CAP * sizeof(SmallOp) + 16 * sizeof(double2);
-    HIPC(h, hipEventRecord(h->ev0, h->stream));
+    if (!zero_copy) HIPC(h, hipEventRecord(h->ev0, h->stream));
     if (real) {
         if (!lds_state) rc = launch_small<true, false, 1024, 10>(h, A, grid, smem);
         else if (nt == 1024) rc = launch_small<true, true, 1024, 10>(h, A, grid, smem);
@@ -1578,6 +1608,12 @@ int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies, b
         else rc = launch_small<false, true, 64, 6>(h, A, grid, smem);
     }
     if (rc) return rc;
+    if (zero_copy) {
+        HIPC(h, hipStreamSynchronize(h->stream));
+        std::memcpy(energies, h->h_io + (size_t)B * h->K, (size_t)B * sizeof(double));
+        h->last_batch_ms = 0.f;  // not timed: no events on the latency path
+        return OVQE_OK;
+    }
     HIPC(h, hipEventRecord(h->ev1, h->stream));
     if (!on_device)
         HIPC(h, hipMemcpyAsync(energies, h->cur_energies, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1699,7 +1735,12 @@ int run_sparse(ovqe_handle h, int64_t B, const double *theta, double *energies, 
     int rc = OVQE_OK;
     const double *d_theta = theta;
     double *d_energies = energies;
-    if (!on_device) {
+    const bool zero_copy = !on_device && mapped_io(h, B);
+    if (zero_copy) {
+        std::memcpy(h->h_io, theta, (size_t)B * h->K * sizeof(double));
+        d_theta = h->d_io;
+        d_energies = h->d_io + (size_t)B * h->K;
+    } else if (!on_device) {
         rc = ensure(h, h->d_theta, (size_t)B * std::max(1, h->K) * sizeof(double));
         if (!rc) rc = ensure(h, h->d_energies, (size_t)B * sizeof(double));
         if (rc) return rc;
@@ -1725,11 +1766,17 @@ int run_sparse(ovqe_handle h, int64_t B, const double *theta, double *energies, 
     if (per_eval * spw > 150 * 1024) return fail(h, OVQE_ERR_INVALID, "support too large for the compacted kernel");
     const int64_t nwork = (B + spw - 1) / spw;
     const int grid = (int)std::min<int64_t>(nwork, 256 * 32);
-    HIPC(h, hipEventRecord(h->ev0, h->stream));
+    if (!zero_copy) HIPC(h, hipEventRecord(h->ev0, h->stream));
     if (spw == 4) rc = launch_sparse<4>(h, A, grid, per_eval * 4);
     else if (spw == 2) rc = launch_sparse<2>(h, A, grid, per_eval * 2);
     else rc = launch_sparse<1>(h, A, grid, per_eval);
     if (rc) return rc;
+    if (zero_copy) {
+        HIPC(h, hipStreamSynchronize(h->stream));
+        std::memcpy(energies, h->h_io + (size_t)B * h->K, (size_t)B * sizeof(double));
+        h->last_batch_ms = 0.f;
+        return OVQE_OK;
+    }
     HIPC(h, hipEventRecord(h->ev1, h->stream));
     if (!on_device)
         HIPC(h, hipMemcpyAsync(energies, h->cur_energies, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1826,6 +1873,7 @@ int ovqe_destroy(ovqe_handle h) {
         if (b->p) (void)hipFree(b->p);
     if (h->h_rp) (void)hipHostFree(h->h_rp);
     if (h->h_result) (void)hipHostFree(h->h_result);
+    if (h->h_io) (void)hipHostFree(h->h_io);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
