@@ -1715,15 +1715,15 @@ int build_sparse_program(ovqe_handle h) {
     return OVQE_OK;
 }
 
-template <int SPW>
+template <int SPW, bool STAGE = false>
 int launch_sparse(ovqe_handle h, const SparseArgs &A, int grid, size_t smem) {
     static bool attr_done = false;
     if (!attr_done) {
-        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sparse_vqe<SPW>),
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sparse_vqe<SPW, STAGE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_sparse_vqe<SPW>), dim3(grid), dim3(64), smem, h->stream, A, h->cur_theta,
+    hipLaunchKernelGGL((k_sparse_vqe<SPW, STAGE>), dim3(grid), dim3(64), smem, h->stream, A, h->cur_theta,
                        (const SmallRot *)h->d_rots.p, (const SpOp *)h->d_sp_ops.p, (const uint32_t *)h->d_sp_pairs.p,
                        (const SpEntry *)h->d_sp_entries.p, h->cur_energies);
     HIPC(h, hipGetLastError());
@@ -1756,18 +1756,22 @@ int run_sparse(ovqe_handle h, int64_t B, const double *theta, double *energies, 
     A.nops = h->sp_nops;
     A.ntab = (int)h->srots.size();
     A.nent = h->sp_nent;
-    A.pad = 0;
+    A.npairs = (int)h->sp_npairs;
     A.B = B;
     A.constant = h->ham.constant;
     const size_t per_eval = (size_t)A.m * sizeof(double) + (size_t)A.ntab * sizeof(double2);
     int spw = h->opt_sparse_spw;
     if (spw != 1 && spw != 2 && spw != 4) spw = B >= 2048 ? 2 : 1;  // measured: 2 evaluations per wave is the sweet spot
+    if (B <= 64) spw = 1;
     while (spw > 1 && per_eval * spw > 64 * 1024) spw >>= 1;
     if (per_eval * spw > 150 * 1024) return fail(h, OVQE_ERR_INVALID, "support too large for the compacted kernel");
     const int64_t nwork = (B + spw - 1) / spw;
     const int grid = (int)std::min<int64_t>(nwork, 256 * 32);
     if (!zero_copy) HIPC(h, hipEventRecord(h->ev0, h->stream));
-    if (spw == 4) rc = launch_sparse<4>(h, A, grid, per_eval * 4);
+    // latency path: op table + pair words staged in LDS (one wave per evaluation, occupancy does not matter)
+    const size_t staged = per_eval + (size_t)A.nops * sizeof(SpOp) + (size_t)A.npairs * sizeof(uint32_t);
+    if (B <= 64 && staged <= 96 * 1024) rc = launch_sparse<1, true>(h, A, grid, staged);
+    else if (spw == 4) rc = launch_sparse<4>(h, A, grid, per_eval * 4);
     else if (spw == 2) rc = launch_sparse<2>(h, A, grid, per_eval * 2);
     else rc = launch_sparse<1>(h, A, grid, per_eval);
     if (rc) return rc;

@@ -38,12 +38,14 @@ struct SparseArgs {
     int nops;
     int ntab;
     int nent;
-    int pad;
+    int npairs;   // all active pairs of the program (STAGE: copied to LDS once per launch)
     int64_t B;
     double constant;
 };
 
-template <int SPW>
+// STAGE = true (small batches, the latency path of one-evaluation-per-call optimisers): the op table and the pair
+// words are copied to LDS at kernel start, so the chain op -> pair word -> amplitudes never waits for global memory.
+template <int SPW, bool STAGE>
 __global__ __launch_bounds__(64) void k_sparse_vqe(SparseArgs A, const double *__restrict__ theta,
                                                    const SmallRot *__restrict__ tabrots,
                                                    const SpOp *__restrict__ ops, const uint32_t *__restrict__ pairs,
@@ -53,6 +55,12 @@ __global__ __launch_bounds__(64) void k_sparse_vqe(SparseArgs A, const double *_
     double *st = reinterpret_cast<double *>(smem);                        // [SPW][m]
     double2 *cs = reinterpret_cast<double2 *>(st + (size_t)SPW * A.m);    // [SPW][ntab]
     const int lane = threadIdx.x;
+    SpOp *lops = reinterpret_cast<SpOp *>(cs + (size_t)SPW * A.ntab);     // [nops]   (STAGE)
+    uint32_t *lpairs = reinterpret_cast<uint32_t *>(lops + A.nops);       // [npairs] (STAGE)
+    if constexpr (STAGE) {
+        for (int i = lane; i < A.nops; i += 64) lops[i] = ops[i];
+        for (int i = lane; i < A.npairs; i += 64) lpairs[i] = pairs[i];
+    }
     // the wave's lanes are split evenly over its SPW evaluations (no index division in the inner loops)
     constexpr int LPS = 64 / SPW;
     const int s = lane / LPS, l = lane % LPS;
@@ -75,9 +83,17 @@ __global__ __launch_bounds__(64) void k_sparse_vqe(SparseArgs A, const double *_
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (int o = 0; o < A.nops; ++o) {
-            const SpOp op = ops[o];
+            SpOp op;
+            if constexpr (STAGE) {
+                op = lops[o];
+                op.first = __builtin_amdgcn_readfirstlane(op.first);
+                op.npairs = __builtin_amdgcn_readfirstlane(op.npairs);
+                op.tab0 = __builtin_amdgcn_readfirstlane(op.tab0);
+            } else {
+                op = ops[o];
+            }
             for (int pe = l; pe < op.npairs; pe += LPS) {
-                const uint32_t pw = pairs[op.first + pe];
+                const uint32_t pw = STAGE ? lpairs[op.first + pe] : pairs[op.first + pe];
                 const uint32_t ci = pw & 0xfffu, cj = (pw >> 12) & 0xfffu;
                 const double2 t = csb[op.tab0 + (int)(pw >> 25)];
                 const double sn = (pw & (1u << 24)) ? -t.y : t.y;
