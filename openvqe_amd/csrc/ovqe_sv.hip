@@ -97,6 +97,7 @@ struct ovqe_sv {
     std::vector<uint64_t> sop_zc;  // OP_TAB: the run's common z mask outside x, all 64 bits
     std::vector<SmallSeg> segs;
     DevBuf d_ops, d_rots, d_segs, d_stream;
+    DevBuf d_rots_seq;            // the sequential program's rotations (device-side angle resolution)
     std::vector<uint16_t> idx_stream;  // precomputed (sign<<15 | index) streams of the OP_TAB ops
     int cs_capacity = 512;
     // batched evaluation workspace
@@ -145,6 +146,7 @@ namespace {
 
 int rebuild_small_program(ovqe_handle h);
 int build_tile_program(ovqe_handle h);
+bool mapped_io(ovqe_handle h, int64_t B);
 
 int fail(ovqe_handle h, int code, const std::string &msg) {
     if (h) h->err = msg; else g_create_error = msg;
@@ -969,10 +971,24 @@ int run_program_streaming(ovqe_handle h, const double *theta, bool real = false)
     const size_t S = h->srots.size(), R = h->rots.size();
     rc = ensure_rp(h, std::max<size_t>(S + R, 1));
     if (rc) return rc;
-    for (size_t r = 0; r < S; ++r) h->h_rp[r] = resolve_rot(h->srots[r], theta);
-    for (size_t r = 0; r < R; ++r) h->h_rp[S + r] = resolve_rot(h->rots[r], theta);
-    if (S + R)
-        HIPC(h, hipMemcpyAsync(h->d_rp.p, h->h_rp, (S + R) * sizeof(RotParam), hipMemcpyHostToDevice, h->stream));
+    static_assert(sizeof(RotSpec) == sizeof(SmallRot), "RotSpec mirrors SmallRot");
+    if (S + R >= 256 && (size_t)h->K <= ovqe_sv::IO_DOUBLES && mapped_io(h, 1)) {
+        // angles resolved on the device from the parameter vector (read through the pinned, mapped buffer): no host
+        // trigonometry and no table upload on the evaluation path
+        std::memcpy(h->h_io, theta, (size_t)h->K * sizeof(double));
+        if (S)
+            hipLaunchKernelGGL(k_resolve_rots, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, h->stream,
+                               (const RotSpec *)h->d_rots.p, (int)S, (const double *)h->d_io, (RotParam *)h->d_rp.p);
+        if (R)
+            hipLaunchKernelGGL(k_resolve_rots, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, h->stream,
+                               (const RotSpec *)h->d_rots_seq.p, (int)R, (const double *)h->d_io,
+                               (RotParam *)h->d_rp.p + S);
+    } else {
+        for (size_t r = 0; r < S; ++r) h->h_rp[r] = resolve_rot(h->srots[r], theta);
+        for (size_t r = 0; r < R; ++r) h->h_rp[S + r] = resolve_rot(h->rots[r], theta);
+        if (S + R)
+            HIPC(h, hipMemcpyAsync(h->d_rp.p, h->h_rp, (S + R) * sizeof(RotParam), hipMemcpyHostToDevice, h->stream));
+    }
     const RotParam *d_rp = (const RotParam *)h->d_rp.p;
     const TilePlan &tp = real ? h->tp_real : h->tp;
     const int nbr = reduce_blocks(h->namps);
@@ -1153,6 +1169,8 @@ int rebuild_small_program(ovqe_handle h) {
     int rc = upload(h, h->d_ops, h->sops.data(), h->sops.size() * sizeof(SmallOp));
     if (rc) return rc;
     rc = upload(h, h->d_rots, h->srots.data(), h->srots.size() * sizeof(SmallRot));
+    if (rc) return rc;
+    rc = upload(h, h->d_rots_seq, h->rots.data(), h->rots.size() * sizeof(SmallRot));
     if (rc) return rc;
     rc = upload(h, h->d_stream, h->idx_stream.data(), h->idx_stream.size() * sizeof(uint16_t));
     if (rc) return rc;
@@ -1866,7 +1884,8 @@ int ovqe_destroy(ovqe_handle h) {
     if (h->own_state && h->state) (void)hipFree(h->state);
     for (int k = 0; k < 2; ++k)
         if (h->scratch[k]) (void)hipFree(h->scratch[k]);
-    std::vector<DevBuf *> bufs = {&h->d_partials, &h->d_result, &h->d_rp, &h->d_ops, &h->d_rots, &h->d_segs, &h->d_stream,
+    std::vector<DevBuf *> bufs = {&h->d_partials, &h->d_result, &h->d_rp, &h->d_ops, &h->d_rots, &h->d_rots_seq, &h->d_segs,
+                                  &h->d_stream,
                                   &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups, &h->d_eterms, &h->d_echunks,
                                   &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries};
     for (TilePlan *tp : {&h->tp, &h->tp_adhoc, &h->tp_real}) bufs.insert(bufs.end(), {&tp->d_tops, &tp->d_trots});
