@@ -79,7 +79,7 @@ struct ovqe_sv {
     // two event records and their completion round trips
     double *h_io = nullptr;
     double *d_io = nullptr;       // device alias of h_io
-    static constexpr size_t IO_DOUBLES = 8192;
+    static constexpr size_t IO_DOUBLES = 131072;
 
     HamDev ham;
     HamDev ham_adhoc;             // last Hermitian sum evaluated by ovqe_expectation / ovqe_bilinear on the own state
@@ -1545,7 +1545,7 @@ int build_exp_tables(ovqe_handle h, int lbits, bool real) {
 // host <-> device traffic of a small batch through the mapped buffer: [theta B x K][energies B]
 bool mapped_io(ovqe_handle h, int64_t B) {
     // measured: zero-copy wins up to the 64-KiB buffer (H2O: 16 evaluations 63 us against 89 us through copies)
-    if ((size_t)B * (size_t)(h->K + 1) > ovqe_sv::IO_DOUBLES || B > 64) return false;
+    if ((size_t)B * (size_t)(h->K + 1) > ovqe_sv::IO_DOUBLES || B > 1024) return false;
     if (!h->h_io) {
         if (hipHostMalloc((void **)&h->h_io, ovqe_sv::IO_DOUBLES * sizeof(double), hipHostMallocMapped) != hipSuccess) {
             h->h_io = nullptr;
