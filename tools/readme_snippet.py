@@ -1,0 +1,14 @@
+import sys; sys.path.insert(0, "/root/repo")
+from openvqe_amd import chem, fermion
+from openvqe_amd.ucc_family.get_energy_ucc import EnergyUCC
+mol = chem.molecule("H2O"); mol.rhf()
+ham, hf = mol.jw_hamiltonian(), mol.hf_init()
+gens = fermion.uccsd_generators(mol.nao, mol.n_elec // 2)
+print(EnergyUCC().ucc_action([0.0] * len(gens), ham, gens, hf, []), mol.e_hf)
+from openvqe_amd.backend import Statevector
+with Statevector(ham.nbqbits) as sv:
+    sv.set_hamiltonian(ham); sv.set_ucc_program(gens, hf)
+    e, grad = sv.energy_gradient([0.01] * len(gens))
+    e0, residual, steps = sv.ground_state()
+    print(e, abs(grad).max(), e0, residual, steps)
+    print(sv.program_info())
