@@ -647,7 +647,8 @@ int launch_tile_expect(ovqe_handle h, const HamDev &H, const ExSweep &sw, double
     constexpr int NT = 1 << TILE_EXPECT_LOG_NT;
     const size_t smem = ((size_t)(REAL ? 8 : 16) << M) + TILE_TERM_CAP * sizeof(ExTermLds) + (NT / 64) * sizeof(double2);
     const dim3 grid((unsigned)(h->namps >> M), (unsigned)expect_ysplit(h, M));
-    static bool attr_done = false;
+    static bool attr_done_dev[64] = {};  // function attributes are per device
+    bool &attr_done = attr_done_dev[h->device & 63];
     if (!attr_done) {
         HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_expect<M, NT, true, REAL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -732,7 +733,8 @@ int launch_tile_apply(ovqe_handle h, const HamDev &H, const ExSweep &sw, const a
                       double ident) {
     constexpr int NT = 1 << TILE_EXPECT_LOG_NT;  // the sweeps' thread / trip masks are laid out for this group size
     const size_t smem = ((size_t)16 << M) + TILE_TERM_CAP * sizeof(ExTermLds) + TILE_APPLY_GROUPS * sizeof(ExAGroupT);
-    static bool attr_done = false;
+    static bool attr_done_dev[64] = {};  // function attributes are per device
+    bool &attr_done = attr_done_dev[h->device & 63];
     if (!attr_done) {
         HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_apply<M, NT, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -797,7 +799,8 @@ int launch_tile(ovqe_handle h, const TilePlan &tp, const TileSeg &sg) {
     const size_t smem = ((size_t)(REAL ? 8 : 16) << M) + TILE_ROT_CAP * sizeof(RotLds);
     const unsigned grid = (unsigned)(h->namps >> M);
     const bool ntl = h->n_local >= 25;
-    static bool attr_done = false;
+    static bool attr_done_dev[64] = {};  // function attributes are per device
+    bool &attr_done = attr_done_dev[h->device & 63];
     if (!attr_done) {
         HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sweep<M, NT, true, REAL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -1369,7 +1372,8 @@ bool use_small_path(ovqe_handle h, int64_t B) {
 
 template <bool REAL, bool LDS, int NT, int LBITS>
 int launch_small(ovqe_handle h, const SmallArgs &A, int grid, size_t smem) {
-    static bool attr_done = false;
+    static bool attr_done_dev[64] = {};  // function attributes are per device
+    bool &attr_done = attr_done_dev[h->device & 63];
     if (!attr_done) {
         HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_vqe<REAL, LDS, NT, LBITS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1736,7 +1740,8 @@ int build_sparse_program(ovqe_handle h) {
 
 template <int SPW, bool STAGE = false>
 int launch_sparse(ovqe_handle h, const SparseArgs &A, int grid, size_t smem) {
-    static bool attr_done = false;
+    static bool attr_done_dev[64] = {};  // function attributes are per device
+    bool &attr_done = attr_done_dev[h->device & 63];
     if (!attr_done) {
         HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sparse_vqe<SPW, STAGE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
