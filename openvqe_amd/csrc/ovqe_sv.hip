@@ -1942,6 +1942,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "clifford_frame") h->opt_clifford_frame = (int)value;  // applies to the next ovqe_set_gate_program
     else if (k == "tile_bits" || k == "tile_low") {
         (k == "tile_bits" ? h->opt_tile_bits : h->opt_tile_low) = (int)value;
+        h->tp_real_built = false;  // the real-amplitude plan follows on its next use
         if (h->prog_set) return build_tile_program(h);
     }
     else if (k == "persist_blocks") h->opt_persist_blocks = (int)value;
