@@ -262,13 +262,14 @@ int launch_rot_run(ovqe_handle h, uint64_t x, const RotParam *d_rp, int nrot) {
 #define OVQE_LAUNCH_D(NT, U, NTL)                                                                                \
     hipLaunchKernelGGL((k_rot_diag_v<NT, U, NTL>), dim3((unsigned)((n + (uint64_t)NT * U - 1) / ((uint64_t)NT * U))), \
                        dim3(NT), 0, h->stream, h->state, n, h->base, d_rp, nrot);
-        if (variant == 0 && nl >= 14) variant = nl >= 25 ? 100 : (nl >= 21 ? 108 : 100);
+        if (variant == 0 && nl >= 14) variant = nl >= 32 ? 105 : (nl >= 25 ? 100 : (nl >= 21 ? 108 : 100));
         if (nl < 14 || variant < 100) variant = (variant == -1 || nl < 14) ? -1 : 100;
         switch (variant) {
         case 100: OVQE_LAUNCH_D(64, 1, true) break;
         case 101: OVQE_LAUNCH_D(128, 1, true) break;
         case 102: OVQE_LAUNCH_D(256, 1, true) break;
         case 104: OVQE_LAUNCH_D(128, 2, true) break;
+        case 105: OVQE_LAUNCH_D(64, 4, true) break;  // n >= 32: a launch holds fewer than 2^32 threads
         case 108: OVQE_LAUNCH_D(256, 1, false) break;
         default:
             if (h->opt_unroll >= 4 && n >= 256u * 4u) {
@@ -290,7 +291,8 @@ int launch_rot_run(ovqe_handle h, uint64_t x, const RotParam *d_rp, int nrot) {
         hipLaunchKernelGGL((k_rot_pairs_v<NT, U, NTL, PERSIST>), dim3(grid), dim3(NT), 0, h->stream, h->state, np,  \
                            pivot, x, h->base, d_rp, nrot);                                                         \
     }
-        if (variant == 0 && nl >= 14) variant = nl >= 25 ? (pivot >= 7 ? 16 : 13) : (nl >= 21 ? 17 : 16);
+        if (variant == 0 && nl >= 14)
+            variant = nl >= 32 ? 21 : (nl >= 25 ? (pivot >= 7 ? 16 : 13) : (nl >= 21 ? 17 : 16));
         if (nl < 14 || variant >= 100) variant = -1;
         switch (variant) {
         case 1: OVQE_LAUNCH_V(256, 4, true, false) break;
@@ -302,6 +304,7 @@ int launch_rot_run(ovqe_handle h, uint64_t x, const RotParam *d_rp, int nrot) {
         case 16: OVQE_LAUNCH_V(64, 1, true, false) break;
         case 17: OVQE_LAUNCH_V(256, 1, false, false) break;
         case 19: OVQE_LAUNCH_V(64, 2, true, false) break;
+        case 21: OVQE_LAUNCH_V(64, 4, true, false) break;  // n >= 32: a launch holds fewer than 2^32 threads
         default:
             if (h->opt_unroll >= 4 && np >= 256u * 4u) {
                 hipLaunchKernelGGL(k_rot_pairs<4>, dim3((unsigned)((np + 1023) / 1024)), dim3(256), 0, h->stream,

@@ -143,3 +143,25 @@ def test_30_qubit_tiled_program_and_expectation_against_sparse_oracle(gpu_lib, r
         assert abs(n2 - 1.0) < 1e-12
         mask = ~np.isin(extra, support)
         assert np.all(others[mask] == 0.0)
+
+
+def test_32_qubit_state_on_one_gpu(gpu_lib):
+    """64 GiB state (a launch may hold fewer than 2^32 threads: the sweeps switch to four pairs per thread):
+    diagonal and pair sweeps against the oracle formula on sampled amplitudes, inverse, norm"""
+    from openvqe_amd.backend import Statevector
+    n = 32
+    rng = np.random.default_rng(32)
+    seed = 20250227
+    with Statevector(n) as sv:
+        scale = sv.randomize(seed)
+        idx = rng.integers(0, 1 << n, 2048).astype(np.uint64)
+        base = synth.amplitudes(seed, idx) * scale
+        assert np.array_equal(sv.get_amplitudes(idx), base)
+        for op, qs in (("XZY", [0, 13, n - 1]), ("Z" * n, list(range(n))), ("YX", [n - 2, n - 1])):
+            x, z = pack_string(n, op, qs)
+            sv.apply_pauli_rotation(x, z, 0.37)
+            want = _host_rotate(seed, scale, idx, x, z, 0.37)
+            assert np.abs(sv.get_amplitudes(idx) - want).max() < 1e-19 + 4 * np.finfo(float).eps * np.abs(want).max()
+            sv.apply_pauli_rotation(x, z, -0.37)
+            assert np.abs(sv.get_amplitudes(idx) - base).max() < 8 * np.finfo(float).eps * np.abs(base).max()
+        assert abs(sv.norm2() - 1.0) < 1e-10
