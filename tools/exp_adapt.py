@@ -1,3 +1,4 @@
+"""H2O/STO-3G ADAPT gradient screen (1246-operator pool) and exact-exponential step: timings"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

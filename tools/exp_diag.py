@@ -1,3 +1,4 @@
+"""diagonal-string sweeps at 30 qubits: launch geometry experiments (round-1 tuning)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,3 +1,4 @@
+"""H2O/STO-3G UCCSD on the fused kernels: thread counts / options sweep (round-1 tuning)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,3 +1,4 @@
+"""H2O QUCCSD gate list in Clifford-frame form: dense LDS kernel vs support-compacted kernel"""
 import sys, os, time
 sys.path.insert(0, "/root/repo")
 import numpy as np

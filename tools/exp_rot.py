@@ -1,3 +1,4 @@
+"""pair-sweep launch geometry at 26-30 qubits, first sweep of variants (round-1 tuning)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

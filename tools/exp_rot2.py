@@ -1,3 +1,4 @@
+"""pair-sweep launch geometry, second sweep (threads per group, non-temporal accesses)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

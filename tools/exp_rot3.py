@@ -1,3 +1,4 @@
+"""pair-sweep launch geometry, third sweep (per-pivot behaviour, mid sizes)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,4 +1,5 @@
 #!/bin/bash
+# kernel stats of the adjoint gradient at 24 qubits (tools/exp_grad.py 12 5 5) under rocprofv3
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_grad
 mkdir -p $OUT
