@@ -765,7 +765,8 @@ int apply_hamiltonian(ovqe_handle h, amp_t *out, const amp_t *in, double ident) 
         int rc = build_ham_tiles(h, H, false);
         if (rc) return rc;
     }
-    if (H.tsweeps.empty() || H.n_rest) {
+    // below ~2^8 tiles the tile sweeps leave most of the chip idle: the gather kernel (state in L2) is faster there
+    if (H.tsweeps.empty() || H.n_rest || (h->namps >> H.tile_bits) < 256) {
         hipLaunchKernelGGL(k_apply_sum, dim3(reduce_blocks(h->namps)), dim3(256), 0, h->stream, out, in, (amp_t *)nullptr,
                            h->namps, h->base, (const HGroup *)H.d_groups.p, (int)H.groups.size(),
                            (const HTerm *)H.d_terms.p, 1.0, 0.0, ident, 0.0);
