@@ -80,7 +80,8 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * whose rotation strings all have an odd number of Y — every UCC / ADAPT generator, the QUCCSD templates in frame form —
  * keeps the amplitudes real; streaming energies (n >= 15) then store the state as 2^n doubles: half the HBM bytes per
  * sweep, one more mixing bit per LDS tile; ovqe_prepare_state always delivers the complex state),
- * "clifford_frame" (read by the NEXT ovqe_set_gate_program: 0 = execute the literal gate list; 1 (default) = when
+ * "apply_min_tiles" (sigma = H psi uses the tile cover from this many tiles on, default 256; the gather
+ * kernel below), "clifford_frame" (read by the NEXT ovqe_set_gate_program: 0 = execute the literal gate list; 1 (default) = when
  * the Clifford part of the list — X, H, CNOT, quarter-turn rotations — multiplies to the identity, run the
  * algebraically identical sequence of Pauli rotations with conjugated strings instead; 2 = always, Clifford part
  * appended literally) */

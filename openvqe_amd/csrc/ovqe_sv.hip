@@ -137,6 +137,7 @@ struct ovqe_sv {
     TilePlan tp_real;             // same program on a real-amplitude state (built on first use)
     bool tp_real_built = false;
     bool prog_real_ok = false;    // every rotation has an odd number of Y and there is no diagonal run
+    int opt_apply_min_tiles = 256;  // H psi goes through the tile cover from this many tiles on
     int opt_real_stream = 1;      // streaming energies of such programs keep the state as 2^n doubles
     HamDev ham_real;              // tile cover of the stored Hamiltonian for the real-amplitude state
     TilePlan tp_adhoc;            // of the rotation list of the current ovqe_apply_pauli_rotations call
@@ -766,7 +767,7 @@ int apply_hamiltonian(ovqe_handle h, amp_t *out, const amp_t *in, double ident) 
         if (rc) return rc;
     }
     // below ~2^8 tiles the tile sweeps leave most of the chip idle: the gather kernel (state in L2) is faster there
-    if (H.tsweeps.empty() || H.n_rest || (h->namps >> H.tile_bits) < 256) {
+    if (H.tsweeps.empty() || H.n_rest || (int64_t)(h->namps >> H.tile_bits) < h->opt_apply_min_tiles) {
         hipLaunchKernelGGL(k_apply_sum, dim3(reduce_blocks(h->namps)), dim3(256), 0, h->stream, out, in, (amp_t *)nullptr,
                            h->namps, h->base, (const HGroup *)H.d_groups.p, (int)H.groups.size(),
                            (const HTerm *)H.d_terms.p, 1.0, 0.0, ident, 0.0);
@@ -1943,6 +1944,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     }
     else if (k == "rot_variant") h->opt_rot_variant = (int)value;
     else if (k == "real_stream") h->opt_real_stream = (int)value;
+    else if (k == "apply_min_tiles") h->opt_apply_min_tiles = (int)value;
     else if (k == "clifford_frame") h->opt_clifford_frame = (int)value;  // applies to the next ovqe_set_gate_program
     else if (k == "tile_bits" || k == "tile_low") {
         (k == "tile_bits" ? h->opt_tile_bits : h->opt_tile_low) = (int)value;

@@ -306,6 +306,7 @@ def test_tiled_operator_application_in_screen_and_lanczos(SV, m, o, bits):
     res = {}
     with SV(n) as sv:
         sv.set_option("force_path", 2)
+        sv.set_option("apply_min_tiles", 1)   # small registers use the gather kernel by default: force the tile form
         sv.set_hamiltonian(ham)
         sv.set_ucc_program(gens, hf)
         for b in (bits, 0):
