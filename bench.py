@@ -104,19 +104,8 @@ def extra_workloads_leg(device):
 
 
 def _quccsd_gates(m, o, stride=1):
-    """literal gate list of the reference's fermionic QUCCSD templates (ref:openvqe/common_files/circuit.py:13-106)
-    on the UCCSD excitations of m spatial orbitals / o occupied, every `stride`-th excitation"""
-    from openvqe_amd import fermion
-    from openvqe_amd.common_files.circuit import efficient_fermionic_ansatz
-    from openvqe_amd.qat_compat import AffineParam, Program, lower_circuit
-    singles, doubles = fermion.uccsd_excitations(m, o)
-    exci = ([[i, a] for i, a in singles] + [[i, j, a, b] for i, j, a, b in doubles])[::stride]
-    prog = Program()
-    reg = prog.qalloc(2 * m)
-    efficient_fermionic_ansatz(reg, prog, exci, [AffineParam(k) for k in range(len(exci))])
-    _, kind, gates = lower_circuit(prog.to_circ())
-    assert kind == "gates"
-    return gates, len(exci), fermion.hf_integer(2 * m, 2 * o)
+    from openvqe_amd.common_files.circuit import quccsd_gate_list
+    return quccsd_gate_list(m, o, stride)
 
 
 def gate_and_midsize_workloads(device):

@@ -108,6 +108,22 @@ def efficient_qubit_ansatz(q, qc, list_exci, list_theta):
     return qc
 
 
+def quccsd_gate_list(n_spatial, n_occ_spatial, stride=1):
+    """literal gate list [(name, qubits, angle_scale, angle_const, param_index)] of the fermionic templates above on
+    every ``stride``-th UCCSD excitation of n_spatial orbitals / n_occ_spatial occupied (traced with symbolic
+    angles; the input of ``Statevector.set_gate_program``) -> (gates, n_params, hf_integer)"""
+    from .. import fermion
+    from ..qat_compat import AffineParam, Program, lower_circuit
+    singles, doubles = fermion.uccsd_excitations(n_spatial, n_occ_spatial)
+    exci = ([[i, a] for i, a in singles] + [[i, j, a, b] for i, j, a, b in doubles])[::stride]
+    prog = Program()
+    reg = prog.qalloc(2 * n_spatial)
+    efficient_fermionic_ansatz(reg, prog, exci, [AffineParam(k) for k in range(len(exci))])
+    _, kind, gates = lower_circuit(prog.to_circ())
+    assert kind == "gates"
+    return gates, len(exci), fermion.hf_integer(2 * n_spatial, 2 * n_occ_spatial)
+
+
 def count(gate, mylist):
     """number of instructions whose text contains gate='<GATE>' (circuit.py:186-205); lower-case
     names are upper-cased first."""

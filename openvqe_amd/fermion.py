@@ -48,6 +48,13 @@ def psum_add(A, B, scale=1.0):
     return out
 
 
+def psum_iadd(A, B, scale=1.0):
+    """A += scale * B in place (same insertion order and arithmetic as psum_add, without the copy)."""
+    for k, c in B.items():
+        A[k] = A.get(k, 0) + scale * c
+    return A
+
+
 def jw_ladder(p, dagger):
     """a_p (dagger=False) or a_p^dagger as a Pauli sum."""
     zchain = (1 << p) - 1
@@ -113,7 +120,7 @@ def jw_molecular_hamiltonian(hpq, hpqrs, constant=0.0, tol=1e-12):
     for p in range(n):
         for q in range(n):
             if abs(hpq[p, q]) > tol:
-                total = psum_add(total, psum_mul(ladders_c[p], ladders_a[q]), hpq[p, q])
+                psum_iadd(total, psum_mul(ladders_c[p], ladders_a[q]), hpq[p, q])
     # cache a+_p a+_q and a_r a_s
     cc = {}
     aa = {}
@@ -126,7 +133,7 @@ def jw_molecular_hamiltonian(hpq, hpqrs, constant=0.0, tol=1e-12):
         for r, s in aa:
             v = hpqrs[p, q, r, s]
             if abs(v) > tol:
-                total = psum_add(total, psum_mul(cc[(p, q)], aa[(r, s)]), 0.5 * v)
+                psum_iadd(total, psum_mul(cc[(p, q)], aa[(r, s)]), 0.5 * v)
     return psum_to_hamiltonian(n, total, constant, tol=tol, real=True)
 
 

@@ -165,3 +165,57 @@ def test_32_qubit_state_on_one_gpu(gpu_lib):
             sv.apply_pauli_rotation(x, z, -0.37)
             assert np.abs(sv.get_amplitudes(idx) - base).max() < 8 * np.finfo(float).eps * np.abs(base).max()
         assert abs(sv.norm2() - 1.0) < 1e-10
+
+
+def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
+    """BASELINE configs[3] at its size: the literal QUCCSD gate list (ref:openvqe/common_files/circuit.py:13-106
+    templates on every 5th UCCSD excitation of 10 electrons / 12 orbitals: 343 parameters, ~13 k gates, 24 qubits)
+    against the plain-C oracle's gate-by-gate execution (orc_gate_energy: 256-MiB host state) — energy on a
+    molecule-shaped 24-qubit JW Hamiltonian and sampled amplitudes, for the three forms the backend can run it in:
+    literal LDS-tiled sweeps, Clifford-frame form on real-amplitude streams, Clifford-frame form on the complex state."""
+    from openvqe_amd import fermion
+    from openvqe_amd.backend import GATE_OPCODES, Statevector
+    from openvqe_amd.common_files.circuit import quccsd_gate_list
+    from oracle import cref
+    m, o, stride = 12, 5, 5
+    n = 2 * m
+    gates, K, hf = quccsd_gate_list(m, o, stride)
+    assert K == 343 and len(gates) > 12000
+    from openvqe_amd.operators import Hamiltonian
+    full, _, hf2 = fermion.synthetic_molecule(m, o, 24)
+    assert hf2 == hf
+    # every 10th of the 29736 JW terms (2974 strings, ~1900 distinct x masks): the oracle evaluates term by term
+    ham = Hamiltonian(n, full.terms[::10], full.constant_coeff, do_clean_up=False)
+    rng = np.random.default_rng(2424)
+    theta = rng.uniform(-0.1, 0.1, K)
+    hx, hz, hc = ham.packed()
+    hc = np.ascontiguousarray(hc.real)
+    opc = [GATE_OPCODES[g[0]] for g in gates]
+    b0 = [n - 1 - g[1][0] for g in gates]
+    b1 = [n - 1 - g[1][1] if len(g[1]) > 1 else 0 for g in gates]
+    e_ref, psi_ref = cref.gate_energy(n, hf, opc, b0, b1, [g[2] for g in gates], [g[3] for g in gates],
+                                      [g[4] for g in gates], theta, hx, hz, hc, ham.constant_coeff)
+    assert abs(np.vdot(psi_ref, psi_ref).real - 1.0) < 1e-10
+    big = np.argsort(-np.abs(psi_ref))[:3000].astype(np.uint64)           # the amplitudes that carry the state
+    idx = np.concatenate([big, rng.integers(0, 1 << n, 5000).astype(np.uint64)])
+    want = psi_ref[idx.astype(np.int64)]
+    l1 = float(np.abs(hc).sum())
+    res = {}
+    with Statevector(n) as sv:
+        sv.set_hamiltonian(ham)
+        for label, frame, real in (("literal_tiled", 0, 1), ("frame_real", 1, 1), ("frame_complex", 1, 0)):
+            sv.set_option("clifford_frame", frame)
+            sv.set_option("real_stream", real)
+            sv.set_gate_program(gates, K, hf)
+            info = sv.program_info()
+            e = sv.energy(theta)
+            sv.prepare_state(theta)
+            res[label] = (e, sv.get_amplitudes(idx), sv.norm2(), info)
+    assert res["literal_tiled"][3]["literal_gates"] > 0 and res["literal_tiled"][3]["tiled_sweeps"] > 0
+    assert res["literal_tiled"][3]["real_stream"] == 0
+    assert res["frame_real"][3]["literal_gates"] == 0 and res["frame_real"][3]["real_stream"] == 1
+    assert res["frame_complex"][3]["real_stream"] == 0
+    for label, (e, amps, n2, _) in res.items():
+        assert abs(e - e_ref) < 1e-10 * max(1.0, l1), (label, e, e_ref)
+        assert np.abs(amps - want).max() < 1e-12, label
+        assert abs(n2 - 1.0) < 1e-11, label
