@@ -220,6 +220,7 @@ def cpu_baseline_leg(ham, gens, hf, thetas, budget_s=12.0):
     CNOT-staircase circuit + term-wise observable (what one reference/myQLM evaluation does algorithmically)."""
     from oracle import cref
     from openvqe_amd.backend import compile_ucc_program
+    flags = cref.use_native_build() if cref._lib is None else "as loaded"
     n = ham.nbqbits
     rx, rz, rc, pidx, K = compile_ucc_program(n, gens)
     hx, hz, hc = ham.packed()
@@ -252,6 +253,7 @@ def cpu_baseline_leg(ham, gens, hf, thetas, budget_s=12.0):
         L.orc_pauli_rotation(psi, nq, int(x), int(z), 0.1)
     dt = (time.perf_counter() - t0) / reps
     out["sweep_26q"] = {"ms": 1e3 * dt, "GBs": 32.0 * (1 << nq) / dt / 1e9, "threads": cores}
+    out["cflags"] = flags
     return out, cores
 
 
@@ -439,6 +441,7 @@ def main():
                           f"(OpenMP x{cores}); the gate-level restatement of the reference's myQLM algorithm "
                           f"(CNOT staircase gate by gate, observable term by term) on the same cores: "
                           f"{cpu['gate_level']['evals_per_s']:.2f} evals/s over {cpu['gate_level']['evals']} evaluations",
+                "cflags": cpu["cflags"],
                 "gate_level_evals_per_s": cpu["gate_level"]["evals_per_s"],
                 "single_string_sweep_26_qubits": cpu["sweep_26q"],
                 "gpu_minus_cpu_energy": e_gpu0 - cpu["fused"]["energy0"],

@@ -62,7 +62,8 @@ const char *ovqe_last_error(ovqe_handle h);
 int ovqe_device_count(int *count);
 
 /* ---- lifecycle.  Replaces the per-submit state allocation of qat.qpus.get_default_qpu().submit
- * (ref:openvqe/ucc_family/get_energy_ucc.py:38-48): the library owns the device buffers. */
+ * (ref:openvqe/ucc_family/get_energy_ucc.py:38-48): the library owns the device buffers.
+ * 1 <= n_qubits (n_local) <= 33 per device (128 GiB state); larger registers are sharded. */
 int ovqe_create(int n_qubits, int device, ovqe_handle *out);
 /* one shard of a distributed state: n_local local bits, n_global rank bits, this shard's index */
 int ovqe_create_shard(int n_local, int n_global, uint64_t shard_index, int device, ovqe_handle *out);
@@ -138,7 +139,9 @@ int ovqe_set_hamiltonian(ovqe_handle h, int64_t T, const uint64_t *x, const uint
 int ovqe_set_program(ovqe_handle h, int64_t R, const uint64_t *x, const uint64_t *z, const double *coeff,
                      const double *phi0, const int32_t *pidx, int32_t K, uint64_t hf_index);
 /* literal gate program on |hf_index>: gate g has angle ascale[g]*theta[pidx[g]] + aconst[g]
- * (ref:openvqe/ucc_family/get_energy_qucc.py:37-51 + circuit.py:95-106 efficient_fermionic_ansatz) */
+ * (ref:openvqe/ucc_family/get_energy_qucc.py:37-51 + circuit.py:95-106 efficient_fermionic_ansatz).
+ * With option "clifford_frame" != 0 the call OVERWRITES the resident state buffer (the Clifford part of the list is
+ * executed once on |hf_index> to read its global phase); on any error the handle is left with NO program set. */
 int ovqe_set_gate_program(ovqe_handle h, int64_t G, const int32_t *opcode, const int32_t *b0, const int32_t *b1,
                           const double *ascale, const double *aconst, const int32_t *pidx, int32_t K,
                           uint64_t hf_index);

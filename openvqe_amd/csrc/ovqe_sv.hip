@@ -107,6 +107,12 @@ struct ovqe_sv {
     int sp_m = 0, sp_nops = 0, sp_nent = 0;
     int64_t sp_npairs = 0;
     DevBuf d_sp_ops, d_sp_pairs, d_sp_entries;
+    // device copy of the ADAPT pool of the last ovqe_pool_gradients call (+ its host image for the change test)
+    DevBuf d_pg_off, d_pg_xs, d_pg_terms, d_pg_out, d_pg_part;
+    std::vector<int64_t> pg_off;
+    std::vector<uint64_t> pg_xs;
+    std::vector<HTerm> pg_terms;
+    bool pg_valid = false;
     int opt_sparse = 1;           // allow the support-compacted path
     int opt_sparse_spw = 0;       // evaluations per wave (0 = automatic)
     // pair-index-space expectation tables of the fused kernel, built per (thread bits, real mode)
@@ -1344,13 +1350,25 @@ int compile_gate_program_frame(ovqe_handle h, int64_t G, const int32_t *opcode, 
         h->rots.clear();
         for (const int64_t g : tail) push_literal_gate(h, opcode[g], b0[g], b1[g], ascale[g], aconst[g], pidx[g]);
         if (!tail.empty()) {
+            // the Clifford part is installed as the handle's program only for this one execution: whatever happens
+            // below, the handle must not keep reporting it as a valid program (prog_set stays false until the final
+            // program is installed by the last finish_program)
             int rc = finish_program(h);
-            if (rc) return rc;
-            std::vector<double> zero((size_t)std::max(h->K, 1), 0.0);
-            rc = run_program_streaming(h, zero.data());
-            if (rc) return rc;
-            double2 amp;
-            HIPC(h, hipMemcpy(&amp, h->state + h->hf, sizeof(double2), hipMemcpyDeviceToHost));
+            if (!rc) {
+                std::vector<double> zero((size_t)std::max(h->K, 1), 0.0);
+                rc = run_program_streaming(h, zero.data());
+            }
+            double2 amp = make_double2(0.0, 0.0);
+            if (!rc) {
+                const hipError_t e = hipMemcpy(&amp, h->state + h->hf, sizeof(double2), hipMemcpyDeviceToHost);
+                if (e != hipSuccess) rc = fail(h, OVQE_ERR_HIP, hipGetErrorString(e));
+            }
+            h->prog_set = false;
+            if (rc) {
+                h->ops.clear();
+                h->rots.clear();
+                return rc;
+            }
             if (std::fabs(amp.x * amp.x + amp.y * amp.y - 1.0) > 1e-12) return OVQE_OK;  // cannot happen: literal
             phase = amp;
         }
@@ -1781,6 +1799,7 @@ int run_sparse(ovqe_handle h, int64_t B, const double *theta, double *energies, 
     h->cur_energies = d_energies;
     SparseArgs A;
     A.m = h->sp_m;
+    A.mpad = (h->sp_m + 1) & ~1;
     A.K = h->K;
     A.nops = h->sp_nops;
     A.ntab = (int)h->srots.size();
@@ -1788,7 +1807,8 @@ int run_sparse(ovqe_handle h, int64_t B, const double *theta, double *energies, 
     A.npairs = (int)h->sp_npairs;
     A.B = B;
     A.constant = h->ham.constant;
-    const size_t per_eval = (size_t)A.m * sizeof(double) + (size_t)A.ntab * sizeof(double2);
+    const size_t per_eval = (size_t)A.mpad * sizeof(double) + (size_t)A.ntab * sizeof(double2);
+    static_assert(sizeof(double2) == 16 && sizeof(SpOp) == 16, "LDS carve-up of k_sparse_vqe assumes 16-byte records");
     int spw = h->opt_sparse_spw;
     if (spw != 1 && spw != 2 && spw != 4) spw = B >= 2048 ? 2 : 1;  // measured: 2 evaluations per wave is the sweet spot
     if (B <= 1024) spw = 1;
@@ -1828,8 +1848,11 @@ int check_theta(ovqe_handle h, const double *theta, int32_t K) {
 int create_common(int n_local, int n_global, uint64_t shard, int device, ovqe_handle *out) {
     if (!out) return fail(nullptr, OVQE_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (n_local < 1 || n_local > 36 || n_global < 0 || n_local + n_global > 64)
-        return fail(nullptr, OVQE_ERR_INVALID, "qubit count out of range (1 <= n_local <= 36, total <= 64)");
+    // 33 local qubits (128 GiB) is what the sweep launchers cover (four pairs per thread keep a launch below 2^32
+    // threads up to there) and what leaves room for any scratch in 288 GB; larger registers are sharded
+    if (n_local < 1 || n_local > 33 || n_global < 0 || n_local + n_global > 64)
+        return fail(nullptr, OVQE_ERR_INVALID,
+                    "qubit count out of range (1 <= n_local <= 33 per device, total <= 64; shard larger registers)");
     if (n_global < 64 && shard >> n_global) return fail(nullptr, OVQE_ERR_INVALID, "shard index out of range");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -1898,7 +1921,8 @@ int ovqe_destroy(ovqe_handle h) {
     std::vector<DevBuf *> bufs = {&h->d_partials, &h->d_result, &h->d_rp, &h->d_ops, &h->d_rots, &h->d_rots_seq, &h->d_segs,
                                   &h->d_stream,
                                   &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups, &h->d_eterms, &h->d_echunks,
-                                  &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries};
+                                  &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries, &h->d_pg_off, &h->d_pg_xs, &h->d_pg_terms,
+                                  &h->d_pg_out, &h->d_pg_part};
     for (TilePlan *tp : {&h->tp, &h->tp_adhoc, &h->tp_real}) bufs.insert(bufs.end(), {&tp->d_tops, &tp->d_trots});
     for (HamDev *H : {&h->ham, &h->ham_adhoc, &h->ham_real})
         bufs.insert(bufs.end(), {&H->d_groups, &H->d_terms, &H->d_tchunks, &H->d_tgroups, &H->d_tterms, &H->d_tflats,
@@ -2061,6 +2085,7 @@ int ovqe_randomize(ovqe_handle h, uint64_t seed, double norm2_total, double *sca
 }
 
 int ovqe_norm2(ovqe_handle h, double *out) {
+    OVQE_ENTER(h);
     if (!h || !out) return OVQE_ERR_INVALID;
     const int nb = reduce_blocks(h->namps);
     int rc = ensure(h, h->d_partials, (size_t)nb * sizeof(double2));
@@ -2398,8 +2423,9 @@ int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, co
     rc = apply_hamiltonian(h, sig, h->state, h->ham.constant);
     if (rc) return rc;
     std::vector<double2> vals(n_ops);
-    if (h->n_local <= 22) {
-        // one block per pool operator, terms in caller order with i^ny folded
+    {
+        // terms in caller order with i^ny folded.  The pool is the same host data on every ADAPT iteration: its device
+        // copy lives on the handle and is uploaded again only when the content changes.
         const uint64_t lmask = local_mask(h);
         std::vector<HTerm> terms(T);
         std::vector<uint64_t> xs(T);
@@ -2418,32 +2444,45 @@ int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, co
             terms[t] = ht;
             xs[t] = x[t];
         }
-        DevBuf d_off, d_xs, d_terms, d_out;
-        rc = upload(h, d_off, offsets, (n_ops + 1) * sizeof(int64_t));
-        if (!rc) rc = upload(h, d_xs, xs.data(), T * sizeof(uint64_t));
-        if (!rc) rc = upload(h, d_terms, terms.data(), T * sizeof(HTerm));
-        if (!rc) rc = ensure(h, d_out, n_ops * sizeof(double2));
-        if (!rc) {
-            hipLaunchKernelGGL(k_pool_grad, dim3((unsigned)n_ops), dim3(256), 0, h->stream, (const amp_t *)sig,
-                               (const amp_t *)h->state, h->namps, h->base, (const int64_t *)d_off.p,
-                               (const uint64_t *)d_xs.p, (const HTerm *)d_terms.p, (double2 *)d_out.p);
-            hipError_t e = hipGetLastError();
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(vals.data(), d_out.p, n_ops * sizeof(double2), hipMemcpyDeviceToHost, h->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-            if (e != hipSuccess) rc = fail(h, OVQE_ERR_HIP, std::string("pool_gradients: ") + hipGetErrorString(e));
-        }
-        for (DevBuf *b : {&d_off, &d_xs, &d_terms, &d_out})
-            if (b->p) (void)hipFree(b->p);
-        if (rc) return rc;
-    } else {
-        for (int64_t k = 0; k < n_ops; ++k) {
-            const int64_t t0 = offsets[k], nt = offsets[k + 1] - t0;
-            double res[2];
-            rc = ovqe_bilinear(h, sig, nullptr, nt, x + t0, z + t0, coeff_re + t0, coeff_im ? coeff_im + t0 : nullptr, res);
+        const bool same = h->pg_valid && (int64_t)h->pg_off.size() == n_ops + 1 && (int64_t)h->pg_xs.size() == T &&
+                          std::memcmp(h->pg_off.data(), offsets, (n_ops + 1) * sizeof(int64_t)) == 0 &&
+                          (T == 0 || (std::memcmp(h->pg_xs.data(), xs.data(), T * sizeof(uint64_t)) == 0 &&
+                                      std::memcmp(h->pg_terms.data(), terms.data(), T * sizeof(HTerm)) == 0));
+        if (!same) {
+            h->pg_valid = false;
+            rc = upload(h, h->d_pg_off, offsets, (n_ops + 1) * sizeof(int64_t));
+            if (!rc) rc = upload(h, h->d_pg_xs, xs.data(), std::max<int64_t>(T, 1) * sizeof(uint64_t));
+            if (!rc) rc = upload(h, h->d_pg_terms, terms.data(), std::max<int64_t>(T, 1) * sizeof(HTerm));
             if (rc) return rc;
-            vals[k] = make_double2(res[0], res[1]);
+            h->pg_off.assign(offsets, offsets + n_ops + 1);
+            h->pg_xs.swap(xs);
+            h->pg_terms.swap(terms);
+            h->pg_valid = true;
         }
+        // one workgroup per operator while the state re-streams from L2/MALL; above that 2^16 amplitudes per workgroup
+        const int nchunks = h->n_local <= 22 ? 1 : (int)(h->namps >> 16);
+        const int64_t ops_per_launch = 32768;
+        rc = ensure(h, h->d_pg_out, n_ops * sizeof(double2));
+        if (!rc && nchunks > 1)
+            rc = ensure(h, h->d_pg_part, (size_t)std::min<int64_t>(n_ops, ops_per_launch) * nchunks * sizeof(double2));
+        if (rc) return rc;
+        for (int64_t op0 = 0; op0 < n_ops; op0 += ops_per_launch) {
+            const int64_t cnt = std::min<int64_t>(ops_per_launch, n_ops - op0);
+            double2 *out = (double2 *)h->d_pg_out.p + op0;
+            double2 *part = nchunks > 1 ? (double2 *)h->d_pg_part.p : out;
+            hipLaunchKernelGGL(k_pool_grad, dim3((unsigned)nchunks, (unsigned)cnt), dim3(256), 0, h->stream,
+                               (const amp_t *)sig, (const amp_t *)h->state, h->namps, h->base,
+                               (const int64_t *)h->d_pg_off.p, (const uint64_t *)h->d_pg_xs.p,
+                               (const HTerm *)h->d_pg_terms.p, op0, part);
+            if (nchunks > 1)
+                hipLaunchKernelGGL(k_reduce_rows2, dim3((unsigned)cnt), dim3(256), 0, h->stream, (const double2 *)part,
+                                   nchunks, out);
+        }
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(vals.data(), h->d_pg_out.p, n_ops * sizeof(double2), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) return fail(h, OVQE_ERR_HIP, std::string("pool_gradients: ") + hipGetErrorString(e));
     }
     for (int64_t k = 0; k < n_ops; ++k)
         grads[k] = mode == OVQE_GRAD_FERMIONIC ? 2.0 * vals[k].x : 2.0 * std::hypot(vals[k].x, vals[k].y);
@@ -2560,7 +2599,7 @@ struct Lanczos {
         *out = h->h_result[0];
         return OVQE_OK;
     }
-    void apply_h(amp_t *out, const amp_t *in) { (void)apply_hamiltonian(h, out, in, 0.0); }
+    int apply_h(amp_t *out, const amp_t *in) { return apply_hamiltonian(h, out, in, 0.0); }
     int dot(const amp_t *a, const amp_t *b, double2 *out) {
         hipLaunchKernelGGL(k_dot, dim3(nb), dim3(256), 0, h->stream, a, b, h->namps, (double2 *)h->d_partials.p);
         return reduce_to_host(out);
@@ -2612,7 +2651,8 @@ extern "C" int ovqe_ground_state(ovqe_handle h, double tol, int max_iter, uint64
             hipLaunchKernelGGL(k_axpy_real, dim3(L.nb), dim3(256), 0, h->stream, h->state, (const amp_t *)B, s[0], h->namps, 1);
         const int steps = accumulate ? m - 1 : max_iter;
         for (int j = 0; j < steps; ++j) {
-            L.apply_h(C, B);
+            r = L.apply_h(C, B);
+            if (r) return r;
             double bj;
             if (accumulate) {
                 r = L.update(C, B, j ? A : nullptr, alpha[j], j ? beta[j - 1] : 0.0, &bj);
@@ -2654,8 +2694,8 @@ extern "C" int ovqe_ground_state(ovqe_handle h, double tol, int max_iter, uint64
         rc = L.dot(h->state, h->state, &d);
         if (!rc) {
             hipLaunchKernelGGL(k_scale, dim3(L.nb), dim3(256), 0, h->stream, h->state, h->namps, 1.0 / std::sqrt(d.x));
-            L.apply_h(tmp, h->state);
-            rc = L.dot(h->state, tmp, &d);
+            rc = L.apply_h(tmp, h->state);
+            if (!rc) rc = L.dot(h->state, tmp, &d);
         }
         if (!rc) {
             lam = d.x;
@@ -2693,9 +2733,9 @@ extern "C" int ovqe_energy_gradient(ovqe_handle h, const double *theta, int32_t 
     if (!rc) rc = ensure(h, d_w, std::max<size_t>(R, 1) * sizeof(double));
     if (rc) return rc;
     amp_t *lam = h->scratch[0];
-    L.apply_h(lam, h->state);
-    double2 e;
-    rc = L.dot(h->state, lam, &e);
+    double2 e = make_double2(0.0, 0.0);
+    rc = L.apply_h(lam, h->state);
+    if (!rc) rc = L.dot(h->state, lam, &e);
     const RotParam *d_rp = (const RotParam *)h->d_rp.p + S;
     double *partials = (double *)h->d_partials.p;
     for (int oi = (int)h->ops.size() - 1; oi >= 0 && !rc; --oi) {
@@ -2773,6 +2813,7 @@ int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, 
 }
 
 int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
+    OVQE_ENTER(h);
     if (!h || !info || count < 0) return OVQE_ERR_INVALID;
     if (!h->prog_set) return fail(h, OVQE_ERR_STATE, "no program set");
     const bool real_on = h->opt_real_stream && h->prog_real_ok && h->n_global == 0 && tile_ok(h, true);

@@ -408,14 +408,18 @@ __global__ __launch_bounds__(256) void k_apply_sum(amp_t *__restrict__ out, cons
     }
 }
 
-// pool gradient screen, one block per pool operator (state small enough to re-stream from L2/MALL):
+// pool gradient screen: block (chunk c, operator k) sums its slice [c, c+1) * namps / gridDim.x of
 // val_k = sum_{t in op k} sum_i conj(sig_i) (-1)^{parity((i^x_t)&z_t)} (cr_t + i ci_t) psi_{i^x_t}
+// into partials[k * gridDim.x + c].  One chunk per operator while the state re-streams from L2/MALL (n <= 22: the
+// partial IS the value); larger registers are cut into chunks so that operators x chunks workgroups fill the chip in
+// ONE launch, and k_reduce_rows2 adds the chunks of an operator in a fixed order (deterministic ranking).
 __global__ __launch_bounds__(256) void k_pool_grad(const amp_t *__restrict__ sig, const amp_t *__restrict__ psi,
                                                    uint64_t namps, uint64_t base, const int64_t *__restrict__ offsets,
                                                    const uint64_t *__restrict__ xs, const HTerm *__restrict__ terms,
-                                                   double2 *__restrict__ out) {
+                                                   int64_t op0, double2 *__restrict__ partials) {
     __shared__ double2 red[4];
-    const int64_t op = blockIdx.x;
+    const int64_t op = op0 + blockIdx.y;
+    const uint64_t len = namps / gridDim.x, i0 = (uint64_t)blockIdx.x * len, i1 = i0 + len;
     double2 acc = make_double2(0.0, 0.0);
     const int64_t t1 = offsets[op + 1];
     for (int64_t t = offsets[op]; t < t1;) {
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(256) void k_pool_grad(const amp_t *__restrict__ sig
         const uint64_t x = xs[t];
         int64_t te = t + 1;
         while (te < t1 && xs[te] == x) ++te;
-        for (uint64_t i = threadIdx.x; i < namps; i += 256) {
+        for (uint64_t i = i0 + threadIdx.x; i < i1; i += 256) {
             const uint64_t jl = i ^ x;
             const amp_t b = sig[i], k = psi[jl];
             double cr = 0.0, ci = 0.0;
@@ -442,7 +446,21 @@ __global__ __launch_bounds__(256) void k_pool_grad(const amp_t *__restrict__ sig
         t = te;
     }
     double2 t = block_sum<256>(acc, red);
-    if (threadIdx.x == 0) out[op] = t;
+    if (threadIdx.x == 0) partials[(size_t)(op - op0) * gridDim.x + blockIdx.x] = t;
+}
+
+// out[row] = sum of the row's `count` double2 partials (fixed order)
+__global__ __launch_bounds__(256) void k_reduce_rows2(const double2 *__restrict__ partials, int count,
+                                                      double2 *__restrict__ out) {
+    __shared__ double2 red[4];
+    double2 acc = make_double2(0.0, 0.0);
+    const double2 *row = partials + (size_t)blockIdx.x * count;
+    for (int i = threadIdx.x; i < count; i += 256) {
+        acc.x += row[i].x;
+        acc.y += row[i].y;
+    }
+    const double2 t = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = t;
 }
 
 // ------------------------------------------------------------------------------------------------

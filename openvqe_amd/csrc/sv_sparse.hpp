@@ -34,6 +34,8 @@ struct SpEntry {
 
 struct SparseArgs {
     int m;        // support size
+    int mpad;     // per-evaluation stride of the LDS state in doubles: m rounded up to even, so that the double2
+                  // cos/sin table behind SPW states starts on a 16-byte boundary (ds_read/write_b128)
     int K;
     int nops;
     int ntab;
@@ -52,8 +54,8 @@ __global__ __launch_bounds__(64) void k_sparse_vqe(SparseArgs A, const double *_
                                                    const SpEntry *__restrict__ entries,
                                                    double *__restrict__ energies) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *st = reinterpret_cast<double *>(smem);                        // [SPW][m]
-    double2 *cs = reinterpret_cast<double2 *>(st + (size_t)SPW * A.m);    // [SPW][ntab]
+    double *st = reinterpret_cast<double *>(smem);                          // [SPW][mpad]
+    double2 *cs = reinterpret_cast<double2 *>(st + (size_t)SPW * A.mpad);   // [SPW][ntab], 16-byte aligned
     const int lane = threadIdx.x;
     SpOp *lops = reinterpret_cast<SpOp *>(cs + (size_t)SPW * A.ntab);     // [nops]   (STAGE)
     uint32_t *lpairs = reinterpret_cast<uint32_t *>(lops + A.nops);       // [npairs] (STAGE)
@@ -64,13 +66,13 @@ __global__ __launch_bounds__(64) void k_sparse_vqe(SparseArgs A, const double *_
     // the wave's lanes are split evenly over its SPW evaluations (no index division in the inner loops)
     constexpr int LPS = 64 / SPW;
     const int s = lane / LPS, l = lane % LPS;
-    double *base = st + (size_t)s * A.m;
+    double *base = st + (size_t)s * A.mpad;
     const double2 *csb = cs + (size_t)s * A.ntab;
     const int64_t nwork = (A.B + SPW - 1) / SPW;
     for (int64_t w = blockIdx.x; w < nwork; w += gridDim.x) {
         const int64_t b0 = w * SPW;
         // |HF> (compact index 0) and the cos/sin table of every active pattern, per evaluation
-        for (int i = lane; i < SPW * A.m; i += 64) st[i] = (i % A.m == 0) ? 1.0 : 0.0;
+        for (int i = lane; i < SPW * A.mpad; i += 64) st[i] = (i % A.mpad == 0) ? 1.0 : 0.0;
         {
             const int64_t b = b0 + s < A.B ? b0 + s : A.B - 1;
             const double *th = theta + b * A.K;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(64) void k_sparse_vqe(SparseArgs A, const double *_
             const SpEntry en = entries[e];
             const uint32_t ci = en.ij & 0xfffu, cj = (en.ij >> 12) & 0xfffu;
 #pragma unroll
-            for (int s = 0; s < SPW; ++s) acc[s] += en.c * st[(size_t)s * A.m + ci] * st[(size_t)s * A.m + cj];
+            for (int s = 0; s < SPW; ++s) acc[s] += en.c * st[(size_t)s * A.mpad + ci] * st[(size_t)s * A.mpad + cj];
         }
 #pragma unroll
         for (int s = 0; s < SPW; ++s) {

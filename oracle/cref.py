@@ -22,6 +22,20 @@ def build(force=False):
     return _SO
 
 
+def use_native_build():
+    """bench.py's CPU-baseline leg: (re)build the library with -march=native ON THIS MACHINE and make lib() load it;
+    falls back to the portable build when the compiler is missing.  Call before the first lib().  -> flags used"""
+    global _SO
+    assert _lib is None, "use_native_build() must precede the first lib()"
+    try:
+        subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(_HERE, "c"), "native"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _SO = os.path.join(_HERE, "c", "libovqe_oracle_native.so")
+        return "-O3 -march=native"
+    except (OSError, subprocess.CalledProcessError):
+        return "-O3 -march=x86-64-v2"
+
+
 def lib():
     global _lib
     if _lib is None:
