@@ -187,6 +187,15 @@ class Molecule:
             if abs(e - e_old) < tol and np.abs(err).max() < 1e-9:
                 break
             e_old = e
+        # orbital phase gauge of PySCF's SCF eigensolver (pyscf.scf.hf.eig): the AO coefficient of largest magnitude of
+        # every MO is positive (first such coefficient on ties, which symmetric molecules have).  Energies of UCC-type
+        # circuits at FIXED parameters depend on this gauge (theta_k -> -theta_k under a sign flip of an orbital that
+        # excitation k touches an odd number of times), so replaying the reference's stored evaluations needs it.
+        for k in range(C.shape[1]):
+            col = np.abs(C[:, k])
+            lead = int(np.argmax(col >= col.max() * (1.0 - 1e-9)))
+            if C[lead, k] < 0:
+                C[:, k] = -C[:, k]
         self.mo_coeff, self.mo_energy = C, eps
         self.e_hf = e + self.nuclear_repulsion()
         self.h_mo = C.T @ hcore @ C
@@ -205,6 +214,131 @@ class Molecule:
 
     def hf_init(self):
         return fermion.hf_integer(2 * self.nao, self.n_elec)
+
+    # -- correlated quantities the reference prints / selects with --------------------------------------------------
+    def mp2_energy(self):
+        """closed-shell MP2 total energy (``info['MP2']``, ref:openvqe/common_files/molecule_factory.py:318-322)"""
+        if not hasattr(self, "h_mo"):
+            self.rhf()
+        o, e, g = self.n_elec // 2, self.mo_energy, self.eri_mo
+        ov = g[:o, o:, :o, o:]                                   # (ia|jb)
+        den = e[:o, None, None, None] - e[None, o:, None, None] + e[None, None, :o, None] - e[None, None, None, o:]
+        return self.e_hf + float(np.sum(ov * (2.0 * ov - ov.transpose(0, 3, 2, 1)) / den))
+
+    def ci_ground_state(self, max_excitation=None):
+        """lowest eigenpair of the JW Hamiltonian in the N-electron determinant space, optionally restricted to
+        determinants at most ``max_excitation``-fold excited from the HF determinant (2 = CISD; None = FCI).
+        -> (energy, {basis index: amplitude}).  Determinant space built from the 2^n x 2^n sparse matrix: registers up to
+        ~16 qubits, which is where the reference's own PySCF FCI / CISD step is used."""
+        import scipy.sparse.linalg
+        ham = self.jw_hamiltonian()
+        n = ham.nbqbits
+        if n > 18:
+            raise ValueError("determinant-space CI restated for registers up to 18 qubits")
+        hf = self.hf_init()
+        idx = np.array([i for i in range(1 << n) if bin(i).count("1") == self.n_elec and
+                        (max_excitation is None or bin(i & ~hf).count("1") <= max_excitation)], dtype=np.int64)
+        sub = ham.get_matrix(sparse=True)[idx][:, idx].real
+        if len(idx) <= 600:
+            w, v = np.linalg.eigh(sub.toarray())
+            vec = v[:, 0]
+        else:
+            w, v = scipy.sparse.linalg.eigsh(sub, k=1, which="SA", tol=1e-12)
+            vec = v[:, 0]
+        return float(w[0]), dict(zip(idx.tolist(), vec.tolist()))
+
+    def natural_occupations(self, max_excitation=2):
+        """(noons descending, natural orbitals as columns in the MO basis) of the spin-summed one-particle density of the
+        CISD wave function — the ``rdm1`` of myQLM's ``perform_pyscf_computation`` (H4/STO-3G: the reference prints
+        Noons = [1.98158247, 1.94333400, 0.06054808, 0.01453545], ref:notebooks/demo_quccsd.ipynb; CISD reproduces
+        them to 3e-7, FCI differs at 1e-3), diagonalised as ref:openvqe/common_files/molecule_factory.py:367-373 does
+        (eigh, both reversed)."""
+        _, psi = self.ci_ground_state(max_excitation)
+        n = 2 * self.nao
+        rdm = np.zeros((self.nao, self.nao))
+        for det, amp in psi.items():
+            occ = [q for q in range(n) if (det >> (n - 1 - q)) & 1]
+            for q in occ:                                  # annihilate q, create p of the same spin
+                rest = det & ~(1 << (n - 1 - q))
+                for p in range(q % 2, n, 2):
+                    if (rest >> (n - 1 - p)) & 1:
+                        continue
+                    new = rest | (1 << (n - 1 - p))
+                    if new not in psi:
+                        continue
+                    lo, hi = min(p, q), max(p, q)
+                    between = sum((rest >> (n - 1 - r)) & 1 for r in range(lo + 1, hi))
+                    rdm[p // 2, q // 2] += (-1) ** between * psi[new] * amp
+        w, v = np.linalg.eigh(rdm)
+        return w[::-1].copy(), v[:, ::-1].copy()
+
+    def problem(self, active=False):
+        """The objects ``MoleculeFactory.generate_hamiltonian(symbol, active)`` returns
+        (ref:openvqe/common_files/molecule_factory.py:306-434) as one ``Problem``: full space in the HF orbitals, or the
+        NOON-selected active space in the natural orbitals."""
+        if not hasattr(self, "h_mo"):
+            self.rhf()
+        noons, natorb = self.natural_occupations()
+        if not active:
+            return Problem(self.h_mo, self.eri_mo, self.nuclear_repulsion(), self.n_elec, list(noons), list(self.mo_energy))
+        h = natorb.T @ self.h_mo @ natorb
+        g = np.einsum("pqrs,pi,qj,rk,sl->ijkl", self.eri_mo, natorb, natorb, natorb, natorb, optimize=True)
+        eps1 = 2.0 - noons[0]                                    # molecule_factory.py:378-383
+        eps2 = 0.01 if len(noons) < 3 else noons[3]
+        frozen, act = select_active_orbitals(noons, self.n_elec, eps1, eps2)
+        const = self.nuclear_repulsion()
+        for i in frozen:
+            const += 2.0 * h[i, i]
+            for j in frozen:
+                const += 2.0 * g[i, i, j, j] - g[i, j, j, i]
+        h_act = h[np.ix_(act, act)].copy()
+        for i in frozen:
+            h_act += 2.0 * g[np.ix_(act, act, [i], [i])][:, :, 0, 0] - g[np.ix_(act, [i], [i], act)][:, 0, 0, :]
+        g_act = g[np.ix_(act, act, act, act)]
+        return Problem(h_act, g_act, const, self.n_elec - 2 * len(frozen), [noons[i] for i in act],
+                       [self.mo_energy[i] for i in act], thresholds=(eps1, eps2), frozen=frozen, active=act)
+
+
+def select_active_orbitals(noons, n_elec, threshold_1, threshold_2):
+    """NOON-based selection of myQLM's ``get_active_space_hamiltonian`` (called at
+    ref:openvqe/common_files/molecule_factory.py:384-392; published rule): active A = {i : e2 <= n_i < 2 - e1} +
+    {i : n_i >= 2 - e1 and 2(i+1) >= N_e}; frozen doubly occupied O = {i : n_i >= 2 - e1 and 2(i+1) < N_e}; the rest
+    is discarded.  Pins: H4/STO-3G -> 6 qubits (pool sizes 8 / 18 / 69, ref:tests/test_main_*_active_space.py:15,
+    ref:tests/test_main_fermionic_adapt.py:15), H2/6-31G -> all 8 qubits (ref:notebooks/demo_fermionic_adapt.ipynb)."""
+    frozen, active = [], []
+    for i, ni in enumerate(noons):
+        if ni >= 2.0 - threshold_1:
+            (active if 2 * (i + 1) >= n_elec else frozen).append(i)
+        elif ni >= threshold_2:
+            active.append(i)
+    return frozen, active
+
+
+class Problem:
+    """spatial-orbital integrals + electron count of one (full or active-space) electronic-structure problem and the
+    hot-path inputs derived from them"""
+
+    def __init__(self, h, eri, constant, n_elec, noons, orbital_energies, thresholds=None, frozen=(), active=None):
+        self.h, self.eri, self.constant, self.n_elec = np.asarray(h), np.asarray(eri), float(constant), int(n_elec)
+        self.noons_full = [v for n in noons for v in (n, n)]
+        self.orb_energies_full = [v for e in orbital_energies for v in (e, e)]
+        self.thresholds, self.frozen = thresholds, list(frozen)
+        self.active = list(range(len(noons))) if active is None else list(active)
+        self.nbqbits = 2 * self.h.shape[0]
+        self.hpq, self.hpqrs = fermion.spin_orbital_integrals(self.h, self.eri)
+
+    def jw_hamiltonian(self):
+        return fermion.jw_molecular_hamiltonian(self.hpq, self.hpqrs, self.constant)
+
+    def hf_init(self):
+        return fermion.hf_integer(self.nbqbits, self.n_elec)
+
+    def uccsd(self, transform="JW"):
+        """(pool_size, cluster_ops, cluster_ops_sp, theta_MP2, hf_init) of ``MoleculeFactory.calculate_uccsd`` /
+        ``uccsd`` (ref:openvqe/common_files/molecule_factory.py:436-470, ref:…generator_excitations.py:40-80)"""
+        from .fermionic import spin_operator
+        ops, theta, hf = fermion.cluster_ops_and_mp2_guess(self.n_elec, self.orb_energies_full, self.hpqrs)
+        return len(ops), ops, [spin_operator(o, transform) for o in ops], theta, hf
 
 
 def molecule(symbol):

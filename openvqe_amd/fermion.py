@@ -216,3 +216,59 @@ def synthetic_molecule(n_spatial, n_occ_spatial, seed):
     ham = jw_molecular_hamiltonian(hpq, hpqrs, 0.0)
     gens = uccsd_generators(n_spatial, n_occ_spatial)
     return ham, gens, hf_integer(2 * n_spatial, 2 * n_occ_spatial)
+
+
+# ---------------------------------------------------------------- UCCSD in the reference's operator order + MP2 guess
+def cluster_excitations(nqbits, n_elec, order="auto"):
+    """Excitation tuples in the ORDER and FORM in which ``qat.fermion…get_cluster_ops_and_init_guess`` hands the
+    cluster operators to the reference (ref:openvqe/common_files/generator_excitations.py:75-79) — third-party code that
+    is not in the reference tree.  Form (both stored runs): singles (a, i), doubles (a, b, i, j) with a < b virtual,
+    i < j occupied, same total spin; ``op.terms[0].qbits`` of cluster operator k is exactly tuple k
+    (ref:openvqe/ucc_family/get_energy_qucc.py:46-49).  Order, as pinned by the two stored QUCCSD runs
+    (tests/test_reference_traces.py::test_k5_*, energies to < 1e-8, CNOT counts 292 / 70):
+      "descending" — H4/STO-3G full space, 8 qubits / 4 electrons (ref:notebooks/demo_quccsd.ipynb): singles by
+          (A, I) spatial descending, beta before alpha; doubles in decreasing lexicographic order of (a, b, i, j);
+      "ascending"  — H4 active space, 6 qubits / 2 electrons (ref:notebooks/demo_quccsd_active_space.ipynb): singles by
+          A ascending, beta before alpha; doubles in increasing lexicographic order of (b, a, j, i) — the mirror image.
+    No single enumeration rule reproducing both was found (per-orbital sort keys cannot: the stored first-order
+    gradients show the LOWEST virtual orbital first in one run and the HIGHEST in the other), so "auto" keeps the
+    observed split: descending when two or more spatial orbitals are occupied, ascending for a single occupied orbital."""
+    if order == "auto":
+        order = "descending" if n_elec >= 4 else "ascending"
+    occ = list(range(n_elec))
+    virt = list(range(n_elec, nqbits))
+    no, nv = n_elec // 2, (nqbits - n_elec) // 2
+    doubles = [(a, b, i, j) for a, b in itertools.combinations(virt, 2) for i, j in itertools.combinations(occ, 2)
+               if (a % 2) + (b % 2) == (i % 2) + (j % 2)]
+    if order == "descending":
+        singles = [(2 * (no + A) + s, 2 * I + s) for A in reversed(range(nv)) for I in reversed(range(no)) for s in (1, 0)]
+        doubles.sort(reverse=True)
+    elif order == "ascending":
+        singles = [(2 * (no + A) + s, 2 * I + s) for A in range(nv) for I in range(no) for s in (1, 0)]
+        doubles.sort(key=lambda t: (t[1], t[0], t[3], t[2]))
+    else:
+        raise ValueError(order)
+    return singles, doubles
+
+
+def cluster_ops_and_mp2_guess(n_elec, orb_energies_full, hpqrs):
+    """(cluster_ops, theta_MP2, hf_init) — the triple of ``get_cluster_ops_and_init_guess(n_elec, noons, orbital
+    energies, hpqrs)`` (call sites ref:…generator_excitations.py:75-79, ref:openvqe/common_files/molecule_factory.py:
+    487-491).  cluster_ops: Hermitian fermionic generators i(T - T^+) ("we must skip 1j", ref:openvqe/algorithms/ucc.py:
+    26), T = c+_a c_i resp. c+_a c+_b c_i c_j on the tuples of ``cluster_excitations``;
+    theta_MP2: 0 for singles, (h_abij - h_abji) / (e_i + e_j - e_a - e_b) for doubles, with H = sum h_pq c+_p c_q +
+    1/2 sum h_pqrs c+_p c+_q c_r c_s (the Moller-Plesset amplitude of that T; E(theta_MP2) of the stored run is
+    reproduced to 3e-9); hf_init: the first n_elec spin orbitals occupied, orbital 0 = most significant bit."""
+    from .fermionic import FermionHamiltonian, Term
+    nq = len(orb_energies_full)
+    singles, doubles = cluster_excitations(nq, n_elec)
+    e = orb_energies_full
+    ops, theta = [], []
+    for a, i in singles:
+        ops.append(FermionHamiltonian(nq, [Term(1j, "Cc", [a, i]), Term(-1j, "Cc", [i, a])], do_clean_up=False))
+        theta.append(0.0)
+    for a, b, i, j in doubles:
+        ops.append(FermionHamiltonian(nq, [Term(1j, "CCcc", [a, b, i, j]), Term(-1j, "CCcc", [j, i, b, a])],
+                                      do_clean_up=False))
+        theta.append(float((hpqrs[a, b, i, j] - hpqrs[a, b, j, i]) / (e[i] + e[j] - e[a] - e[b])))
+    return ops, theta, hf_integer(nq, n_elec)

@@ -52,22 +52,205 @@ def spin_complement_gsd(n_elec, orbital_number, transform="JW"):
     return len(pool), pool
 
 
-def singlet_upccgsd(n_orb, transform="JW", perm=0):
-    """-> (pool_size, cluster_ops_sp): spin-adapted generalised singles + paired doubles, the list repeated
-    ``perm`` extra times (k-UpCCGSD) — enumeration of ref:openvqe/common_files/generator_excitations.py:403-466
-    (pool size 36 for H2/6-31G with perm = 2, ref:tests/test_main_ucc.py:15)."""
-    if transform != "JW":
-        raise NotImplementedError("only the Jordan-Wigner mapping is restated")
+def singlet_upccgsd(n_orb, transform="JW", perm=0, with_fermionic=False):
+    """-> (pool_size, cluster_ops_sp) [or (pool_size, cluster_ops, cluster_ops_sp) ``with_fermionic``]: spin-adapted
+    generalised singles + paired doubles, the list repeated ``perm`` extra times (k-UpCCGSD) — enumeration of
+    ref:openvqe/common_files/generator_excitations.py:403-466 (pool size 36 for H2/6-31G with perm = 2,
+    ref:tests/test_main_ucc.py:15)."""
+    import itertools
     n = 2 * n_orb
-    singles, doubles = [], []
+    ops = []
     for p in range(0, n, 2):
         for q in range(0, p, 2):
-            singles.append([(1, _cc(q, p)), (-1, _cc(p, q)), (1, _cc(q + 1, p + 1)), (-1, _cc(p + 1, q + 1))])
-    import itertools
+            ops.append(_pool_op(n, [(1, "Cc", [q, p]), (1, "Cc", [q + 1, p + 1])], ordered=False))
     for p, q in itertools.combinations(range(0, n, 2), 2):
-        doubles.append([(1.0, _cccc(q, p, q + 1, p + 1)), (-1.0, _cccc(p + 1, q + 1, p, q))])
-    pool = [fermion.psum_to_hamiltonian(n, _jw_sum(n, terms), tol=1e-13) for terms in singles + doubles]
-    pool = pool + pool * perm
+        ops.append(_pool_op(n, [(1.0, "CcCc", [q, p, q + 1, p + 1])]))
+    size, fermi, spin = _finish(ops, transform, perm)
+    return (size, fermi, spin) if with_fermionic else (size, spin)
+
+
+# ---------------------------------------------------------------------------------------------- pools through the
+# fermionic layer (normal ordering + merge + JW), the route of ref:…generator_excitations.py:159-609
+def _pool_op(n, base, hc_after_all=False, ordered=True, normalise=False):
+    """anti-Hermitian operator  sum_k (t_k - t_k^dagger)  from base terms [(coeff, op, orbitals)].  Emission order:
+    t_0, -t_0^dagger, t_1, -t_1^dagger, ... (or all t_k first, then all -t_k^dagger); every term is normal-ordered
+    before the merge when ``ordered``.  ``normalise``: divide by the 2-norm of the merged coefficients and return None
+    for an operator that vanishes (ref:…generator_excitations.py:353-357, 546-550)."""
+    from .fermionic import FermionHamiltonian, Term, normal_ordered_terms
+    flip = {"C": "c", "c": "C"}
+    fwd = [Term(c, op, list(q)) for c, op, q in base]
+    bwd = [Term(-c, "".join(flip[o] for o in reversed(op)), list(reversed(q))) for c, op, q in base]
+    seq = fwd + bwd if hc_after_all else [t for pair in zip(fwd, bwd) for t in pair]
+    if ordered:
+        seq = [u for t in seq for u in normal_ordered_terms(t)]
+    op = FermionHamiltonian(n, seq)
+    if normalise:
+        norm = sum(abs(t.coeff) ** 2 for t in op.terms) ** 0.5
+        if not norm > 0:
+            return None
+        op = op / norm
+    return op
+
+
+def _finish(fermi_ops, transform, perm=0):
+    """``_apply_transforms`` (ref:…generator_excitations.py:16-36): JW image of every operator, the list repeated
+    ``perm`` extra times -> (pool_size, cluster_ops, cluster_ops_sp).  The reference drops operators whose image has
+    ``terms == []``; with myQLM that never fires for these pools — the pinned sizes 69 / 175 / 70
+    (ref:tests/test_main_fermionic_adapt.py:11,15, ref:tests/test_main_qubit_adapt.py:11) count the identically-zero
+    operators of the raw enumeration (p == q singles, ...) — so nothing is dropped here either: such operators carry no
+    Pauli strings and rank with gradient 0."""
+    from .fermionic import spin_operator
+    keep_f = list(fermi_ops)
+    keep_s = [spin_operator(op, transform) for op in keep_f]
+    keep_f = keep_f + keep_f * perm
+    keep_s = keep_s + keep_s * perm
+    return len(keep_s), keep_f, keep_s
+
+
+def _spin_flip(q):
+    return [p + 1 for p in q]
+
+
+def singlet_sd(n_elec, orbital_number, transform="JW"):
+    """occupied -> virtual singles and doubles in singlet spin coupling (ref:…generator_excitations.py:274-359):
+    per (i <= j occupied, a <= b virtual) the two singlet couplings A (coefficients 2,2,1,1,1,1 / sqrt 12) and B
+    (+-1/2), each normalised, vanishing ones skipped."""
+    n = 2 * orbital_number
+    nocc = -(-n_elec // 2)
+    r12 = 12 ** 0.5
+    singles, doubles = [], []
+    for i in range(0, 2 * nocc, 2):
+        for j in range(i, 2 * nocc, 2):
+            for a in range(2 * nocc, n, 2):
+                if j == i:
+                    singles.append(_pool_op(n, [(0.5, "Cc", [a, i]), (0.5, "Cc", [a + 1, i + 1])], hc_after_all=True,
+                                            ordered=False))
+                for b in range(a, n, 2):
+                    mixed = [[a, b + 1, i, j + 1], [a + 1, b, i + 1, j], [a, b + 1, i + 1, j], [a + 1, b, i, j + 1]]
+                    coupling_a = [(2 / r12, "CCcc", [a, b, i, j]), (2 / r12, "CCcc", [a + 1, b + 1, i + 1, j + 1])] + \
+                                 [(1 / r12, "CCcc", q) for q in mixed]
+                    coupling_b = [(s, "CCcc", q) for s, q in zip((0.5, 0.5, -0.5, -0.5), mixed)]
+                    for base in (coupling_a, coupling_b):
+                        op = _pool_op(n, base, normalise=True)
+                        if op is not None:
+                            doubles.append(op)
+    return _finish(singles + doubles, transform)
+
+
+def singlet_gsd(n_elec, orbital_number, transform="JW"):
+    """generalised singles and doubles in singlet coupling (ref:…generator_excitations.py:468-552); H2/6-31G: 70
+    operators (ref:tests/test_main_qubit_adapt.py:11)."""
+    n = 2 * orbital_number
+    r12 = 12 ** 0.5
+    singles, doubles = [], []
+    for p in range(0, n, 2):
+        for q in range(p, n, 2):
+            singles.append(_pool_op(n, [(0.5, "Cc", [p, q]), (0.5, "Cc", [p + 1, q + 1])], ordered=False))
+            for r in range(p, n, 2):
+                for s in range(q if r == p else r, n, 2):
+                    same = [[r, p, s, q], [r + 1, p + 1, s + 1, q + 1]]
+                    mixed = [[r, p, s + 1, q + 1], [r + 1, p + 1, s, q], [r, p + 1, s + 1, q], [r + 1, p, s, q + 1]]
+                    coupling_a = [(2 / r12, "CcCc", t) for t in same] + [(1 / r12, "CcCc", t) for t in mixed]
+                    coupling_b = [(c, "CcCc", t) for c, t in zip((0.5, 0.5, -0.5, -0.5), mixed)]
+                    for base in (coupling_a, coupling_b):
+                        op = _pool_op(n, base, normalise=True)
+                        if op is not None:
+                            doubles.append(op)
+    return _finish(singles + doubles, transform)
+
+
+def uccgsd(n_elec, orbital_number, transform="JW"):
+    """generalised singles and doubles over SPIN orbitals, no spin adaptation (ref:…generator_excitations.py:555-609)"""
+    n = 2 * orbital_number
+    singles, doubles = [], []
+    for p in range(n):
+        for q in range(p, n):
+            singles.append(_pool_op(n, [(1, "Cc", [p, q])], ordered=False))
+            for r in range(p, n):
+                for s in range(q if r == p else r, n):
+                    doubles.append(_pool_op(n, [(1, "CCcc", [p, q, r, s])]))
+    return _finish(singles + doubles, transform)
+
+
+def spin_complement_gsd_twin(n_elec, orbital_number, transform="JW"):
+    """the "twin" enumeration of the spin-complemented generalised pool (ref:…generator_excitations.py:159-271):
+    singles over alpha pairs p < q; same-spin doubles over ordered pair-of-pairs (counter pq >= rs); opposite-spin
+    doubles over (alpha, beta) pairs with their spin-swapped partner."""
+    n = 2 * orbital_number
+    alpha = range(0, n, 2)
+    beta = range(1, n, 2)
+    ops = []
+    for p in alpha:
+        for q in alpha:
+            if p < q:
+                ops.append(_pool_op(n, [(1, "Cc", [q, p]), (1, "Cc", [q + 1, p + 1])], ordered=False))
+    pq = 0
+    for p in alpha:
+        for q in alpha:
+            if p > q:
+                continue
+            rs = 0
+            for r in alpha:
+                for s in alpha:
+                    if r > s:
+                        continue
+                    if pq >= rs:   # (the reference tests pq < rs BEFORE advancing rs: rs only counts accepted pairs)
+                        t = [r, p, s, q]
+                        ops.append(_pool_op(n, [(1, "CcCc", t), (1, "CcCc", _spin_flip(t))]))
+                        rs += 1
+            pq += 1
+    pq = 0
+    for p in alpha:
+        for q in beta:
+            rs = 0
+            for r in alpha:
+                for s in beta:
+                    if pq < rs or p > q:
+                        continue
+                    ops.append(_pool_op(n, [(1, "CcCc", [r, p, s, q]), (1, "CcCc", [s - 1, q - 1, r + 1, p + 1])],
+                                        hc_after_all=True))
+                    rs += 1
+            pq += 1
+    return _finish(ops, transform)
+
+
+# ---------------------------------------------------------------------------------------------- qubit pools derived
+# from cluster operators (ref:openvqe/common_files/qubit_pool.py:29-274, 1270-1316)
+def generate_pool_from_cluster(pool_condition, cluster_ops, nbqbits):
+    """'full': every distinct Pauli string of the JW images of the cluster operators, first-appearance order;
+    'full_without_Z': the same strings with their Z factors removed, duplicates dropped;
+    'reduced_without_Z': per qubit support of the Z-stripped strings only the first string seen.
+    Every pool operator is Hamiltonian(n, [Term(-1.0, string, qubits)]) -> (pool_size, pool).  The reference works
+    on a text rendering of the strings ("[X0 Z1 Y2]"); here the same selection runs on (letters, qubits) tuples."""
+    from .fermionic import spin_operator
+    from .operators import Hamiltonian, Term
+    print("The current pool is", pool_condition)
+    seen, strings = set(), []
+    for op in cluster_ops:
+        sp = op if not hasattr(op, "to_spin") else spin_operator(op)
+        for t in sp.terms:
+            key = (t.op, tuple(t.qbits))
+            if key not in seen:
+                seen.add(key)
+                strings.append(key)
+
+    def strip_z(key):
+        kept = [(c, q) for c, q in zip(*key) if c != "Z"]
+        return "".join(c for c, _ in kept), tuple(q for _, q in kept)
+
+    if pool_condition == "full":
+        chosen = strings
+    elif pool_condition == "full_without_Z":
+        chosen = list(dict.fromkeys(strip_z(k) for k in strings))
+    elif pool_condition == "reduced_without_Z":
+        first = {}
+        for k in strings:
+            letters, qs = strip_z(k)
+            first.setdefault(qs, (letters, qs))
+        chosen = list(first.values())
+    else:
+        return None, None
+    pool = [Hamiltonian(nbqbits, [Term(-1.0, letters, list(qs))], do_clean_up=False) for letters, qs in chosen]
     return len(pool), pool
 
 

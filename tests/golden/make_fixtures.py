@@ -154,10 +154,63 @@ def make_k3_k5():
     return out
 
 
+def make_k5_k7():
+    """Stored QUCCSD runs (ref:notebooks/demo_quccsd.ipynb: H4/STO-3G, 26 operators; ref:notebooks/
+    demo_quccsd_active_space.ipynb: NOON-selected active space, 8 operators), the SECOND run of
+    ref:notebooks/demo_puccgsd.ipynb (the derived 'reduced_without_Z' qubit pool as generators), and the active-space
+    run of ref:notebooks/demo_fermionic_adapt.ipynb.  Numbers only: every energy evaluated by the reference's BFGS in call
+    order, optimised parameters, gate counts, printed NOONs / thresholds."""
+    out = {"source": "stored cell outputs of ref:notebooks/demo_quccsd.ipynb, demo_quccsd_active_space.ipynb, "
+                     "demo_puccgsd.ipynb, demo_fermionic_adapt.ipynb (second run)"}
+    for key, nb in (("h4_quccsd", "demo_quccsd.ipynb"), ("h4_quccsd_active", "demo_quccsd_active_space.ipynb")):
+        run = "\n".join(notebook_stdout(os.path.join(REF, "notebooks", nb)))
+        it = _dict_after(run, "iterations are:")
+        res = _dict_after(run, "results are:")
+        out[key] = {
+            "noons": eval(re.search(r"Noons =\s+(\[[^\]]+\])", run).group(1)),
+            "info": eval(re.search(r"Hamiltonian info (\{.*?\})", run).group(1)),
+            "CNOT1": res["CNOT1"], "CNOT2": res["CNOT2"], "len_op1": res["len_op1"],
+            "minimum_energy_result1_guess": it["minimum_energy_result1_guess"][0],
+            "minimum_energy_result2_guess": it["minimum_energy_result2_guess"][0],
+            "theta_optimized_result1": it["theta_optimized_result1"][0],
+            "theta_optimized_result2": it["theta_optimized_result2"][0],
+            "energies_1": res["energies_1"], "energies_2": res["energies_2"],   # run 1 starts at theta_MP2, run 2 at 0.01
+        }
+        m = re.search(r"threshold_1 chosen =\s+([0-9.e-]+)\s+threshold_2 chosen =\s+([0-9.e-]+)", run)
+        if m:
+            out[key]["thresholds"] = [float(m.group(1)), float(m.group(2))]
+            out[key]["active_qubits"] = int(re.search(r"qubits after active space selection =\s*(\d+)", run).group(1))
+    run = "\n".join(notebook_stdout(os.path.join(REF, "notebooks/demo_puccgsd.ipynb")))
+    res = _dict_after(run, "results are:")
+    it = _dict_after(run, "iterations are:")
+    out["h2_631g_upccgsd_run2"] = {"theta0": 0.01, "len_op2": res["len_op2"], "energies_2_first19": res["energies_2"][:19],
+                                   "n_function_evaluations_2": len(res["energies_2"]),
+                                   "minimum_energy_result2_guess": it["minimum_energy_result2_guess"][0]}
+    run = "\n".join(notebook_stdout(os.path.join(REF, "notebooks/demo_fermionic_adapt.ipynb")))
+    run = run[run.index("Running in the active case"):]
+    it = _dict_after(run, "iterations are:")
+    res = _dict_after(run, "results are:")
+    out["h2_631g_adapt_active"] = {
+        "noons": eval(re.search(r"Noons =\s+(\[[^\]]+\])", run).group(1)),
+        "thresholds": [float(re.search(r"threshold_1 chosen =\s+([0-9.e-]+)", run).group(1)),
+                       float(re.search(r"threshold_2 chosen =\s+([0-9.e-]+)", run).group(1))],
+        "active_qubits": int(re.search(r"qubits after active space selection =\s*(\d+)", run).group(1)),
+        "reference_energy": float(re.search(r"\n(-1\.126469[0-9]+)\n", run).group(1)),
+        "iterations": {k: it[k] for k in ("energies", "norms", "Max_gradients", "CNOTs", "Hadamard", "fidelity")},
+        "result": {k: res[k] for k in ("indices", "Number_operators", "final_norm", "parameters", "Number_CNOT_gates",
+                                       "final_energy_last_iteration")},
+    }
+    json.dump(out, open(os.path.join(HERE, "k5_k7_notebook_runs.json"), "w"), indent=1)
+    return out
+
+
 if __name__ == "__main__":
     k1 = make_k1()
     k2 = make_k2()
     k3 = make_k3_k5()
+    k5 = make_k5_k7()
+    print("K5 first energies", k5["h4_quccsd"]["energies_1"][0], k5["h4_quccsd"]["energies_2"][0], "active trace",
+          k5["h2_631g_adapt_active"]["result"]["indices"])
     print("K3 indices", k3["h2_631g_adapt_result"]["indices"], "H4 info", k3["h4_sto3g_info"])
     print("K1 terms", len(k1["terms"]), "K2 sizes", {k: len(v["terms"]) for k, v in k2["hams"].items()})
     print(k2["logs"])
