@@ -140,7 +140,13 @@ class Molecule:
         return eri
 
     # -- restricted Hartree-Fock ------------------------------------------------------------------
-    def rhf(self, tol=1e-12, max_iter=200):
+    def rhf(self, tol=1e-12, max_iter=200, grad_tol=1e-9):
+        """restricted Hartree-Fock with DIIS.  Converged when |dE| < tol and the orbital gradient (max element of the
+        orthonormalised commutator FDS - SDF) < grad_tol.  PySCF's defaults — what the reference's myQLM front-end runs
+        with — are conv_tol = 1e-9 on the energy and sqrt(conv_tol) = 3.2e-5 on the gradient norm: ``rhf(tol=1e-9,
+        grad_tol=3.2e-5)`` stops there and leaves orbitals that are rotated by ~1e-7 .. 1e-6 against the converged ones
+        (tests/test_scf_threshold.py: that rotation IS the 1e-8-level offset between the stored notebook numbers and a
+        tightly converged replay)."""
         if self.general:
             from . import gto
             S, T, V, eri = gto.integrals(self.functions, [(CHARGE[s], r) for s, r in self.atoms])
@@ -184,7 +190,7 @@ class Molecule:
             J = np.einsum("pqrs,rs->pq", eri, D)
             Kx = np.einsum("prqs,rs->pq", eri, D)
             e = np.sum(D * (2.0 * hcore + 2.0 * J - Kx))
-            if abs(e - e_old) < tol and np.abs(err).max() < 1e-9:
+            if abs(e - e_old) < tol and np.abs(err).max() < grad_tol:
                 break
             e_old = e
         # orbital phase gauge of PySCF's SCF eigensolver (pyscf.scf.hf.eig): the AO coefficient of largest magnitude of
@@ -201,6 +207,27 @@ class Molecule:
         self.h_mo = C.T @ hcore @ C
         self.eri_mo = np.einsum("pqrs,pi,qj,rk,sl->ijkl", eri, C, C, C, C, optimize=True)
         return self.e_hf
+
+    def rotate_orbitals(self, kappa):
+        """C <- C exp(K), K the antisymmetric matrix with K[p, q] = kappa[(p, q)] = -K[q, p]; MO integrals are rebuilt,
+        orbital energies kept.  Models a not-fully-converged SCF (orbitals rotated against the stationary ones)."""
+        import scipy.linalg
+        K = np.zeros((self.nao, self.nao))
+        for (p, q), v in kappa.items():
+            K[p, q] += v
+            K[q, p] -= v
+        self._set_orbitals(self.mo_coeff @ scipy.linalg.expm(K))
+
+    def _set_orbitals(self, C):
+        if self.general:
+            from . import gto
+            _, T, V, eri = gto.integrals(self.functions, [(CHARGE[s], r) for s, r in self.atoms])
+        else:
+            _, T, V = self.one_electron()
+            eri = self.two_electron()
+        self.mo_coeff = C
+        self.h_mo = C.T @ (T + V) @ C
+        self.eri_mo = np.einsum("pqrs,pi,qj,rk,sl->ijkl", eri, C, C, C, C, optimize=True)
 
     # -- qubit objects ------------------------------------------------------------------------------
     def jw_hamiltonian(self):
