@@ -85,7 +85,9 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * kernel below), "clifford_frame" (read by the NEXT ovqe_set_gate_program: 0 = execute the literal gate list; 1 (default) = when
  * the Clifford part of the list — X, H, CNOT, quarter-turn rotations — multiplies to the identity, run the
  * algebraically identical sequence of Pauli rotations with conjugated strings instead; 2 = always, Clifford part
- * appended literally) */
+ * appended literally), "expect_sparse" (tiled <H>: a tile in which at most 1/value of the amplitudes are non-zero — the
+ * particle-number / spin sector of a UCC-type state — is evaluated over the compacted list of its non-zero amplitudes
+ * instead of over all pairs; skipped work is multiplication by exact zeros; default 4, 0 = never) */
 int ovqe_set_option(ovqe_handle h, const char *name, int64_t value);
 /* device pointer to the 2^n_local amplitudes (for RCCL exchange by the host layer) */
 int ovqe_state_ptr(ovqe_handle h, void **dev_ptr);

@@ -50,6 +50,7 @@ struct HamDev {  // grouped Pauli sum resident on the device
     bool tile_real = false;       // cover built for a real-amplitude state (masks in pair-index space, M + 1 bits)
     int version = 0;              // ham_real: the version of the stored Hamiltonian it was copied from
     std::vector<ExSweep> tsweeps;
+    std::vector<int> tsweep_terms;  // apply-form terms per sweep: the compute weight of a sweep on sparse tiles
     int n_rest = 0;  // groups that fit no tile keep their own sweep (k_expect_pairs)
     int64_t tile_work = 0, tile_entries = 0, tile_terms = 0;  // pair x term evaluations per tile over all sweeps
     DevBuf d_tchunks, d_tgroups, d_tterms, d_tflats, d_titems, d_rest;
@@ -119,6 +120,11 @@ struct ovqe_sv {
     DevBuf d_egroups, d_eterms, d_echunks, d_eflat;
     int exp_lbits = -1, exp_real = -1, exp_ngroups = 0, exp_nchunks = 0, exp_nflat = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // second stream of the tiled <H>: the compute-heavy sweeps (many x-groups) and the bandwidth-bound ones (few groups,
+    // one read of the state each) run side by side
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int opt_expect_streams = 2;
     float last_batch_ms = 0.f;
     const double *cur_theta = nullptr;  // device pointers of the batch being evaluated
     double *cur_energies = nullptr;
@@ -145,6 +151,8 @@ struct ovqe_sv {
     bool prog_real_ok = false;    // every rotation has an odd number of Y and there is no diagonal run
     int opt_apply_min_tiles = 256;  // H psi goes through the tile cover from this many tiles on
     int opt_real_stream = 1;      // streaming energies of such programs keep the state as 2^n doubles
+    int opt_expect_sparse = 4;    // tiled <H>: a tile with at most 1/den of its amplitudes non-zero is evaluated over the
+                                  // compacted list of those amplitudes (0 = always the dense entry walks)
     HamDev ham_real;              // tile cover of the stored Hamiltonian for the real-amplitude state
     TilePlan tp_adhoc;            // of the rotation list of the current ovqe_apply_pauli_rotations call
 };
@@ -427,12 +435,16 @@ inline uint32_t extract_bits(uint64_t v, uint64_t mask) {  // pext
 // ---- tiled expectation (sv_tile.hpp) -----------------------------------------------------------------------
 // Greedy cover of the x-groups by tile bit sets: a set starts from the mandatory low bits and grows by the bit that
 // brings the most still-uncovered groups within reach (groups that are nearly inside count more).
+static int achunks_g0(const std::vector<ExChunkT> &a, int a0, const ExChunkT &cur) { return a0 < (int)a.size() ? a[a0].g0 : cur.g0; }
+static int achunks_t0(const std::vector<ExChunkT> &a, int a0, const ExChunkT &cur) { return a0 < (int)a.size() ? a[a0].t0 : cur.t0; }
+
 int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
     const int M = tile_bits(h, real), L = h->opt_tile_low;
     H.tile_bits = M;
     H.tile_low = L;
     H.tile_real = real;
     H.tsweeps.clear();
+    H.tsweep_terms.clear();
     H.n_rest = 0;
     H.tile_work = 0;
     const bool tiled = tile_ok(h, real) && H.groups.size() >= 3;
@@ -503,10 +515,18 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
             ++took;
             const HGroup &gr = H.groups[g];
             const uint32_t xl = extract_bits(gr.x, S);
-            if (!real) {  // operator-application form: the group's raw terms, split when they exceed a chunk
-                for (int t0 = gr.t0; t0 < gr.t1; t0 += TILE_TERM_CAP) {
-                    const int t1 = std::min(gr.t1, t0 + TILE_TERM_CAP);
-                    if ((int)aterms.size() - ak.t0 + (t1 - t0) > TILE_TERM_CAP ||
+            {   // operator-application form (k_tile_apply; sparse tiles of k_tile_expect): the group's raw terms, split
+                // when they exceed a chunk.  Real state: strings with an imaginary folded coefficient (odd number of
+                // Y) have <P> = 0 and are left out.
+                std::vector<int> keep;
+                for (int t = gr.t0; t < gr.t1; ++t)
+                    if (!(real && H.terms[t].ci != 0.0)) keep.push_back(t);
+                // a group enters in pieces of at most TILE_APPLY_TERMS terms (D_g is a sum over its terms, so the pieces
+                // are independent work units): one wave serves a piece, and the diagonal group with its hundreds of
+                // Z strings no longer keeps a single wave busy while the others idle
+                for (size_t k0 = 0; k0 < keep.size(); k0 += TILE_APPLY_TERMS) {
+                    const size_t k1 = std::min(keep.size(), k0 + TILE_APPLY_TERMS);
+                    if ((int)aterms.size() - ak.t0 + (int)(k1 - k0) > TILE_TERM_CAP ||
                         (int)agroups.size() - ak.g0 + 1 > TILE_APPLY_GROUPS) {
                         ak.g1 = (int32_t)agroups.size();
                         ak.t1 = (int32_t)aterms.size();
@@ -514,8 +534,8 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
                         ak = {ak.g1, ak.g1, ak.t1, ak.t1};
                     }
                     ExAGroupT ag = {xl, (int32_t)aterms.size(), 0, 0};
-                    for (int t = t0; t < t1; ++t) {
-                        const HTerm &ht = H.terms[t];
+                    for (size_t k = k0; k < k1; ++k) {
+                        const HTerm &ht = H.terms[keep[k]];
                         ExTermT et = {};
                         et.zin = extract_bits(ht.z, S);
                         et.zout = ht.z & ~S;
@@ -622,7 +642,13 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
         if (ak.g1 > ak.g0) achunks.push_back(ak);
         sw.a1 = (int32_t)achunks.size();
         if (took == 0) return fail(h, OVQE_ERR_INVALID, "internal: tile cover made no progress");
+        if (std::getenv("OVQE_DEBUG_COVER"))
+            std::fprintf(stderr, "cover sweep %zu: S=%llx groups=%d pieces=%d apply_terms=%d entries=%d items=%d\n",
+                         H.tsweeps.size(), (unsigned long long)S, took, (int)agroups.size() - achunks_g0(achunks, sw.a0, ak),
+                         (int)aterms.size() - achunks_t0(achunks, sw.a0, ak), (int)tgroups.size() - (int)(sw.c0 < (int)chunks.size() ? chunks[sw.c0].g0 : ck.g0),
+                         (int)titems.size() - sw.i0);
         H.tsweeps.push_back(sw);
+        H.tsweep_terms.push_back((int)aterms.size() - achunks_t0(achunks, sw.a0, ak));
     }
     H.n_rest = (int)rest.size();
     for (const ExEntryT &en : tgroups) H.tile_work += (int64_t)en.nk * (en.t1 - en.t0);
@@ -653,10 +679,15 @@ inline int expect_ysplit(ovqe_handle h, int M) {  // workgroups per tile: fill t
 }
 
 template <int M, bool REAL>
-int launch_tile_expect(ovqe_handle h, const HamDev &H, const ExSweep &sw, double2 *partials, int accumulate) {
+int launch_tile_expect(ovqe_handle h, const HamDev &H, const ExSweep &sw, double2 *partials, int accumulate,
+                       hipStream_t stream) {
     constexpr int NT = 1 << TILE_EXPECT_LOG_NT;
-    const size_t smem = ((size_t)(REAL ? 8 : 16) << M) + TILE_TERM_CAP * sizeof(ExTermLds) + (NT / 64) * sizeof(double2);
+    static_assert(TILE_SPARSE_TERMS >= 2 * TILE_TERM_CAP && TILE_SPARSE_GROUPS >= 2 * TILE_APPLY_GROUPS, "two host chunks per pass");
+    const size_t smem = ((size_t)(REAL ? 8 : 16) << M) + TILE_SPARSE_TERMS * sizeof(ExTermLds) +
+                        TILE_SPARSE_GROUPS * sizeof(ExAGroupT) + (NT / 64) * sizeof(double2) + (NT / 64 + 2) * sizeof(int) +
+                        ((size_t)2 << M);
     const dim3 grid((unsigned)(h->namps >> M), (unsigned)expect_ysplit(h, M));
+    const int sparse_den = H.d_agroups.p && sw.a1 > sw.a0 ? h->opt_expect_sparse : 0;
     static bool attr_done_dev[64] = {};  // function attributes are per device
     bool &attr_done = attr_done_dev[h->device & 63];
     if (!attr_done) {
@@ -667,15 +698,17 @@ int launch_tile_expect(ovqe_handle h, const HamDev &H, const ExSweep &sw, double
         attr_done = true;
     }
     if (h->n_local >= 25) {
-        hipLaunchKernelGGL((k_tile_expect<M, NT, true, REAL>), grid, dim3(NT), smem, h->stream, (const void *)h->state, h->base, sw,
+        hipLaunchKernelGGL((k_tile_expect<M, NT, true, REAL>), grid, dim3(NT), smem, stream, (const void *)h->state, h->base, sw,
                            (const ExChunkT *)H.d_tchunks.p, (const ExEntryT *)H.d_tgroups.p,
                            (const ExTermT *)H.d_tterms.p, (const ExFlatT *)H.d_tflats.p, (const ExItemT *)H.d_titems.p, partials,
-                           accumulate);
+                           accumulate, (const ExChunkT *)H.d_achunks.p, (const ExAGroupT *)H.d_agroups.p,
+                           (const ExTermT *)H.d_aterms.p, sparse_den);
     } else {
-        hipLaunchKernelGGL((k_tile_expect<M, NT, false, REAL>), grid, dim3(NT), smem, h->stream, (const void *)h->state, h->base, sw,
+        hipLaunchKernelGGL((k_tile_expect<M, NT, false, REAL>), grid, dim3(NT), smem, stream, (const void *)h->state, h->base, sw,
                            (const ExChunkT *)H.d_tchunks.p, (const ExEntryT *)H.d_tgroups.p,
                            (const ExTermT *)H.d_tterms.p, (const ExFlatT *)H.d_tflats.p, (const ExItemT *)H.d_titems.p, partials,
-                           accumulate);
+                           accumulate, (const ExChunkT *)H.d_achunks.p, (const ExAGroupT *)H.d_agroups.p,
+                           (const ExTermT *)H.d_aterms.p, sparse_den);
     }
     HIPC(h, hipGetLastError());
     return OVQE_OK;
@@ -693,37 +726,71 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bo
     // partial sums: one per workgroup of the tile sweeps (none when every group keeps its own sweep)
     const int64_t ntiles = H.tsweeps.empty() ? 0 : (int64_t)(h->namps >> M) * expect_ysplit(h, M);
     const int nb = reduce_blocks(h->namps);
-    int rc = ensure(h, h->d_partials, (size_t)(ntiles + nb) * sizeof(double2));
+    int rc = ensure(h, h->d_partials, (size_t)(2 * ntiles + nb) * sizeof(double2));
     if (rc) return rc;
     rc = ensure(h, h->d_result, 64 * sizeof(double2));
     if (rc) return rc;
     double2 *partials = (double2 *)h->d_partials.p;
-    int acc = 0;
-    for (const ExSweep &sw : H.tsweeps) {
+    // two streams when the cover has enough sweeps: the sweeps are taken heaviest-first by the main stream and
+    // lightest-first by the second one until they meet (estimated duration: one read of the state + compute per term)
+    const int ns = (int)H.tsweeps.size();
+    const bool dual = h->opt_expect_streams >= 2 && ns >= 8 && h->n_local >= 20 && h->n_global == 0;
+    if (dual && !h->stream2) {
+        HIPC(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        HIPC(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIPC(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    std::vector<char> on_second(ns, 0);
+    if (dual) {
+        const double mem = 16.0 * (double)h->namps * (real ? 0.5 : 1.0) / 2.8e6;        // us at ~2.8 TB/s
+        const double per_term = 0.23 * (double)h->namps / (double)(1ull << 24);       // us, measured at 24 qubits
+        double ta = 0.0, tb = 0.0;
+        int i = 0, j = ns - 1;
+        while (i <= j) {
+            if (ta <= tb) ta += mem + per_term * H.tsweep_terms[i++];
+            else {
+                tb += mem + per_term * H.tsweep_terms[j];
+                on_second[j--] = 1;
+            }
+        }
+        HIPC(h, hipEventRecord(h->ev_fork, h->stream));
+        HIPC(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    }
+    int acc[2] = {0, 0};
+    for (int k = 0; k < ns; ++k) {
+        const ExSweep &sw = H.tsweeps[k];
+        const int which = on_second[k];
+        hipStream_t strm = which ? h->stream2 : h->stream;
+        double2 *part = partials + (which ? ntiles : 0);
         if (real) {
             switch (M) {
-            case 11: rc = launch_tile_expect<11, true>(h, H, sw, partials, acc); break;
-            case 12: rc = launch_tile_expect<12, true>(h, H, sw, partials, acc); break;
-            default: rc = launch_tile_expect<13, true>(h, H, sw, partials, acc); break;
+            case 11: rc = launch_tile_expect<11, true>(h, H, sw, part, acc[which], strm); break;
+            case 12: rc = launch_tile_expect<12, true>(h, H, sw, part, acc[which], strm); break;
+            default: rc = launch_tile_expect<13, true>(h, H, sw, part, acc[which], strm); break;
             }
         } else {
             switch (M) {
-            case 10: rc = launch_tile_expect<10, false>(h, H, sw, partials, acc); break;
-            case 11: rc = launch_tile_expect<11, false>(h, H, sw, partials, acc); break;
-            default: rc = launch_tile_expect<12, false>(h, H, sw, partials, acc); break;
+            case 10: rc = launch_tile_expect<10, false>(h, H, sw, part, acc[which], strm); break;
+            case 11: rc = launch_tile_expect<11, false>(h, H, sw, part, acc[which], strm); break;
+            default: rc = launch_tile_expect<12, false>(h, H, sw, part, acc[which], strm); break;
             }
         }
         if (rc) return rc;
-        acc = 1;
+        acc[which] = 1;
     }
-    int64_t count = ntiles;
+    const int nparts = (dual && acc[1]) ? 2 : 1;
+    if (dual) {
+        HIPC(h, hipEventRecord(h->ev_join, h->stream2));
+        HIPC(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    }
+    int64_t count = ntiles * nparts;
     if (H.n_rest) {
         if (real)
             hipLaunchKernelGGL(k_expect_pairs_real, dim3(nb), dim3(256), 0, h->stream, (const double *)h->state, h->namps,
-                               (const HGroup *)H.d_rest.p, 0, H.n_rest, (const HTerm *)H.d_terms.p, partials + ntiles);
+                               (const HGroup *)H.d_rest.p, 0, H.n_rest, (const HTerm *)H.d_terms.p, partials + count);
         else
             hipLaunchKernelGGL(k_expect_pairs, dim3(nb), dim3(256), 0, h->stream, h->state, h->namps,
-                               (const HGroup *)H.d_rest.p, 0, H.n_rest, (const HTerm *)H.d_terms.p, partials + ntiles);
+                               (const HGroup *)H.d_rest.p, 0, H.n_rest, (const HTerm *)H.d_terms.p, partials + count);
         count += nb;
     }
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->stream, (const double2 *)partials, count,
@@ -1934,6 +2001,9 @@ int ovqe_destroy(ovqe_handle h) {
     if (h->h_io) (void)hipHostFree(h->h_io);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     delete h;
     return OVQE_OK;
 }
@@ -1975,6 +2045,8 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
         h->tp_real_built = false;  // the real-amplitude plan follows on its next use
         if (h->prog_set) return build_tile_program(h);
     }
+    else if (k == "expect_sparse") h->opt_expect_sparse = (int)std::max<int64_t>(0, value);
+    else if (k == "expect_streams") h->opt_expect_streams = value >= 2 ? 2 : 1;
     else if (k == "persist_blocks") h->opt_persist_blocks = (int)value;
     else if (k == "small_threads") {
         h->opt_small_threads = (int)value;

@@ -169,6 +169,8 @@ __global__ __launch_bounds__(NT) void k_tile_sweep(void *__restrict__ st, uint64
 // coefficients cancel exactly are never visited.  One wave owns an entry (<= 256 pairs); z bits outside the tile
 // are per-tile signs, folded into the coefficients while a chunk of the term table is staged in LDS.
 constexpr int TILE_TERM_CAP = 512;
+constexpr int TILE_APPLY_GROUPS = 128;  // x-groups of a chunk staged in LDS (operator-application form)
+constexpr int TILE_APPLY_TERMS = 16;    // terms per piece of an x-group in that form
 constexpr int TILE_ENTRY_PAIRS = 256;
 constexpr int TILE_EXPECT_LOG_NT = 9;   // threads per workgroup of k_tile_expect (256 measured faster than 1024)
 
@@ -222,6 +224,65 @@ struct ExTermLds {
     uint32_t zin, pad;
 };
 
+// Sparse tiles of k_tile_expect: the pieces (x-group restricted to <= TILE_APPLY_TERMS of its terms) of one staging
+// chunk over NQ x 64 entries of the tile's non-zero list: sum_i conj(a_i) D(i ^ x) a_{i ^ x}.  The lane's entries (index,
+// amplitude) are loaded once; per piece one LDS gather of the partner amplitude per entry, then per (term, entry) four
+// vector instructions: j & z, popcount, the coefficient's high word + parity << 31 (a carry-free sign flip), and the add.
+constexpr int TILE_SPARSE_TERMS = 1024;   // terms staged in LDS per chunk of the sparse path
+constexpr int TILE_SPARSE_GROUPS = 384;   // pieces per chunk
+template <bool REAL, int NQ>
+__device__ __forceinline__ double tile_sparse_pieces(const typename Amp<REAL>::T *tile, const uint16_t *nz, int nnz, int lb,
+                                                     uint32_t lane, const ExAGroupT *sg, int g_begin, int g_end, int g_step,
+                                                     const ExTermLds *st) {
+    typedef typename Amp<REAL>::T amp;
+    uint32_t ii[NQ];
+    amp a[NQ];
+    bool live[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int l = lb + 64 * q + (int)lane;
+        live[q] = l < nnz;
+        ii[q] = live[q] ? nz[l] : 0u;
+        a[q] = tile[tile_swz<REAL>(ii[q])];
+    }
+    double part = 0.0;
+    for (int g = g_begin; g < g_end; g += g_step) {
+        const ExAGroupT gr = sg[g];
+        const uint32_t xl = __builtin_amdgcn_readfirstlane(gr.x);
+        const int t0 = __builtin_amdgcn_readfirstlane(gr.t0), t1 = __builtin_amdgcn_readfirstlane(gr.t1);
+        uint32_t jj[NQ];
+        double vx[NQ], vy[NQ], dr[NQ], di[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            jj[q] = ii[q] ^ xl;
+            const amp c = tile[tile_swz<REAL>(jj[q])];
+            if constexpr (REAL) {
+                vx[q] = live[q] ? a[q] * c : 0.0;
+                vy[q] = 0.0;
+            } else {
+                vx[q] = live[q] ? a[q].x * c.x + a[q].y * c.y : 0.0;
+                vy[q] = live[q] ? a[q].x * c.y - a[q].y * c.x : 0.0;
+            }
+            dr[q] = 0.0;
+            di[q] = 0.0;
+        }
+        for (int t = t0; t < t1; ++t) {
+            const ExTermLds tl = st[t];
+            const uint64_t cr = (uint64_t)__double_as_longlong(tl.cr), ci = (uint64_t)__double_as_longlong(tl.ci);
+            const uint32_t crl = (uint32_t)cr, crh = (uint32_t)(cr >> 32), cil = (uint32_t)ci, cih = (uint32_t)(ci >> 32);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const uint32_t par = (uint32_t)__popc(jj[q] & tl.zin);
+                dr[q] += __hiloint2double((int)(crh + (par << 31)), (int)crl);
+                if constexpr (!REAL) di[q] += __hiloint2double((int)(cih + (par << 31)), (int)cil);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) part += dr[q] * vx[q] - di[q] * vy[q];
+    }
+    return part;
+}
+
 template <int M, int NT, bool NTL, bool REAL>
 __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st, uint64_t base, ExSweep sw,
                                                     const ExChunkT *__restrict__ chunks,
@@ -229,7 +290,9 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
                                                     const ExTermT *__restrict__ terms,
                                                     const ExFlatT *__restrict__ flats,
                                                     const ExItemT *__restrict__ items, double2 *__restrict__ partials,
-                                                    int accumulate) {
+                                                    int accumulate, const ExChunkT *__restrict__ achunks,
+                                                    const ExAGroupT *__restrict__ agroups,
+                                                    const ExTermT *__restrict__ aterms, int sparse_den) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Amp<REAL>::T amp;
     constexpr uint32_t NEL = 1u << M;
@@ -238,8 +301,14 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
     constexpr int PP = TILE_ENTRY_PAIRS / 64;  // pairs per lane
     const amp *tile = reinterpret_cast<const amp *>(smem);
     double2 *tilev = reinterpret_cast<double2 *>(smem);
+    // [tile][dense path: term table | sparse path: staged terms + pieces (same bytes)][reduction][scan][non-zero list]
     ExTermLds *lt = reinterpret_cast<ExTermLds *>(smem + (size_t)NELV * sizeof(double2));
-    double2 *red = reinterpret_cast<double2 *>(lt + TILE_TERM_CAP);
+    ExTermLds *spt = lt;                                             // sparse path: staged terms ...
+    ExAGroupT *spg = reinterpret_cast<ExAGroupT *>(spt + TILE_SPARSE_TERMS);  // ... and pieces of a pass
+    double2 *red = reinterpret_cast<double2 *>(spg + TILE_SPARSE_GROUPS);
+    int *scan = reinterpret_cast<int *>(red + NT / 64);             // NT / 64 wave totals + the tile's count
+    uint16_t *nz = reinterpret_cast<uint16_t *>(scan + NT / 64 + 2);  // tile-local indices of the non-zero amplitudes
+    static_assert(TILE_SPARSE_TERMS >= TILE_TERM_CAP, "the dense term table lives in the sparse staging bytes");
     const v2d *p = reinterpret_cast<const v2d *>(st);
 
     uint64_t tb = blockIdx.x;
@@ -260,6 +329,95 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
     const uint32_t lane = threadIdx.x & 63u;
     double acc = 0.0;
     __syncthreads();  // tile visible
+    // ---- sparse tiles.  A UCC-type state lives on a particle-number / spin sector (24 qubits, 10 electrons: 3.7 % of the
+    // amplitudes), so nearly every pair product of the entry walks below multiplies exact zeros.  The tile's non-zero
+    // amplitudes are compacted (ascending index: thread t owns NEL / NT consecutive amplitudes, block-wide exclusive
+    // scan — a fixed order, so the sum stays reproducible), and when they are few the sweep's x-groups are evaluated in
+    // operator-application form over that list only: E += sum_{i non-zero} conj(a_i) D_g(i ^ x) a_{i ^ x}, one wave per
+    // group, lanes over the list.  Skipped work is multiplication by exact zeros; dense tiles take the entry walks.
+    if (sparse_den > 0) {
+        constexpr int K = NEL / NT;
+        uint32_t found[K];
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t e = threadIdx.x * K + k;
+            const amp a = tile[tile_swz<REAL>(e)];
+            bool nzero;
+            if constexpr (REAL) nzero = a != 0.0; else nzero = a.x != 0.0 || a.y != 0.0;
+            found[k] = e;
+            cnt += nzero ? 1 : 0;
+            if (!nzero) found[k] = 0xffffffffu;
+        }
+        int incl = cnt;  // inclusive scan inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d, 64);
+            if ((int)lane >= d) incl += up;
+        }
+        if (lane == 63) scan[wave] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) {
+            const int c = scan[w];
+            before += w < wave ? c : 0;
+            total += c;
+        }
+        if ((int64_t)total * sparse_den <= (int64_t)NEL) {
+            int pos = before + incl - cnt;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (found[k] != 0xffffffffu) nz[pos++] = (uint16_t)found[k];
+            const int nnz = __builtin_amdgcn_readfirstlane(total);
+            // the sweep's pieces are one contiguous range of the apply tables (host chunks of <= TILE_TERM_CAP terms /
+            // TILE_APPLY_GROUPS pieces); up to two host chunks are staged in LDS per pass — term signs of the z bits outside
+            // the tile folded in —, then every wave walks its pieces of the pass without further barriers
+            for (int ch = sw.a0; ch < sw.a1; ch += 2) {
+                const ExChunkT c0 = achunks[ch], c1 = achunks[min(ch + 1, sw.a1 - 1)];
+                const int tb0 = c0.t0, tb1 = c1.t1, gb0 = c0.g0, gb1 = c1.g1;
+                __syncthreads();  // list complete / previous pass's tables no longer read
+                for (int t = tb0 + (int)threadIdx.x; t < tb1; t += NT) {
+                    const ExTermT et = aterms[t];
+                    const bool neg = parity64(gbase & et.zout);
+                    ExTermLds l;
+                    l.cr = neg ? -et.cr : et.cr;
+                    l.ci = neg ? -et.ci : et.ci;
+                    l.zin = et.zin;
+                    l.pad = 0;
+                    spt[t - tb0] = l;
+                }
+                for (int g = gb0 + (int)threadIdx.x; g < gb1; g += NT) {
+                    ExAGroupT gr = agroups[g];
+                    gr.t0 -= tb0;
+                    gr.t1 -= tb0;
+                    spg[g - gb0] = gr;
+                }
+                __syncthreads();
+                const int gfirst = wave + (NT / 64) * (int)blockIdx.y, gstep = (NT / 64) * (int)gridDim.y, ng = gb1 - gb0;
+                for (int lb = 0; lb < nnz; lb += 256) {  // up to four list entries per lane share one walk over the pieces
+                    switch (min(4, (nnz - lb + 63) >> 6)) {
+                    case 1: acc += tile_sparse_pieces<REAL, 1>(tile, nz, nnz, lb, lane, spg, gfirst, ng, gstep, spt); break;
+                    case 2: acc += tile_sparse_pieces<REAL, 2>(tile, nz, nnz, lb, lane, spg, gfirst, ng, gstep, spt); break;
+                    case 3: acc += tile_sparse_pieces<REAL, 3>(tile, nz, nnz, lb, lane, spg, gfirst, ng, gstep, spt); break;
+                    default: acc += tile_sparse_pieces<REAL, 4>(tile, nz, nnz, lb, lane, spg, gfirst, ng, gstep, spt); break;
+                    }
+                }
+            }
+            __syncthreads();
+            const double2 t = block_sum<NT>(make_double2(acc, 0.0), red);
+            if (threadIdx.x == 0) {
+                const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+                if (accumulate) {
+                    const double2 o = partials[slot];
+                    partials[slot] = make_double2(o.x + t.x, o.y);
+                } else {
+                    partials[slot] = t;
+                }
+            }
+            return;
+        }
+    }
     for (int t = sw.i0 + (int)threadIdx.x + NT * (int)blockIdx.y; t < sw.i1; t += NT * (int)gridDim.y) {
         const ExItemT it = items[t];
         const ExFlatT fe = flats[it.entry];
@@ -413,7 +571,6 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
 // The output is accumulated across the sweeps (first sweep: out = ident * in + ..., later: out += ...), so a sweep
 // moves 48 bytes per amplitude where the gather kernel k_apply_sum re-reads the input once per x-group.  VALU-bound
 // (every term of every group is evaluated for every amplitude): about twice as fast as the gather kernel at 24 qubits.
-constexpr int TILE_APPLY_GROUPS = 128;  // x-groups of a chunk staged in LDS
 
 template <int M, int NT, bool NTL>
 __global__ __launch_bounds__(NT) void k_tile_apply(const amp_t *__restrict__ in, amp_t *__restrict__ out, uint64_t base,
