@@ -11,6 +11,7 @@
 #include <map>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "sv_kernels.hpp"
@@ -54,7 +55,19 @@ struct HamDev {  // grouped Pauli sum resident on the device
     int n_rest = 0;  // groups that fit no tile keep their own sweep (k_expect_pairs)
     int64_t tile_work = 0, tile_entries = 0, tile_terms = 0;  // pair x term evaluations per tile over all sweeps
     DevBuf d_tchunks, d_tgroups, d_tterms, d_tflats, d_titems, d_rest;
-    DevBuf d_achunks, d_agroups, d_aterms;  // operator-application form of the cover (k_tile_apply), complex covers only
+    DevBuf d_achunks, d_agroups, d_aterms;  // operator-application form of the cover (k_tile_apply, sparse tiles)
+    std::vector<ExChunkT> h_achunks;        // host copy (launch geometry of the compact cover)
+    int cover_id = 0;                       // bumped whenever the cover is rebuilt
+};
+
+// compact cover (sv_tile.hpp k_tile_expect_compact): the support of the program's states, sorted by tile for every sweep
+struct CompactCover {
+    bool valid = false, disabled = false;
+    int prog_version = -1, ham_version = -1, cover_id = -1;
+    int seen = 0;                 // evaluations of this (program, Hamiltonian) pair before the cover is built
+    uint32_t K = 0, max_nnz = 0;
+    uint64_t ntiles = 0;
+    DevBuf d_sup, d_psic, d_loc, d_cid, d_off, d_sweeps;
 };
 
 }  // namespace
@@ -125,6 +138,10 @@ struct ovqe_sv {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int opt_expect_streams = 2;
+    CompactCover cc;              // of (current program, ham_real)
+    int opt_compact = 1;          // allow the compact cover (real-amplitude streaming energies, 18..28 qubits)
+    int opt_compact_cpp = 1;      // host chunks (512 terms each) staged in LDS per pass of the compact-cover kernel
+    int prog_version = 0;
     float last_batch_ms = 0.f;
     const double *cur_theta = nullptr;  // device pointers of the batch being evaluated
     double *cur_energies = nullptr;
@@ -445,6 +462,8 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
     H.tile_real = real;
     H.tsweeps.clear();
     H.tsweep_terms.clear();
+    H.h_achunks.clear();
+    H.cover_id++;
     H.n_rest = 0;
     H.tile_work = 0;
     const bool tiled = tile_ok(h, real) && H.groups.size() >= 3;
@@ -664,6 +683,7 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
     if (rc) return rc;
     rc = upload(h, H.d_titems, titems.data(), titems.size() * sizeof(ExItemT));
     if (rc) return rc;
+    H.h_achunks = achunks;
     rc = upload(h, H.d_achunks, achunks.data(), achunks.size() * sizeof(ExChunkT));
     if (!rc) rc = upload(h, H.d_agroups, agroups.data(), agroups.size() * sizeof(ExAGroupT));
     if (!rc) rc = upload(h, H.d_aterms, aterms.data(), aterms.size() * sizeof(ExTermT));
@@ -800,6 +820,165 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bo
     HIPC(h, hipStreamSynchronize(h->stream));
     *out = h->h_result[0];
     *used = true;
+    return OVQE_OK;
+}
+
+// ---- compact cover -----------------------------------------------------------------------------------------------
+int run_program_streaming(ovqe_handle h, const double *theta, bool real);
+
+// Support of the program's states (non-zeros of the real state prepared at a generic parameter vector: structural zeros
+// are exact zeros for every theta, and a structurally non-zero amplitude vanishes exactly only on a null set) and, for
+// every sweep of the real cover, that support sorted by tile.  Clobbers the state buffer.
+int build_compact_cover(ovqe_handle h, HamDev &H) {
+    CompactCover &C = h->cc;
+    C.valid = false;
+    C.disabled = true;   // until everything below succeeded
+    C.prog_version = h->prog_version;
+    C.ham_version = H.version;
+    C.cover_id = H.cover_id;
+    const int M = H.tile_bits;
+    if (H.tsweeps.empty() || H.n_rest || !H.tile_real || h->n_local > 28 || M > 13) return OVQE_OK;
+    std::vector<double> theta((size_t)std::max(h->K, 1));
+    for (int k = 0; k < h->K; ++k) {
+        const double f = 0.6180339887498949 * (k + 1);
+        theta[k] = 0.4 + 0.7 * (f - std::floor(f));
+    }
+    int rc = run_program_streaming(h, theta.data(), true);
+    if (rc) return rc;
+    std::vector<double> host(h->namps);
+    HIPC(h, hipMemcpyAsync(host.data(), h->state, h->namps * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    std::vector<uint32_t> sup;
+    for (uint64_t i = 0; i < h->namps; ++i)
+        if (host[i] != 0.0) sup.push_back((uint32_t)i);
+    std::vector<double>().swap(host);
+    const uint32_t K = (uint32_t)sup.size();
+    if (K == 0 || (uint64_t)K * 8ull > h->namps) return OVQE_OK;   // not sparse enough to pay off
+    const int ns = (int)H.tsweeps.size();
+    const uint64_t ntiles = h->namps >> M;
+    std::vector<uint16_t> loc((size_t)ns * K);
+    std::vector<uint32_t> cid((size_t)ns * K), off((size_t)ns * (ntiles + 1));
+    std::vector<uint32_t> maxn(ns, 0);
+    const uint64_t allbits = h->namps - 1ull;
+    auto work = [&](int s0, int s1) {
+        std::vector<uint32_t> cnt(ntiles + 1), tile_of(K);
+        for (int s = s0; s < s1; ++s) {
+            const uint64_t samp = (H.tsweeps[s].smask << 1) | 1ull;   // the tile's bits in amplitude-index space
+            const uint64_t outside = allbits & ~samp;
+            // byte tables of the two bit extractions
+            uint32_t tl[4][256], tt[4][256];
+            for (int b = 0; b < 4; ++b) {
+                const uint64_t ms = (samp >> (8 * b)) & 0xffull, mo = (outside >> (8 * b)) & 0xffull;
+                const int sh_s = __builtin_popcountll(samp & ((1ull << (8 * b)) - 1ull));
+                const int sh_o = __builtin_popcountll(outside & ((1ull << (8 * b)) - 1ull));
+                for (int v = 0; v < 256; ++v) {
+                    tl[b][v] = extract_bits((uint64_t)v, ms) << sh_s;
+                    tt[b][v] = extract_bits((uint64_t)v, mo) << sh_o;
+                }
+            }
+            std::fill(cnt.begin(), cnt.end(), 0u);
+            for (uint32_t k = 0; k < K; ++k) {
+                const uint32_t i = sup[k];
+                const uint32_t t = tt[0][i & 255u] | tt[1][(i >> 8) & 255u] | tt[2][(i >> 16) & 255u] | tt[3][i >> 24];
+                tile_of[k] = t;
+                cnt[t + 1]++;
+            }
+            uint32_t mx = 0;
+            for (uint64_t t = 0; t < ntiles; ++t) {
+                mx = std::max(mx, cnt[t + 1]);
+                cnt[t + 1] += cnt[t];
+            }
+            maxn[s] = mx;
+            uint32_t *o = off.data() + (size_t)s * (ntiles + 1);
+            std::copy(cnt.begin(), cnt.end(), o);
+            uint16_t *L = loc.data() + (size_t)s * K;
+            uint32_t *Cd = cid.data() + (size_t)s * K;
+            for (uint32_t k = 0; k < K; ++k) {   // ascending k inside a tile: a stable order
+                const uint32_t i = sup[k];
+                const uint32_t l = tl[0][i & 255u] | tl[1][(i >> 8) & 255u] | tl[2][(i >> 16) & 255u] | tl[3][i >> 24];
+                const uint32_t pos = cnt[tile_of[k]]++;
+                L[pos] = (uint16_t)l;
+                Cd[pos] = k;   // compact id of the element at this tile-sorted position
+            }
+        }
+    };
+    {
+        const int nthr = std::max(1, std::min<int>({ns, 16, (int)std::thread::hardware_concurrency()}));
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthr; ++t) pool.emplace_back(work, (int)((int64_t)ns * t / nthr), (int)((int64_t)ns * (t + 1) / nthr));
+        for (std::thread &t : pool) t.join();
+    }
+    rc = upload(h, C.d_sup, sup.data(), (size_t)K * sizeof(uint32_t));
+    if (!rc) rc = upload(h, C.d_loc, loc.data(), loc.size() * sizeof(uint16_t));
+    if (!rc) rc = upload(h, C.d_cid, cid.data(), cid.size() * sizeof(uint32_t));
+    if (!rc) rc = upload(h, C.d_off, off.data(), off.size() * sizeof(uint32_t));
+    if (!rc) rc = ensure(h, C.d_psic, ((size_t)ns + 1) * K * sizeof(double));   // [compact state][per-sweep tile order]
+    if (!rc) rc = upload(h, C.d_sweeps, H.tsweeps.data(), (size_t)ns * sizeof(ExSweep));
+    if (rc) return rc;
+    C.K = K;
+    C.ntiles = ntiles;
+    C.max_nnz = *std::max_element(maxn.begin(), maxn.end());
+    C.valid = true;
+    C.disabled = false;
+    return OVQE_OK;
+}
+
+template <int M>
+int launch_tile_expect_compact(ovqe_handle h, const HamDev &H, double2 *partials) {
+    constexpr int NT = 1 << TILE_EXPECT_LOG_NT;
+    const CompactCover &C = h->cc;
+    const int cpp = h->opt_compact_cpp, term_cap = cpp * TILE_TERM_CAP, group_cap = cpp * TILE_APPLY_GROUPS;
+    const size_t smem = ((size_t)8 << M) + (size_t)term_cap * sizeof(ExTermLds) + (size_t)group_cap * sizeof(ExAGroupT) +
+                        (NT / 64) * sizeof(double2) + (((size_t)C.max_nnz * 2 + 15) & ~(size_t)15);
+    static bool attr_done_dev[64] = {};
+    bool &attr_done = attr_done_dev[h->device & 63];
+    if (!attr_done) {
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_expect_compact<M, NT, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_tile_expect_compact<M, NT, true>), dim3((unsigned)C.ntiles, (unsigned)H.tsweeps.size()), dim3(NT),
+                       smem, h->stream, (const double *)C.d_psic.p + C.K, (const uint16_t *)C.d_loc.p, (const uint32_t *)C.d_off.p,
+                       h->base, (const ExSweep *)C.d_sweeps.p, C.K, (const ExChunkT *)H.d_achunks.p,
+                       (const ExAGroupT *)H.d_agroups.p, (const ExTermT *)H.d_aterms.p, partials, term_cap, group_cap, cpp);
+    HIPC(h, hipGetLastError());
+    return OVQE_OK;
+}
+
+// <state|H|state> of a real state through the compact cover; *ok = false when the guard failed (support not closed)
+int run_expectation_compact(ovqe_handle h, HamDev &H, double2 *out, bool *ok) {
+    CompactCover &C = h->cc;
+    *ok = false;
+    const int ns = (int)H.tsweeps.size();
+    const uint64_t total = (uint64_t)ns * C.K;
+    const int nbg = (int)std::min<uint32_t>(2048u, (C.K + 255u) / 256u);
+    const size_t nslots = (size_t)ns * C.ntiles;
+    int rc = ensure(h, h->d_partials, (nslots + (size_t)ns + nbg) * sizeof(double2));
+    if (!rc) rc = ensure(h, h->d_result, 64 * sizeof(double2));
+    if (rc) return rc;
+    double2 *partials = (double2 *)h->d_partials.p, *rows = partials + nslots, *pnorm = rows + ns;
+    hipLaunchKernelGGL(k_compact_gather<true>, dim3(nbg), dim3(256), 0, h->stream, (const double *)h->state,
+                       (const uint32_t *)C.d_sup.p, C.K, (double *)C.d_psic.p, pnorm);
+    hipLaunchKernelGGL(k_compact_permute<true>, dim3((unsigned)std::min<uint64_t>(16384u, (total + 255u) / 256u)), dim3(256), 0,
+                       h->stream, (const double *)C.d_psic.p, (const uint32_t *)C.d_cid.p, total, (double *)C.d_psic.p + C.K);
+    switch (H.tile_bits) {
+    case 11: rc = launch_tile_expect_compact<11>(h, H, partials); break;
+    case 12: rc = launch_tile_expect_compact<12>(h, H, partials); break;
+    default: rc = launch_tile_expect_compact<13>(h, H, partials); break;
+    }
+    if (rc) return rc;
+    // fixed-order reduction: per sweep over its tiles, then over the sweeps
+    hipLaunchKernelGGL(k_reduce_rows2, dim3((unsigned)ns), dim3(256), 0, h->stream, (const double2 *)partials, (int)C.ntiles, rows);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->stream, (const double2 *)rows, (int64_t)ns, (double2 *)h->d_result.p, 0);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->stream, (const double2 *)pnorm, (int64_t)nbg,
+                       (double2 *)h->d_result.p, 1);
+    HIPC(h, hipGetLastError());
+    HIPC(h, hipMemcpyAsync(h->h_result, h->d_result.p, 2 * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    // guard: the circuit is unitary, so the amplitudes on the support must carry the whole norm
+    if (std::fabs(h->h_result[1].x - 1.0) > 1e-9) return OVQE_OK;
+    *out = h->h_result[0];
+    *ok = true;
     return OVQE_OK;
 }
 
@@ -1264,6 +1443,7 @@ int finish_program(ovqe_handle h) {
     rc = build_tile_program(h);
     if (rc) return rc;
     h->tp_real_built = false;
+    h->prog_version++;
     h->prog_real_ok = !h->ops.empty();
     for (const SmallOp &op : h->ops) h->prog_real_ok = h->prog_real_ok && op.kind != OP_DIAG;
     for (const SmallRot &sr : h->rots) h->prog_real_ok = h->prog_real_ok && (sr.ny & 1);
@@ -1989,7 +2169,7 @@ int ovqe_destroy(ovqe_handle h) {
                                   &h->d_stream,
                                   &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups, &h->d_eterms, &h->d_echunks,
                                   &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries, &h->d_pg_off, &h->d_pg_xs, &h->d_pg_terms,
-                                  &h->d_pg_out, &h->d_pg_part};
+                                  &h->d_pg_out, &h->d_pg_part, &h->cc.d_sup, &h->cc.d_psic, &h->cc.d_loc, &h->cc.d_cid, &h->cc.d_off, &h->cc.d_sweeps};
     for (TilePlan *tp : {&h->tp, &h->tp_adhoc, &h->tp_real}) bufs.insert(bufs.end(), {&tp->d_tops, &tp->d_trots});
     for (HamDev *H : {&h->ham, &h->ham_adhoc, &h->ham_real})
         bufs.insert(bufs.end(), {&H->d_groups, &H->d_terms, &H->d_tchunks, &H->d_tgroups, &H->d_tterms, &H->d_tflats,
@@ -2047,6 +2227,13 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     }
     else if (k == "expect_sparse") h->opt_expect_sparse = (int)std::max<int64_t>(0, value);
     else if (k == "expect_streams") h->opt_expect_streams = value >= 2 ? 2 : 1;
+    else if (k == "compact_cpp") h->opt_compact_cpp = (int)std::min<int64_t>(4, std::max<int64_t>(1, value));
+    else if (k == "compact") {
+        h->opt_compact = value ? 1 : 0;
+        h->cc.valid = false;
+        h->cc.disabled = false;
+        h->cc.seen = 0;
+    }
     else if (k == "persist_blocks") h->opt_persist_blocks = (int)value;
     else if (k == "small_threads") {
         h->opt_small_threads = (int)value;
@@ -2430,11 +2617,41 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
             R.tile_bits = -1;
             R.version = h->ham.version;
         }
+        bool use_cc = false;
+        if (real && h->opt_compact && h->n_local >= 18) {
+            // compact cover: built at the second evaluation of a (program, Hamiltonian) pair — one-shot callers never pay
+            HamDev &R = h->ham_real;
+            CompactCover &C = h->cc;
+            if (R.tile_bits != tile_bits(h, true) || R.tile_low != h->opt_tile_low || !R.tile_real) {
+                rc = build_ham_tiles(h, R, true);
+                if (rc) return rc;
+            }
+            if (C.prog_version != h->prog_version || C.ham_version != R.version || C.cover_id != R.cover_id) {
+                C.valid = C.disabled = false;
+                C.prog_version = h->prog_version;
+                C.ham_version = R.version;
+                C.cover_id = R.cover_id;
+                C.seen = 0;
+            }
+            if (!C.valid && !C.disabled && ++C.seen >= 2) {
+                rc = build_compact_cover(h, R);
+                if (rc) return rc;
+            }
+            use_cc = C.valid;
+        }
         rc = run_program_streaming(h, theta + b * (int64_t)K, real);
         if (rc) return rc;
         double2 res;
         bool tiled = false;
-        rc = run_expectation_tiled(h, real ? h->ham_real : h->ham, &res, &tiled, real);
+        if (use_cc) {
+            rc = run_expectation_compact(h, h->ham_real, &res, &tiled);
+            if (rc) return rc;
+            if (!tiled) {  // the state left the recorded support: this program does not qualify
+                h->cc.valid = false;
+                h->cc.disabled = true;
+            }
+        }
+        if (!tiled) rc = run_expectation_tiled(h, real ? h->ham_real : h->ham, &res, &tiled, real);
         if (rc) return rc;
         if (real && !tiled) return fail(h, OVQE_ERR_INVALID, "internal: real-amplitude path without a tile cover");
         if (!tiled)

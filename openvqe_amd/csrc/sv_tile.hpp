@@ -230,7 +230,7 @@ struct ExTermLds {
 // vector instructions: j & z, popcount, the coefficient's high word + parity << 31 (a carry-free sign flip), and the add.
 constexpr int TILE_SPARSE_TERMS = 1024;   // terms staged in LDS per chunk of the sparse path
 constexpr int TILE_SPARSE_GROUPS = 384;   // pieces per chunk
-template <bool REAL, int NQ>
+template <bool REAL, int NQ, bool SWZ = true>
 __device__ __forceinline__ double tile_sparse_pieces(const typename Amp<REAL>::T *tile, const uint16_t *nz, int nnz, int lb,
                                                      uint32_t lane, const ExAGroupT *sg, int g_begin, int g_end, int g_step,
                                                      const ExTermLds *st) {
@@ -243,7 +243,7 @@ __device__ __forceinline__ double tile_sparse_pieces(const typename Amp<REAL>::T
         const int l = lb + 64 * q + (int)lane;
         live[q] = l < nnz;
         ii[q] = live[q] ? nz[l] : 0u;
-        a[q] = tile[tile_swz<REAL>(ii[q])];
+        a[q] = tile[SWZ ? tile_swz<REAL>(ii[q]) : ii[q]];
     }
     double part = 0.0;
     for (int g = g_begin; g < g_end; g += g_step) {
@@ -255,7 +255,7 @@ __device__ __forceinline__ double tile_sparse_pieces(const typename Amp<REAL>::T
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             jj[q] = ii[q] ^ xl;
-            const amp c = tile[tile_swz<REAL>(jj[q])];
+            const amp c = tile[SWZ ? tile_swz<REAL>(jj[q]) : jj[q]];
             if constexpr (REAL) {
                 vx[q] = live[q] ? a[q] * c : 0.0;
                 vy[q] = 0.0;
@@ -555,6 +555,134 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
     const double2 t = block_sum<NT>(make_double2(acc, 0.0), red);
     if (threadIdx.x == 0) {
         const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        if (accumulate) {
+            const double2 o = partials[slot];
+            partials[slot] = make_double2(o.x + t.x, o.y);
+        } else {
+            partials[slot] = t;
+        }
+    }
+}
+
+// ---- <psi|H|psi> on the COMPACTED support (the tile cover above, fed from a compact state) -------------------------
+// A state whose non-zero amplitudes are a small, parameter-independent subset S of the register (the particle-number /
+// spin sector of a UCC-type ansatz: 3.7 % at 24 qubits / 10 electrons) is gathered once per evaluation into psic[k] =
+// psi[sup[k]]; for every sweep of the cover the host keeps S sorted by tile — (tile-local index, compact id) per element,
+// offsets per tile — so a workgroup builds its LDS tile from ~150 gathered amplitudes instead of reading 2^M of them from
+// HBM, and evaluates the sweep's pieces over exactly that list (tile_sparse_pieces).  Same arithmetic as the sparse
+// tiles of k_tile_expect, summation order fixed by the host's stable sort.  The support is found structurally-by-example
+// (non-zeros of the state prepared at a generic parameter vector) and guarded at every evaluation: the compact state
+// must carry the whole norm, otherwise the evaluation is redone on the dense cover (ovqe_sv.hip, compact cover).
+template <bool REAL>
+__global__ __launch_bounds__(256) void k_compact_gather(const typename Amp<REAL>::T *__restrict__ st,
+                                                        const uint32_t *__restrict__ sup, uint32_t K,
+                                                        typename Amp<REAL>::T *__restrict__ psic,
+                                                        double2 *__restrict__ partials) {
+    // psic[k] = psi[sup[k]] (ascending indices: one touch of every occupied line of the dense state) + the norm carried
+    // by the support, per workgroup
+    __shared__ double2 red[4];
+    double acc = 0.0;
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < K; k += gridDim.x * 256u) {
+        const typename Amp<REAL>::T a = st[sup[k]];
+        psic[k] = a;
+        if constexpr (REAL) acc += a * a; else acc += a.x * a.x + a.y * a.y;
+    }
+    const double2 t = block_sum<256>(make_double2(acc, 0.0), red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// vals[s * K + pos] = psic[cid[s * K + pos]]: the compact state in the tile order of every sweep (coalesced writes, the
+// source is cache-resident)
+template <bool REAL>
+__global__ __launch_bounds__(256) void k_compact_permute(const typename Amp<REAL>::T *__restrict__ psic,
+                                                         const uint32_t *__restrict__ cid, uint64_t total,
+                                                         typename Amp<REAL>::T *__restrict__ vals) {
+    for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k < total; k += (uint64_t)gridDim.x * 256u)
+        vals[k] = psic[cid[k]];
+}
+
+template <int M, int NT, bool REAL>
+__global__ __launch_bounds__(NT) void k_tile_expect_compact(const typename Amp<REAL>::T *__restrict__ vals,
+                                                            const uint16_t *__restrict__ loc,
+                                                            const uint32_t *__restrict__ off, uint64_t base,
+                                                            const ExSweep *__restrict__ sweeps, uint32_t K,
+                                                            const ExChunkT *__restrict__ achunks,
+                                                            const ExAGroupT *__restrict__ agroups,
+                                                            const ExTermT *__restrict__ aterms,
+                                                            double2 *__restrict__ partials, int term_cap,
+                                                            int group_cap, int chunks_per_pass) {
+    // ONE launch for the whole cover: blockIdx.y = sweep, blockIdx.x = tile.  The compute-heavy sweeps (hundreds of
+    // x-groups) and the latency-bound ones (a handful of groups per tile) share the chip instead of running back to back.
+    const ExSweep sw = sweeps[blockIdx.y];
+    vals += (size_t)blockIdx.y * K;
+    loc += (size_t)blockIdx.y * K;
+    off += (size_t)blockIdx.y * (gridDim.x + 1);
+    constexpr int accumulate = 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename Amp<REAL>::T amp;
+    constexpr uint32_t NEL = 1u << M;
+    amp *tile = reinterpret_cast<amp *>(smem);                                   // natural order (no bank swizzle)
+    ExTermLds *spt = reinterpret_cast<ExTermLds *>(smem + (size_t)NEL * sizeof(amp));
+    ExAGroupT *spg = reinterpret_cast<ExAGroupT *>(spt + term_cap);
+    double2 *red = reinterpret_cast<double2 *>(spg + group_cap);
+    uint16_t *nz = reinterpret_cast<uint16_t *>(red + NT / 64);
+    const uint32_t n0 = off[blockIdx.x], nnz = off[blockIdx.x + 1] - n0;
+    const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (nnz == 0) {   // no support in this tile (uniform): contributes nothing
+        if (threadIdx.x == 0 && !accumulate) partials[slot] = make_double2(0.0, 0.0);
+        return;
+    }
+    uint64_t tb = blockIdx.x;
+    for (uint64_t mk = sw.smask; mk; mk &= mk - 1ull) tb = insert_zero(tb, __ffsll((long long)mk) - 1);
+    const uint64_t gbase = base | (REAL ? tb << 1 : tb);
+    {
+        double2 *tz = reinterpret_cast<double2 *>(smem);
+        constexpr uint32_t NV = NEL * sizeof(amp) / sizeof(double2);
+        for (uint32_t v = threadIdx.x; v < NV; v += NT) tz[v] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nnz; k += NT) {
+        const uint32_t l = loc[n0 + k];
+        tile[l] = vals[n0 + k];
+        nz[k] = (uint16_t)l;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u;
+    double acc = 0.0;
+    for (int ch = sw.a0; ch < sw.a1; ch += chunks_per_pass) {
+        const ExChunkT c0 = achunks[ch], c1 = achunks[min(ch + chunks_per_pass, (int)sw.a1) - 1];
+        const int tb0 = c0.t0, tb1 = c1.t1, gb0 = c0.g0, gb1 = c1.g1;
+        __syncthreads();  // tile + list complete / previous pass's tables no longer read
+        for (int t = tb0 + (int)threadIdx.x; t < tb1; t += NT) {
+            const ExTermT et = aterms[t];
+            const bool neg = parity64(gbase & et.zout);
+            ExTermLds l;
+            l.cr = neg ? -et.cr : et.cr;
+            l.ci = neg ? -et.ci : et.ci;
+            l.zin = et.zin;
+            l.pad = 0;
+            spt[t - tb0] = l;
+        }
+        for (int g = gb0 + (int)threadIdx.x; g < gb1; g += NT) {
+            ExAGroupT gr = agroups[g];
+            gr.t0 -= tb0;
+            gr.t1 -= tb0;
+            spg[g - gb0] = gr;
+        }
+        __syncthreads();
+        const int gfirst = wave, gstep = NT / 64, ng = gb1 - gb0;
+        for (int lb = 0; lb < (int)nnz; lb += 256) {
+            switch (min(4, ((int)nnz - lb + 63) >> 6)) {
+            case 1: acc += tile_sparse_pieces<REAL, 1, false>(tile, nz, (int)nnz, lb, lane, spg, gfirst, ng, gstep, spt); break;
+            case 2: acc += tile_sparse_pieces<REAL, 2, false>(tile, nz, (int)nnz, lb, lane, spg, gfirst, ng, gstep, spt); break;
+            case 3: acc += tile_sparse_pieces<REAL, 3, false>(tile, nz, (int)nnz, lb, lane, spg, gfirst, ng, gstep, spt); break;
+            default: acc += tile_sparse_pieces<REAL, 4, false>(tile, nz, (int)nnz, lb, lane, spg, gfirst, ng, gstep, spt); break;
+            }
+        }
+    }
+    __syncthreads();
+    const double2 t = block_sum<NT>(make_double2(acc, 0.0), red);
+    if (threadIdx.x == 0) {
         if (accumulate) {
             const double2 o = partials[slot];
             partials[slot] = make_double2(o.x + t.x, o.y);

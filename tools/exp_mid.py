@@ -8,7 +8,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 if "--cache" in sys.argv: args = [a for a in args if a != sys.argv[sys.argv.index("--cache") + 1]]
 m, o = (int(args[0]), int(args[1])) if len(args) > 1 else (12, 5)
 cache = sys.argv[sys.argv.index("--cache") + 1] if "--cache" in sys.argv else None
-reps = 1 if "--once" in sys.argv else 2
+reps = 1 if "--once" in sys.argv else 4
 t = time.time()
 if cache and os.path.exists(cache):
     ham, gens, hf = pickle.load(open(cache, "rb"))

@@ -7,6 +7,6 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/tools/exp_mid.py 12 5 --cache /tmp/wl24.pkl > $OUT/plain.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/tools/exp_mid.py 12 5 --cache /tmp/wl24.pkl > $OUT/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/tools/exp_mid.py 12 5 --cache /tmp/wl24.pkl --once > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/tools/exp_mid.py 12 5 --cache /tmp/wl24.pkl --once > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/tools/exp_mid.py 12 5 --cache /tmp/wl24.pkl > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/tools/exp_mid.py 12 5 --cache /tmp/wl24.pkl > $OUT/pmc_write.log 2>&1
 tail -3 $OUT/plain.log
