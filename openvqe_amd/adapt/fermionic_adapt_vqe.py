@@ -18,6 +18,7 @@ from ..backend import GRAD_FERMIONIC, Statevector
 from ..common_files.circuit import count
 from ..common_files.sorted_gradient import abs_sort_desc, corresponding_index, index_without_0, value_without_0
 from ..evaluator import UCCEvaluator
+from .driver import AdaptEngine, Flavour, rank_gradients
 from ..qat_compat import Program, X, build_ucc_ansatz, get_default_qpu
 
 _DENSE_EIGH_MAX_QUBITS = 12
@@ -59,6 +60,14 @@ def return_gradient_list(cluster_ops_sp, hamiltonian_sp, screen):
             next_deriv = gi
             next_index = oi
     return list_grad, curr_norm, next_deriv, next_index
+
+
+def return_signed_gradients(cluster_ops_sp, hamiltonian_sp, screen):
+    """g_i = 2 Re <sigma|A_i|psi> for every pool operator, signed, one device call"""
+    if getattr(screen, "_ham_token", None) is not hamiltonian_sp:
+        screen.set_hamiltonian(hamiltonian_sp)
+        screen._ham_token = hamiltonian_sp
+    return [float(g) for g in screen.pool_gradients(cluster_ops_sp, GRAD_FERMIONIC)]
 
 
 _evaluators = {}
@@ -138,105 +147,91 @@ def _ground_space(hamiltonian_sp):
     return np.array([energy]), sv.get_state().reshape(-1, 1)
 
 
+_FLAVOUR = Flavour(
+    title="Fermionic_ADAPT-VQE iteration: ",
+    stall=1e-8,
+    trace_keys={"energy": "energies", "error": "energies_substracted_from_FCI", "norm": "norms",
+                "leader": "Max_gradients", "fidelity": "fidelity"},
+)
+
+
+def _announce(threshold_needed, max_external_iterations, n_max_grads, optimizer, tolerance):
+    for text, value in (("threshold needed for convergence", threshold_needed),
+                        ("Max_external_iterations:", max_external_iterations),
+                        ("how many maximum gradient are selected", n_max_grads),
+                        ("The optimizer method used:", optimizer),
+                        ("Tolerance for reaching convergence", tolerance)):
+        print(text, value)
+
+
+def _banner(title, n_iter):
+    rule = " " + "-" * 74
+    print("\n\n\n")
+    print(rule)
+    print(" " * 21 + title, n_iter)
+    print(rule)
+
+
 def fermionic_adapt_vqe(hamiltonian_sparse, cluster_ops_sparse, reference_ket, hamiltonian_sp, cluster_ops_sp,
                         hf_init_sp, n_max_grads, fci, optimizer, tolerance, type_conver, threshold_needed,
                         max_external_iterations=30):
-    """The ADAPT grow / optimise / converge loop of fermionic_adapt_vqe.py:371-593."""
-    iterations = {"energies": [], "energies_substracted_from_FCI": [], "norms": [], "Max_gradients": [],
-                  "fidelity": [], "CNOTs": [], "Hadamard": [], "RY": [], "RX": []}
+    """Fermionic ADAPT-VQE with the reference's signature and result schemas (fermionic_adapt_vqe.py:371-593); the loop
+    itself is ``adapt.driver.AdaptEngine``.  Per iteration: device gradient screen over the whole pool on the
+    exact-exponential state, ranking, stop test, ``n_max_grads`` new generators 1j * A at 0.01, re-optimisation of all
+    parameters on the compiled Trotterised ansatz, trace record (energy, error, norm, leading gradient, fidelity, gates)."""
+    nbqbits = hamiltonian_sp.nbqbits
+    trace = {key: [] for key in (*_FLAVOUR.trace_keys.values(), *_FLAVOUR.gate_keys)}
     result = {}
-    print("threshold needed for convergence", threshold_needed)
-    print("Max_external_iterations:", max_external_iterations)
-    print("how many maximum gradient are selected", n_max_grads)
-    print("The optimizer method used:", optimizer)
-    print("Tolerance for reaching convergence", tolerance)
-    ansatz_ops = []      # Hermitian generators 1j * A_k (energy circuit)
-    ansatz_pool = []     # anti-Hermitian A_k (exact-exponential screen state)
-    op_indices = []
-    parameters_ansatz = []
+    _announce(threshold_needed, max_external_iterations, n_max_grads, optimizer, tolerance)
     eigenvalues, eigenvectors = _ground_space(hamiltonian_sp)
-    hf_state = prepare_hf_state(hf_init_sp, cluster_ops_sp)
-    ref_energy = hf_energy(hf_state, hamiltonian_sp)
+    hf_circuit = prepare_hf_state(hf_init_sp, cluster_ops_sp)
+    ref_energy = hf_energy(hf_circuit, hamiltonian_sp)
     print(ref_energy)
     print(" The reference energy of the molecular system is: %12.8f" % ref_energy)
-    curr_state = hf_state
-    screen = prepare_adapt_state(hf_init_sp, [], [], hamiltonian_sp)
-    prev_norm = 0.0
-    opt_result = None
-    for n_iter in range(0, max_external_iterations):
-        print("\n\n\n")
-        print(" --------------------------------------------------------------------------")
-        print("                     Fermionic_ADAPT-VQE iteration: ", n_iter)
-        print(" --------------------------------------------------------------------------")
+    state = {"screen": prepare_adapt_state(hf_init_sp, [], [], hamiltonian_sp)}
+
+    def rebuild(selected, theta):
+        state["screen"] = prepare_adapt_state(hf_init_sp, [cluster_ops_sp[i] for i in selected], theta, hamiltonian_sp)
+        return prepare_state_ansatz(engine.generators, hf_init_sp, theta)
+
+    engine = AdaptEngine(
+        flavour=_FLAVOUR, pool=cluster_ops_sp,
+        screen_gradients=lambda: return_signed_gradients(cluster_ops_sp, hamiltonian_sp, state["screen"]),
+        energy=lambda gens, t: ucc_action(hamiltonian_sp, gens, hf_init_sp, t),
+        make_generator=lambda idx: complex(0.0, 1.0) * cluster_ops_sp[idx],
+        new_parameters=lambda values, index, how_many: [0.01] * how_many,
+        rebuild=rebuild)
+    engine.circuit = hf_circuit
+    for n_iter in range(max_external_iterations):
+        _banner(_FLAVOUR.title, n_iter)
         print(" Check gradient list chronological order")
-        list_grad, curr_norm, next_deriv, next_index = return_gradient_list(cluster_ops_sp, hamiltonian_sp, screen)
-        sorted_values, sorted_index = print_gradient_lists_and_indices(list_grad)
-        curr_norm = np.sqrt(curr_norm)
-        print(" Norm of the gradients in current iteration = %12.8f" % curr_norm)
-        print(" Max gradient in current iteration= %12.8f" % next_deriv)
-        print(" Index of the Max gradient in current iteration= ", next_index)
-        nbqbits = hamiltonian_sp.nbqbits
-        fid = fun_fidelity(curr_state, eigenvalues, eigenvectors, nbqbits)
-        converged = False
-        if type_conver == "norm":
-            if curr_norm < threshold_needed:
-                converged = True
-        else:
-            print(" type convergence is not defined")
-            raise SystemExit()
-        if converged or (abs(curr_norm - prev_norm) < 10 ** (-8)):
+        signed, norm, leader, leader_at = engine.screen()
+        ranked, ranked_index = rank_gradients([abs(g) for g in signed])
+        print(" Norm of the gradients in current iteration = %12.8f" % norm)
+        print(" Max gradient in current iteration= %12.8f" % leader)
+        print(" Index of the Max gradient in current iteration= ", leader_at)
+        fidelity = fun_fidelity(engine.circuit, eigenvalues, eigenvectors, nbqbits)
+        if engine.should_stop(norm, type_conver, threshold_needed):
             print("Convergence is done")
-            result["indices"] = op_indices
-            result["Number_operators"] = len(ansatz_ops)
-            result["final_norm"] = curr_norm
-            result["parameters"] = parameters_ansatz
-            gates = curr_state.ops
-            result["Number_CNOT_gates"] = count("CNOT", gates)
-            result["Number_Hadamard_gates"] = count("H", gates)
-            result["Number_RX_gates"] = count("RX", gates)
+            gates = engine.circuit.ops
+            result.update(indices=engine.selected, Number_operators=len(engine.generators), final_norm=norm,
+                          parameters=engine.theta, Number_CNOT_gates=count("CNOT", gates),
+                          Number_Hadamard_gates=count("H", gates), Number_RX_gates=count("RX", gates))
             print(" -----------Final ansatz----------- ")
-            # the reference reads opt_result here and dies with NameError when it converges at iteration 0
-            print(" *final converged energy iteration is %20.12f" % opt_result.fun)
-            result["final_energy_last_iteration"] = opt_result.fun
+            fit = engine.require_fit()
+            print(" *final converged energy iteration is %20.12f" % fit.fun)
+            result["final_energy_last_iteration"] = fit.fun
             break
-        chosen_batch = sorted_values
-        gamma1 = []
-        sorted_index1 = []
-        curr_norm1 = 0
-        for z in chosen_batch:
-            curr_norm1 += z * z
-        curr_norm1 = np.sqrt(curr_norm1)
-        for i in range(n_max_grads):
-            gamma1.append(chosen_batch[i] / curr_norm1)
-            sorted_index1.append(sorted_index[i])
-        print("sorted_index1: ", sorted_index1)
-        for idx in sorted_index1:
-            parameters_ansatz.append(0.01)
-            ansatz_ops.append(complex(0.0, 1.0) * cluster_ops_sp[idx])
-            ansatz_pool.append(cluster_ops_sp[idx])
-            op_indices.append(idx)
-        opt_result = scipy.optimize.minimize(
-            lambda parameters: ucc_action(hamiltonian_sp, ansatz_ops, hf_init_sp, parameters),
-            x0=parameters_ansatz, method=optimizer, tol=tolerance, options={"maxiter": 100000, "disp": True})
-        xlist = opt_result.x
-        print(" Finished energy iteration_i: %20.12f" % opt_result.fun)
+        ranked_norm = float(np.sqrt(sum(v * v for v in ranked)))
+        picks = engine.grow(ranked, ranked_index, n_max_grads)
+        print("sorted_index1: ", picks)
+        fit = engine.optimise(optimizer, tolerance)
+        print(" Finished energy iteration_i: %20.12f" % fit.fun)
         print(" -----------New ansatz created----------- ")
         print(" %4s \t%s \t%s" % ("#", "Coefficients", "Term"))
-        parameters_ansatz = []
-        for si in range(len(ansatz_ops)):
-            print(" %4i \t%f \t%s" % (si, xlist[si], op_indices[si]))
-            parameters_ansatz.append(xlist[si])
-        curr_state = prepare_state_ansatz(ansatz_ops, hf_init_sp, parameters_ansatz)
-        screen = prepare_adapt_state(hf_init_sp, ansatz_pool, parameters_ansatz, hamiltonian_sp)
-        prev_norm = curr_norm
-        gates = curr_state.ops
-        iterations["energies"].append(opt_result.fun)
-        iterations["energies_substracted_from_FCI"].append(abs(opt_result.fun - fci))
-        iterations["norms"].append(curr_norm1)
-        iterations["Max_gradients"].append(sorted_values[0])
-        iterations["fidelity"].append(fid)
-        iterations["CNOTs"].append(count("CNOT", gates))
-        iterations["Hadamard"].append(count("H", gates))
-        iterations["RY"].append(count("RY", gates))
-        iterations["RX"].append(count("RX", gates))
-    return iterations, result
+        for k, (t, idx) in enumerate(zip(engine.theta, engine.selected)):
+            print(" %4i \t%f \t%s" % (k, t, idx))
+        engine.previous_norm = norm
+        engine.record(trace, {"energy": fit.fun, "error": abs(fit.fun - fci), "norm": ranked_norm, "leader": ranked[0],
+                              "fidelity": fidelity})
+    return trace, result

@@ -11,8 +11,8 @@ from numpy import binary_repr
 
 from ..backend import GRAD_QUBIT, Statevector
 from ..common_files.circuit import count
-from ..common_files.sorted_gradient import abs_sort_desc, corresponding_index, index_without_0, value_without_0
 from ..evaluator import UCCEvaluator
+from .driver import AdaptEngine, Flavour, iterated_root_norm, rank_gradients
 from ..qat_compat import Program, X, build_ucc_ansatz, get_default_qpu
 
 _screens = {}
@@ -86,125 +86,95 @@ def ucc_action(hamiltonian_sp, cluster_ops_sp, hf_init_sp, theta_current):
     return ev.energy(np.asarray(theta_current, dtype=float)[:n_params])
 
 
+_FLAVOUR = Flavour(
+    title="Qubit ADAPT-VQE iteration: ",
+    stall=1e-7,
+    trace_keys={"energy": "energies", "error": "energies_substracted_from_fci", "norm": "norms", "leader": "Max_gradient"},
+    unknown_criterion=" FAIL: Convergence criterion not defined",
+    optimiser_display=False,
+)
+_RULE = " " + "-" * 74
+_SHORT_RULE = " " + "-" * 54
+
+
+def _boxed(text, rule=_RULE, pad=True):
+    print(rule)
+    if pad:
+        print(" " * 58)
+    print(text)
+    if pad:
+        print(" " * 58)
+    print(rule)
+
+
 def qubit_adapt_vqe(hamiltonian_sp, hamiltonian_sp_sparse, reference_ket, nqubits, pool_mix, hf_init_sp, fci,
                     n_max_grads=2, adapt_conver="norm", adapt_thresh=1e-08, adapt_maxiter=45, tolerance_sim=1e-07,
                     method_sim="BFGS"):
-    """The qubit-ADAPT loop of qubit_adapt_vqe.py:310-605; returns
-    (iterations_sim, iterations_ana, result_sim, result_ana) with the 'ana' dicts left empty like the reference."""
-    iterations_sim = {"energies": [], "energies_substracted_from_fci": [], "norms": [], "Max_gradient": [],
-                      "CNOTs": [], "Hadamard": [], "RY": [], "RX": []}
-    result_sim = {}
-    iterations_ana = {"energies": [], "energies_substracted_from_fci": [], "norms": [], "Max_gradient": []}
-    result_ana = {}
-    parameters_sim = []
-    parameters_ana = []
-    ansatz_ops = []
-    curr_state = prepare_hf_state(hf_init_sp, pool_mix)
-    ref_energy = hf_energy(curr_state, hamiltonian_sp)
-    screen = prepare_adapt_state(hf_init_sp, ansatz_ops, parameters_ana, nqubits)
-    if getattr(screen, "_ham_token", None) is not hamiltonian_sp:
-        screen.set_hamiltonian(hamiltonian_sp)
-        screen._ham_token = hamiltonian_sp
-    ref_energy_ana = screen.expectation(hamiltonian_sp)
+    """Qubit ADAPT-VQE with the reference's signature and result schemas (qubit_adapt_vqe.py:310-605); returns
+    (iterations_sim, iterations_ana, result_sim, result_ana), the 'ana' pair left empty like the reference.  The loop is
+    ``adapt.driver.AdaptEngine``: device screen 2 |<psi|H P_i|psi>| over the pool of Pauli strings, ranking, stop test,
+    ``n_max_grads`` new strings whose parameters start at (gradient / iterated-root norm), re-optimisation, record."""
+    trace = {key: [] for key in (*_FLAVOUR.trace_keys.values(), *_FLAVOUR.gate_keys)}
+    result_sim, result_ana = {}, {}
+    iterations_ana = {key: [] for key in _FLAVOUR.trace_keys.values()}
+    hf_circuit = prepare_hf_state(hf_init_sp, pool_mix)
+    ref_energy = hf_energy(hf_circuit, hamiltonian_sp)
+    state = {"screen": prepare_adapt_state(hf_init_sp, [], [], nqubits)}
+    if getattr(state["screen"], "_ham_token", None) is not hamiltonian_sp:
+        state["screen"].set_hamiltonian(hamiltonian_sp)
+        state["screen"]._ham_token = hamiltonian_sp
     print("reference_energy from the simulator:", ref_energy)
-    print("reference_energy from the analytical calculations:", ref_energy_ana)
-    print(" --------------------------------------------------------------------------")
-    print("                                                          ")
-    print("                      Start Qubit ADAPT-VQE algorithm:")
-    print("                                                          ")
-    print(" --------------------------------------------------------------------------")
-    print("                                                          ")
-    Y = int(n_max_grads)
-    print(" ------------------------------------------------------")
-    print("        The number of maximum gradients inserted in each iteration:", Y)
-    print(" ------------------------------------------------------")
-    op_indices = []
-    prev_norm = 0.0
-    opt_result_sim = None
+    print("reference_energy from the analytical calculations:", state["screen"].expectation(hamiltonian_sp))
+    _boxed(" " * 22 + "Start Qubit ADAPT-VQE algorithm:")
+    print(" " * 58)
+    how_many = int(n_max_grads)
+    _boxed("        The number of maximum gradients inserted in each iteration: %d" % how_many, _SHORT_RULE, pad=False)
+
+    def rebuild(selected, theta):
+        state["screen"] = prepare_adapt_state(hf_init_sp, engine.generators, theta, nqubits)
+        return prepare_state_ansatz(engine.generators, hf_init_sp, theta)
+
+    def start_values(ranked, ranked_index, count_new):
+        scale = iterated_root_norm(ranked)
+        return [ranked[k] / scale for k in range(count_new)]
+
+    engine = AdaptEngine(
+        flavour=_FLAVOUR, pool=pool_mix,
+        screen_gradients=lambda: calculate_gradients(pool_mix, hamiltonian_sp, state["screen"]),
+        energy=lambda gens, t: ucc_action(hamiltonian_sp, gens, hf_init_sp, t),
+        make_generator=lambda idx: pool_mix[idx], new_parameters=start_values, rebuild=rebuild)
+    engine.circuit = hf_circuit
     for n_iter in range(adapt_maxiter):
         print("\n")
-        print(" --------------------------------------------------------------------------")
-        print("                         Qubit ADAPT-VQE iteration: ", n_iter)
-        print(" --------------------------------------------------------------------------")
-        next_deriv = 0
-        curr_norm = 0
+        print(_RULE)
+        print(" " * 25 + _FLAVOUR.title, n_iter)
+        print(_RULE)
         print("\n")
-        print(" ------------------------------------------------------")
-        print("        Start the analytical gradient calculation:")
-        print(" ------------------------------------------------------")
-        list_grad = calculate_gradients(pool_mix, hamiltonian_sp, screen)
-        for gi in list_grad:
-            curr_norm += gi * gi
-            if abs(gi) > abs(next_deriv):
-                next_deriv = gi
-        values = value_without_0(list_grad)
-        indices = index_without_0(list_grad)
-        sorted_values = abs_sort_desc(value_without_0(list_grad))
-        print("sorted_mylist_value of gradient_without_0", sorted_values)
-        sorted_index = corresponding_index(values, indices, sorted_values)
-        curr_norm = np.sqrt(curr_norm)
-        max_of_gi = next_deriv
-        print(" Norm of <[H,A]> = %12.8f" % curr_norm)
-        print(" Max  of <[H,A]> = %12.8f" % max_of_gi)
-        converged = False
-        if adapt_conver == "norm":
-            if curr_norm < adapt_thresh:
-                converged = True
-        else:
-            print(" FAIL: Convergence criterion not defined")
-            raise SystemExit()
-        if converged or (abs(curr_norm - prev_norm) < 10 ** (-7)):
+        _boxed("        Start the analytical gradient calculation:", _SHORT_RULE, pad=False)
+        grads, norm, leader, _ = engine.screen()
+        ranked, ranked_index = rank_gradients(grads)
+        print("sorted_mylist_value of gradient_without_0", ranked)
+        print(" Norm of <[H,A]> = %12.8f" % norm)
+        print(" Max  of <[H,A]> = %12.8f" % leader)
+        if engine.should_stop(norm, adapt_conver, adapt_thresh):
             print(" Ansatz Growth Converged!")
-            result_sim["optimizer"] = method_sim
-            result_sim["final_norm"] = curr_norm
-            result_sim["indices"] = op_indices
-            result_sim["len_operators"] = len(op_indices)
-            result_sim["parameters"] = parameters_sim
-            result_sim["final_energy"] = opt_result_sim.fun
+            result_sim.update(optimizer=method_sim, final_norm=norm, indices=engine.selected,
+                              len_operators=len(engine.selected), parameters=engine.theta,
+                              final_energy=engine.require_fit().fun)
             print(" -----------Final ansatz----------- ")
             print(" %4s %12s %18s" % ("#", "Coeff", "Term"))
-            for si in range(len(ansatz_ops)):
-                print(" %4i %12.8f" % (si, parameters_sim[si]))
+            for k, t in enumerate(engine.theta):
+                print(" %4i %12.8f" % (k, t))
             break
-        chosen_batch = sorted_values
-        gamma1 = []
-        sorted_index1 = []
-        curr_norm1 = 0
-        for z in chosen_batch:
-            # the square root is taken INSIDE the accumulation loop in the reference (lines 530-532)
-            curr_norm1 += z * z
-            curr_norm1 = np.sqrt(curr_norm1)
-        for i in range(Y):
-            gamma1.append(chosen_batch[i] / curr_norm1)
-            sorted_index1.append(sorted_index[i])
-        for m in range(len(gamma1)):
-            parameters_sim.append(gamma1[m])
-            parameters_ana.append(gamma1[m])
-            ansatz_ops.append(pool_mix[sorted_index1[m]])
-            op_indices.append(sorted_index1[m])
-        print("initial parameters", parameters_sim)
-        print("op_indices of iteration_%d" % n_iter, op_indices)
-        opt_result_sim = scipy.optimize.minimize(
-            lambda theta: ucc_action(hamiltonian_sp, ansatz_ops, hf_init_sp, theta),
-            x0=parameters_sim, method=method_sim, tol=tolerance_sim, options={"maxiter": 100000, "disp": False})
-        xlist_sim = opt_result_sim.x
+        engine.grow(ranked, ranked_index, how_many)
+        print("initial parameters", engine.theta)
+        print("op_indices of iteration_%d" % n_iter, engine.selected)
+        fit = engine.optimise(method_sim, tolerance_sim)
         print(" ----------- ansatz from the simulator----------- ")
         print(" %s\t %s\t\t %s" % ("#", "Coeff", "Term"))
-        parameters_sim = []
-        for si in range(len(ansatz_ops)):
-            print(" %i\t %f\t %s" % (si, xlist_sim[si], op_indices[si]))
-            parameters_sim.append(xlist_sim[si])
-        print(" Energy reached from the simulator: %20.20f" % opt_result_sim.fun)
-        curr_state = prepare_state_ansatz(ansatz_ops, hf_init_sp, parameters_sim)
-        screen = prepare_adapt_state(hf_init_sp, ansatz_ops, parameters_sim, nqubits)
-        prev_norm = curr_norm
-        gates = curr_state.ops
-        iterations_sim["energies"].append(opt_result_sim.fun)
-        iterations_sim["energies_substracted_from_fci"].append(abs(opt_result_sim.fun - fci))
-        iterations_sim["norms"].append(curr_norm)
-        iterations_sim["Max_gradient"].append(sorted_values[0])
-        iterations_sim["CNOTs"].append(count("CNOT", gates))
-        iterations_sim["Hadamard"].append(count("H", gates))
-        iterations_sim["RY"].append(count("RY", gates))
-        iterations_sim["RX"].append(count("RX", gates))
-    return iterations_sim, iterations_ana, result_sim, result_ana
+        for k, (t, idx) in enumerate(zip(engine.theta, engine.selected)):
+            print(" %i\t %f\t %s" % (k, t, idx))
+        print(" Energy reached from the simulator: %20.20f" % fit.fun)
+        engine.previous_norm = norm
+        engine.record(trace, {"energy": fit.fun, "error": abs(fit.fun - fci), "norm": norm, "leader": ranked[0]})
+    return trace, iterations_ana, result_sim, result_ana
