@@ -130,6 +130,19 @@ int ovqe_expectation(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t
 int ovqe_bilinear(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64_t T, const uint64_t *x,
                   const uint64_t *z, const double *coeff_re, const double *coeff_im, double *out_re_im);
 
+/* out (+)= sum_t (coeff_re + i coeff_im)[t] P_t ket, explicit device buffers of 2^n_local amplitudes (ket NULL = this
+ * handle's state; out != ket).  x masks may carry ONE global (rank) part when ket is the partner shard with that rank
+ * difference: sigma = H psi of a sharded register, assembled group by group by the host layer
+ * (ref:openvqe/adapt/fermionic_adapt_vqe.py:114 `sig = hamiltonian_sparse.dot(curr_state)`). */
+int ovqe_apply_pauli_sum(ovqe_handle h, const void *ket_dev, void *out_dev, int64_t T, const uint64_t *x, const uint64_t *z,
+                         const double *coeff_re, const double *coeff_im, int accumulate);
+/* out[k] = sum_{j in [off[k], off[k+1])} c_j <bra|P_j|ket> (complex, interleaved re/im) for n_ops operators in one launch;
+ * bra / ket as in ovqe_bilinear; all x masks of one call share their global part (the pool gradients of a sharded
+ * register: bra = sigma shard, ket = psi shard of the partner; ref:openvqe/adapt/fermionic_adapt_vqe.py:67-73). */
+int ovqe_bilinear_batch(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64_t n_ops, const int64_t *offsets,
+                        const uint64_t *x, const uint64_t *z, const double *coeff_re, const double *coeff_im,
+                        double *out_re_im);
+
 /* ---- compiled evaluation: E(theta) of a whole ansatz circuit */
 /* observable H = constant + sum_t coeff[t] P_t (real coefficients; ref:...get_energy_ucc.py:47) */
 int ovqe_set_hamiltonian(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff,

@@ -51,6 +51,8 @@ SIGNATURES = {
     "ovqe_apply_gate": (_int, [_H, _int, _int, _int, _dbl]),
     "ovqe_expectation": (_int, [_H, _i64, _u64p, _u64p, _f64p, _dbl, ctypes.POINTER(_dbl)]),
     "ovqe_bilinear": (_int, [_H, _vp, _vp, _i64, _u64p, _u64p, _f64p, _OptF64, _f64p]),
+    "ovqe_apply_pauli_sum": (_int, [_H, _vp, _vp, _i64, _u64p, _u64p, _f64p, _OptF64, _int]),
+    "ovqe_bilinear_batch": (_int, [_H, _vp, _vp, _i64, _i64p, _u64p, _u64p, _f64p, _OptF64, _f64p]),
     "ovqe_set_hamiltonian": (_int, [_H, _i64, _u64p, _u64p, _f64p, _dbl]),
     "ovqe_set_program": (_int, [_H, _i64, _u64p, _u64p, _f64p, _OptF64, _i32p, ctypes.c_int32, _u64]),
     "ovqe_set_gate_program": (_int, [_H, _i64, _i32p, _i32p, _i32p, _f64p, _f64p, _i32p, ctypes.c_int32, _u64]),

@@ -163,6 +163,28 @@ class Statevector:
                                        np.ascontiguousarray(coeff.real), np.ascontiguousarray(coeff.imag), out))
         return complex(out[0], out[1])
 
+    def apply_pauli_sum(self, xs, zs, coeff, out_ptr, ket_ptr=None, accumulate=False):
+        """out (+)= sum_t c_t P_t ket on explicit device buffers (ket None = the resident state); masks may carry one
+        global x part when ket is the partner's shard"""
+        coeff = np.asarray(coeff, np.complex128)
+        self._ck(self._L.ovqe_apply_pauli_sum(self._h, ctypes.c_void_p(ket_ptr), ctypes.c_void_p(out_ptr), len(xs),
+                                              np.ascontiguousarray(xs, np.uint64), np.ascontiguousarray(zs, np.uint64),
+                                              np.ascontiguousarray(coeff.real), np.ascontiguousarray(coeff.imag),
+                                              1 if accumulate else 0))
+
+    def bilinear_batch(self, offsets, xs, zs, coeff, bra_ptr=None, ket_ptr=None):
+        """[sum_{j in op k} c_j <bra|P_j|ket>] for every operator k, one launch -> complex array"""
+        coeff = np.asarray(coeff, np.complex128)
+        n_ops = len(offsets) - 1
+        out = np.zeros(2 * max(n_ops, 1), np.float64)
+        self._ck(self._L.ovqe_bilinear_batch(self._h, ctypes.c_void_p(bra_ptr), ctypes.c_void_p(ket_ptr), n_ops,
+                                             np.ascontiguousarray(offsets, np.int64),
+                                             np.ascontiguousarray(xs if len(xs) else [0], np.uint64),
+                                             np.ascontiguousarray(zs if len(zs) else [0], np.uint64),
+                                             np.ascontiguousarray(coeff.real if len(coeff) else [0.0]),
+                                             np.ascontiguousarray(coeff.imag if len(coeff) else [0.0]), out))
+        return out[0:2 * n_ops:2] + 1j * out[1:2 * n_ops:2]
+
     # -- compiled evaluation --------------------------------------------------------------------
     def set_hamiltonian(self, hamiltonian):
         xs, zs, cs = pack_terms(self.nbqbits, hamiltonian.terms)

@@ -2499,6 +2499,86 @@ int ovqe_bilinear(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64
     return rc;
 }
 
+int ovqe_apply_pauli_sum(ovqe_handle h, const void *ket_dev, void *out_dev, int64_t T, const uint64_t *x, const uint64_t *z,
+                         const double *coeff_re, const double *coeff_im, int accumulate) {
+    OVQE_ENTER(h);
+    if (!h || !out_dev || T < 0 || (T && (!x || !z || !coeff_re))) return OVQE_ERR_INVALID;
+    const amp_t *ket = ket_dev ? (const amp_t *)ket_dev : h->state;
+    if ((const void *)ket == out_dev) return fail(h, OVQE_ERR_INVALID, "ovqe_apply_pauli_sum: out must differ from the ket");
+    std::vector<HGroup> groups;
+    std::vector<HTerm> terms;
+    int rc = build_groups(h, T, x, z, coeff_re, coeff_im, /*allow_global_x=*/ket_dev != nullptr, groups, terms);
+    if (rc) return rc;
+    rc = upload(h, h->d_pg_xs, groups.data(), std::max<size_t>(groups.size(), 1) * sizeof(HGroup));
+    if (!rc) rc = upload(h, h->d_pg_terms, terms.data(), std::max<size_t>(terms.size(), 1) * sizeof(HTerm));
+    if (rc) return rc;
+    h->pg_valid = false;  // the pool buffers were borrowed
+    hipLaunchKernelGGL(k_apply_terms, dim3(reduce_blocks(h->namps)), dim3(256), 0, h->stream, (amp_t *)out_dev, ket, h->namps,
+                       (const HGroup *)h->d_pg_xs.p, (int)groups.size(), (const HTerm *)h->d_pg_terms.p, accumulate);
+    HIPC(h, hipGetLastError());
+    HIPC(h, hipStreamSynchronize(h->stream));
+    return OVQE_OK;
+}
+
+int ovqe_bilinear_batch(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64_t n_ops, const int64_t *offsets,
+                        const uint64_t *x, const uint64_t *z, const double *coeff_re, const double *coeff_im,
+                        double *out_re_im) {
+    OVQE_ENTER(h);
+    if (!h || n_ops < 0 || !offsets || (n_ops && !out_re_im)) return OVQE_ERR_INVALID;
+    if (n_ops == 0) return OVQE_OK;
+    const int64_t T = offsets[n_ops];
+    if (T < 0 || (T && (!x || !z || !coeff_re))) return OVQE_ERR_INVALID;
+    const uint64_t lmask = local_mask(h);
+    std::vector<HTerm> terms(T);
+    std::vector<uint64_t> xs(T);
+    uint64_t xg = 0;
+    for (int64_t t = 0; t < T; ++t) {
+        if (t == 0) xg = x[t] & ~lmask;
+        if ((x[t] & ~lmask) != xg) return fail(h, OVQE_ERR_INVALID, "ovqe_bilinear_batch: one global x part per call");
+        const int ny = __builtin_popcountll(x[t] & z[t]) & 3;
+        const double a = coeff_re[t], b = coeff_im ? coeff_im[t] : 0.0;
+        HTerm ht;
+        ht.z = z[t];
+        switch (ny) {
+        case 0: ht.cr = a; ht.ci = b; break;
+        case 1: ht.cr = -b; ht.ci = a; break;
+        case 2: ht.cr = -a; ht.ci = -b; break;
+        default: ht.cr = b; ht.ci = -a; break;
+        }
+        terms[t] = ht;
+        xs[t] = x[t] & lmask;
+    }
+    if (xg && !ket_dev) return fail(h, OVQE_ERR_INVALID, "x mask touches global (rank) bits: pass the partner's shard as ket");
+    for (int64_t k = 0; k < n_ops; ++k)
+        if (offsets[k] > offsets[k + 1] || offsets[k] < 0) return fail(h, OVQE_ERR_INVALID, "offsets not monotone");
+    h->pg_valid = false;
+    int rc = upload(h, h->d_pg_off, offsets, (n_ops + 1) * sizeof(int64_t));
+    if (!rc) rc = upload(h, h->d_pg_xs, xs.data(), std::max<int64_t>(T, 1) * sizeof(uint64_t));
+    if (!rc) rc = upload(h, h->d_pg_terms, terms.data(), std::max<int64_t>(T, 1) * sizeof(HTerm));
+    const int nchunks = h->n_local <= 22 ? 1 : (int)(h->namps >> 16);
+    const int64_t ops_per_launch = 32768;
+    if (!rc) rc = ensure(h, h->d_pg_out, n_ops * sizeof(double2));
+    if (!rc && nchunks > 1)
+        rc = ensure(h, h->d_pg_part, (size_t)std::min<int64_t>(n_ops, ops_per_launch) * nchunks * sizeof(double2));
+    if (rc) return rc;
+    const amp_t *bra = bra_dev ? (const amp_t *)bra_dev : h->state, *ket = ket_dev ? (const amp_t *)ket_dev : h->state;
+    const uint64_t ket_base = (h->base ^ xg) & ~lmask;
+    for (int64_t op0 = 0; op0 < n_ops; op0 += ops_per_launch) {
+        const int64_t cnt = std::min<int64_t>(ops_per_launch, n_ops - op0);
+        double2 *out = (double2 *)h->d_pg_out.p + op0;
+        double2 *part = nchunks > 1 ? (double2 *)h->d_pg_part.p : out;
+        hipLaunchKernelGGL(k_pool_grad, dim3((unsigned)nchunks, (unsigned)cnt), dim3(256), 0, h->stream, bra, ket, h->namps,
+                           ket_base, (const int64_t *)h->d_pg_off.p, (const uint64_t *)h->d_pg_xs.p,
+                           (const HTerm *)h->d_pg_terms.p, op0, part);
+        if (nchunks > 1)
+            hipLaunchKernelGGL(k_reduce_rows2, dim3((unsigned)cnt), dim3(256), 0, h->stream, (const double2 *)part, nchunks, out);
+    }
+    HIPC(h, hipGetLastError());
+    HIPC(h, hipMemcpyAsync(out_re_im, h->d_pg_out.p, n_ops * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    return OVQE_OK;
+}
+
 int ovqe_expectation(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff,
                      double constant, double *out) {
     OVQE_ENTER(h);

@@ -408,6 +408,36 @@ __global__ __launch_bounds__(256) void k_apply_sum(amp_t *__restrict__ out, cons
     }
 }
 
+// out_i (+)= sum_g D_g(jbase_g | (i ^ x_g)) in_{i ^ x_g}: a Pauli sum applied to an explicit ket buffer that may be ANOTHER
+// shard of a distributed register (jbase = the global index bits of that shard); accumulate = 0 overwrites out
+__global__ __launch_bounds__(256) void k_apply_terms(amp_t *__restrict__ out, const amp_t *__restrict__ in, uint64_t namps,
+                                                     const HGroup *__restrict__ groups, int ngroups,
+                                                     const HTerm *__restrict__ terms, int accumulate) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) {
+        double sx = 0.0, sy = 0.0;
+        for (int g = 0; g < ngroups; ++g) {
+            const HGroup gr = groups[g];
+            const uint64_t jl = i ^ gr.x;
+            const amp_t k = in[jl];
+            const uint64_t gj = gr.jbase | jl;
+            double dr = 0.0, di = 0.0;
+            for (int t = gr.t0; t < gr.t1; ++t) {
+                const HTerm ht = terms[t];
+                const bool neg = parity64(gj & ht.z);
+                dr += neg ? -ht.cr : ht.cr;
+                di += neg ? -ht.ci : ht.ci;
+            }
+            sx += dr * k.x - di * k.y;
+            sy += dr * k.y + di * k.x;
+        }
+        amp_t r = accumulate ? out[i] : make_double2(0.0, 0.0);
+        r.x += sx;
+        r.y += sy;
+        out[i] = r;
+    }
+}
+
 // pool gradient screen: block (chunk c, operator k) sums its slice [c, c+1) * namps / gridDim.x of
 // val_k = sum_{t in op k} sum_i conj(sig_i) (-1)^{parity((i^x_t)&z_t)} (cr_t + i ci_t) psi_{i^x_t}
 // into partials[k * gridDim.x + c].  One chunk per operator while the state re-streams from L2/MALL (n <= 22: the
@@ -417,6 +447,8 @@ __global__ __launch_bounds__(256) void k_pool_grad(const amp_t *__restrict__ sig
                                                    uint64_t namps, uint64_t base, const int64_t *__restrict__ offsets,
                                                    const uint64_t *__restrict__ xs, const HTerm *__restrict__ terms,
                                                    int64_t op0, double2 *__restrict__ partials) {
+    // xs carries the LOCAL part of every x mask; `base` is the global index base of the KET shard (the own shard's, or
+    // the partner's when the operators' x masks share one global part — ovqe_bilinear_batch)
     __shared__ double2 red[4];
     const int64_t op = op0 + blockIdx.y;
     const uint64_t len = namps / gridDim.x, i0 = (uint64_t)blockIdx.x * len, i1 = i0 + len;

@@ -17,8 +17,12 @@ Per Pauli rotation exp(-i phi P), P = (x, z):
 
 Expectation values: Hamiltonian terms are grouped by the global part of their x mask; the x_g = 0 group
 is a local partial sum; for each of the <= 2^g - 1 other groups the partner's shard is received
-(read-only) and ``ovqe_bilinear`` contracts own-shard bra with partner-shard ket; one scalar
-all-reduce at the end.  No other collective exists on the data path.
+(read-only, double-buffered: the transfer for group k + 1 runs under the contraction of group k) and
+``ovqe_bilinear`` contracts own-shard bra with partner-shard ket; one scalar all-reduce at the end.
+The ADAPT gradient screen shards the same way (``apply_hamiltonian`` builds the sigma shard group by
+group, ``pool_gradients`` contracts the pool per partner shard in one batched launch each, one
+all-reduce of the pool-sized result).  Half-shard exchanges travel in pipelined pieces.  No other
+collective exists on the data path.
 """
 from __future__ import annotations
 
@@ -71,6 +75,13 @@ class HipShardEngine:
     def bilinear(self, xs, zs, coeffs, ket=None):
         return self.sv.bilinear(xs, zs, coeffs, ket_ptr=None if ket is None else ket.data_ptr())
 
+    def apply_sum(self, xs, zs, coeffs, out, ket=None, accumulate=False):
+        self.sv.apply_pauli_sum(xs, zs, coeffs, out.data_ptr(), None if ket is None else ket.data_ptr(), accumulate)
+
+    def bilinear_batch(self, offsets, xs, zs, coeffs, bra, ket=None):
+        return self.sv.bilinear_batch(offsets, xs, zs, coeffs, bra_ptr=bra.data_ptr(),
+                                      ket_ptr=None if ket is None else ket.data_ptr())
+
 
 class ShardedStatevector:
     """n-qubit state over ``dist.get_world_size()`` ranks (a power of two)."""
@@ -92,6 +103,8 @@ class ShardedStatevector:
         self.engine = engine_factory(self.n_local, self.g, self.rank)
         self.stats = {"swaps": 0, "bytes_sent": 0, "full_shard_reads": 0}
         self._tmp = None
+        self._shard_bufs = None
+        self._sigma = None
 
     # -- helpers ----------------------------------------------------------------------------
     def _phys(self, mask):
@@ -105,33 +118,64 @@ class ShardedStatevector:
             self._tmp = self.engine.new_buffer(count)
         return self._tmp[:count]
 
+    #: pieces of one exchange: transfer k + 1 runs while piece k is unpacked into the shard / packed for sending
+    EXCHANGE_PIECES = 8
+
+    def _exchange(self, partner, make_send, recv_pieces, on_arrival):
+        """piece p: ``make_send(p)`` (pack, on the compute stream) then its send / receive with ``partner`` is posted —
+        RCCL orders each transfer behind the pack it depends on and runs the transfers in sequence on its own stream, so
+        pack p + 1 and transfer p overlap; then every received piece is handed to ``on_arrival`` as soon as it has
+        landed, while the later pieces are still on the link.  Lower rank sends first in a pair (gloo needs an order)."""
+        works, keep = [], []
+        for p, rcv in enumerate(recv_pieces):
+            snd = make_send(p)
+            keep.append(snd)
+            ops = [dist.P2POp(dist.isend, snd, partner, self.group), dist.P2POp(dist.irecv, rcv, partner, self.group)]
+            if self.rank > partner:
+                ops.reverse()
+            works.append(dist.batch_isend_irecv(ops))
+        for p, ws in enumerate(works):
+            for w in ws:
+                w.wait()
+            on_arrival(p)
+
     def _swap(self, gbit, lbit):
-        """exchange physical global bit ``gbit`` with physical local bit ``lbit`` (half-shard exchange)"""
+        """exchange physical global bit ``gbit`` with physical local bit ``lbit``: each rank sends the half of its shard
+        it no longer owns and receives the half it now owns (S/2 bytes each way on one xGMI link), in EXCHANGE_PIECES
+        pipelined pieces; a strided half (lbit below the top local bit) is packed piece by piece, never as a whole"""
         k = gbit - self.n_local
         alpha = (self.rank >> k) & 1
         partner = self.rank ^ (1 << k)
         t = self.engine.tensor.view(1 << (self.n_local - 1 - lbit), 2, 1 << lbit)
-        mine_out = t[:, 1 - alpha, :]          # the half this rank gives away / receives into
-        half = mine_out.numel()
-        if lbit == self.n_local - 1:
-            send = mine_out.reshape(-1)        # contiguous slice: no staging copy
-        else:
-            send = mine_out.contiguous().view(-1)
+        mine_out = t[:, 1 - alpha, :]          # (A, B): the half this rank gives away / receives into
+        A, B = mine_out.shape
+        half = A * B
+        P = max(1, min(self.EXCHANGE_PIECES, half))
         recv = self._tmp_buffer(half)
+        if A >= P:                              # pieces = row blocks (strided rows of length B)
+            views = [mine_out[(A * p) // P:(A * (p + 1)) // P, :] for p in range(P)]
+        else:                                   # few long rows: cut the columns
+            views = [mine_out[:, (B * p) // P:(B * (p + 1)) // P] for p in range(P)]
+        sizes = [v.numel() for v in views]
+        starts = [sum(sizes[:p]) for p in range(P)]
+        recv_pieces = [recv[starts[p]:starts[p] + sizes[p]] for p in range(P)]
         self.engine.sync()
-        ops = [dist.P2POp(dist.isend, send, partner, self.group), dist.P2POp(dist.irecv, recv, partner, self.group)]
-        if self.rank > partner:
-            ops.reverse()
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        self.engine.sync()
-        mine_out.copy_(recv.view(mine_out.shape))
+
+        def pack(p):
+            v = views[p]
+            return v.reshape(-1) if v.is_contiguous() else v.contiguous().view(-1)
+
+        def unpack(p):
+            views[p].copy_(recv_pieces[p].view(views[p].shape))
+
+        self._exchange(partner, pack, recv_pieces, unpack)
         self.engine.sync()
         # the logical qubits living on these two physical bits trade places
         la, lb = self.perm.index(gbit), self.perm.index(lbit)
         self.perm[la], self.perm[lb] = lbit, gbit
         self.stats["swaps"] += 1
         self.stats["bytes_sent"] += half * 16
+        self.stats["pieces"] = self.stats.get("pieces", 0) + P
 
     def _localise(self, x_logical_seq, r):
         """make every X/Y qubit of rotation r local; victims by farthest next X/Y use"""
@@ -206,42 +250,124 @@ class ShardedStatevector:
     def apply_pauli_rotation(self, x, z, phi):
         self.apply_pauli_rotations([x], [z], [phi])
 
-    def expectation(self, xs, zs, coeffs, constant=0.0):
-        """Re sum_t c_t <psi|P_t|psi> + constant over the whole register (same value on every rank)"""
-        lmask = self._local_mask()
+    def _group_by_partner(self, xs, zs, coeffs):
+        """terms grouped by the GLOBAL part of their physical x mask (= the rank difference of the partner shard),
+        in a rank-independent order"""
         groups = {}
-        for x, z, c in zip(xs, zs, coeffs):
+        for t, (x, z, c) in enumerate(zip(xs, zs, coeffs)):
             xp, zp = self._phys(int(x)), self._phys(int(z))
-            groups.setdefault(xp >> self.n_local, []).append((xp, zp, complex(c)))
-        total = 0.0 + 0.0j
-        # every rank walks the partner patterns in the same order
-        for xg in sorted(groups):  # identical term list + permutation on every rank -> same order everywhere
-            terms = groups.get(xg, [])
-            tx = np.array([t[0] for t in terms], np.uint64)
-            tz = np.array([t[1] for t in terms], np.uint64)
-            tc = np.array([t[2] for t in terms], np.complex128)
-            if xg == 0:
-                if len(terms):
-                    total += self.engine.bilinear(tx, tz, tc, None)
-                continue
-            partner = self.rank ^ xg
-            recv = self._tmp_buffer(1 << self.n_local)
-            self.engine.sync()
+            groups.setdefault(xp >> self.n_local, []).append((xp, zp, complex(c), t))
+        return [(xg, groups[xg]) for xg in sorted(groups)]
+
+    def _partner_shards(self, partners):
+        """generator over ``partners`` (rank differences != 0) yielding the partner's psi shard; the receive of shard
+        k + 1 is posted before shard k is handed out, into the second of two shard-sized buffers (double buffering: the
+        xGMI transfer of the next group overlaps the local contraction of the current one)"""
+        if not partners:
+            return
+        size = 1 << self.n_local
+        if getattr(self, "_shard_bufs", None) is None or self._shard_bufs[0].numel() < size:
+            self._shard_bufs = [self.engine.new_buffer(size), self.engine.new_buffer(size)]
+        self.engine.sync()
+
+        def post(k):
+            partner = self.rank ^ partners[k]
             ops = [dist.P2POp(dist.isend, self.engine.tensor, partner, self.group),
-                   dist.P2POp(dist.irecv, recv, partner, self.group)]
+                   dist.P2POp(dist.irecv, self._shard_bufs[k & 1][:size], partner, self.group)]
             if self.rank > partner:
                 ops.reverse()
-            for w in dist.batch_isend_irecv(ops):
+            return dist.batch_isend_irecv(ops)
+
+        pending = post(0)
+        for k in range(len(partners)):
+            for w in pending:
                 w.wait()
-            self.engine.sync()
+            pending = post(k + 1) if k + 1 < len(partners) else []
             self.stats["full_shard_reads"] += 1
-            self.stats["bytes_sent"] += (1 << self.n_local) * 16
-            if len(terms):
-                total += self.engine.bilinear(tx, tz, tc, recv)
+            self.stats["bytes_sent"] += size * 16
+            yield self._shard_bufs[k & 1][:size]
+            self.engine.sync()   # the buffer is re-used two groups later
+
+    def expectation(self, xs, zs, coeffs, constant=0.0):
+        """Re sum_t c_t <psi|P_t|psi> + constant over the whole register (same value on every rank)"""
+        groups = self._group_by_partner(xs, zs, coeffs)
+        total = 0.0 + 0.0j
+        remote = [(xg, terms) for xg, terms in groups if xg]
+        for xg, terms in groups:
+            if xg == 0:
+                total += self.engine.bilinear(np.array([t[0] for t in terms], np.uint64),
+                                              np.array([t[1] for t in terms], np.uint64),
+                                              np.array([t[2] for t in terms], np.complex128), None)
+        for (xg, terms), ket in zip(remote, self._partner_shards([xg for xg, _ in remote])):
+            total += self.engine.bilinear(np.array([t[0] for t in terms], np.uint64),
+                                          np.array([t[1] for t in terms], np.uint64),
+                                          np.array([t[2] for t in terms], np.complex128), ket)
         val = torch.tensor([total.real], dtype=torch.float64, device=self.engine.tensor.device)
         if self.world > 1:
             dist.all_reduce(val, group=self.group)
         return float(val.item()) + float(np.real(constant))
+
+    # -- ADAPT gradient screen on the sharded register (SURVEY.md section 8e: "ADAPT screen identical with sigma also sharded")
+    def apply_hamiltonian(self, xs, zs, coeffs, constant=0.0):
+        """sigma = (H + constant) psi, sharded like psi: the x_g = 0 terms act inside the shard; for every other rank
+        difference the partner's psi shard is received once (double-buffered) and its terms are accumulated.
+        -> this rank's sigma shard (device buffer owned by the caller until the next call)"""
+        size = 1 << self.n_local
+        if getattr(self, "_sigma", None) is None or self._sigma.numel() < size:
+            self._sigma = self.engine.new_buffer(size)
+        sigma = self._sigma[:size]
+        groups = self._group_by_partner(xs, zs, coeffs)
+        local = [t for xg, terms in groups if xg == 0 for t in terms]
+        tx = np.array([t[0] for t in local] + [0], np.uint64)        # + constant * identity
+        tz = np.array([t[1] for t in local] + [0], np.uint64)
+        tc = np.array([t[2] for t in local] + [complex(constant)], np.complex128)
+        self.engine.apply_sum(tx, tz, tc, sigma, None, accumulate=False)
+        remote = [(xg, terms) for xg, terms in groups if xg]
+        for (xg, terms), ket in zip(remote, self._partner_shards([xg for xg, _ in remote])):
+            self.engine.apply_sum(np.array([t[0] for t in terms], np.uint64), np.array([t[1] for t in terms], np.uint64),
+                                  np.array([t[2] for t in terms], np.complex128), sigma, ket, accumulate=True)
+        return sigma
+
+    def pool_gradients(self, ham, pool, mode="fermionic"):
+        """ADAPT screen over ``pool`` = [(xs, zs, coeffs) per operator] with H = (ham_xs, ham_zs, ham_coeffs, constant):
+        sigma = H psi once (sharded), then v_k = sum_j c_j <sigma|P_j|psi> with the pool terms grouped by partner shard
+        — one batched launch per rank difference —, one all-reduce of the n_ops complex values;
+        g_k = 2 Re v_k (fermionic, ref:openvqe/adapt/fermionic_adapt_vqe.py:67-73) or 2 |v_k| (qubit,
+        ref:openvqe/adapt/qubit_adapt_vqe.py:147-150).  Same values on every rank."""
+        hx, hz, hc, const = ham
+        sigma = self.apply_hamiltonian(hx, hz, hc, const)
+        flat = [(int(x), int(z), complex(c), k) for k, (xs, zs, cs) in enumerate(pool) for x, z, c in zip(xs, zs, cs)]
+        groups = self._group_by_partner([f[0] for f in flat], [f[1] for f in flat], [f[2] for f in flat])
+        owner = [f[3] for f in flat]
+        vals = np.zeros(len(pool), np.complex128)
+
+        def contract(terms, ket):
+            # CSR over the operators that have terms in this group (operator order kept)
+            by_op = {}
+            for xp, zp, c, t in terms:
+                by_op.setdefault(owner[t], []).append((xp, zp, c))
+            ops = sorted(by_op)
+            offsets = np.zeros(len(ops) + 1, np.int64)
+            xs, zs, cs = [], [], []
+            for i, k in enumerate(ops):
+                offsets[i + 1] = offsets[i] + len(by_op[k])
+                for xp, zp, c in by_op[k]:
+                    xs.append(xp); zs.append(zp); cs.append(c)
+            out = self.engine.bilinear_batch(offsets, np.array(xs, np.uint64), np.array(zs, np.uint64),
+                                             np.array(cs, np.complex128), sigma, ket)
+            vals[ops] += out
+
+        remote = [(xg, terms) for xg, terms in groups if xg]
+        for xg, terms in groups:
+            if xg == 0:
+                contract(terms, None)
+        for (xg, terms), ket in zip(remote, self._partner_shards([xg for xg, _ in remote])):
+            contract(terms, ket)
+        buf = torch.from_numpy(np.stack([vals.real, vals.imag])).to(self.engine.tensor.device)
+        if self.world > 1:
+            dist.all_reduce(buf, group=self.group)
+        v = buf[0].cpu().numpy() + 1j * buf[1].cpu().numpy()
+        return 2.0 * v.real if mode == "fermionic" else 2.0 * np.abs(v)
 
     def energy(self, ham_xs, ham_zs, ham_coeffs, constant, rot_xs, rot_zs, rot_phis, hf_index):
         """one whole evaluation: |hf> -> rotations -> <H>"""
