@@ -77,6 +77,11 @@ class FermionHamiltonian:
                                                       list(reversed(t.qbits))) for t in self.terms],
                                   complex(self.constant_coeff).conjugate(), do_clean_up=False)
 
+    def get_matrix(self, sparse=False):
+        """2^n x 2^n matrix of the Jordan-Wigner image (what the reference's sparse factory asks of every pool operator,
+        ref:openvqe/common_files/molecule_factory_with_sparse.py:601-617)"""
+        return transform_to_jw_basis(self).get_matrix(sparse=sparse)
+
     def to_spin(self, transform="JW"):
         return transform_to_jw_basis(self) if transform == "JW" else _no_transform(transform)
 

@@ -1,0 +1,122 @@
+"""Stand-ins for the chemistry slice of myQLM that OpenVQE's L2 front-end touches
+(ref:openvqe/common_files/molecule_factory.py:4-22, molecule_factory_with_sparse.py:4-22): ``perform_pyscf_computation``,
+``convert_to_h_integrals`` / ``transform_integrals_to_new_basis``, ``ElectronicStructureHamiltonian``,
+``get_active_space_hamiltonian`` / ``get_cluster_ops_and_init_guess``, the fermion -> qubit transforms and codes.
+``qat_compat.install()`` registers them under the ``qat.fermion…`` names, so the reference's ``MoleculeFactory``, its
+algorithm drivers and ``VQE.algorithm(...).execute()`` run UNCHANGED for every molecule the in-repo integral code covers
+(s/p shells: H2, H4, H6, HeH+, LiH, H2O).  SURVEY.md section 8f row 1; conventions pinned by tests/test_reference_quccsd.py.
+
+Integral conventions between these functions (internal to the stand-ins, like they are internal to myQLM):
+one_body_integrals[p, q] = h_pq, two_body_integrals[p, q, r, s] = (pq|rs) (chemists' notation), both over spatial MOs;
+``convert_to_h_integrals`` turns them into the spin-orbital h_pq / h_pqrs of
+H = sum h_pq c+_p c_q + 1/2 sum h_pqrs c+_p c+_q c_r c_s (spin orbitals interleaved, alpha even)."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import chem, fermion
+from .fermionic import FermionHamiltonian, transform_to_jw_basis as _jw_of_fermion_op
+
+
+def perform_pyscf_computation(geometry, basis, spin=0, charge=0, run_fci=False, **_ignored):
+    """(rdm1, orbital_energies, nuclear_repulsion, n_electrons, one_body_integrals, two_body_integrals, info) like
+    ``qat.fermion.chemistry.pyscf_tools.perform_pyscf_computation``: RHF in this repository's Gaussian-integral code,
+    the spin-summed CISD one-particle density in the MO basis (the NOONs the reference prints are its eigenvalues),
+    MP2 / FCI / HF energies in ``info``."""
+    if spin != 0:
+        raise NotImplementedError("restricted closed-shell molecules only")
+    mol = chem.Molecule([(str(sym).capitalize(), tuple(xyz)) for sym, xyz in geometry], basis, charge)
+    e_hf = mol.rhf()
+    noons, natorb = mol.natural_occupations()
+    rdm1 = natorb @ np.diag(noons) @ natorb.T
+    info = {"MP2": mol.mp2_energy(), "FCI": mol.ci_ground_state()[0] if run_fci else None, "HF": e_hf}
+    return rdm1, mol.mo_energy.copy(), mol.nuclear_repulsion(), mol.n_elec, mol.h_mo.copy(), mol.eri_mo.copy(), info
+
+
+def convert_to_h_integrals(one_body_integrals, two_body_integrals):
+    return fermion.spin_orbital_integrals(np.asarray(one_body_integrals), np.asarray(two_body_integrals))
+
+
+def transform_integrals_to_new_basis(one_body_integrals, two_body_integrals, U):
+    U = np.asarray(U)
+    one = U.T @ np.asarray(one_body_integrals) @ U
+    two = np.einsum("pqrs,pi,qj,rk,sl->ijkl", np.asarray(two_body_integrals), U, U, U, U, optimize=True)
+    return one, two
+
+
+class ElectronicStructureHamiltonian:
+    """H = constant + sum h_pq c+_p c_q + 1/2 sum h_pqrs c+_p c+_q c_r c_s over ``nbqbits`` spin orbitals"""
+
+    def __init__(self, hpq, hpqrs, constant_coeff=0.0):
+        self.hpq, self.hpqrs = np.asarray(hpq), np.asarray(hpqrs)
+        self.constant_coeff = constant_coeff
+        self.nbqbits = self.hpq.shape[0]
+        self._spin = None
+
+    def to_spin(self):
+        if self._spin is None:
+            self._spin = fermion.jw_molecular_hamiltonian(self.hpq, self.hpqrs, self.constant_coeff)
+        return self._spin
+
+    def get_matrix(self, sparse=False):
+        return self.to_spin().get_matrix(sparse=sparse)
+
+
+def get_active_space_hamiltonian(one_body_integrals, two_body_integrals, noons, nels, nuclear_repulsion, threshold_1=0.02,
+                                 threshold_2=0.001):
+    """(active-space ElectronicStructureHamiltonian, active indices, frozen occupied indices): NOON selection
+    (chem.select_active_orbitals) + the frozen orbitals folded into the constant and the one-body part"""
+    h, g = np.asarray(one_body_integrals), np.asarray(two_body_integrals)
+    frozen, act = chem.select_active_orbitals(list(noons), nels, threshold_1, threshold_2)
+    const = float(nuclear_repulsion)
+    for i in frozen:
+        const += 2.0 * h[i, i]
+        for j in frozen:
+            const += 2.0 * g[i, i, j, j] - g[i, j, j, i]
+    h_act = h[np.ix_(act, act)].copy()
+    for i in frozen:
+        h_act += 2.0 * g[np.ix_(act, act, [i], [i])][:, :, 0, 0] - g[np.ix_(act, [i], [i], act)][:, 0, 0, :]
+    hpq, hpqrs = fermion.spin_orbital_integrals(h_act, g[np.ix_(act, act, act, act)])
+    return ElectronicStructureHamiltonian(hpq, hpqrs, const), act, frozen
+
+
+def get_cluster_ops_and_init_guess(n_elec, noons_full, orb_energies_full, hpqrs):
+    return fermion.cluster_ops_and_mp2_guess(n_elec, list(orb_energies_full), np.asarray(hpqrs))
+
+
+class _TermList(list):
+    """term list of a transformed operator.  The reference drops pool operators with ``hamilt_sp.terms != []`` false
+    (ref:openvqe/common_files/generator_excitations.py:29), yet the pool sizes its tests pin (175 / 69 / 70) are the RAW
+    enumeration counts, identically-zero operators and operators whose terms all vanished in the normal ordering
+    included: with myQLM that comparison never comes out false (its ``terms`` is not a plain list).  Same here."""
+
+    def __eq__(self, other):
+        return self is other
+
+    def __ne__(self, other):
+        return self is not other
+
+    __hash__ = None
+
+
+def transform_to_jw_basis(op):
+    if isinstance(op, ElectronicStructureHamiltonian):
+        return op.to_spin()
+    if isinstance(op, FermionHamiltonian):
+        spin = _jw_of_fermion_op(op)
+        spin.terms = _TermList(spin.terms)
+        return spin
+    raise TypeError("transform_to_jw_basis: a fermionic operator is expected")
+
+
+def _unsupported_transform(*_a, **_k):
+    raise NotImplementedError("only the Jordan-Wigner mapping is restated (SURVEY.md section 8f row 1)")
+
+
+def get_jw_code(nbqbits):
+    return np.eye(nbqbits, dtype=int)
+
+
+def recode_integer(integer, code):
+    """occupation integer of the fermionic mode ordering -> integer of the qubit register; identity for Jordan-Wigner"""
+    return int(integer)

@@ -384,25 +384,26 @@ def install(force=False):
     qat.lang.AQASM.gates = mod("qat.lang.AQASM.gates", Gate=Gate, **gates)
     qat.qpus = mod("qat.qpus", get_default_qpu=get_default_qpu)
     qat.core = mod("qat.core", Term=Term, Observable=Observable, Circuit=Circuit, Job=Job, Result=Result)
-    from . import fermion as _fermion
     from . import fermionic as _fermionic
-
-    def _unsupported_transform(*_a, **_k):
-        raise NotImplementedError("only the Jordan-Wigner mapping is restated (SURVEY.md §8f row 1)")
-
-    def get_cluster_ops_and_init_guess(n_elec, noons_full, orb_energies_full, hpqrs):
-        return _fermion.cluster_ops_and_mp2_guess(n_elec, orb_energies_full, hpqrs)
+    from . import qat_chem as _chem
 
     qat.fermion = mod("qat.fermion", Hamiltonian=Hamiltonian, SpinHamiltonian=SpinHamiltonian,
-                      FermionHamiltonian=_fermionic.FermionHamiltonian)
-    qat.fermion.transforms = mod("qat.fermion.transforms", transform_to_jw_basis=_fermionic.transform_to_jw_basis,
-                                 transform_to_bk_basis=_unsupported_transform,
-                                 transform_to_parity_basis=_unsupported_transform,
-                                 get_jw_code=lambda nbqbits: None, recode_integer=lambda integer, code: integer)
+                      FermionHamiltonian=_fermionic.FermionHamiltonian,
+                      ElectronicStructureHamiltonian=_chem.ElectronicStructureHamiltonian)
+    qat.fermion.transforms = mod("qat.fermion.transforms", transform_to_jw_basis=_chem.transform_to_jw_basis,
+                                 transform_to_bk_basis=_chem._unsupported_transform,
+                                 transform_to_parity_basis=_chem._unsupported_transform,
+                                 get_jw_code=_chem.get_jw_code, get_bk_code=_chem._unsupported_transform,
+                                 get_parity_code=_chem._unsupported_transform, recode_integer=_chem.recode_integer)
     qat.fermion.chemistry = mod("qat.fermion.chemistry")
+    qat.fermion.chemistry.pyscf_tools = mod("qat.fermion.chemistry.pyscf_tools",
+                                            perform_pyscf_computation=_chem.perform_pyscf_computation)
+    qat.fermion.chemistry.ucc = mod("qat.fermion.chemistry.ucc", convert_to_h_integrals=_chem.convert_to_h_integrals,
+                                    transform_integrals_to_new_basis=_chem.transform_integrals_to_new_basis)
     qat.fermion.chemistry.ucc_deprecated = mod("qat.fermion.chemistry.ucc_deprecated",
                                                build_ucc_ansatz=build_ucc_ansatz,
-                                               get_cluster_ops_and_init_guess=get_cluster_ops_and_init_guess)
+                                               get_cluster_ops_and_init_guess=_chem.get_cluster_ops_and_init_guess,
+                                               get_active_space_hamiltonian=_chem.get_active_space_hamiltonian)
     qat.fermion.hamiltonians = mod("qat.fermion.hamiltonians", Hamiltonian=Hamiltonian,
                                    SpinHamiltonian=SpinHamiltonian, FermionHamiltonian=_fermionic.FermionHamiltonian)
     del me
