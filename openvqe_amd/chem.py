@@ -357,8 +357,14 @@ class Problem:
     def jw_hamiltonian(self):
         return fermion.jw_molecular_hamiltonian(self.hpq, self.hpqrs, self.constant)
 
-    def hf_init(self):
-        return fermion.hf_integer(self.nbqbits, self.n_elec)
+    def spin_hamiltonian(self, transform="JW"):
+        """"JW" | "Bravyi-Kitaev" | "parity_basis" (ref:openvqe/common_files/molecule_factory.py:349-356)"""
+        return fermion.jw_molecular_hamiltonian(self.hpq, self.hpqrs, self.constant, transform=transform)
+
+    def hf_init(self, transform="JW"):
+        """HF determinant as a basis index of the encoded register (``recode_integer(hf_init, get_*_code(n))``,
+        ref:…molecule_factory.py:478-486)"""
+        return fermion.recode_occupation(fermion.hf_integer(self.nbqbits, self.n_elec), self.nbqbits, transform)
 
     def uccsd(self, transform="JW"):
         """(pool_size, cluster_ops, cluster_ops_sp, theta_MP2, hf_init) of ``MoleculeFactory.calculate_uccsd`` /

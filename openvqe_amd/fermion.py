@@ -71,6 +71,86 @@ def jw_product(ladder_ops):
     return out
 
 
+# ---------------------------------------------------------------- linear fermion -> qubit encodings
+# qubit occupation vector q = beta f (mod 2), f = orbital occupations.  Jordan-Wigner: beta = 1; parity basis: q_i =
+# f_0 + ... + f_i; Bravyi-Kitaev: the binary-tree (Fenwick) matrix.  The transforms the reference offers next to JW
+# (ref:openvqe/common_files/molecule_factory.py:349-356, ref:…generator_excitations.py:17-22).
+def encoding_matrix(nqbits, transform):
+    if transform == "JW":
+        return np.eye(nqbits, dtype=np.uint8)
+    if transform == "parity_basis":
+        return np.tril(np.ones((nqbits, nqbits), dtype=np.uint8))
+    if transform == "Bravyi-Kitaev":
+        size = 1
+        beta = np.ones((1, 1), dtype=np.uint8)
+        while size < nqbits:                      # beta_{2m} = [[beta_m, 0], [0 with last row 1, beta_m]]
+            big = np.zeros((2 * size, 2 * size), dtype=np.uint8)
+            big[:size, :size] = beta
+            big[size:, size:] = beta
+            big[2 * size - 1, :size] = 1
+            beta, size = big, 2 * size
+        return beta[:nqbits, :nqbits].copy()
+    raise ValueError(f"unknown transform '{transform}'")
+
+
+def _gf2_inverse(m):
+    n = m.shape[0]
+    a = np.concatenate([m.copy() % 2, np.eye(n, dtype=np.uint8)], axis=1)
+    for c in range(n):
+        piv = next(r for r in range(c, n) if a[r, c])
+        a[[c, piv]] = a[[piv, c]]
+        for r in range(n):
+            if r != c and a[r, c]:
+                a[r] ^= a[c]
+    return a[:, n:]
+
+
+_LADDERS = {}
+
+
+def encoded_ladder(nqbits, p, dagger, transform):
+    """a_p / a+_p as a Pauli sum under a linear encoding: with c = X_{column p of beta} Z_{parity set of p} (the operator that
+    flips occupation p with the sign of the orbitals below it) and n_p read from the flip set F(p) (row p of beta^-1),
+    a_p = c (1 - Z_F) / 2 and a+_p = c (1 + Z_F) / 2."""
+    key = (nqbits, transform)
+    if key not in _LADDERS:
+        beta = encoding_matrix(nqbits, transform)
+        inv = _gf2_inverse(beta)
+        cols = [sum(1 << i for i in range(nqbits) if beta[i, j]) for j in range(nqbits)]
+        flips = [sum(1 << i for i in range(nqbits) if inv[j, i]) for j in range(nqbits)]
+        below = np.cumsum(np.vstack([np.zeros((1, nqbits), dtype=np.int64), inv[:-1].astype(np.int64)]), axis=0) % 2
+        pars = [sum(1 << i for i in range(nqbits) if below[j, i]) for j in range(nqbits)]
+        _LADDERS[key] = (cols, pars, flips)
+    cols, pars, flips = _LADDERS[key]
+    x, zp, zf = cols[p], pars[p], pars[p] ^ flips[p]
+
+    def string(z):   # the operator product X^x Z^z written as coefficient * (Hermitian string (x, z))
+        return (x, z), (-1j) ** (bin(x & z).count("1") % 4)
+    (k1, c1), (k2, c2) = string(zp), string(zf)
+    out = {k1: 0.5 * c1}
+    out[k2] = out.get(k2, 0) + (0.5 if dagger else -0.5) * c2
+    return out
+
+
+def encoded_product(nqbits, ladder_ops, transform):
+    if transform == "JW":
+        return jw_product(ladder_ops)
+    out = {(0, 0): 1.0}
+    for p, dag in ladder_ops:
+        out = psum_mul(out, encoded_ladder(nqbits, p, dag, transform))
+    return out
+
+
+def recode_occupation(integer, nqbits, transform):
+    """occupation integer (orbital 0 = most significant bit) -> basis index of the encoded qubit register"""
+    if transform == "JW":
+        return int(integer)
+    beta = encoding_matrix(nqbits, transform)
+    f = np.array([(int(integer) >> (nqbits - 1 - q)) & 1 for q in range(nqbits)], dtype=np.int64)
+    q = (beta.astype(np.int64) @ f) % 2
+    return int(sum(int(b) << (nqbits - 1 - i) for i, b in enumerate(q)))
+
+
 def psum_to_hamiltonian(nqbits, psum, constant=0.0, tol=1e-13, real=False):
     """dict[(x,z)] -> Hamiltonian (insertion order kept); the identity string goes to the constant."""
     terms = []
@@ -111,11 +191,16 @@ def spin_orbital_integrals(h1_spatial, eri_chem):
     return hpq, hpqrs
 
 
-def jw_molecular_hamiltonian(hpq, hpqrs, constant=0.0, tol=1e-12):
-    """JW transform of the electronic-structure Hamiltonian (spin-orbital integrals)."""
+def jw_molecular_hamiltonian(hpq, hpqrs, constant=0.0, tol=1e-12, transform="JW"):
+    """qubit image of the electronic-structure Hamiltonian (spin-orbital integrals); Jordan-Wigner by default,
+    "Bravyi-Kitaev" / "parity_basis" through the linear-encoding ladder operators"""
     n = hpq.shape[0]
-    ladders_c = [jw_ladder(p, True) for p in range(n)]
-    ladders_a = [jw_ladder(p, False) for p in range(n)]
+    if transform == "JW":
+        ladders_c = [jw_ladder(p, True) for p in range(n)]
+        ladders_a = [jw_ladder(p, False) for p in range(n)]
+    else:
+        ladders_c = [encoded_ladder(n, p, True, transform) for p in range(n)]
+        ladders_a = [encoded_ladder(n, p, False, transform) for p in range(n)]
     total = {}
     for p in range(n):
         for q in range(n):

@@ -83,14 +83,14 @@ class FermionHamiltonian:
         return transform_to_jw_basis(self).get_matrix(sparse=sparse)
 
     def to_spin(self, transform="JW"):
-        return transform_to_jw_basis(self) if transform == "JW" else _no_transform(transform)
+        return spin_operator(self, transform)
 
     def __repr__(self):
         return " + ".join([f"{self.constant_coeff}"] + [f"{t.coeff}*{t.op}{t.qbits}" for t in self.terms])
 
 
 def _no_transform(name):
-    raise NotImplementedError(f"transform '{name}': only the Jordan-Wigner mapping is restated (SURVEY.md §8f row 1)")
+    raise NotImplementedError(f"transform '{name}': 'JW', 'Bravyi-Kitaev' and 'parity_basis' are restated")
 
 
 # ---------------------------------------------------------------------------------------------- normal ordering
@@ -164,10 +164,24 @@ def transform_to_jw_basis(op):
     return fermion.psum_to_hamiltonian(op.nbqbits, total, op.constant_coeff, tol=1e-13)
 
 
+def transform_to_encoding(op, transform):
+    """FermionHamiltonian -> spin Hamiltonian under "Bravyi-Kitaev" / "parity_basis" (``transform_to_bk_basis`` /
+    ``transform_to_parity_basis`` of myQLM; linear encodings of fermion.encoding_matrix).  Isospectral with the JW image;
+    myQLM's own index conventions for these two encodings are not pinned by anything the reference stores."""
+    from . import fermion
+    total = {}
+    for t in sorted(op.terms, key=lambda t: t.qbits):
+        fermion.psum_iadd(total, fermion.encoded_product(op.nbqbits, [(p, o == "C") for o, p in zip(t.op, t.qbits)],
+                                                         transform), t.coeff)
+    return fermion.psum_to_hamiltonian(op.nbqbits, total, op.constant_coeff, tol=1e-13)
+
+
 def spin_operator(op, transform="JW"):
-    if transform != "JW":
-        _no_transform(transform)
-    return transform_to_jw_basis(op)
+    if transform == "JW":
+        return transform_to_jw_basis(op)
+    if transform in ("Bravyi-Kitaev", "parity_basis"):
+        return transform_to_encoding(op, transform)
+    _no_transform(transform)
 
 
 __all__ = ["FermionHamiltonian", "Hamiltonian", "Term", "normal_ordered_terms", "normal_ordered", "transform_to_jw_basis",

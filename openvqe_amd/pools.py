@@ -11,11 +11,11 @@ from __future__ import annotations
 from . import fermion
 
 
-def _jw_sum(nqbits, terms):
+def _jw_sum(nqbits, terms, transform="JW"):
     """terms: [(coeff, [(orbital, dagger), ...])] -> Pauli-sum dict"""
     total = {}
     for coeff, ladder in terms:
-        total = fermion.psum_add(total, fermion.jw_product(ladder), coeff)
+        total = fermion.psum_add(total, fermion.encoded_product(nqbits, ladder, transform), coeff)
     return total
 
 
@@ -29,8 +29,6 @@ def _cccc(i, j, k, l):
 
 def spin_complement_gsd(n_elec, orbital_number, transform="JW"):
     """-> (pool_size, cluster_ops_sp): anti-Hermitian spin-complemented generalised singles and doubles"""
-    if transform != "JW":
-        raise NotImplementedError("only the Jordan-Wigner mapping is restated")
     n = 2 * orbital_number
     singles, doubles = [], []
     for p in range(0, n, 2):
@@ -48,7 +46,7 @@ def spin_complement_gsd(n_elec, orbital_number, transform="JW"):
     # NB no operator is dropped: with myQLM every entry of the raw enumeration survives `_apply_transforms`
     # (the pinned sizes 69 / 175 ARE the raw loop counts), identically-zero ones included —
     # they simply carry no Pauli terms here and rank with gradient 0.
-    pool = [fermion.psum_to_hamiltonian(n, _jw_sum(n, terms), tol=1e-13) for terms in singles + doubles]
+    pool = [fermion.psum_to_hamiltonian(n, _jw_sum(n, terms, transform), tol=1e-13) for terms in singles + doubles]
     return len(pool), pool
 
 

@@ -109,14 +109,40 @@ def transform_to_jw_basis(op):
     raise TypeError("transform_to_jw_basis: a fermionic operator is expected")
 
 
-def _unsupported_transform(*_a, **_k):
-    raise NotImplementedError("only the Jordan-Wigner mapping is restated (SURVEY.md section 8f row 1)")
+def _encoded(transform):
+    def apply(op):
+        if isinstance(op, ElectronicStructureHamiltonian):
+            return fermion.jw_molecular_hamiltonian(op.hpq, op.hpqrs, op.constant_coeff, transform=transform)
+        from .fermionic import transform_to_encoding
+        spin = transform_to_encoding(op, transform)
+        spin.terms = _TermList(spin.terms)
+        return spin
+    return apply
+
+
+transform_to_bk_basis = _encoded("Bravyi-Kitaev")
+transform_to_parity_basis = _encoded("parity_basis")
+
+
+class _Code:
+    """what ``get_*_code(nbqbits)`` hands to ``recode_integer``: the encoding's name and register size"""
+
+    def __init__(self, nbqbits, transform):
+        self.nbqbits, self.transform = nbqbits, transform
 
 
 def get_jw_code(nbqbits):
-    return np.eye(nbqbits, dtype=int)
+    return _Code(nbqbits, "JW")
+
+
+def get_bk_code(nbqbits):
+    return _Code(nbqbits, "Bravyi-Kitaev")
+
+
+def get_parity_code(nbqbits):
+    return _Code(nbqbits, "parity_basis")
 
 
 def recode_integer(integer, code):
-    """occupation integer of the fermionic mode ordering -> integer of the qubit register; identity for Jordan-Wigner"""
-    return int(integer)
+    """occupation integer of the fermionic mode ordering -> basis index of the encoded qubit register"""
+    return fermion.recode_occupation(int(integer), code.nbqbits, code.transform)

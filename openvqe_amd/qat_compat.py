@@ -391,10 +391,10 @@ def install(force=False):
                       FermionHamiltonian=_fermionic.FermionHamiltonian,
                       ElectronicStructureHamiltonian=_chem.ElectronicStructureHamiltonian)
     qat.fermion.transforms = mod("qat.fermion.transforms", transform_to_jw_basis=_chem.transform_to_jw_basis,
-                                 transform_to_bk_basis=_chem._unsupported_transform,
-                                 transform_to_parity_basis=_chem._unsupported_transform,
-                                 get_jw_code=_chem.get_jw_code, get_bk_code=_chem._unsupported_transform,
-                                 get_parity_code=_chem._unsupported_transform, recode_integer=_chem.recode_integer)
+                                 transform_to_bk_basis=_chem.transform_to_bk_basis,
+                                 transform_to_parity_basis=_chem.transform_to_parity_basis,
+                                 get_jw_code=_chem.get_jw_code, get_bk_code=_chem.get_bk_code,
+                                 get_parity_code=_chem.get_parity_code, recode_integer=_chem.recode_integer)
     qat.fermion.chemistry = mod("qat.fermion.chemistry")
     qat.fermion.chemistry.pyscf_tools = mod("qat.fermion.chemistry.pyscf_tools",
                                             perform_pyscf_computation=_chem.perform_pyscf_computation)
