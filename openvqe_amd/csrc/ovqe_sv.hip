@@ -129,6 +129,7 @@ struct ovqe_sv {
     bool pg_valid = false;
     int opt_sparse = 1;           // allow the support-compacted path
     int opt_sparse_spw = 0;       // evaluations per wave (0 = automatic)
+    int opt_sparse_dealias = 1;   // arrange the restricted-Hamiltonian entries against LDS bank conflicts
     // pair-index-space expectation tables of the fused kernel, built per (thread bits, real mode)
     DevBuf d_egroups, d_eterms, d_echunks, d_eflat;
     int exp_lbits = -1, exp_real = -1, exp_ngroups = 0, exp_nchunks = 0, exp_nflat = 0;
@@ -1996,6 +1997,66 @@ int build_sparse_program(ovqe_handle h) {
             if (entries.size() > (size_t)16 << 20) return OVQE_OK;
         }
     }
+    // LDS bank conflicts: a wave reads the two amplitudes of 64 consecutive entries at once (ds_read_b64 is served in two
+    // 32-lane groups, bank = double slot mod 32).  The entries are a plain sum, so their order is free: they are
+    // re-arranged greedily so that inside every aligned group of 32 the first indices are distinct mod 32 and so are the
+    // second ones — conflict-free reads wherever the entry set allows it (a fixed order: results stay reproducible).
+    if (h->opt_sparse_dealias && entries.size() > 64) {
+        std::vector<std::vector<uint32_t>> by_bank(32);
+        for (uint32_t e = 0; e < (uint32_t)entries.size(); ++e) by_bank[entries[e].ij & 31u].push_back(e);
+        std::vector<SpEntry> arranged;
+        arranged.reserve(entries.size());
+        size_t left = entries.size();
+        std::vector<uint32_t> order(32);
+        while (left) {
+            std::iota(order.begin(), order.end(), 0u);
+            std::stable_sort(order.begin(), order.end(),
+                             [&](uint32_t a, uint32_t b) { return by_bank[a].size() > by_bank[b].size(); });
+            uint32_t used_j = 0;
+            size_t taken = 0;
+            for (uint32_t bi : order) {
+                std::vector<uint32_t> &lst = by_bank[bi];
+                if (lst.empty()) continue;
+                size_t pick = lst.size();
+                for (size_t k = lst.size(); k-- > 0;) {           // newest first: cheap erase
+                    const uint32_t bj = (entries[lst[k]].ij >> 12) & 31u;
+                    if (!((used_j >> bj) & 1u)) {
+                        pick = k;
+                        break;
+                    }
+                }
+                if (pick == lst.size()) continue;                 // every candidate collides on the second index
+                used_j |= 1u << ((entries[lst[pick]].ij >> 12) & 31u);
+                arranged.push_back(entries[lst[pick]]);
+                lst.erase(lst.begin() + (long)pick);
+                ++taken;
+                --left;
+            }
+            if (taken == 0) {                                     // only colliding entries remain: take one anyway
+                for (auto &lst : by_bank)
+                    if (!lst.empty()) {
+                        arranged.push_back(entries[lst.back()]);
+                        lst.pop_back();
+                        --left;
+                        break;
+                    }
+            }
+            // pad the group to 32 with whatever is left so that later groups stay aligned
+            while (taken && taken < 32 && left) {
+                bool any = false;
+                for (auto &lst : by_bank)
+                    if (!lst.empty() && taken < 32) {
+                        arranged.push_back(entries[lst.back()]);
+                        lst.pop_back();
+                        --left;
+                        ++taken;
+                        any = true;
+                    }
+                if (!any) break;
+            }
+        }
+        entries.swap(arranged);
+    }
     int rc = upload(h, h->d_sp_ops, ops.data(), ops.size() * sizeof(SpOp));
     if (!rc) rc = upload(h, h->d_sp_pairs, pairs.data(), pairs.size() * sizeof(uint32_t));
     if (!rc) rc = upload(h, h->d_sp_entries, entries.data(), entries.size() * sizeof(SpEntry));
@@ -2224,6 +2285,10 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
         (k == "tile_bits" ? h->opt_tile_bits : h->opt_tile_low) = (int)value;
         h->tp_real_built = false;  // the real-amplitude plan follows on its next use
         if (h->prog_set) return build_tile_program(h);
+    }
+    else if (k == "sparse_dealias") {
+        h->opt_sparse_dealias = value ? 1 : 0;
+        h->sp_tried = false;
     }
     else if (k == "expect_sparse") h->opt_expect_sparse = (int)std::max<int64_t>(0, value);
     else if (k == "expect_streams") h->opt_expect_streams = value >= 2 ? 2 : 1;

@@ -84,28 +84,52 @@ __global__ __launch_bounds__(64) void k_sparse_vqe(SparseArgs A, const double *_
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int o = 0; o < A.nops; ++o) {
-            SpOp op;
-            if constexpr (STAGE) {
-                op = lops[o];
+        if constexpr (STAGE) {
+            for (int o = 0; o < A.nops; ++o) {
+                SpOp op = lops[o];
                 op.first = __builtin_amdgcn_readfirstlane(op.first);
                 op.npairs = __builtin_amdgcn_readfirstlane(op.npairs);
                 op.tab0 = __builtin_amdgcn_readfirstlane(op.tab0);
-            } else {
-                op = ops[o];
+                for (int pe = l; pe < op.npairs; pe += LPS) {
+                    const uint32_t pw = lpairs[op.first + pe];
+                    const uint32_t ci = pw & 0xfffu, cj = (pw >> 12) & 0xfffu;
+                    const double2 t = csb[op.tab0 + (int)(pw >> 25)];
+                    const double sn = (pw & (1u << 24)) ? -t.y : t.y;
+                    const double u = base[ci], v = base[cj];
+                    base[ci] = t.x * u + sn * v;
+                    base[cj] = t.x * v - sn * u;
+                }
+                // pairs of one op are disjoint; the next op may touch them from other lanes of this wave: the LDS unit
+                // executes a wave's DS instructions in issue order, so only the COMPILER must not reorder across ops
+                asm volatile("" ::: "memory");
             }
-            for (int pe = l; pe < op.npairs; pe += LPS) {
-                const uint32_t pw = STAGE ? lpairs[op.first + pe] : pairs[op.first + pe];
-                const uint32_t ci = pw & 0xfffu, cj = (pw >> 12) & 0xfffu;
-                const double2 t = csb[op.tab0 + (int)(pw >> 25)];
-                const double sn = (pw & (1u << 24)) ? -t.y : t.y;
-                const double u = base[ci], v = base[cj];
-                base[ci] = t.x * u + sn * v;
-                base[cj] = t.x * v - sn * u;
+        } else {
+            // op records and pair words stream from L2: the chain record -> pair word -> amplitudes of consecutive ops is
+            // what bounds this kernel, so both are fetched AHEAD — the record of op o + 3 and the first pair words of ops o + 1,
+            // o + 2 are in flight while op o rotates its pairs (most ops have fewer pairs than lanes: one word per lane)
+            const int last = A.nops - 1;
+            SpOp op1 = ops[0], op2 = ops[min(1, last)], op3 = ops[min(2, last)];
+            uint32_t pw1 = l < op1.npairs ? pairs[op1.first + l] : 0u;
+            uint32_t pw2 = (last >= 1 && l < op2.npairs) ? pairs[op2.first + l] : 0u;
+            for (int o = 0; o < A.nops; ++o) {
+                const SpOp op = op1;
+                uint32_t pw = pw1;
+                op1 = op2;
+                pw1 = pw2;
+                op2 = op3;
+                op3 = ops[min(o + 3, last)];
+                pw2 = (o + 2 <= last && l < op2.npairs) ? pairs[op2.first + l] : 0u;
+                for (int pe = l; pe < op.npairs; pe += LPS) {
+                    if (pe != l) pw = pairs[op.first + pe];
+                    const uint32_t ci = pw & 0xfffu, cj = (pw >> 12) & 0xfffu;
+                    const double2 t = csb[op.tab0 + (int)(pw >> 25)];
+                    const double sn = (pw & (1u << 24)) ? -t.y : t.y;
+                    const double u = base[ci], v = base[cj];
+                    base[ci] = t.x * u + sn * v;
+                    base[cj] = t.x * v - sn * u;
+                }
+                asm volatile("" ::: "memory");
             }
-            // pairs of one op are disjoint; the next op may touch them from other lanes of this wave: the LDS unit
-            // executes a wave's DS instructions in issue order, so only the COMPILER must not reorder across ops
-            asm volatile("" ::: "memory");
         }
         double acc[SPW];
 #pragma unroll
