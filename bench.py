@@ -207,6 +207,39 @@ def gate_and_midsize_workloads(device):
                     "ms_first_call_dense_cover": times[0], "ms_second_call_builds_compact_cover": times[1],
                     "ms_steady_state": min(times[2:]), "energy": float(e24),
                     "algorithmic_GBs": b_eval / (min(times[2:]) * 1e-3) / 1e9, "program": sv.program_info()})
+    # BASELINE.json configs[3] on its molecule: N2 / cc-pVDZ, (10 electrons, 12 orbitals) active space = 24 qubits, from the
+    # in-repo front-end (d-shell integrals, RHF, frozen core).  UCCSD (JW generators in the reference's operator order) at
+    # the MP2 amplitudes, and the reference's QUCCSD gate list (Clifford-frame form) on the same operators.
+    from openvqe_amd import chem
+    from openvqe_amd.common_files.circuit import quccsd_gate_list
+    mol = chem.molecule("N2-CCPVDZ")
+    e_rhf = mol.rhf()
+    prob = chem.cas_problem(mol, 2, 12)
+    hamn = prob.jw_hamiltonian()
+    size, cluster_ops, spin_ops, theta_mp2, hfn = prob.uccsd()
+    rown = {"workload": "N2/cc-pVDZ (10e,12o) active space, 24 qubits (configs[3])", "qubits": prob.nbqbits,
+            "E_RHF": e_rhf, "E_MP2": mol.mp2_energy(), "cluster_operators": size, "hamiltonian_terms": len(hamn.terms) + 1,
+            "x_groups": len(set(hamn.packed()[0].tolist()))}
+    with Statevector(prob.nbqbits, device=device) as sv:
+        sv.set_hamiltonian(hamn)
+        sv.set_ucc_program(spin_ops, hfn)
+        times = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            e_ucc = sv.energy(theta_mp2)
+            times.append(1e3 * (time.perf_counter() - t0))
+        rown["uccsd_at_theta_mp2"] = {"energy": float(e_ucc), "ms_first_call": times[0], "ms_steady_state": min(times[2:]),
+                                      "program": sv.program_info()}
+        gates, K, _ = quccsd_gate_list(12, 5, 1, excitations=[op.terms[0].qbits for op in cluster_ops])
+        sv.set_gate_program(gates, K, hfn)
+        times = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            e_q = sv.energy(theta_mp2)
+            times.append(1e3 * (time.perf_counter() - t0))
+        rown["quccsd_gate_list_at_theta_mp2"] = {"literal_gates": len(gates), "energy": float(e_q), "ms_first_call": times[0],
+                                                 "ms_steady_state": min(times[2:]), "program": sv.program_info()}
+    out.append(rown)
     return out
 
 

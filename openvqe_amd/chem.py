@@ -30,6 +30,20 @@ BASIS_SP = {
                (0, [0.6362897, 0.1478601, 0.0480887], _STO3G_2S), (1, [0.6362897, 0.1478601, 0.0480887], _STO3G_2P)],
         "O": [(0, [130.7093200, 23.8088610, 6.4436083], _STO3G_1S),
               (0, [5.0331513, 1.1695961, 0.3803890], _STO3G_2S), (1, [5.0331513, 1.1695961, 0.3803890], _STO3G_2P)],
+        "N": [(0, [99.1061690, 18.0523120, 4.8856602], _STO3G_1S),
+              (0, [3.7804559, 0.8784966, 0.2857144], _STO3G_2S), (1, [3.7804559, 0.8784966, 0.2857144], _STO3G_2P)],
+    },
+    # Dunning's correlation-consistent polarised valence double zeta, (9s4p1d) -> [3s2p1d], spherical d functions
+    "cc-pvdz": {
+        "N": [(0, [9046.0, 1357.0, 309.3, 87.73, 28.56, 10.21, 3.838, 0.7466],
+               [0.000700, 0.005389, 0.027406, 0.103207, 0.278723, 0.448540, 0.278238, 0.015440]),
+              (0, [9046.0, 1357.0, 309.3, 87.73, 28.56, 10.21, 3.838, 0.7466],
+               [-0.000153, -0.001208, -0.005992, -0.024544, -0.067459, -0.158078, -0.121831, 0.549003]),
+              (0, [0.2248], [1.0]),
+              (1, [13.55, 2.917, 0.7973], [0.039919, 0.217169, 0.510319]),
+              (1, [0.2185], [1.0]),
+              (2, [0.817], [1.0])],
+        "H": [(0, [13.01, 1.962, 0.4446], [0.019685, 0.137977, 0.478148]), (0, [0.122], [1.0]), (1, [0.727], [1.0])],
     },
 }
 BASIS = {
@@ -44,7 +58,7 @@ BASIS = {
                ([0.2979640], [1.0])],
     },
 }
-CHARGE = {"H": 1, "He": 2, "Li": 3, "O": 8}
+CHARGE = {"H": 1, "He": 2, "Li": 3, "N": 7, "O": 8}
 
 
 def _f0(t):
@@ -66,12 +80,24 @@ class Molecule:
         self.general = any(sym not in BASIS.get(self.basis_name, {}) for sym, _ in self.atoms)
         if self.general:
             from . import gto
+            cart = {0: [(0, 0, 0)], 1: [(1, 0, 0), (0, 1, 0), (0, 0, 1)],
+                    2: [(2, 0, 0), (0, 2, 0), (0, 0, 2), (1, 1, 0), (1, 0, 1), (0, 1, 1)]}
             self.functions = []
+            blocks = []          # Cartesian -> spherical transformation, block by block (identity for s and p)
             for sym, pos in self.atoms:
                 for l, exps, coefs in BASIS_SP[self.basis_name][sym]:
-                    for lmn in ([(0, 0, 0)] if l == 0 else [(1, 0, 0), (0, 1, 0), (0, 0, 1)]):
+                    for lmn in cart[l]:
                         self.functions.append(gto.BasisFunction(pos, lmn, exps, coefs))
-            self.nao = len(self.functions)
+                    blocks.append(gto.spherical_d_transform(cart[2]) if l == 2 else np.eye(len(cart[l])))
+            nc, ns = sum(b.shape[0] for b in blocks), sum(b.shape[1] for b in blocks)
+            self.cart2sph = np.zeros((nc, ns))
+            r = c = 0
+            for b in blocks:
+                self.cart2sph[r:r + b.shape[0], c:c + b.shape[1]] = b
+                r += b.shape[0]
+                c += b.shape[1]
+            self.has_d = nc != ns
+            self.nao = ns
             return
         # contracted s functions: (centre, exponents, coefficients incl. primitive normalisation)
         self.shells = []
@@ -140,6 +166,51 @@ class Molecule:
         return eri
 
     # -- restricted Hartree-Fock ------------------------------------------------------------------
+    def ao_integrals(self):
+        """S, T, V, (ij|kl) over the molecule's atomic orbitals (s-only closed forms; McMurchie-Davidson for p and d shells —
+        compiled when libovqe_gto.so is built, which d shells require; d functions as the five spherical components)"""
+        if not self.general:
+            S, T, V = self.one_electron()
+            return S, T, V, self.two_electron()
+        from . import gto
+        charges = [(CHARGE[s], r) for s, r in self.atoms]
+        if gto._clib() is not None:
+            S, T, V, eri = gto.integrals_compiled(self.functions, charges)
+        elif self.has_d:
+            raise RuntimeError("d shells need the compiled integral code: run __graft_entry__.build()")
+        else:
+            S, T, V, eri = gto.integrals(self.functions, charges)
+        if self.has_d:
+            U = self.cart2sph
+            S, T, V = U.T @ S @ U, U.T @ T @ U, U.T @ V @ U
+            eri = np.einsum("pqrs,pi,qj,rk,sl->ijkl", eri, U, U, U, U, optimize=True)
+        return S, T, V, eri
+
+    def _atomic_guess_density(self):
+        """diagonal AO density (in units of electron PAIRS, like C_occ C_occ^T) from the atoms' ground configurations:
+        s electrons fill the atom's s shells in listing order, p electrons its first p shell evenly; zero (= the
+        core-Hamiltonian guess) for the s-only molecules, which have no competing SCF solutions"""
+        D = np.zeros((self.nao, self.nao))
+        if not self.general:
+            return D
+        config = {"H": (1, 0), "He": (2, 0), "Li": (3, 0), "N": (4, 3), "O": (4, 4)}    # (s electrons, p electrons)
+        k = 0
+        for sym, _ in self.atoms:
+            ns, np_ = config[sym]
+            first_p = True
+            for l, _, _ in BASIS_SP[self.basis_name][sym]:
+                width = {0: 1, 1: 3, 2: 5}[l]
+                if l == 0:
+                    occ = min(2, ns)
+                    ns -= occ
+                    D[k, k] = occ / 2.0
+                elif l == 1 and first_p:
+                    for c in range(3):
+                        D[k + c, k + c] = np_ / 6.0
+                    first_p = False
+                k += width
+        return D
+
     def rhf(self, tol=1e-12, max_iter=200, grad_tol=1e-9):
         """restricted Hartree-Fock with DIIS.  Converged when |dE| < tol and the orbital gradient (max element of the
         orthonormalised commutator FDS - SDF) < grad_tol.  PySCF's defaults — what the reference's myQLM front-end runs
@@ -147,17 +218,14 @@ class Molecule:
         grad_tol=3.2e-5)`` stops there and leaves orbitals that are rotated by ~1e-7 .. 1e-6 against the converged ones
         (tests/test_scf_threshold.py: that rotation IS the 1e-8-level offset between the stored notebook numbers and a
         tightly converged replay)."""
-        if self.general:
-            from . import gto
-            S, T, V, eri = gto.integrals(self.functions, [(CHARGE[s], r) for s, r in self.atoms])
-        else:
-            S, T, V = self.one_electron()
-            eri = self.two_electron()
+        S, T, V, eri = self.ao_integrals()
         hcore = T + V
         nocc = self.n_elec // 2
         sval, svec = np.linalg.eigh(S)
         X = svec @ np.diag(sval ** -0.5) @ svec.T
-        D = np.zeros_like(S)
+        # start from a superposition of atomic ground-state occupations (the role of PySCF's default 'minao' guess): the bare
+        # core-Hamiltonian guess locks N2 onto an excited closed-shell SCF solution 0.73 Ha above the ground state
+        D = self._atomic_guess_density()
         e_old = 0.0
         fock_hist, err_hist = [], []
         for it in range(max_iter):
@@ -219,12 +287,7 @@ class Molecule:
         self._set_orbitals(self.mo_coeff @ scipy.linalg.expm(K))
 
     def _set_orbitals(self, C):
-        if self.general:
-            from . import gto
-            _, T, V, eri = gto.integrals(self.functions, [(CHARGE[s], r) for s, r in self.atoms])
-        else:
-            _, T, V = self.one_electron()
-            eri = self.two_electron()
+        _, T, V, eri = self.ao_integrals()
         self.mo_coeff = C
         self.h_mo = C.T @ (T + V) @ C
         self.eri_mo = np.einsum("pqrs,pi,qj,rk,sl->ijkl", eri, C, C, C, C, optimize=True)
@@ -326,6 +389,30 @@ class Molecule:
                        [self.mo_energy[i] for i in act], thresholds=(eps1, eps2), frozen=frozen, active=act)
 
 
+def cas_problem(mol, n_frozen, n_active):
+    """user-chosen complete active space in the HF orbitals: the lowest ``n_frozen`` orbitals stay doubly occupied (folded
+    into the constant and the one-body part), the next ``n_active`` orbitals are kept — e.g. N2/cc-pVDZ (10 electrons, 12
+    orbitals) = 24 qubits, the size of BASELINE.json configs[3].  (The reference selects active spaces by NOON thresholds,
+    ``Molecule.problem(active=True)``; its CISD step is out of reach at 56 qubits, hence the explicit choice here.)"""
+    if not hasattr(mol, "h_mo"):
+        mol.rhf()
+    frozen = list(range(n_frozen))
+    act = list(range(n_frozen, n_frozen + n_active))
+    h, g = mol.h_mo, mol.eri_mo
+    const = mol.nuclear_repulsion()
+    for i in frozen:
+        const += 2.0 * h[i, i]
+        for j in frozen:
+            const += 2.0 * g[i, i, j, j] - g[i, j, j, i]
+    h_act = h[np.ix_(act, act)].copy()
+    for i in frozen:
+        h_act += 2.0 * g[np.ix_(act, act, [i], [i])][:, :, 0, 0] - g[np.ix_(act, [i], [i], act)][:, 0, 0, :]
+    n_act_el = mol.n_elec - 2 * n_frozen
+    occ = [2.0 if k < n_act_el // 2 else 0.0 for k in range(n_active)]
+    return Problem(h_act, g[np.ix_(act, act, act, act)], const, n_act_el, occ, [mol.mo_energy[i] for i in act],
+                   frozen=frozen, active=act)
+
+
 def select_active_orbitals(noons, n_elec, threshold_1, threshold_2):
     """NOON-based selection of myQLM's ``get_active_space_hamiltonian`` (called at
     ref:openvqe/common_files/molecule_factory.py:384-392; published rule): active A = {i : e2 <= n_i < 2 - e1} +
@@ -394,6 +481,10 @@ def molecule(symbol):
         r, theta = 1.0285, 0.538 * np.pi
         return Molecule([("O", (0, 0, 0)), ("H", (0, 0, r)),
                          ("H", (0, r * np.sin(np.pi - theta), r * np.cos(np.pi - theta)))], "sto-3g")
+    if s == "N2":                      # ref:openvqe/common_files/molecule_factory.py:245-250
+        return Molecule([("N", (0, 0, 0.5488)), ("N", (0, 0, -0.5488))], "sto-3g")
+    if s == "N2-CCPVDZ":               # the basis BASELINE.json configs[3] names (not in the reference's table)
+        return Molecule([("N", (0, 0, 0.5488)), ("N", (0, 0, -0.5488))], "cc-pvdz")
     if s == "HEH+":
         return Molecule([("He", (0, 0, 0)), ("H", (0, 0, 1.0))], "6-31g", charge=1)
     raise KeyError(symbol)

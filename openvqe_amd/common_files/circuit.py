@@ -108,14 +108,17 @@ def efficient_qubit_ansatz(q, qc, list_exci, list_theta):
     return qc
 
 
-def quccsd_gate_list(n_spatial, n_occ_spatial, stride=1):
+def quccsd_gate_list(n_spatial, n_occ_spatial, stride=1, excitations=None):
     """literal gate list [(name, qubits, angle_scale, angle_const, param_index)] of the fermionic templates above on
-    every ``stride``-th UCCSD excitation of n_spatial orbitals / n_occ_spatial occupied (traced with symbolic
-    angles; the input of ``Statevector.set_gate_program``) -> (gates, n_params, hf_integer)"""
+    every ``stride``-th UCCSD excitation of n_spatial orbitals / n_occ_spatial occupied — or on the explicit index lists
+    ``excitations`` (e.g. ``[op.terms[0].qbits for op in cluster_ops]``, what ref:openvqe/ucc_family/get_energy_qucc.py:46-49
+    extracts) — traced with symbolic angles; the input of ``Statevector.set_gate_program`` -> (gates, n_params, hf_integer)"""
     from .. import fermion
     from ..qat_compat import AffineParam, Program, lower_circuit
-    singles, doubles = fermion.uccsd_excitations(n_spatial, n_occ_spatial)
-    exci = ([[i, a] for i, a in singles] + [[i, j, a, b] for i, j, a, b in doubles])[::stride]
+    if excitations is None:
+        singles, doubles = fermion.uccsd_excitations(n_spatial, n_occ_spatial)
+        excitations = [[i, a] for i, a in singles] + [[i, j, a, b] for i, j, a, b in doubles]
+    exci = [list(e) for e in excitations][::stride]
     prog = Program()
     reg = prog.qalloc(2 * n_spatial)
     efficient_fermionic_ansatz(reg, prog, exci, [AffineParam(k) for k in range(len(exci))])

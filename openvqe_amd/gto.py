@@ -180,3 +180,58 @@ def integrals(functions, charges):
                                          (k, l, i, j), (l, k, i, j), (k, l, j, i), (l, k, j, i)):
                         eri[w, x, y, z] = val
     return S, T, V, eri
+
+
+# ---------------------------------------------------------------- compiled form (openvqe_amd/csrc/gto_integrals.c)
+_CLIB = None
+
+
+def _clib():
+    """libovqe_gto.so (built by __graft_entry__.build()); None when it has not been built"""
+    global _CLIB
+    if _CLIB is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libovqe_gto.so")
+        if not os.path.exists(path):
+            return None
+        lib = ctypes.CDLL(path)
+        f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+        i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+        lib.gto_integrals.argtypes = [ctypes.c_int, f64, i32, i32, i32, f64, f64, ctypes.c_int, f64, f64, f64, f64, f64]
+        lib.gto_integrals.restype = ctypes.c_int
+        _CLIB = lib
+    return _CLIB
+
+
+def integrals_compiled(functions, charges):
+    """same contract as ``integrals`` through the C implementation (any angular momentum up to d, OpenMP)"""
+    lib = _clib()
+    if lib is None:
+        raise RuntimeError("libovqe_gto.so is not built: run __graft_entry__.build()")
+    n = len(functions)
+    centers = np.ascontiguousarray([f.origin for f in functions], np.float64).reshape(-1)
+    lmn = np.ascontiguousarray([f.lmn for f in functions], np.int32).reshape(-1)
+    nprim = np.array([len(f.exps) for f in functions], np.int32)
+    offset = np.concatenate([[0], np.cumsum(nprim)[:-1]]).astype(np.int32)
+    exps = np.ascontiguousarray(np.concatenate([f.exps for f in functions]), np.float64)
+    coefs = np.ascontiguousarray(np.concatenate([f.coefs for f in functions]), np.float64)
+    ch = np.ascontiguousarray([[Z, *C] for Z, C in charges], np.float64).reshape(-1)
+    S, T, V = (np.zeros((n, n)) for _ in range(3))
+    eri = np.zeros((n, n, n, n))
+    rc = lib.gto_integrals(n, centers, lmn, nprim, offset, exps, coefs, len(charges), ch, S, T, V, eri)
+    if rc:
+        raise RuntimeError(f"gto_integrals failed ({rc}): angular momentum above d?")
+    return S, T, V, eri
+
+
+def spherical_d_transform(shell_cartesians):
+    """columns: the five real solid-harmonic d functions in terms of the six NORMALISED Cartesian ones, given in the
+    order (xx, yy, zz, xy, xz, yz) -> (6, 5) matrix; each column has unit norm (<xx|yy> = 1/3 for normalised functions)"""
+    order = {(2, 0, 0): 0, (0, 2, 0): 1, (0, 0, 2): 2, (1, 1, 0): 3, (1, 0, 1): 4, (0, 1, 1): 5}
+    rows = [order[tuple(c)] for c in shell_cartesians]
+    canon = np.zeros((6, 5))
+    canon[2, 0], canon[0, 0], canon[1, 0] = 1.0, -0.5, -0.5           # d_z2
+    canon[0, 1], canon[1, 1] = np.sqrt(3.0) / 2.0, -np.sqrt(3.0) / 2.0  # d_x2-y2
+    canon[3, 2] = canon[4, 3] = canon[5, 4] = 1.0                      # d_xy, d_xz, d_yz
+    return canon[rows, :]

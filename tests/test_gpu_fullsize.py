@@ -168,26 +168,31 @@ def test_32_qubit_state_on_one_gpu(gpu_lib):
 
 
 def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
-    """BASELINE configs[3] at its size: the literal QUCCSD gate list (ref:openvqe/common_files/circuit.py:13-106
-    templates on every 5th UCCSD excitation of 10 electrons / 12 orbitals: 343 parameters, ~13 k gates, 24 qubits)
-    against the plain-C oracle's gate-by-gate execution (orc_gate_energy: 256-MiB host state) — energy on a
-    molecule-shaped 24-qubit JW Hamiltonian and sampled amplitudes, for the three forms the backend can run it in:
+    """BASELINE configs[3] at its size AND on its molecule: N2 / cc-pVDZ, (10 electrons, 12 orbitals) active space = 24 qubits
+    (integrals, RHF and frozen core from the in-repo front-end).  The literal QUCCSD gate list
+    (ref:openvqe/common_files/circuit.py:13-106 templates on every 5th cluster operator in the reference's operator order:
+    343 parameters, ~13 k gates) against the plain-C oracle's gate-by-gate execution (orc_gate_energy: 256-MiB host
+    state) — energy on the molecule's JW Hamiltonian and sampled amplitudes, for the three forms the backend can run it in:
     literal LDS-tiled sweeps, Clifford-frame form on real-amplitude streams, Clifford-frame form on the complex state."""
-    from openvqe_amd import fermion
+    from openvqe_amd import chem
     from openvqe_amd.backend import GATE_OPCODES, Statevector
     from openvqe_amd.common_files.circuit import quccsd_gate_list
-    from oracle import cref
-    m, o, stride = 12, 5, 5
-    n = 2 * m
-    gates, K, hf = quccsd_gate_list(m, o, stride)
-    assert K == 343 and len(gates) > 12000
     from openvqe_amd.operators import Hamiltonian
-    full, _, hf2 = fermion.synthetic_molecule(m, o, 24)
-    assert hf2 == hf
-    # every 10th of the 29736 JW terms (2974 strings, ~1900 distinct x masks): the oracle evaluates term by term
-    ham = Hamiltonian(n, full.terms[::10], full.constant_coeff, do_clean_up=False)
+    from oracle import cref
+    mol = chem.molecule("N2-CCPVDZ")
+    mol.rhf()
+    prob = chem.cas_problem(mol, 2, 12)
+    n = prob.nbqbits
+    assert n == 24
+    size, cluster_ops, _, theta_mp2, hf = prob.uccsd()
+    stride = 5
+    gates, K, hf2 = quccsd_gate_list(12, 5, stride, excitations=[op.terms[0].qbits for op in cluster_ops])
+    assert K == 343 and hf2 == hf and len(gates) > 10000
+    full = prob.jw_hamiltonian()
+    # every 3rd of the 6464 JW terms: the oracle evaluates term by term
+    ham = Hamiltonian(n, full.terms[::3], full.constant_coeff, do_clean_up=False)
     rng = np.random.default_rng(2424)
-    theta = rng.uniform(-0.1, 0.1, K)
+    theta = np.array(theta_mp2[::stride]) + rng.uniform(-0.05, 0.05, K)      # MP2 amplitudes + noise: no parameter is zero
     hx, hz, hc = ham.packed()
     hc = np.ascontiguousarray(hc.real)
     opc = [GATE_OPCODES[g[0]] for g in gates]
@@ -209,13 +214,15 @@ def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
             sv.set_gate_program(gates, K, hf)
             info = sv.program_info()
             e = sv.energy(theta)
+            e_again = sv.energy(theta)                                    # second call: compact cover where it applies
             sv.prepare_state(theta)
-            res[label] = (e, sv.get_amplitudes(idx), sv.norm2(), info)
+            res[label] = (e, sv.get_amplitudes(idx), sv.norm2(), info, e_again)
     assert res["literal_tiled"][3]["literal_gates"] > 0 and res["literal_tiled"][3]["tiled_sweeps"] > 0
     assert res["literal_tiled"][3]["real_stream"] == 0
     assert res["frame_real"][3]["literal_gates"] == 0 and res["frame_real"][3]["real_stream"] == 1
     assert res["frame_complex"][3]["real_stream"] == 0
-    for label, (e, amps, n2, _) in res.items():
+    for label, (e, amps, n2, _, e_again) in res.items():
         assert abs(e - e_ref) < 1e-10 * max(1.0, l1), (label, e, e_ref)
+        assert abs(e_again - e_ref) < 1e-10 * max(1.0, l1), (label, e_again, e_ref)
         assert np.abs(amps - want).max() < 1e-12, label
         assert abs(n2 - 1.0) < 1e-11, label
