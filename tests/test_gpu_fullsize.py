@@ -226,3 +226,23 @@ def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
         assert abs(e_again - e_ref) < 1e-10 * max(1.0, l1), (label, e_again, e_ref)
         assert np.abs(amps - want).max() < 1e-12, label
         assert abs(n2 - 1.0) < 1e-11, label
+    # the whole list (1715 parameters, ~63 k gates): its Clifford part is ~49 k gates long and still has to be recognised as
+    # closed (the rounding of that many quarter turns once sent it down the literal path); frame form == literal form
+    gates, K, _ = quccsd_gate_list(12, 5, 1, excitations=[op.terms[0].qbits for op in cluster_ops])
+    assert K == size == 1715
+    theta = np.array(theta_mp2)
+    idx = idx[:2000]
+    with Statevector(n) as sv:
+        sv.set_hamiltonian(full)
+        out = {}
+        for frame in (0, 1):
+            sv.set_option("clifford_frame", frame)
+            sv.set_gate_program(gates, K, hf)
+            info = sv.program_info()
+            e = sv.energy(theta)
+            sv.prepare_state(theta)
+            out[frame] = (e, sv.get_amplitudes(idx), info)
+    assert out[0][2]["literal_gates"] > 40000
+    assert out[1][2]["literal_gates"] == 0 and out[1][2]["real_stream"] == 1
+    assert abs(out[0][0] - out[1][0]) < 1e-10 * float(np.abs(full.packed()[2]).sum())
+    assert np.abs(out[0][1] - out[1][1]).max() < 1e-11
