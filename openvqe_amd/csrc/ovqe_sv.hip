@@ -18,6 +18,8 @@
 #include "sv_small.hpp"
 #include "sv_sparse.hpp"
 #include "sv_tile.hpp"
+#include "sv_sector.hpp"
+#include <hipcub/hipcub.hpp>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -68,6 +70,38 @@ struct CompactCover {
     uint32_t K = 0, max_nnz = 0;
     uint64_t ntiles = 0;
     DevBuf d_sup, d_psic, d_loc, d_cid, d_off, d_sweeps;
+};
+
+// sector path (sv_sector.hpp): the program and the Hamiltonian restated on the support of the program's states
+struct SectorLayout {   // the support sorted for one tile bit set
+    uint32_t smask = 0;
+    int M = 0;
+    uint32_t ntiles = 0, max_tile = 0;
+    DevBuf d_cid, d_off, d_src;
+};
+struct SectorSeg {      // one sweep of the circuit
+    SectorLayout L;
+    int nops = 0;
+    uint32_t hf_pos = 0;
+    uint64_t npairs = 0;
+    DevBuf d_tab0, d_poff, d_pairs;
+};
+struct SectorHSweep {   // one sweep of the materialised <H>
+    SectorLayout L;
+    uint64_t nnz = 0;
+    DevBuf d_ebase, d_words, d_vals;
+};
+struct SectorEngine {
+    bool valid = false, disabled = false;
+    int prog_version = -1, ham_version = -1;
+    int seen = 0;                 // evaluations of this (program, Hamiltonian) pair before the tables are built
+    uint32_t K = 0, max_tile = 0;
+    int M = 0;
+    uint64_t npairs = 0, nnz = 0;
+    size_t bytes = 0;
+    std::vector<SectorSeg> segs;
+    std::vector<SectorHSweep> hs;
+    DevBuf d_sup, d_buf[2], d_hdesc, d_flag;
 };
 
 }  // namespace
@@ -143,6 +177,12 @@ struct ovqe_sv {
     int opt_compact = 1;          // allow the compact cover (real-amplitude streaming energies, 18..28 qubits)
     int opt_compact_cpp = 1;      // host chunks (512 terms each) staged in LDS per pass of the compact-cover kernel
     int prog_version = 0;
+    SectorEngine sec;             // of (current program, stored Hamiltonian)
+    int opt_sector = 1;           // allow the sector path (real-amplitude streaming energies on a sparse support)
+    int opt_sector_bits = 0;      // index bits per tile (0 = automatic: n - 8, at most 16)
+    int opt_sector_max_gb = 64;   // table budget (also capped at half of the free device memory)
+    int opt_sector_threads = 256; // workgroup size of the circuit sweeps (64: one wave per tile, no barriers)
+    int opt_sector_min_qubits = 18;
     float last_batch_ms = 0.f;
     const double *cur_theta = nullptr;  // device pointers of the batch being evaluated
     double *cur_energies = nullptr;
@@ -1212,23 +1252,10 @@ inline RotParam resolve_rot(const SmallRot &sr, const double *theta) {
     return rp;
 }
 
-// run the compiled program with the streaming kernels (state left in h->state).
-// Angle table: [0, S) the entries of the table-fused program (tile sweeps, sequential runs), [S, S+R) the original
-// rotations (commuting runs that keep their own sweep run in their sequential form).
-int run_program_streaming(ovqe_handle h, const double *theta, bool real = false) {
+// Angle table of one evaluation in h->d_rp: [0, S) the entries of the table-fused program (tile sweeps, sequential runs),
+// [S, S+R) the original rotations (commuting runs that keep their own sweep run in their sequential form).
+int resolve_angles(ovqe_handle h, const double *theta) {
     int rc = OVQE_OK;
-    if (real) {
-        if (!h->tp_real_built) {
-            rc = build_tile_plan(h, h->sops, h->srots, h->sop_zc, h->tp_real, true);
-            if (rc) return rc;
-            h->tp_real_built = true;
-        }
-        hipLaunchKernelGGL(k_init_basis_real, dim3(reduce_blocks(h->namps)), dim3(256), 0, h->stream, (double *)h->state,
-                           h->namps, h->hf);
-    } else {
-        rc = init_basis(h, h->hf, h->init_amp);
-    }
-    if (rc) return rc;
     const size_t S = h->srots.size(), R = h->rots.size();
     rc = ensure_rp(h, std::max<size_t>(S + R, 1));
     if (rc) return rc;
@@ -1250,6 +1277,29 @@ int run_program_streaming(ovqe_handle h, const double *theta, bool real = false)
         if (S + R)
             HIPC(h, hipMemcpyAsync(h->d_rp.p, h->h_rp, (S + R) * sizeof(RotParam), hipMemcpyHostToDevice, h->stream));
     }
+    return OVQE_OK;
+}
+
+// run the compiled program with the streaming kernels (state left in h->state).
+// Angle table: [0, S) the entries of the table-fused program (tile sweeps, sequential runs), [S, S+R) the original
+// rotations (commuting runs that keep their own sweep run in their sequential form).
+int run_program_streaming(ovqe_handle h, const double *theta, bool real = false) {
+    int rc = OVQE_OK;
+    if (real) {
+        if (!h->tp_real_built) {
+            rc = build_tile_plan(h, h->sops, h->srots, h->sop_zc, h->tp_real, true);
+            if (rc) return rc;
+            h->tp_real_built = true;
+        }
+        hipLaunchKernelGGL(k_init_basis_real, dim3(reduce_blocks(h->namps)), dim3(256), 0, h->stream, (double *)h->state,
+                           h->namps, h->hf);
+    } else {
+        rc = init_basis(h, h->hf, h->init_amp);
+    }
+    if (rc) return rc;
+    const size_t S = h->srots.size();
+    rc = resolve_angles(h, theta);
+    if (rc) return rc;
     const RotParam *d_rp = (const RotParam *)h->d_rp.p;
     const TilePlan &tp = real ? h->tp_real : h->tp;
     const int nbr = reduce_blocks(h->namps);
@@ -1300,6 +1350,8 @@ int run_program_streaming(ovqe_handle h, const double *theta, bool real = false)
     HIPC(h, hipStreamSynchronize(h->stream));
     return OVQE_OK;
 }
+
+#include "sector_host.inc"
 
 // commuting-run fusion analysis of one same-x run (see sv_small.hpp OP_TAB); returns false when the run
 // does not have the structure (then it stays a sequential OP_PAIR)
@@ -2241,6 +2293,7 @@ int ovqe_destroy(ovqe_handle h) {
                                  &H->d_titems, &H->d_rest, &H->d_achunks, &H->d_agroups, &H->d_aterms});
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    free_sector(h->sec);
     if (h->h_rp) (void)hipHostFree(h->h_rp);
     if (h->h_result) (void)hipHostFree(h->h_result);
     if (h->h_io) (void)hipHostFree(h->h_io);
@@ -2281,6 +2334,14 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
         h->opt_index_streams = (int)value;
         if (h->prog_set) return finish_program(h);
     }
+    else if (k == "sector" || k == "sector_bits" || k == "sector_max_gb" || k == "sector_min_qubits") {
+        (k == "sector" ? h->opt_sector : k == "sector_bits" ? h->opt_sector_bits : k == "sector_max_gb" ? h->opt_sector_max_gb
+                                                                                                      : h->opt_sector_min_qubits) = (int)value;
+        free_sector(h->sec);
+        h->sec.disabled = false;
+        h->sec.seen = 0;
+        h->sec.prog_version = -1;
+    } else if (k == "sector_threads") h->opt_sector_threads = value == 64 ? 64 : 256;
     else if (k == "rot_variant") h->opt_rot_variant = (int)value;
     else if (k == "real_stream") h->opt_real_stream = (int)value;
     else if (k == "apply_min_tiles") h->opt_apply_min_tiles = (int)value;
@@ -2765,6 +2826,33 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
             if (rc) return rc;
             R.tile_bits = -1;
             R.version = h->ham.version;
+        }
+        if (real && h->opt_sector && h->n_local >= h->opt_sector_min_qubits) {
+            // sector path: tables built at the second evaluation of a (program, Hamiltonian) pair, as the compact cover
+            SectorEngine &E = h->sec;
+            if (E.prog_version != h->prog_version || E.ham_version != h->ham.version) {
+                free_sector(E);
+                E.disabled = false;
+                E.seen = 0;
+                E.prog_version = h->prog_version;
+                E.ham_version = h->ham.version;
+            }
+            if (!E.valid && !E.disabled && ++E.seen >= 2) {
+                rc = build_sector(h);
+                if (rc) return rc;
+            }
+            if (E.valid) {
+                double2 res;
+                bool ok = false;
+                rc = run_sector_energy(h, theta + b * (int64_t)K, &res, &ok);
+                if (rc) return rc;
+                if (ok) {
+                    energies[b] = res.x + h->ham.constant;
+                    continue;
+                }
+                free_sector(E);   // a structurally-zero amplitude was not: the tables do not describe this program
+                E.disabled = true;
+            }
         }
         bool use_cc = false;
         if (real && h->opt_compact && h->n_local >= 18) {
@@ -3265,6 +3353,10 @@ int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
                      h->sp_valid ? (int64_t)h->sp_nent : 0};
     for (const SmallOp &op : h->ops) v[2] += (op.kind == OP_X || op.kind == OP_H || op.kind == OP_CNOT);
     for (int i = 0; i < count && i < 16; ++i) info[i] = v[i];
+    const SectorEngine &E = h->sec;
+    const int64_t sv[6] = {E.valid ? (int64_t)E.K : 0, E.valid ? (int64_t)E.segs.size() : 0, E.valid ? (int64_t)E.npairs : 0,
+                           E.valid ? (int64_t)E.hs.size() : 0, E.valid ? (int64_t)E.nnz : 0, E.valid ? (int64_t)E.bytes : 0};
+    for (int i = 16; i < count && i < 22; ++i) info[i] = sv[i - 16];
     return OVQE_OK;
 }
 
