@@ -82,6 +82,7 @@ struct SectorLayout {   // the support sorted for one tile bit set
 struct SectorSeg {      // one sweep of the circuit
     SectorLayout L;
     int nops = 0;
+    int rot0 = 0, nrot = 0;       // the sweep's range of the angle table
     uint32_t hf_pos = 0;
     uint64_t npairs = 0;
     DevBuf d_tab0, d_poff, d_pairs;

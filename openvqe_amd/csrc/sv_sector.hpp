@@ -215,48 +215,124 @@ __global__ __launch_bounds__(NT) void k_sec_pairs(const uint32_t *__restrict__ s
 
 // ---- one sweep of the circuit -----------------------------------------------------------------------------------------
 // in: the compact state in the previous sweep's order (src = position of every entry there; nullptr: |hf> at hf_pos);
-// out: the state in this sweep's order.  NT == 64: one wave owns the tile and the LDS unit keeps its accesses in order,
-// so no barrier separates the ops.
+// out: the state in this sweep's order.  The chain pair offsets -> pair word -> cos/sin -> amplitudes would cost three
+// dependent trips to L2 per op (measured: 1.7 us per op), so the tile's pair offsets and the sweep's cos/sin table are
+// staged in LDS up front and the first pair word of op o + 1 is fetched while op o rotates its pairs.
+// NT == 64: one wave owns the tile and the LDS unit keeps its accesses in order, so no barrier separates the ops.
+struct SecOpLds {
+    uint32_t p0;    // first pair of the op in this tile
+    int32_t tab;    // first table entry, relative to the sweep's table
+};
+constexpr int SEC_WORDS_PER_THREAD = 16;   // pair words per thread and staging buffer
+template <int NT>
+__device__ __forceinline__ void sec_rotate(double *tile, const double2 *tab, uint32_t pw, bool &bad) {
+    const uint32_t si = pw & SEC_SLOT_MASK, sj = (pw >> SEC_SLOT_BITS) & SEC_SLOT_MASK;
+    if (sj == SEC_ORPHAN) {
+        bad |= tile[si] != 0.0;
+        return;
+    }
+    const double2 r = tab[pw >> 27];
+    const double s = (pw & (1u << 26)) ? -r.y : r.y;
+    const double u = tile[si], v = tile[sj];
+    tile[si] = r.x * u + s * v;
+    tile[sj] = r.x * v - s * u;
+}
 template <int NT>
 __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ in, double *__restrict__ out,
                                                      const uint32_t *__restrict__ src, const uint32_t *__restrict__ off,
                                                      const int32_t *__restrict__ tab0, int nops,
                                                      const uint32_t *__restrict__ poff, const uint32_t *__restrict__ pairs,
-                                                     const RotParam *__restrict__ rp, uint32_t hf_pos, int *__restrict__ flag) {
-    extern __shared__ double sec_tile[];
+                                                     const RotParam *__restrict__ rp, int rot0, int nrot, uint32_t tile_cap,
+                                                     uint32_t hf_pos, int *__restrict__ flag) {
+    // The pair words of the tile are consecutive in memory (op after op): they are staged in LDS in op-aligned chunks of
+    // at most W words, the loads of chunk c + 1 in flight (registers) while chunk c is processed — an op never waits for
+    // global memory.  Barriers wait for LDS only (s_waitcnt lgkmcnt), not for those loads.
+    constexpr uint32_t W = SEC_WORDS_PER_THREAD * NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
+    double *tile = reinterpret_cast<double *>(sec_smem);
+    double2 *cs = reinterpret_cast<double2 *>(tile + ((tile_cap + 1u) & ~1u));
+    SecOpLds *lop = reinterpret_cast<SecOpLds *>(cs + nrot);
+    uint32_t *wbuf = reinterpret_cast<uint32_t *>(lop + nops + 2);
     const uint32_t t = blockIdx.x, e0 = off[t];
     const int n = (int)(off[t + 1] - e0);
     if (n == 0) return;
-    if (src) {
-        for (int k = threadIdx.x; k < n; k += NT) sec_tile[k] = in[src[e0 + k]];
-    } else {
-        for (int k = threadIdx.x; k < n; k += NT) sec_tile[k] = (e0 + (uint32_t)k == hf_pos) ? 1.0 : 0.0;
-    }
-    if (NT > 64) __syncthreads();
     const uint32_t *po = poff + (size_t)t * (nops + 1);
-    uint32_t p0 = po[0];
-    bool bad = false;
-    for (int o = 0; o < nops; ++o) {
-        const uint32_t p1 = po[o + 1];
-        const RotParam *tab = rp + tab0[o];
-        for (uint32_t k = p0 + threadIdx.x; k < p1; k += NT) {
-            const uint32_t pw = pairs[k];
-            const uint32_t si = pw & SEC_SLOT_MASK, sj = (pw >> SEC_SLOT_BITS) & SEC_SLOT_MASK;
-            if (sj == SEC_ORPHAN) {
-                bad |= sec_tile[si] != 0.0;
-                continue;
-            }
-            const RotParam r = tab[pw >> 27];
-            const double s = (pw & (1u << 26)) ? -r.s : r.s;
-            const double u = sec_tile[si], v = sec_tile[sj];
-            sec_tile[si] = r.c * u + s * v;
-            sec_tile[sj] = r.c * v - s * u;
-        }
-        p0 = p1;
-        if (NT > 64) __syncthreads(); else asm volatile("" ::: "memory");
+    for (int o = threadIdx.x; o <= nops; o += NT) lop[o] = SecOpLds{po[o], o < nops ? tab0[o] - rot0 : 0};
+    for (int r = threadIdx.x; r < nrot; r += NT) {
+        const RotParam rr = rp[rot0 + r];
+        cs[r] = make_double2(rr.c, rr.s);
     }
-    if (NT == 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    for (int k = threadIdx.x; k < n; k += NT) out[e0 + k] = sec_tile[k];
+    if (src) {
+        for (int k = threadIdx.x; k < n; k += NT) tile[k] = in[src[e0 + k]];
+    } else {
+        for (int k = threadIdx.x; k < n; k += NT) tile[k] = (e0 + (uint32_t)k == hf_pos) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    auto chunk_end = [&](int oa) {   // ops [oa, ob) whose pair words fit one buffer (ob == oa: op oa alone is larger)
+        int ob = oa;
+        const uint32_t pa = lop[oa].p0;
+        while (ob < nops && lop[ob + 1].p0 - pa <= W) ++ob;
+        return ob;
+    };
+    uint32_t regs[SEC_WORDS_PER_THREAD];
+    auto fetch = [&](int oa, int ob) {
+        const uint32_t base = lop[oa].p0, cnt = lop[ob].p0 - base;
+#pragma unroll
+        for (int r = 0; r < SEC_WORDS_PER_THREAD; ++r) {
+            const uint32_t idx = threadIdx.x + (uint32_t)r * NT;
+            regs[r] = idx < cnt ? pairs[base + idx] : 0u;
+        }
+    };
+    auto stash = [&](uint32_t *buf) {
+#pragma unroll
+        for (int r = 0; r < SEC_WORDS_PER_THREAD; ++r) buf[threadIdx.x + (uint32_t)r * NT] = regs[r];
+    };
+    bool bad = false;
+    int oa = 0, ob = chunk_end(0), cb = 0;
+    if (ob > oa) {
+        fetch(oa, ob);
+        stash(wbuf);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    while (oa < nops) {
+        if (ob == oa) {   // one op with more pairs in this tile than a buffer holds: straight from memory
+            const uint32_t p0 = lop[oa].p0, p1 = lop[oa + 1].p0;
+            const double2 *tab = cs + lop[oa].tab;
+            for (uint32_t k = p0 + threadIdx.x; k < p1; k += NT) sec_rotate<NT>(tile, tab, pairs[k], bad);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            ++oa;
+            if (oa < nops) {
+                ob = chunk_end(oa);
+                if (ob > oa) {
+                    fetch(oa, ob);
+                    stash(wbuf + (size_t)cb * W);
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+            }
+            continue;
+        }
+        const int na = ob, nb = na < nops ? chunk_end(na) : na;
+        if (nb > na) fetch(na, nb);   // in flight while this chunk is processed
+        const uint32_t *wb = wbuf + (size_t)cb * W;
+        const uint32_t base = lop[oa].p0;
+        uint32_t p0 = 0;
+        for (int o = oa; o < ob; ++o) {
+            const uint32_t p1 = lop[o + 1].p0 - base;
+            const double2 *tab = cs + lop[o].tab;
+            for (uint32_t k = p0 + threadIdx.x; k < p1; k += NT) sec_rotate<NT>(tile, tab, wb[k], bad);
+            p0 = p1;
+            if (NT > 64) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("" ::: "memory");
+        }
+        if (nb > na) {
+            stash(wbuf + (size_t)(cb ^ 1) * W);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        cb ^= 1;
+        oa = na;
+        ob = nb;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int k = threadIdx.x; k < n; k += NT) out[e0 + k] = tile[k];
     if (bad) atomicOr(flag, 1);
 }
 

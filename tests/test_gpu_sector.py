@@ -1,0 +1,172 @@
+"""Sector path (openvqe_amd/csrc/sv_sector.hpp): circuit + materialised <H> on the support of the program's states.
+Parity with the plain-C oracle and with the dense streaming kernels, through the C ABI.  The tables are built at the second
+evaluation of a (program, Hamiltonian) pair, so every test evaluates at least three parameter vectors."""
+from math import comb
+
+import numpy as np
+import pytest
+
+from tests.util import random_hamiltonian, random_string
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def SV(gpu_lib):
+    from openvqe_amd.backend import Statevector
+    return Statevector
+
+
+def _oracle_energies(n, gens, hf, H, thetas):
+    from openvqe_amd.backend import compile_ucc_program
+    from oracle import cref
+    rx, rz, rc, pidx, _ = compile_ucc_program(n, gens)
+    hx, hz, hc = H.packed()
+    return [cref.ucc_energy(n, hf, rx, rz, rc, pidx, th, hx, hz, hc.real.copy(), H.constant_coeff, 0)[0] for th in thetas]
+
+
+@pytest.mark.parametrize("m,o,bits,threads", [(7, 2, 0, 256), (7, 3, 8, 256), (8, 3, 0, 64), (8, 4, 10, 256), (9, 4, 0, 256),
+                                              (10, 4, 12, 256), (10, 5, 0, 256)])
+def test_sector_uccsd_matches_c_oracle(SV, m, o, bits, threads):
+    """molecule-shaped UCCSD (JW generators in table-fused form, a JW two-body Hamiltonian): the support is the
+    (o alpha, o beta) sector; energies of the sector path == oracle == dense kernels"""
+    from openvqe_amd import fermion
+    n = 2 * m
+    ham, gens, hf = fermion.synthetic_molecule(m, o, seed=100 + m)
+    rng = np.random.default_rng(10 * m + o)
+    thetas = [rng.uniform(-0.3, 0.3, len(gens)) for _ in range(4)]
+    thetas.append(np.zeros(len(gens)))                      # |hf> itself: every rotation is the identity
+    want = _oracle_energies(n, gens, hf, ham, thetas)
+    l1 = float(np.abs(ham.packed()[2]).sum())
+    with SV(n) as sv:
+        sv.set_option("force_path", 2)
+        sv.set_option("sector_min_qubits", 8)
+        sv.set_option("sector_bits", bits)
+        sv.set_option("sector_threads", threads)
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, hf)
+        got = [sv.energy(th) for th in thetas]
+        info = sv.program_info()
+        batch = sv.energy_batch(np.stack(thetas))
+        sv.set_option("sector", 0)
+        dense = [sv.energy(th) for th in thetas]
+        assert sv.program_info()["sector_support"] == 0
+    assert info["sector_support"] == comb(m, o) ** 2, info
+    assert info["sector_sweeps"] >= 1 and info["sector_h_sweeps"] >= 1 and info["sector_pairs"] > 0
+    assert info["sector_h_elements"] > info["sector_support"]
+    for e, eb, ed, ew in zip(got, batch, dense, want):
+        assert abs(e - ew) < 1e-10 * max(1.0, l1)
+        assert abs(eb - ew) < 1e-10 * max(1.0, l1)
+        assert abs(e - ed) < 1e-12 * max(1.0, l1)
+
+
+def test_sector_on_h2o_uccsd_and_table_invalidation(SV):
+    """H2O / STO-3G UCCSD (14 qubits) at the MP2 amplitudes through the sector path; then a new Hamiltonian and a new
+    program on the same handle: the tables are rebuilt for them"""
+    from openvqe_amd import chem, fermion
+    mol = chem.molecule("H2O")
+    mol.rhf()
+    prob = mol.problem(active=False)
+    ham = prob.jw_hamiltonian()
+    _, _, gens, theta_mp2, hf = prob.uccsd()
+    n = ham.nbqbits
+    rng = np.random.default_rng(14)
+    thetas = [np.array(theta_mp2), np.array(theta_mp2) * 0.5, rng.uniform(-0.2, 0.2, len(gens))]
+    want = _oracle_energies(n, gens, hf, ham, thetas)
+    ham2 = fermion.synthetic_molecule(7, 5, seed=3)[0]       # another JW two-body operator on the same register
+    gens2 = gens[::3]
+    thetas2 = [t[::3] for t in thetas]
+    want2 = _oracle_energies(n, gens2, hf, ham2, thetas2)
+    with SV(n) as sv:
+        sv.set_option("force_path", 2)
+        sv.set_option("sector_min_qubits", 8)
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, hf)
+        got = [sv.energy(t) for t in thetas]
+        info = sv.program_info()
+        sv.set_hamiltonian(ham2)
+        mixed = [sv.energy(t) for t in thetas]          # same program, other Hamiltonian
+        sv.set_ucc_program(gens2, hf)
+        got2 = [sv.energy(t) for t in thetas2]
+        info2 = sv.program_info()
+    assert info["sector_support"] == 441 and 0 < info2["sector_support"] <= 441
+    want_mixed = _oracle_energies(n, gens, hf, ham2, thetas)
+    for e, ew in zip(got + mixed + got2, want + want_mixed + want2):
+        assert abs(e - ew) < 1e-10
+
+
+def test_sector_with_single_string_rotations(SV):
+    """OP_PAIR ops (single Pauli strings with an odd number of Y, no table fusion): x masks from a small set keep the support
+    at a few hundred of 2^16 amplitudes; several rotations share an x mask with different z masks"""
+    from openvqe_amd.operators import Hamiltonian, Term
+    n = 16
+    rng = np.random.default_rng(1616)
+    supports = [[0, 5], [3, 9, 12, 15], [1, 2], [7, 8, 10, 11], [4, 13], [0, 5], [3, 9, 12, 15], [6, 14]]
+    gens = []
+    for qs in supports * 2:
+        ops = ["X"] * len(qs)
+        for k in rng.choice(len(qs), 1 if len(qs) == 2 else int(rng.choice([1, 3])), replace=False):
+            ops[k] = "Y"
+        zq = [q for q in range(n) if q not in qs and rng.random() < 0.4]
+        gens.append(Hamiltonian(n, [Term(float(rng.uniform(0.5, 1.5)), "".join(ops) + "Z" * len(zq), qs + zq)], do_clean_up=False))
+    hf = int(rng.integers(0, 1 << n))
+    seen, terms = set(), []
+    while len(terms) < 150:                                  # strings of weight <= 5: every x-group fits a sector tile
+        op, qs = random_string(rng, n, 1, 5)
+        if (op, tuple(qs)) not in seen:
+            seen.add((op, tuple(qs)))
+            terms.append(Term(float(rng.normal()), op, qs))
+    H = Hamiltonian(n, terms, 0.25)
+    thetas = [rng.uniform(-1, 1, len(gens)) for _ in range(4)]
+    want = _oracle_energies(n, gens, hf, H, thetas)
+    with SV(n) as sv:
+        sv.set_option("force_path", 2)
+        sv.set_option("sector_min_qubits", 8)
+        sv.set_hamiltonian(H)
+        sv.set_ucc_program(gens, hf)
+        got = [sv.energy(t) for t in thetas]
+        info = sv.program_info()
+    assert info["real_stream"] == 1
+    assert 0 < info["sector_support"] <= 256, info
+    for e, ew in zip(got, want):
+        assert abs(e - ew) < 1e-10 * max(1.0, float(np.abs(H.packed()[2]).sum()))
+
+
+def test_sector_declines_a_dense_support(SV):
+    """a program whose states fill the register: no tables are built, the dense kernels keep serving the energies"""
+    from openvqe_amd.operators import Hamiltonian, Term
+    n = 14
+    rng = np.random.default_rng(1414)
+    gens = [Hamiltonian(n, [Term(1.0, "Y", [q])], do_clean_up=False) for q in range(n)]
+    H = random_hamiltonian(rng, n, 60)
+    thetas = [rng.uniform(-1, 1, n) for _ in range(3)]
+    want = _oracle_energies(n, gens, 0, H, thetas)
+    with SV(n) as sv:
+        sv.set_option("force_path", 2)
+        sv.set_option("sector_min_qubits", 8)
+        sv.set_hamiltonian(H)
+        sv.set_ucc_program(gens, 0)
+        got = [sv.energy(t) for t in thetas]
+        info = sv.program_info()
+    assert info["sector_support"] == 0 and info["sector_bytes"] == 0
+    for e, ew in zip(got, want):
+        assert abs(e - ew) < 1e-10 * max(1.0, float(np.abs(H.packed()[2]).sum()))
+
+
+def test_sector_table_budget(SV):
+    """sector_max_gb = 0: the tables do not fit the budget, nothing is kept, energies come from the dense kernels"""
+    from openvqe_amd import fermion
+    ham, gens, hf = fermion.synthetic_molecule(8, 3, seed=5)
+    rng = np.random.default_rng(5)
+    thetas = [rng.uniform(-0.3, 0.3, len(gens)) for _ in range(3)]
+    want = _oracle_energies(16, gens, hf, ham, thetas)
+    with SV(16) as sv:
+        sv.set_option("force_path", 2)
+        sv.set_option("sector_min_qubits", 8)
+        sv.set_option("sector_max_gb", 0)
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, hf)
+        got = [sv.energy(t) for t in thetas]
+        assert sv.program_info()["sector_support"] == 0
+    for e, ew in zip(got, want):
+        assert abs(e - ew) < 1e-10 * max(1.0, float(np.abs(ham.packed()[2]).sum()))
