@@ -188,25 +188,32 @@ def gate_and_midsize_workloads(device):
     out.append(row)
     # the whole 24-qubit molecule-shaped UCCSD evaluation (1715 generators = 13300 rotations, 29736-term
     # JW Hamiltonian / 5479 x-groups) on the streaming path: real-amplitude tile sweeps + tiled <H>; from the second call
-    # on through the compact cover (profiles/r2_n24)
+    # on through the sector path (circuit and materialised <H> on the support of the program's states, profiles/r2_sector);
+    # the same handle with the sector path off = the compact cover of profiles/r2_n24
     ham24, gens24, hf24 = fermion.synthetic_molecule(m, o, seed=24)
     th24 = rng.uniform(-0.1, 0.1, len(gens24))
-    with Statevector(n, device=device) as sv:
-        sv.set_hamiltonian(ham24)
-        sv.set_ucc_program(gens24, hf24)
-        times = []
-        for _ in range(4):
-            t0 = time.perf_counter()
-            e24 = sv.energy(th24)
-            times.append(1e3 * (time.perf_counter() - t0))
-        R24 = sum(len(g.terms) for g in gens24)
-        G24 = len(set(ham24.packed()[0].tolist()))
-        b_eval = 32.0 * (1 << n) * R24 + 16.0 * (1 << n) * G24
-        out.append({"workload": "24-qubit UCCSD energy evaluation (SURVEY 8d M3)", "qubits": n, "generators": len(gens24),
-                    "rotations": R24, "hamiltonian_terms": len(ham24.terms) + 1, "x_groups": G24,
-                    "ms_first_call_dense_cover": times[0], "ms_second_call_builds_compact_cover": times[1],
-                    "ms_steady_state": min(times[2:]), "energy": float(e24),
-                    "algorithmic_GBs": b_eval / (min(times[2:]) * 1e-3) / 1e9, "program": sv.program_info()})
+    row24 = {"workload": "24-qubit UCCSD energy evaluation (SURVEY 8d M3)", "qubits": n, "generators": len(gens24),
+             "rotations": sum(len(g.terms) for g in gens24), "hamiltonian_terms": len(ham24.terms) + 1,
+             "x_groups": len(set(ham24.packed()[0].tolist()))}
+    b_eval = 32.0 * (1 << n) * row24["rotations"] + 16.0 * (1 << n) * row24["x_groups"]
+    for label, sector in (("sector_path", 1), ("dense_state_compact_cover", 0)):
+        with Statevector(n, device=device) as sv:
+            sv.set_option("sector", sector)
+            sv.set_hamiltonian(ham24)
+            sv.set_ucc_program(gens24, hf24)
+            times = []
+            for _ in range(6):
+                t0 = time.perf_counter()
+                e24 = sv.energy(th24)
+                times.append(1e3 * (time.perf_counter() - t0))
+            info = sv.program_info()
+            row24[label] = {"ms_first_call_dense": times[0], "ms_second_call_builds_tables": times[1],
+                            "ms_steady_state": min(times[2:]), "energy": float(e24),
+                            "algorithmic_GBs": b_eval / (min(times[2:]) * 1e-3) / 1e9, "program": info}
+            if sector:
+                row24["ms_steady_state"] = min(times[2:])
+                row24[label]["table_GB"] = info["sector_bytes"] / 1e9
+    out.append(row24)
     # BASELINE.json configs[3] on its molecule: N2 / cc-pVDZ, (10 electrons, 12 orbitals) active space = 24 qubits, from the
     # in-repo front-end (d-shell integrals, RHF, frozen core).  UCCSD (JW generators in the reference's operator order) at
     # the MP2 amplitudes, and the reference's QUCCSD gate list (Clifford-frame form) on the same operators.
@@ -224,11 +231,12 @@ def gate_and_midsize_workloads(device):
         sv.set_hamiltonian(hamn)
         sv.set_ucc_program(spin_ops, hfn)
         times = []
-        for _ in range(4):
+        for _ in range(6):
             t0 = time.perf_counter()
             e_ucc = sv.energy(theta_mp2)
             times.append(1e3 * (time.perf_counter() - t0))
-        rown["uccsd_at_theta_mp2"] = {"energy": float(e_ucc), "ms_first_call": times[0], "ms_steady_state": min(times[2:]),
+        rown["uccsd_at_theta_mp2"] = {"energy": float(e_ucc), "ms_first_call": times[0], "ms_second_call_builds_tables": times[1],
+                                      "ms_steady_state": min(times[2:]),
                                       "program": sv.program_info()}
         gates, K, _ = quccsd_gate_list(12, 5, 1, excitations=[op.terms[0].qbits for op in cluster_ops])
         sv.set_gate_program(gates, K, hfn)

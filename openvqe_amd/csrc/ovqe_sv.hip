@@ -94,6 +94,7 @@ struct SectorHSweep {   // one sweep of the materialised <H>
 };
 struct SectorEngine {
     bool valid = false, disabled = false;
+    bool h_tables = false;        // the materialised <H> is part of the engine (else: circuit only, <H> by the compact cover)
     int prog_version = -1, ham_version = -1;
     int seen = 0;                 // evaluations of this (program, Hamiltonian) pair before the tables are built
     uint32_t K = 0, max_tile = 0;
@@ -184,6 +185,7 @@ struct ovqe_sv {
     int opt_sector_max_gb = 64;   // table budget (also capped at half of the free device memory)
     int opt_sector_threads = 256; // workgroup size of the circuit sweeps (64: one wave per tile, no barriers)
     int opt_sector_min_qubits = 18;
+    int opt_sector_h = 1;         // materialise <H> on the support when it fits the budget
     float last_batch_ms = 0.f;
     const double *cur_theta = nullptr;  // device pointers of the batch being evaluated
     double *cur_energies = nullptr;
@@ -988,7 +990,7 @@ int launch_tile_expect_compact(ovqe_handle h, const HamDev &H, double2 *partials
 }
 
 // <state|H|state> of a real state through the compact cover; *ok = false when the guard failed (support not closed)
-int run_expectation_compact(ovqe_handle h, HamDev &H, double2 *out, bool *ok) {
+int run_expectation_compact(ovqe_handle h, HamDev &H, double2 *out, bool *ok, bool psic_ready = false) {
     CompactCover &C = h->cc;
     *ok = false;
     const int ns = (int)H.tsweeps.size();
@@ -999,8 +1001,9 @@ int run_expectation_compact(ovqe_handle h, HamDev &H, double2 *out, bool *ok) {
     if (!rc) rc = ensure(h, h->d_result, 64 * sizeof(double2));
     if (rc) return rc;
     double2 *partials = (double2 *)h->d_partials.p, *rows = partials + nslots, *pnorm = rows + ns;
-    hipLaunchKernelGGL(k_compact_gather<true>, dim3(nbg), dim3(256), 0, h->stream, (const double *)h->state,
-                       (const uint32_t *)C.d_sup.p, C.K, (double *)C.d_psic.p, pnorm);
+    if (!psic_ready)   // (else the sector path's circuit left the compact state in C.d_psic: nothing to gather, norm 1 by construction)
+        hipLaunchKernelGGL(k_compact_gather<true>, dim3(nbg), dim3(256), 0, h->stream, (const double *)h->state,
+                           (const uint32_t *)C.d_sup.p, C.K, (double *)C.d_psic.p, pnorm);
     hipLaunchKernelGGL(k_compact_permute<true>, dim3((unsigned)std::min<uint64_t>(16384u, (total + 255u) / 256u)), dim3(256), 0,
                        h->stream, (const double *)C.d_psic.p, (const uint32_t *)C.d_cid.p, total, (double *)C.d_psic.p + C.K);
     switch (H.tile_bits) {
@@ -1012,13 +1015,14 @@ int run_expectation_compact(ovqe_handle h, HamDev &H, double2 *out, bool *ok) {
     // fixed-order reduction: per sweep over its tiles, then over the sweeps
     hipLaunchKernelGGL(k_reduce_rows2, dim3((unsigned)ns), dim3(256), 0, h->stream, (const double2 *)partials, (int)C.ntiles, rows);
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->stream, (const double2 *)rows, (int64_t)ns, (double2 *)h->d_result.p, 0);
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->stream, (const double2 *)pnorm, (int64_t)nbg,
-                       (double2 *)h->d_result.p, 1);
+    if (!psic_ready)
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->stream, (const double2 *)pnorm, (int64_t)nbg,
+                           (double2 *)h->d_result.p, 1);
     HIPC(h, hipGetLastError());
     HIPC(h, hipMemcpyAsync(h->h_result, h->d_result.p, 2 * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
     // guard: the circuit is unitary, so the amplitudes on the support must carry the whole norm
-    if (std::fabs(h->h_result[1].x - 1.0) > 1e-9) return OVQE_OK;
+    if (!psic_ready && std::fabs(h->h_result[1].x - 1.0) > 1e-9) return OVQE_OK;
     *out = h->h_result[0];
     *ok = true;
     return OVQE_OK;
@@ -2335,9 +2339,9 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
         h->opt_index_streams = (int)value;
         if (h->prog_set) return finish_program(h);
     }
-    else if (k == "sector" || k == "sector_bits" || k == "sector_max_gb" || k == "sector_min_qubits") {
+    else if (k == "sector" || k == "sector_bits" || k == "sector_max_gb" || k == "sector_min_qubits" || k == "sector_h") {
         (k == "sector" ? h->opt_sector : k == "sector_bits" ? h->opt_sector_bits : k == "sector_max_gb" ? h->opt_sector_max_gb
-                                                                                                      : h->opt_sector_min_qubits) = (int)value;
+         : k == "sector_h" ? h->opt_sector_h : h->opt_sector_min_qubits) = (int)value;
         free_sector(h->sec);
         h->sec.disabled = false;
         h->sec.seen = 0;
@@ -2842,7 +2846,7 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
                 rc = build_sector(h);
                 if (rc) return rc;
             }
-            if (E.valid) {
+            if (E.valid && E.h_tables) {
                 double2 res;
                 bool ok = false;
                 rc = run_sector_energy(h, theta + b * (int64_t)K, &res, &ok);
@@ -2876,6 +2880,23 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
                 if (rc) return rc;
             }
             use_cc = C.valid;
+        }
+        if (use_cc && real && h->opt_sector && h->sec.valid && !h->sec.h_tables && h->sec.K == h->cc.K) {
+            // circuit on the sector tables, <H> by the compact cover on the canonical compact state
+            double2 res;
+            bool ok = false;
+            rc = run_sector_state(h, theta + b * (int64_t)K, (double *)h->cc.d_psic.p, &ok);
+            if (rc) return rc;
+            if (ok) {
+                rc = run_expectation_compact(h, h->ham_real, &res, &ok, true);
+                if (rc) return rc;
+            }
+            if (ok) {
+                energies[b] = res.x + h->ham.constant;
+                continue;
+            }
+            free_sector(h->sec);
+            h->sec.disabled = true;
         }
         rc = run_program_streaming(h, theta + b * (int64_t)K, real);
         if (rc) return rc;

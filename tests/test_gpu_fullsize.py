@@ -246,3 +246,34 @@ def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
     assert out[1][2]["literal_gates"] == 0 and out[1][2]["real_stream"] == 1
     assert abs(out[0][0] - out[1][0]) < 1e-10 * float(np.abs(full.packed()[2]).sum())
     assert np.abs(out[0][1] - out[1][1]).max() < 1e-11
+
+
+def test_24_qubit_uccsd_sector_path_on_n2(gpu_lib):
+    """N2 / cc-pVDZ (10e, 12o), UCCSD in the reference's operator order (1715 cluster operators, 6464-term JW Hamiltonian) through
+    the sector path: (5 alpha, 5 beta) sector = 627 264 amplitudes, against the dense-state kernels on the same handle inputs,
+    and E(theta = 0) against the RHF energy of the SCF front-end (an independent number)"""
+    from openvqe_amd import chem
+    from openvqe_amd.backend import Statevector
+    mol = chem.molecule("N2-CCPVDZ")
+    e_rhf = mol.rhf()
+    prob = chem.cas_problem(mol, 2, 12)
+    ham = prob.jw_hamiltonian()
+    size, _, spin_ops, theta_mp2, hf = prob.uccsd()
+    rng = np.random.default_rng(2412)
+    thetas = [np.array(theta_mp2), np.zeros(size), np.array(theta_mp2) + rng.uniform(-0.05, 0.05, size), np.array(theta_mp2)]
+    res = {}
+    for sector in (1, 0):
+        with Statevector(24) as sv:
+            sv.set_option("sector", sector)
+            sv.set_hamiltonian(ham)
+            sv.set_ucc_program(spin_ops, hf)
+            res[sector] = ([sv.energy(t) for t in thetas], sv.program_info())
+    info = res[1][1]
+    assert info["sector_support"] == 792 ** 2 and info["sector_sweeps"] > 0 and info["sector_h_elements"] > 10 ** 8
+    assert res[0][1]["sector_support"] == 0
+    l1 = float(np.abs(ham.packed()[2]).sum())
+    for a, b in zip(res[1][0], res[0][0]):
+        assert abs(a - b) < 1e-10 * l1
+    assert abs(res[1][0][1] - e_rhf) < 1e-8                      # |hf> is the RHF determinant
+    assert abs(res[1][0][0] - res[1][0][3]) < 1e-12             # dense first call == sector call, same theta
+    assert res[1][0][0] < e_rhf - 0.05                          # MP2 amplitudes recover correlation energy

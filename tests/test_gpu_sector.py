@@ -60,6 +60,29 @@ def test_sector_uccsd_matches_c_oracle(SV, m, o, bits, threads):
         assert abs(e - ed) < 1e-12 * max(1.0, l1)
 
 
+@pytest.mark.parametrize("m,o", [(9, 4), (10, 5)])
+def test_sector_circuit_with_compact_cover_expectation(SV, m, o):
+    """sector_h = 0 (what happens when the materialised <H> would not fit the table budget): the circuit runs on the sector
+    tables, <H> is evaluated by the compact cover of sv_tile.hpp from the canonical compact state"""
+    from openvqe_amd import fermion
+    n = 2 * m
+    ham, gens, hf = fermion.synthetic_molecule(m, o, seed=200 + m)
+    rng = np.random.default_rng(20 * m + o)
+    thetas = [rng.uniform(-0.3, 0.3, len(gens)) for _ in range(4)]
+    want = _oracle_energies(n, gens, hf, ham, thetas)
+    l1 = float(np.abs(ham.packed()[2]).sum())
+    with SV(n) as sv:
+        sv.set_option("sector_h", 0)
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, hf)
+        got = [sv.energy(th) for th in thetas]
+        info = sv.program_info()
+    assert info["sector_support"] == comb(m, o) ** 2 and info["sector_sweeps"] >= 1, info
+    assert info["sector_h_sweeps"] == 0 and info["sector_h_elements"] == 0
+    for e, ew in zip(got, want):
+        assert abs(e - ew) < 1e-10 * max(1.0, l1)
+
+
 def test_sector_on_h2o_uccsd_and_table_invalidation(SV):
     """H2O / STO-3G UCCSD (14 qubits) at the MP2 amplitudes through the sector path; then a new Hamiltonian and a new
     program on the same handle: the tables are rebuilt for them"""
