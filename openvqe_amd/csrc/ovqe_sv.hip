@@ -90,15 +90,17 @@ struct SectorSeg {      // one sweep of the circuit
 struct SectorHSweep {   // one sweep of the materialised <H>
     SectorLayout L;
     uint64_t nnz = 0;
-    DevBuf d_ebase, d_words, d_vals;
+    int ndict = 0;          // magnitudes in the sweep's dictionary (0: the coded stream keeps explicit values)
+    DevBuf d_cbase, d_cwords, d_cvals, d_dict, d_xbase, d_xwords, d_xvals;
 };
 struct SectorEngine {
     bool valid = false, disabled = false;
     bool h_tables = false;        // the materialised <H> is part of the engine (else: circuit only, <H> by the compact cover)
     int prog_version = -1, ham_version = -1;
     int seen = 0;                 // evaluations of this (program, Hamiltonian) pair before the tables are built
-    uint32_t K = 0, max_tile = 0;
-    int M = 0;
+    uint32_t K = 0, max_tile = 0, h_max_tile = 0;
+    int M = 0, Mh = 0;            // index bits per tile: circuit sweeps, <H> sweeps
+    int sb = 13;                  // slot bits of the pair words
     uint64_t npairs = 0, nnz = 0;
     size_t bytes = 0;
     std::vector<SectorSeg> segs;
@@ -183,9 +185,13 @@ struct ovqe_sv {
     int opt_sector = 1;           // allow the sector path (real-amplitude streaming energies on a sparse support)
     int opt_sector_bits = 0;      // index bits per tile (0 = automatic: n - 8, at most 16)
     int opt_sector_max_gb = 64;   // table budget (also capped at half of the free device memory)
-    int opt_sector_threads = 256; // workgroup size of the circuit sweeps (64: one wave per tile, no barriers)
+    int opt_sector_threads = 0;   // workgroup size of the circuit sweeps (0 = automatic; 64: one wave per tile, no barriers)
     int opt_sector_min_qubits = 18;
     int opt_sector_h = 1;         // materialise <H> on the support when it fits the budget
+    int opt_sector_h_bits = 0;    // index bits per <H> tile (0 = automatic: 300 .. 600 amplitudes per tile)
+    int opt_sector_dict = 1;      // dictionary coding of the double-excitation-like matrix elements
+    int opt_sector_debug = 0;     // measurements only (1: circuit sweeps without their ops — wrong results)
+    int opt_sector_h_groups = 128; // workgroups per <H> sweep (they share the sweep's tiles round robin)
     float last_batch_ms = 0.f;
     const double *cur_theta = nullptr;  // device pointers of the batch being evaluated
     double *cur_energies = nullptr;
@@ -2339,14 +2345,18 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
         h->opt_index_streams = (int)value;
         if (h->prog_set) return finish_program(h);
     }
-    else if (k == "sector" || k == "sector_bits" || k == "sector_max_gb" || k == "sector_min_qubits" || k == "sector_h") {
+    else if (k == "sector" || k == "sector_bits" || k == "sector_max_gb" || k == "sector_min_qubits" || k == "sector_h" ||
+             k == "sector_h_bits" || k == "sector_dict") {
         (k == "sector" ? h->opt_sector : k == "sector_bits" ? h->opt_sector_bits : k == "sector_max_gb" ? h->opt_sector_max_gb
-         : k == "sector_h" ? h->opt_sector_h : h->opt_sector_min_qubits) = (int)value;
+         : k == "sector_h" ? h->opt_sector_h : k == "sector_h_bits" ? h->opt_sector_h_bits : k == "sector_dict" ? h->opt_sector_dict
+                                                                                                              : h->opt_sector_min_qubits) = (int)value;
         free_sector(h->sec);
         h->sec.disabled = false;
         h->sec.seen = 0;
         h->sec.prog_version = -1;
-    } else if (k == "sector_threads") h->opt_sector_threads = value == 64 ? 64 : 256;
+    } else if (k == "sector_threads") h->opt_sector_threads = (value == 0 || value == 64 || value == 512 || value == 1024) ? (int)value : 256;
+    else if (k == "sector_h_groups") h->opt_sector_h_groups = (int)value;
+    else if (k == "sector_debug") h->opt_sector_debug = (int)value;
     else if (k == "rot_variant") h->opt_rot_variant = (int)value;
     else if (k == "real_stream") h->opt_real_stream = (int)value;
     else if (k == "apply_min_tiles") h->opt_apply_min_tiles = (int)value;

@@ -14,7 +14,11 @@
 //     small, so M is 16 where the dense tiles stop at 12-13: a third of the sweeps, and 27x less data per sweep.
 //   * <H>: the Hamiltonian restricted to the support is MATERIALISED once per (program, Hamiltonian): for every sweep of a
 //     tile cover of the x-groups and every tile, the list of (slot_i, slot_j, H_ij) with H_ij != 0.  An evaluation streams
-//     that list once (12 bytes per matrix element) against the tile's amplitudes in LDS: HBM-bound, no Pauli arithmetic left.
+//     that list once against the tile's amplitudes in LDS: HBM-bound, no Pauli arithmetic left.  The matrix elements of the
+//     x-groups with three or more mixing bits (double excitations: 96 % of the elements) take few distinct magnitudes per
+//     sweep, so they are stored as ONE 32-bit word (slot_i, slot_j, sign, index into the sweep's dictionary of magnitudes:
+//     4 bytes per element); the others (diagonal, single-excitation-like groups: occupation-dependent values) keep an
+//     explicit double (12 bytes).  <H> tiles are smaller than the circuit's (<= 1023 amplitudes: 10-bit slots).
 //
 // All tables are built on the device (radix sort of the permuted indices, binary search of partners inside a tile).
 #pragma once
@@ -22,13 +26,12 @@
 
 namespace ovqe {
 
-constexpr int SEC_SLOT_BITS = 13;
-constexpr uint32_t SEC_SLOT_MASK = (1u << SEC_SLOT_BITS) - 1u;
-constexpr uint32_t SEC_ORPHAN = SEC_SLOT_MASK;    // "partner outside the support" (slots are 0 .. 8190)
-constexpr uint32_t SEC_MAX_TILE = SEC_SLOT_MASK;  // entries per compact tile
-constexpr int SEC_MAX_PAT = 32;                   // active patterns of an OP_TAB op (5 bits of the pair word)
-
-// pair word: slot_i | slot_j << 13 | sign << 26 | pattern << 27;  u' = c u + s v, v' = c v - s u, s = sign ? -sin : sin
+// pair word, sb = slot bits of the engine (13, 14 or 15: tiles of up to 2^sb - 1 amplitudes; the all-ones slot means "partner
+// outside the support"): slot_i | slot_j << sb | sign << 2 sb | pattern << (2 sb + 1), i.e. 32 / 8 / 2 active patterns per
+// OP_TAB op;  u' = c u + s v, v' = c v - s u, s = sign ? -sin : sin
+constexpr int SEC_MAX_PAT = 32;
+constexpr uint32_t SEC_TILE_LDS_CAP = 14000;      // amplitudes of a circuit tile that fit LDS next to the staging buffers
+constexpr uint32_t SEC_STAGE_WORDS = 4096;        // pair words per staging buffer
 struct SecBuildOp {   // one compact op = one OP_TAB op, or one rotation of an OP_PAIR run
     uint64_t x;       // mixing mask
     uint64_t zs;      // sign = parity(i & zs) ^ flip, i = the pair's member that matches the pattern
@@ -42,12 +45,23 @@ struct SecGroup {     // x-group of the Hamiltonian, global masks
     uint64_t x;
     int32_t t0, t1;
 };
+constexpr int SEC_HSLOT_BITS = 10;
+constexpr uint32_t SEC_HSLOT_MASK = (1u << SEC_HSLOT_BITS) - 1u;
+constexpr uint32_t SEC_HMAX_TILE = SEC_HSLOT_MASK;   // entries per <H> tile
+constexpr int SEC_DICT_MAX = 2048;                   // magnitudes per sweep (11 bits of the coded word)
+constexpr int SEC_CODED_MIN_WEIGHT = 3;              // x-groups with at least this many mixing bits go through the dictionary
+// coded word: slot_i | slot_j << 10 | sign << 20 | dictionary index << 21;  explicit word: slot_i | slot_j << 10
 struct SecHSweep {    // one sweep of the materialised <H>: device pointers
     const uint32_t *src;    // [K] position of the entry in the circuit's final order
     const uint32_t *off;    // [ntiles + 1]
-    const uint32_t *ebase;  // [K + 1] first matrix element of every entry
-    const uint32_t *words;  // slot_i | slot_j << 13
-    const double *vals;     // H_ii, or 2 H_ij (pair counted once)
+    const uint32_t *cbase;  // [K + 1] first coded element of every entry
+    const uint32_t *cwords;
+    const double *cvals;    // the coded stream's values when the sweep has no dictionary (ndict == 0), else unused
+    const double *dict;     // [ndict] magnitudes (ascending)
+    const uint32_t *xbase;  // [K + 1] first explicit element of every entry
+    const uint32_t *xwords;
+    const double *xvals;    // H_ii, or 2 H_ij (pair counted once)
+    int32_t ndict, ntiles;
 };
 
 __device__ __forceinline__ uint32_t sec_pext(uint32_t v, uint32_t mask) {  // mask is wave-uniform
@@ -146,14 +160,15 @@ __device__ __forceinline__ int sec_find(const uint32_t *lk, int n, uint32_t key)
 // ---- pair lists of one circuit sweep ----------------------------------------------------------------------------------
 // One workgroup per tile.  FILL = false: cnt[tile * nops + o] = pairs of op o in the tile;  FILL = true: the pair words at
 // poff[tile * (nops + 1) + o], in ascending slot order (a fixed order: results are reproducible).  A member of an active
-// pair whose partner is not in the support is recorded with SEC_ORPHAN: its amplitude is structurally zero at that point of
+// pair whose partner is not in the support is recorded with the all-ones slot: its amplitude is structurally zero at that point of
 // the circuit (otherwise the partner would have been populated at the probe parameters) and the sweep checks just that.
 template <bool FILL, int NT>
 __global__ __launch_bounds__(NT) void k_sec_pairs(const uint32_t *__restrict__ sup, const uint32_t *__restrict__ keys,
                                                   const uint32_t *__restrict__ cid, const uint32_t *__restrict__ off, int M,
                                                   uint32_t smask, const SecBuildOp *__restrict__ ops, int nops,
                                                   const SecPat *__restrict__ pats, uint32_t *__restrict__ cnt,
-                                                  const uint32_t *__restrict__ poff, uint32_t *__restrict__ pairs) {
+                                                  const uint32_t *__restrict__ poff, uint32_t *__restrict__ pairs, int sb) {
+    const uint32_t orphan = (1u << sb) - 1u;
     extern __shared__ uint32_t sec_lk[];
     __shared__ uint32_t wtot[NT / 64];
     const uint32_t t = blockIdx.x, e0 = off[t];
@@ -184,13 +199,13 @@ __global__ __launch_bounds__(NT) void k_sec_pairs(const uint32_t *__restrict__ s
                     if (bits == pt.pv) {
                         const int sj = sec_find(sec_lk, n, sec_lk[k] ^ xl);
                         const uint32_t sign = (uint32_t)(parity64(i & op.zs) ^ op.flip);
-                        word = (uint32_t)k | ((sj < 0 ? SEC_ORPHAN : (uint32_t)sj) << SEC_SLOT_BITS) | (sign << 26) | ((uint32_t)p << 27);
+                        word = (uint32_t)k | ((sj < 0 ? orphan : (uint32_t)sj) << sb) | (sign << (2 * sb)) | ((uint32_t)p << (2 * sb + 1));
                         emit = true;
                         break;
                     }
                     if (bits == (pt.pv ^ (op.x & pt.pm))) {   // second member: only its orphans are recorded
                         if (sec_find(sec_lk, n, sec_lk[k] ^ xl) < 0) {
-                            word = (uint32_t)k | (SEC_ORPHAN << SEC_SLOT_BITS) | ((uint32_t)p << 27);
+                            word = (uint32_t)k | (orphan << sb) | ((uint32_t)p << (2 * sb + 1));
                             emit = true;
                         }
                         break;
@@ -223,16 +238,16 @@ struct SecOpLds {
     uint32_t p0;    // first pair of the op in this tile
     int32_t tab;    // first table entry, relative to the sweep's table
 };
-constexpr int SEC_WORDS_PER_THREAD = 16;   // pair words per thread and staging buffer
 template <int NT>
-__device__ __forceinline__ void sec_rotate(double *tile, const double2 *tab, uint32_t pw, bool &bad) {
-    const uint32_t si = pw & SEC_SLOT_MASK, sj = (pw >> SEC_SLOT_BITS) & SEC_SLOT_MASK;
-    if (sj == SEC_ORPHAN) {
+__device__ __forceinline__ void sec_rotate(double *tile, const double2 *tab, uint32_t pw, bool &bad, int sb) {
+    const uint32_t mask = (1u << sb) - 1u;
+    const uint32_t si = pw & mask, sj = (pw >> sb) & mask;
+    if (sj == mask) {
         bad |= tile[si] != 0.0;
         return;
     }
-    const double2 r = tab[pw >> 27];
-    const double s = (pw & (1u << 26)) ? -r.y : r.y;
+    const double2 r = tab[pw >> (2 * sb + 1)];
+    const double s = ((pw >> (2 * sb)) & 1u) ? -r.y : r.y;
     const double u = tile[si], v = tile[sj];
     tile[si] = r.x * u + s * v;
     tile[sj] = r.x * v - s * u;
@@ -243,11 +258,12 @@ __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ 
                                                      const int32_t *__restrict__ tab0, int nops,
                                                      const uint32_t *__restrict__ poff, const uint32_t *__restrict__ pairs,
                                                      const RotParam *__restrict__ rp, int rot0, int nrot, uint32_t tile_cap,
-                                                     uint32_t hf_pos, int *__restrict__ flag) {
+                                                     uint32_t hf_pos, int *__restrict__ flag, int dbg, int sb) {
     // The pair words of the tile are consecutive in memory (op after op): they are staged in LDS in op-aligned chunks of
     // at most W words, the loads of chunk c + 1 in flight (registers) while chunk c is processed — an op never waits for
     // global memory.  Barriers wait for LDS only (s_waitcnt lgkmcnt), not for those loads.
-    constexpr uint32_t W = SEC_WORDS_PER_THREAD * NT;
+    constexpr uint32_t W = SEC_STAGE_WORDS;
+    constexpr int SEC_WORDS_PER_THREAD = SEC_STAGE_WORDS / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
     double *tile = reinterpret_cast<double *>(sec_smem);
     double2 *cs = reinterpret_cast<double2 *>(tile + ((tile_cap + 1u) & ~1u));
@@ -289,6 +305,7 @@ __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ 
     };
     bool bad = false;
     int oa = 0, ob = chunk_end(0), cb = 0;
+    if (dbg == 1) oa = ob = nops;   // measurement only: the sweep without its ops
     if (ob > oa) {
         fetch(oa, ob);
         stash(wbuf);
@@ -298,7 +315,7 @@ __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ 
         if (ob == oa) {   // one op with more pairs in this tile than a buffer holds: straight from memory
             const uint32_t p0 = lop[oa].p0, p1 = lop[oa + 1].p0;
             const double2 *tab = cs + lop[oa].tab;
-            for (uint32_t k = p0 + threadIdx.x; k < p1; k += NT) sec_rotate<NT>(tile, tab, pairs[k], bad);
+            for (uint32_t k = p0 + threadIdx.x; k < p1; k += NT) sec_rotate<NT>(tile, tab, pairs[k], bad, sb);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             ++oa;
             if (oa < nops) {
@@ -319,7 +336,7 @@ __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ 
         for (int o = oa; o < ob; ++o) {
             const uint32_t p1 = lop[o + 1].p0 - base;
             const double2 *tab = cs + lop[o].tab;
-            for (uint32_t k = p0 + threadIdx.x; k < p1; k += NT) sec_rotate<NT>(tile, tab, wb[k], bad);
+            for (uint32_t k = p0 + threadIdx.x; k < p1; k += NT) sec_rotate<NT>(tile, tab, wb[k], bad, sb);
             p0 = p1;
             if (NT > 64) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("" ::: "memory");
         }
@@ -338,15 +355,18 @@ __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ 
 
 // ---- materialised <H> -------------------------------------------------------------------------------------------------
 // One thread per entry of the tile; for every x-group of the sweep D_g(i) = sum_t c_t (-1)^{|j & z_t|}, j = i ^ x, the pair
-// taken from its member with a clear pivot bit.  FILL = false: ecnt[e] = non-zero elements of entry e; FILL = true: they
-// are written at ebase[e] (entry-major: a wave of the evaluation kernel reads one amplitude for a run of elements).
+// taken from its member with a clear pivot bit.  FILL = false: ccnt[e] / xcnt[e] = non-zero elements of entry e in the two
+// streams; FILL = true: they are written at cbase[e] / xbase[e] (entry-major: a wave of the evaluation kernel reads one
+// amplitude for a run of elements).  The coded stream is written with its values; k_sec_encode replaces them.
 template <bool FILL, int NT>
 __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ sup, const uint32_t *__restrict__ keys,
                                                    const uint32_t *__restrict__ cid, const uint32_t *__restrict__ off, int M,
                                                    uint32_t smask, const SecGroup *__restrict__ groups, int ngroups,
-                                                   const HTerm *__restrict__ terms, uint32_t *__restrict__ ecnt,
-                                                   const uint32_t *__restrict__ ebase, uint32_t *__restrict__ words,
-                                                   double *__restrict__ vals) {
+                                                   const HTerm *__restrict__ terms, uint32_t *__restrict__ ccnt,
+                                                   uint32_t *__restrict__ xcnt, const uint32_t *__restrict__ cbase,
+                                                   const uint32_t *__restrict__ xbase, uint32_t *__restrict__ cwords,
+                                                   double *__restrict__ cvals, uint32_t *__restrict__ xwords,
+                                                   double *__restrict__ xvals) {
     extern __shared__ uint32_t sec_lk[];
     const uint32_t t = blockIdx.x, e0 = off[t];
     const int n = (int)(off[t + 1] - e0);
@@ -357,8 +377,8 @@ __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ 
     for (int k = threadIdx.x; k < n; k += NT) {
         const uint64_t i = sup[cid[e0 + k]];
         const uint32_t li = sec_lk[k];
-        uint32_t c = 0;
-        const uint32_t wb = FILL ? ebase[e0 + k] : 0u;
+        uint32_t cc = 0, xc = 0;
+        const uint32_t cb = FILL ? cbase[e0 + k] : 0u, xb = FILL ? xbase[e0 + k] : 0u;
         for (int g = 0; g < ngroups; ++g) {
             const SecGroup gr = groups[g];
             int sj = k;
@@ -375,49 +395,126 @@ __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ 
                 if (__popcll(gr.x & ht.z) & 1) continue;   // odd number of Y: <P> = 0 on a real state
                 d += parity64(j & ht.z) ? -ht.cr : ht.cr;
             }
-            if (d != 0.0) {
+            if (d == 0.0) continue;
+            const uint32_t word = (uint32_t)k | ((uint32_t)sj << SEC_HSLOT_BITS);
+            if (__popcll(gr.x) >= SEC_CODED_MIN_WEIGHT) {
                 if (FILL) {
-                    words[wb + c] = (uint32_t)k | ((uint32_t)sj << SEC_SLOT_BITS);
-                    vals[wb + c] = gr.x ? 2.0 * d : d;
+                    cwords[cb + cc] = word;
+                    cvals[cb + cc] = 2.0 * d;
                 }
-                ++c;
+                ++cc;
+            } else {
+                if (FILL) {
+                    xwords[xb + xc] = word;
+                    xvals[xb + xc] = gr.x ? 2.0 * d : d;
+                }
+                ++xc;
             }
         }
-        if (!FILL) ecnt[e0 + k] = c;
+        if (!FILL) {
+            ccnt[e0 + k] = cc;
+            xcnt[e0 + k] = xc;
+        }
     }
 }
+// dictionary of a sweep: sort keys = |value| (the bit pattern of a non-negative double orders like the number)
+__global__ __launch_bounds__(256) void k_sec_abs_keys(const double *__restrict__ vals, uint32_t n, uint64_t *__restrict__ keys) {
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e < n) keys[e] = (uint64_t)__double_as_longlong(fabs(vals[e]));
+}
+__global__ __launch_bounds__(256) void k_sec_encode(uint32_t *__restrict__ words, const double *__restrict__ vals, uint32_t n,
+                                                    const uint64_t *__restrict__ dict, int ndict) {
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= n) return;
+    const double v = vals[e];
+    const uint64_t key = (uint64_t)__double_as_longlong(fabs(v));
+    int lo = 0, hi = ndict - 1;
+    while (lo < hi) {   // the key is in the dictionary
+        const int mid = (lo + hi) >> 1;
+        if (dict[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    words[e] |= (v < 0.0 ? 1u << 20 : 0u) | ((uint32_t)lo << 21);
+}
 
-// E = sum over the sweeps and tiles of sum_e vals[e] a[slot_i] a[slot_j]: blockIdx.y = sweep, blockIdx.x = tile
+// E = sum over the sweeps and tiles of sum_e H_e a[slot_i] a[slot_j]: blockIdx.y = sweep; the workgroups of a sweep share
+// its tiles round robin (the dictionary is staged once per workgroup, the amplitudes of the next tile are in flight while
+// the elements of the current one stream)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_sector_expect(const double *__restrict__ state, const SecHSweep *__restrict__ sweeps,
                                                       double2 *__restrict__ partials) {
-    extern __shared__ double sec_tile[];
+    constexpr int PER = (SEC_HMAX_TILE + NT) / NT;   // amplitudes of a tile per thread
+    __shared__ double tile[SEC_HMAX_TILE + 1];
+    __shared__ double dict[SEC_DICT_MAX];
     __shared__ double2 red[NT / 64];
     const SecHSweep sw = sweeps[blockIdx.y];
-    const uint32_t t = blockIdx.x, e0 = sw.off[t];
-    const int n = (int)(sw.off[t + 1] - e0);
-    const size_t slot = (size_t)blockIdx.y * gridDim.x + t;
-    if (n == 0) {
-        if (threadIdx.x == 0) partials[slot] = make_double2(0.0, 0.0);
-        return;
-    }
-    for (int k = threadIdx.x; k < n; k += NT) sec_tile[k] = state[sw.src[e0 + k]];
-    __syncthreads();
-    const uint32_t b0 = sw.ebase[e0], b1 = sw.ebase[e0 + n];
+    const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    uint32_t e = b0 + threadIdx.x;
-    for (; e + 3u * NT < b1; e += 4u * NT) {
-        const uint32_t w0 = sw.words[e], w1 = sw.words[e + NT], w2 = sw.words[e + 2 * NT], w3 = sw.words[e + 3 * NT];
-        const double v0 = sw.vals[e], v1 = sw.vals[e + NT], v2 = sw.vals[e + 2 * NT], v3 = sw.vals[e + 3 * NT];
-        acc0 += v0 * sec_tile[w0 & SEC_SLOT_MASK] * sec_tile[w0 >> SEC_SLOT_BITS];
-        acc1 += v1 * sec_tile[w1 & SEC_SLOT_MASK] * sec_tile[w1 >> SEC_SLOT_BITS];
-        acc2 += v2 * sec_tile[w2 & SEC_SLOT_MASK] * sec_tile[w2 >> SEC_SLOT_BITS];
-        acc3 += v3 * sec_tile[w3 & SEC_SLOT_MASK] * sec_tile[w3 >> SEC_SLOT_BITS];
+    for (int k = threadIdx.x; k < sw.ndict; k += NT) dict[k] = sw.dict[k];
+    double nxt[PER];
+    uint32_t e0 = 0, n = 0;
+    auto fetch = [&](uint32_t t) {
+        e0 = sw.off[t];
+        n = sw.off[t + 1] - e0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const uint32_t k = threadIdx.x + (uint32_t)q * NT;
+            nxt[q] = k < n ? state[sw.src[e0 + k]] : 0.0;
+        }
+    };
+    uint32_t t = blockIdx.x;
+    if (t < (uint32_t)sw.ntiles) fetch(t);
+    for (; t < (uint32_t)sw.ntiles; t += gridDim.x) {
+        const uint32_t ce0 = e0, cn = n;
+        __syncthreads();   // the previous tile's elements are done with the LDS copy
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const uint32_t k = threadIdx.x + (uint32_t)q * NT;
+            if (k < cn) tile[k] = nxt[q];
+        }
+        __syncthreads();
+        if (t + gridDim.x < (uint32_t)sw.ntiles) fetch(t + gridDim.x);
+        if (cn == 0) continue;
+        {
+            const uint32_t b1 = sw.cbase[ce0 + cn];
+            uint32_t e = sw.cbase[ce0] + threadIdx.x;
+            if (sw.ndict) {
+                auto term = [&](uint32_t w) {
+                    const double v = dict[w >> 21] * tile[w & SEC_HSLOT_MASK] * tile[(w >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK];
+                    return (w & (1u << 20)) ? -v : v;
+                };
+                for (; e + 7u * NT < b1; e += 8u * NT) {
+                    uint32_t w[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) w[q] = __builtin_nontemporal_load(&sw.cwords[e + q * NT]);
+                    acc0 += term(w[0]) + term(w[4]);
+                    acc1 += term(w[1]) + term(w[5]);
+                    acc2 += term(w[2]) + term(w[6]);
+                    acc3 += term(w[3]) + term(w[7]);
+                }
+                for (; e < b1; e += NT) acc0 += term(sw.cwords[e]);
+            } else {
+                for (; e < b1; e += NT) {
+                    const uint32_t w = sw.cwords[e];
+                    acc0 += sw.cvals[e] * tile[w & SEC_HSLOT_MASK] * tile[(w >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK];
+                }
+            }
+        }
+        {
+            const uint32_t b1 = sw.xbase[ce0 + cn];
+            uint32_t e = sw.xbase[ce0] + threadIdx.x;
+            for (; e + NT < b1; e += 2u * NT) {
+                const uint32_t w0 = sw.xwords[e], w1 = sw.xwords[e + NT];
+                const double v0 = sw.xvals[e], v1 = sw.xvals[e + NT];
+                acc1 += v0 * tile[w0 & SEC_HSLOT_MASK] * tile[(w0 >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK];
+                acc2 += v1 * tile[w1 & SEC_HSLOT_MASK] * tile[(w1 >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK];
+            }
+            for (; e < b1; e += NT) {
+                const uint32_t w0 = sw.xwords[e];
+                acc3 += sw.xvals[e] * tile[w0 & SEC_HSLOT_MASK] * tile[(w0 >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK];
+            }
+        }
     }
-    for (; e < b1; e += NT) {
-        const uint32_t w0 = sw.words[e];
-        acc0 += sw.vals[e] * sec_tile[w0 & SEC_SLOT_MASK] * sec_tile[w0 >> SEC_SLOT_BITS];
-    }
+    __syncthreads();
     const double2 tsum = block_sum<NT>(make_double2((acc0 + acc1) + (acc2 + acc3), 0.0), red);
     if (threadIdx.x == 0) partials[slot] = tsum;
 }

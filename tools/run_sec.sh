@@ -1,3 +1,4 @@
-for args in "" "--opt=sector_bits=15" "--opt=sector_bits=14" "--opt=sector_bits=14 --opt=sector_threads=64"; do
-echo "== $args"; python tools/exp_sector.py 12 5 $args 2>&1 | grep -E "^sector=1|^E " | cut -c1-100
-done
+python tools/exp_sector.py 12 5 --sector-only 2>&1 | grep -E "^sector=1|^E " | cut -c1-100
+python tools/exp_sector.py 13 6 --sector-only| cut -c1-100
+python tools/exp_sector.py 13 6 --sector-only --opt=sector_threads=512| cut -c1-100
+python tools/exp_sector.py 13 6 --sector-only --opt=sector_threads=256| cut -c1-100
