@@ -87,7 +87,17 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * algebraically identical sequence of Pauli rotations with conjugated strings instead; 2 = always, Clifford part
  * appended literally), "expect_sparse" (tiled <H>: a tile in which at most 1/value of the amplitudes are non-zero — the
  * particle-number / spin sector of a UCC-type state — is evaluated over the compacted list of its non-zero amplitudes
- * instead of over all pairs; skipped work is multiplication by exact zeros; default 4, 0 = never) */
+ * instead of over all pairs; skipped work is multiplication by exact zeros; default 4, 0 = never),
+ * "compact" (1, default: compact cover — from the second evaluation of a (program, Hamiltonian) pair on, <H> of a
+ * real-amplitude streaming energy runs over a compact copy of the state's support),
+ * "sector" (1, default: sector path — from the second evaluation on, a real-amplitude program whose states occupy at most
+ * 1/8 of the register runs entirely on that support: circuit over compact tiles from precomputed pair lists, <H> from the
+ * Hamiltonian materialised on the support; results equal the dense kernels' up to rounding; the tables live in device
+ * memory next to the state), "sector_max_gb" (table budget, default 64, also capped at half of the free device memory;
+ * beyond it the circuit stays on the sector path and <H> goes through the compact cover), "sector_h" (0: never materialise
+ * <H>), "sector_dict" (0: explicit doubles instead of dictionary-coded matrix elements), "sector_bits" / "sector_h_bits"
+ * (index bits per circuit / <H> tile, 0 = automatic), "sector_threads" (0 automatic, 64, 256, 512, 1024),
+ * "sector_min_qubits" (default 18).  The state buffer holds unspecified data after an energy evaluation on this path. */
 int ovqe_set_option(ovqe_handle h, const char *name, int64_t value);
 /* device pointer to the 2^n_local amplitudes (for RCCL exchange by the host layer) */
 int ovqe_state_ptr(ovqe_handle h, void **dev_ptr);
@@ -219,7 +229,9 @@ int ovqe_last_batch_ms(ovqe_handle h, double *ms);
  *   [7] tile sweeps of the stored Hamiltonian's expectation (0 until first used / when not tiled)  [8] x-groups
  *   that keep their own sweep  [9] (group, pattern) entries  [10] merged terms  [11] pair x term evaluations per tile
  *   [12] 1 when streaming energies of this program keep the state as 2^n real amplitudes
- *   [13..15] support-compacted program: ops, active pairs per evaluation, entries of the restricted Hamiltonian */
+ *   [13..15] support-compacted program: ops, active pairs per evaluation, entries of the restricted Hamiltonian
+ *   [16..21] sector path (0 until its tables exist): support size, circuit sweeps, active pairs per evaluation, <H> sweeps
+ *   (0: circuit only, <H> by the compact cover), matrix elements of the materialised Hamiltonian, table bytes */
 int ovqe_program_info(ovqe_handle h, int64_t *info, int count);
 
 #ifdef __cplusplus
