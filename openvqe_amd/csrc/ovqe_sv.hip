@@ -106,6 +106,7 @@ struct SectorEngine {
     std::vector<SectorSeg> segs;
     std::vector<SectorHSweep> hs;
     DevBuf d_sup, d_buf[2], d_hdesc, d_flag;
+    DevBuf d_lam[2], d_w, d_wpart;   // adjoint gradient: lambda (ping-pong), per-entry sums, per-tile partials
 };
 
 }  // namespace
@@ -1363,6 +1364,22 @@ int run_program_streaming(ovqe_handle h, const double *theta, bool real = false)
 }
 
 #include "sector_host.inc"
+
+// sector path: the tables of a (program, Hamiltonian) pair are built at its second evaluation (energy or gradient), so
+// one-shot callers never pay for them
+int sector_prepare(ovqe_handle h) {
+    if (!h->opt_sector || h->n_local < h->opt_sector_min_qubits) return OVQE_OK;
+    SectorEngine &E = h->sec;
+    if (E.prog_version != h->prog_version || E.ham_version != h->ham.version) {
+        free_sector(E);
+        E.disabled = false;
+        E.seen = 0;
+        E.prog_version = h->prog_version;
+        E.ham_version = h->ham.version;
+    }
+    if (!E.valid && !E.disabled && ++E.seen >= 2) return build_sector(h);
+    return OVQE_OK;
+}
 
 // commuting-run fusion analysis of one same-x run (see sv_small.hpp OP_TAB); returns false when the run
 // does not have the structure (then it stays a sequential OP_PAIR)
@@ -2842,20 +2859,10 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
             R.tile_bits = -1;
             R.version = h->ham.version;
         }
-        if (real && h->opt_sector && h->n_local >= h->opt_sector_min_qubits) {
-            // sector path: tables built at the second evaluation of a (program, Hamiltonian) pair, as the compact cover
+        if (real) {
+            rc = sector_prepare(h);
+            if (rc) return rc;
             SectorEngine &E = h->sec;
-            if (E.prog_version != h->prog_version || E.ham_version != h->ham.version) {
-                free_sector(E);
-                E.disabled = false;
-                E.seen = 0;
-                E.prog_version = h->prog_version;
-                E.ham_version = h->ham.version;
-            }
-            if (!E.valid && !E.disabled && ++E.seen >= 2) {
-                rc = build_sector(h);
-                if (rc) return rc;
-            }
             if (E.valid && E.h_tables) {
                 double2 res;
                 bool ok = false;
@@ -3278,6 +3285,18 @@ extern "C" int ovqe_energy_gradient(ovqe_handle h, const double *theta, int32_t 
     if (rc) return rc;
     if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
     if (h->n_global) return fail(h, OVQE_ERR_INVALID, "ovqe_energy_gradient is single-device");
+    if (h->opt_real_stream && h->prog_real_ok && tile_ok(h, true) && h->ham.groups.size() >= 3) {
+        // real-amplitude program on a sparse support: the whole adjoint pass on the sector tables
+        rc = sector_prepare(h);
+        if (rc) return rc;
+        if (h->sec.valid && h->sec.h_tables) {
+            bool ok = false;
+            rc = run_sector_gradient(h, theta, energy, grad, &ok);
+            if (rc || ok) return rc;
+            free_sector(h->sec);
+            h->sec.disabled = true;
+        }
+    }
     rc = run_program_streaming(h, theta);  // psi = U(theta)|hf>; angle table: original rotations at offset S
     if (!rc) rc = ensure_scratch(h, 0);
     Lanczos L{h, reduce_blocks(h->namps)};

@@ -519,6 +519,178 @@ __global__ __launch_bounds__(NT) void k_sector_expect(const double *__restrict__
     if (threadIdx.x == 0) partials[slot] = tsum;
 }
 
+// ---- exact gradient on the sector tables (adjoint method) ----------------------------------------------------------------
+// lambda = H psi restricted to the support, from the same element streams as k_sector_expect: an off-diagonal element
+// (pair counted once, value 2 H_ij) adds H_ij a_j to lambda_i and H_ij a_i to lambda_j; accumulation in an LDS copy of the
+// tile (f64 LDS atomics; a wave whose 64 elements share slot_i — the rule in entry-major order — adds their sum once), then
+// f64 atomics into lambda in the circuit's final order.  The order of these additions is not fixed: the gradient
+// reproduces to rounding, not bit for bit.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_sector_apply(const double *__restrict__ state, const SecHSweep *__restrict__ sweeps,
+                                                     double *__restrict__ lam_out) {
+    __shared__ double tile[SEC_HMAX_TILE + 1];
+    __shared__ double lam[SEC_HMAX_TILE + 1];
+    __shared__ double dict[SEC_DICT_MAX];
+    const SecHSweep sw = sweeps[blockIdx.y];
+    for (int k = threadIdx.x; k < sw.ndict; k += NT) dict[k] = sw.dict[k];
+    auto add = [&](uint32_t w, double hv) {   // hv = H_ij (off-diagonal) or H_ii
+        const uint32_t si = w & SEC_HSLOT_MASK, sj = (w >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK;
+        if (si == sj) {
+            __hip_atomic_fetch_add(&lam[si], hv * tile[si], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+        }
+        const double ci = hv * tile[sj];
+        __hip_atomic_fetch_add(&lam[sj], hv * tile[si], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t s0 = __builtin_amdgcn_readfirstlane(si);
+        if (__ballot(si == s0) == __ballot(true)) {   // the active lanes share slot_i: one addition for the wave
+            double t = ci;
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+            if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)__ballot(true)) - 1u)
+                __hip_atomic_fetch_add(&lam[s0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            __hip_atomic_fetch_add(&lam[si], ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    for (uint32_t t = blockIdx.x; t < (uint32_t)sw.ntiles; t += gridDim.x) {
+        const uint32_t e0 = sw.off[t], n = sw.off[t + 1] - e0;
+        if (n == 0) continue;
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < n; k += NT) {
+            tile[k] = state[sw.src[e0 + k]];
+            lam[k] = 0.0;
+        }
+        __syncthreads();
+        {
+            const uint32_t b1 = sw.cbase[e0 + n];
+            for (uint32_t e = sw.cbase[e0] + threadIdx.x; e < b1; e += NT) {
+                const uint32_t w = sw.cwords[e];
+                double v = sw.ndict ? dict[w >> 21] : sw.cvals[e];
+                if (sw.ndict && (w & (1u << 20))) v = -v;
+                add(w, 0.5 * v);
+            }
+        }
+        {
+            const uint32_t b1 = sw.xbase[e0 + n];
+            for (uint32_t e = sw.xbase[e0] + threadIdx.x; e < b1; e += NT) {
+                const uint32_t w = sw.xwords[e];
+                const bool diag = (w & SEC_HSLOT_MASK) == ((w >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK);
+                add(w, diag ? sw.xvals[e] : 0.5 * sw.xvals[e]);
+            }
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < n; k += NT) unsafeAtomicAdd(&lam_out[sw.src[e0 + k]], lam[k]);
+    }
+}
+// <a|b> over the compact state: partials per workgroup (fixed order)
+__global__ __launch_bounds__(256) void k_sec_dot(const double *__restrict__ a, const double *__restrict__ b, uint32_t K,
+                                                 double2 *__restrict__ partials) {
+    __shared__ double2 red[4];
+    double acc = 0.0;
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < K; k += gridDim.x * 256u) acc += a[k] * b[k];
+    const double2 t = block_sum<256>(make_double2(acc, 0.0), red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// One sweep of the circuit BACKWARDS on psi and lambda together (both in this sweep's order): for every op, last to
+// first, w[entry] += sum over its pairs of sigma (lambda_i psi_j - lambda_j psi_i) on the states after the op (dE/dtheta =
+// 2 coeff w), then both states are rotated back.  Output in the PREVIOUS sweep's order (scatter through src; the first
+// sweep needs no output).  Partial sums: one per wave and table entry in LDS, added per tile in wave order, then over the
+// tiles by k_sec_reduce_w — a fixed order.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_sector_adjoint(const double *__restrict__ psi_in, const double *__restrict__ lam_in,
+                                                       double *__restrict__ psi_out, double *__restrict__ lam_out,
+                                                       const uint32_t *__restrict__ src, const uint32_t *__restrict__ off,
+                                                       const int32_t *__restrict__ tab0, int nops,
+                                                       const uint32_t *__restrict__ poff, const uint32_t *__restrict__ pairs,
+                                                       const RotParam *__restrict__ rp, int rot0, int nrot, uint32_t tile_cap,
+                                                       double *__restrict__ wpart, int sb) {
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
+    const uint32_t capp = (tile_cap + 1u) & ~1u;
+    double *tp = reinterpret_cast<double *>(sec_smem);
+    double *tl = tp + capp;
+    double2 *cs = reinterpret_cast<double2 *>(tl + capp);
+    double *wacc = reinterpret_cast<double *>(cs + nrot);          // [NW][nrot]
+    SecOpLds *lop = reinterpret_cast<SecOpLds *>(wacc + (size_t)NW * nrot);
+    const uint32_t t = blockIdx.x, e0 = off[t];
+    const int n = (int)(off[t + 1] - e0);
+    double *wp = wpart + (size_t)t * nrot;
+    if (n == 0) {
+        for (int r = threadIdx.x; r < nrot; r += NT) wp[r] = 0.0;
+        return;
+    }
+    const uint32_t *po = poff + (size_t)t * (nops + 1);
+    for (int o = threadIdx.x; o <= nops; o += NT) lop[o] = SecOpLds{po[o], o < nops ? tab0[o] - rot0 : 0};
+    for (int r = threadIdx.x; r < nrot; r += NT) {
+        const RotParam rr = rp[rot0 + r];
+        cs[r] = make_double2(rr.c, rr.s);
+    }
+    for (int r = threadIdx.x; r < NW * nrot; r += NT) wacc[r] = 0.0;
+    for (int k = threadIdx.x; k < n; k += NT) {
+        tp[k] = psi_in[e0 + k];
+        tl[k] = lam_in[e0 + k];
+    }
+    __syncthreads();
+    const uint32_t mask = (1u << sb) - 1u;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *mine = wacc + (size_t)wave * nrot;
+    for (int o = nops - 1; o >= 0; --o) {
+        const uint32_t p0 = lop[o].p0, p1 = lop[o + 1].p0;
+        const int tb = lop[o].tab;
+        // the pairs of an op carry at most a few patterns: per pattern a wave sum, added by one lane
+        double acc[2] = {0.0, 0.0};
+        for (uint32_t k = p0 + threadIdx.x; k < p1; k += NT) {
+            const uint32_t pw = pairs[k];
+            const uint32_t si = pw & mask, sj = (pw >> sb) & mask;
+            if (sj == mask) continue;
+            const uint32_t pat = pw >> (2 * sb + 1);
+            const double2 r = cs[tb + pat];
+            const bool neg = (pw >> (2 * sb)) & 1u;
+            const double s = neg ? -r.y : r.y;
+            const double u1 = tp[si], v1 = tp[sj], lu = tl[si], lv = tl[sj];
+            const double g = lu * v1 - lv * u1;
+            const double gs = neg ? -g : g;
+            if (pat < 2) acc[pat] += gs;
+            else {   // rare: accumulate straight into the wave's slot
+                __hip_atomic_fetch_add(&mine[tb + pat], gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            tp[si] = r.x * u1 - s * v1;
+            tp[sj] = r.x * v1 + s * u1;
+            tl[si] = r.x * lu - s * lv;
+            tl[sj] = r.x * lv + s * lu;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            double tsum = acc[p];
+            for (int d = 32; d > 0; d >>= 1) tsum += __shfl_xor(tsum, d, 64);
+            if (lane == 0 && tsum != 0.0) mine[tb + p] += tsum;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < nrot; r += NT) {
+        double tsum = 0.0;
+        for (int w = 0; w < NW; ++w) tsum += wacc[(size_t)w * nrot + r];
+        wp[r] = tsum;
+    }
+    if (src) {
+        for (int k = threadIdx.x; k < n; k += NT) {
+            const uint32_t d = src[e0 + k];
+            psi_out[d] = tp[k];
+            lam_out[d] = tl[k];
+        }
+    }
+}
+// w[rot0 + r] = sum over the tiles of wpart[tile][r] (fixed order)
+__global__ __launch_bounds__(256) void k_sec_reduce_w(const double *__restrict__ wpart, uint32_t ntiles, int nrot,
+                                                      double *__restrict__ w) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrot) return;
+    double tsum = 0.0;
+    for (uint32_t t = 0; t < ntiles; ++t) tsum += wpart[(size_t)t * nrot + r];
+    w[r] = tsum;
+}
+
 // the compact state back in canonical (ascending index) order, e.g. for ovqe_get_state-like consumers and tests
 __global__ __launch_bounds__(256) void k_sec_scatter(const double *__restrict__ in, const uint32_t *__restrict__ cid, uint32_t K,
                                                      double *__restrict__ out) {

@@ -193,3 +193,40 @@ def test_sector_table_budget(SV):
         assert sv.program_info()["sector_support"] == 0
     for e, ew in zip(got, want):
         assert abs(e - ew) < 1e-10 * max(1.0, float(np.abs(ham.packed()[2]).sum()))
+
+
+@pytest.mark.parametrize("m,o,bits", [(7, 3, 0), (8, 3, 9), (9, 4, 0), (10, 4, 0)])
+def test_sector_adjoint_gradient(SV, m, o, bits):
+    """ovqe_energy_gradient on the sector tables (forward circuit, lambda = H psi on the support, one backward pass):
+    against the dense-state adjoint pass of the same handle and central differences of the C oracle's energy"""
+    from openvqe_amd import fermion
+    n = 2 * m
+    ham, gens, hf = fermion.synthetic_molecule(m, o, seed=400 + m)
+    rng = np.random.default_rng(40 * m + o)
+    K = len(gens)
+    th1, th2 = rng.uniform(-0.3, 0.3, K), rng.uniform(-0.3, 0.3, K)
+    l1 = float(np.abs(ham.packed()[2]).sum())
+    with SV(n) as sv:
+        sv.set_option("force_path", 2)
+        sv.set_option("sector_min_qubits", 8)
+        sv.set_option("sector_bits", bits)
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, hf)
+        e1, g1 = sv.energy_gradient(th1)          # dense states (first evaluation of the pair)
+        e2, g2 = sv.energy_gradient(th1)          # builds the tables, runs on them
+        e3, g3 = sv.energy_gradient(th2)
+        e3b = sv.energy(th2)
+        info = sv.program_info()
+        sv.set_option("sector", 0)
+        e4, g4 = sv.energy_gradient(th2)
+    assert info["sector_support"] == comb(m, o) ** 2 and info["sector_h_elements"] > 0, info
+    assert abs(e2 - e1) < 1e-12 * l1 and abs(e3 - e4) < 1e-12 * l1 and abs(e3 - e3b) < 1e-12 * l1
+    assert np.abs(g2 - g1).max() < 1e-11 * l1 and np.abs(g3 - g4).max() < 1e-11 * l1
+    picks = rng.choice(K, 4, replace=False)
+    h = 1e-5
+    for k in picks:
+        tp, tm = th2.copy(), th2.copy()
+        tp[k] += h
+        tm[k] -= h
+        ep, em = _oracle_energies(n, gens, hf, ham, [tp, tm])
+        assert abs((ep - em) / (2 * h) - g3[k]) < 1e-6 * max(1.0, l1), k
