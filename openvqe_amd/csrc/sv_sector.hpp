@@ -521,10 +521,10 @@ __global__ __launch_bounds__(NT) void k_sector_expect(const double *__restrict__
 
 // ---- exact gradient on the sector tables (adjoint method) ----------------------------------------------------------------
 // lambda = H psi restricted to the support, from the same element streams as k_sector_expect: an off-diagonal element
-// (pair counted once, value 2 H_ij) adds H_ij a_j to lambda_i and H_ij a_i to lambda_j; accumulation in an LDS copy of the
-// tile (f64 LDS atomics; a wave whose 64 elements share slot_i — the rule in entry-major order — adds their sum once), then
-// f64 atomics into lambda in the circuit's final order.  The order of these additions is not fixed: the gradient
-// reproduces to rounding, not bit for bit.
+// (pair counted once, value 2 H_ij) adds H_ij a_j to lambda_i and H_ij a_i to lambda_j — two f64 LDS atomics per element on
+// an LDS copy of the tile (the lanes of a wave mostly share slot_i in entry-major order: the LDS unit serialises those);
+// the tile's result is added to lambda in the circuit's final order with f64 atomics.  The order of these additions is not
+// fixed: the gradient reproduces to rounding, not bit for bit.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_sector_apply(const double *__restrict__ state, const SecHSweep *__restrict__ sweeps,
                                                      double *__restrict__ lam_out) {
@@ -535,21 +535,9 @@ __global__ __launch_bounds__(NT) void k_sector_apply(const double *__restrict__ 
     for (int k = threadIdx.x; k < sw.ndict; k += NT) dict[k] = sw.dict[k];
     auto add = [&](uint32_t w, double hv) {   // hv = H_ij (off-diagonal) or H_ii
         const uint32_t si = w & SEC_HSLOT_MASK, sj = (w >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK;
-        if (si == sj) {
-            __hip_atomic_fetch_add(&lam[si], hv * tile[si], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            return;
-        }
-        const double ci = hv * tile[sj];
-        __hip_atomic_fetch_add(&lam[sj], hv * tile[si], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t s0 = __builtin_amdgcn_readfirstlane(si);
-        if (__ballot(si == s0) == __ballot(true)) {   // the active lanes share slot_i: one addition for the wave
-            double t = ci;
-            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-            if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)__ballot(true)) - 1u)
-                __hip_atomic_fetch_add(&lam[s0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-            __hip_atomic_fetch_add(&lam[si], ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        const double ai = tile[si], aj = tile[sj];
+        __hip_atomic_fetch_add(&lam[si], hv * aj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (si != sj) __hip_atomic_fetch_add(&lam[sj], hv * ai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     for (uint32_t t = blockIdx.x; t < (uint32_t)sw.ntiles; t += gridDim.x) {
         const uint32_t e0 = sw.off[t], n = sw.off[t + 1] - e0;
@@ -562,11 +550,25 @@ __global__ __launch_bounds__(NT) void k_sector_apply(const double *__restrict__ 
         __syncthreads();
         {
             const uint32_t b1 = sw.cbase[e0 + n];
-            for (uint32_t e = sw.cbase[e0] + threadIdx.x; e < b1; e += NT) {
-                const uint32_t w = sw.cwords[e];
-                double v = sw.ndict ? dict[w >> 21] : sw.cvals[e];
-                if (sw.ndict && (w & (1u << 20))) v = -v;
-                add(w, 0.5 * v);
+            uint32_t e = sw.cbase[e0] + threadIdx.x;
+            if (sw.ndict) {
+                for (; e + 3u * NT < b1; e += 4u * NT) {
+                    uint32_t w[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w[q] = __builtin_nontemporal_load(&sw.cwords[e + q * NT]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double v = 0.5 * dict[w[q] >> 21];
+                        add(w[q], (w[q] & (1u << 20)) ? -v : v);
+                    }
+                }
+                for (; e < b1; e += NT) {
+                    const uint32_t w = sw.cwords[e];
+                    const double v = 0.5 * dict[w >> 21];
+                    add(w, (w & (1u << 20)) ? -v : v);
+                }
+            } else {
+                for (; e < b1; e += NT) add(sw.cwords[e], 0.5 * sw.cvals[e]);
             }
         }
         {
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint(const double *__restrict_
                                                        const int32_t *__restrict__ tab0, int nops,
                                                        const uint32_t *__restrict__ poff, const uint32_t *__restrict__ pairs,
                                                        const RotParam *__restrict__ rp, int rot0, int nrot, uint32_t tile_cap,
-                                                       double *__restrict__ wpart, int sb) {
+                                                       double *__restrict__ wpart, int wstride, int sb) {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
     const uint32_t capp = (tile_cap + 1u) & ~1u;
@@ -614,11 +616,8 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint(const double *__restrict_
     SecOpLds *lop = reinterpret_cast<SecOpLds *>(wacc + (size_t)NW * nrot);
     const uint32_t t = blockIdx.x, e0 = off[t];
     const int n = (int)(off[t + 1] - e0);
-    double *wp = wpart + (size_t)t * nrot;
-    if (n == 0) {
-        for (int r = threadIdx.x; r < nrot; r += NT) wp[r] = 0.0;
-        return;
-    }
+    double *wp = wpart + (size_t)t * wstride + rot0;   // [tile][table entry], zeroed by the host
+    if (n == 0) return;
     const uint32_t *po = poff + (size_t)t * (nops + 1);
     for (int o = threadIdx.x; o <= nops; o += NT) lop[o] = SecOpLds{po[o], o < nops ? tab0[o] - rot0 : 0};
     for (int r = threadIdx.x; r < nrot; r += NT) {
@@ -681,7 +680,7 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint(const double *__restrict_
         }
     }
 }
-// w[rot0 + r] = sum over the tiles of wpart[tile][r] (fixed order)
+// w[r] = sum over the tiles of wpart[tile][r] (fixed order), r over the whole angle table
 __global__ __launch_bounds__(256) void k_sec_reduce_w(const double *__restrict__ wpart, uint32_t ntiles, int nrot,
                                                       double *__restrict__ w) {
     const int r = blockIdx.x * 256 + threadIdx.x;

@@ -277,3 +277,38 @@ def test_24_qubit_uccsd_sector_path_on_n2(gpu_lib):
     assert abs(res[1][0][1] - e_rhf) < 1e-8                      # |hf> is the RHF determinant
     assert abs(res[1][0][0] - res[1][0][3]) < 1e-12             # dense first call == sector call, same theta
     assert res[1][0][0] < e_rhf - 0.05                          # MP2 amplitudes recover correlation energy
+
+
+def test_24_qubit_uccsd_vqe_on_n2_with_exact_gradients(gpu_lib):
+    """BASELINE configs[3] as an optimisation: UCCSD-VQE of N2 / cc-pVDZ (10e, 12o), 1715 parameters, L-BFGS-B from the MP2
+    amplitudes with ovqe_energy_gradient (sector tables from its second call on).  Checks: the energy falls monotonically
+    below E(theta_MP2) to the converged value of a longer run, the final gradient is small, and at the optimum the
+    dense-state kernels (sector = 0) return the same energy and the same gradient"""
+    from scipy.optimize import minimize
+    from openvqe_amd import chem
+    from openvqe_amd.backend import Statevector
+    mol = chem.molecule("N2-CCPVDZ")
+    e_rhf = mol.rhf()
+    prob = chem.cas_problem(mol, 2, 12)
+    ham = prob.jw_hamiltonian()
+    size, _, spin_ops, theta_mp2, hf = prob.uccsd()
+    trace = []
+    with Statevector(24) as sv:
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(spin_ops, hf)
+
+        def fun(th):
+            e, g = sv.energy_gradient(th)
+            trace.append(e)
+            return e, g
+
+        res = minimize(fun, np.array(theta_mp2), jac=True, method="L-BFGS-B", options={"maxiter": 40, "gtol": 1e-6, "ftol": 1e-14})
+        info = sv.program_info()
+        e_opt, g_opt = sv.energy_gradient(res.x)
+        sv.set_option("sector", 0)
+        e_dense, g_dense = sv.energy_gradient(res.x)
+    assert info["sector_support"] == 792 ** 2 and info["sector_h_elements"] > 10 ** 8
+    assert trace[0] < e_rhf - 0.1 and res.fun < trace[0] - 3e-3             # MP2 amplitudes, then 3.2 mHa more
+    assert abs(res.fun - (-109.0745445341)) < 2e-8, res.fun                  # converged value of a 300-iteration run
+    assert np.abs(res.jac).max() < 1e-5 and res.nit <= 40
+    assert abs(e_opt - e_dense) < 1e-10 and np.abs(g_opt - g_dense).max() < 1e-10
