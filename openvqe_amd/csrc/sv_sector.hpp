@@ -593,6 +593,24 @@ __global__ __launch_bounds__(256) void k_sec_dot(const double *__restrict__ a, c
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
+// wave-wide sum by DPP row operations (no LDS crossbar: __shfl_xor on doubles costs two ds_bpermute per step); the total
+// is valid in lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double sec_dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sec_wave_sum63(double v) {
+    v = sec_dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = sec_dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = sec_dpp_add<0x141, 0xf>(v);   // row_half_mirror
+    v = sec_dpp_add<0x140, 0xf>(v);   // row_mirror
+    v = sec_dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = sec_dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // One sweep of the circuit BACKWARDS on psi and lambda together (both in this sweep's order): for every op, last to
 // first, w[entry] += sum over its pairs of sigma (lambda_i psi_j - lambda_j psi_i) on the states after the op (dE/dtheta =
 // 2 coeff w), then both states are rotated back.  Output in the PREVIOUS sweep's order (scatter through src; the first
@@ -614,6 +632,7 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint(const double *__restrict_
     double2 *cs = reinterpret_cast<double2 *>(tl + capp);
     double *wacc = reinterpret_cast<double *>(cs + nrot);          // [NW][nrot]
     SecOpLds *lop = reinterpret_cast<SecOpLds *>(wacc + (size_t)NW * nrot);
+    uint32_t *wbuf = reinterpret_cast<uint32_t *>(lop + nops + 2);
     const uint32_t t = blockIdx.x, e0 = off[t];
     const int n = (int)(off[t + 1] - e0);
     double *wp = wpart + (size_t)t * wstride + rot0;   // [tile][table entry], zeroed by the host
@@ -633,13 +652,34 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint(const double *__restrict_
     const uint32_t mask = (1u << sb) - 1u;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *mine = wacc + (size_t)wave * nrot;
-    for (int o = nops - 1; o >= 0; --o) {
-        const uint32_t p0 = lop[o].p0, p1 = lop[o + 1].p0;
+    // pair words staged in LDS in op-aligned chunks as in k_sector_sweep, walked from the last op to the first
+    constexpr uint32_t W = SEC_STAGE_WORDS;
+    constexpr int WPT = SEC_STAGE_WORDS / NT;
+    auto chunk_begin = [&](int ob) {   // ops [oa, ob) whose pair words fit one buffer (oa == ob: op ob - 1 alone is larger)
+        int oa = ob;
+        const uint32_t pb = lop[ob].p0;
+        while (oa > 0 && pb - lop[oa - 1].p0 <= W) --oa;
+        return oa;
+    };
+    uint32_t regs[WPT];
+    auto fetch = [&](int oa, int ob) {
+        const uint32_t base = lop[oa].p0, cnt = lop[ob].p0 - base;
+#pragma unroll
+        for (int r = 0; r < WPT; ++r) {
+            const uint32_t idx = threadIdx.x + (uint32_t)r * NT;
+            regs[r] = idx < cnt ? pairs[base + idx] : 0u;
+        }
+    };
+    auto stash = [&](uint32_t *buf) {
+#pragma unroll
+        for (int r = 0; r < WPT; ++r) buf[threadIdx.x + (uint32_t)r * NT] = regs[r];
+    };
+    // one op backwards: gradient sums of its (at most few) patterns, then both states rotated back
+    auto back_op = [&](int o, const uint32_t *words, uint32_t p0, uint32_t p1) {
         const int tb = lop[o].tab;
-        // the pairs of an op carry at most a few patterns: per pattern a wave sum, added by one lane
         double acc[2] = {0.0, 0.0};
         for (uint32_t k = p0 + threadIdx.x; k < p1; k += NT) {
-            const uint32_t pw = pairs[k];
+            const uint32_t pw = words[k];
             const uint32_t si = pw & mask, sj = (pw >> sb) & mask;
             if (sj == mask) continue;
             const uint32_t pat = pw >> (2 * sb + 1);
@@ -650,9 +690,7 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint(const double *__restrict_
             const double g = lu * v1 - lv * u1;
             const double gs = neg ? -g : g;
             if (pat < 2) acc[pat] += gs;
-            else {   // rare: accumulate straight into the wave's slot
-                __hip_atomic_fetch_add(&mine[tb + pat], gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            else __hip_atomic_fetch_add(&mine[tb + pat], gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // rare
             tp[si] = r.x * u1 - s * v1;
             tp[sj] = r.x * v1 + s * u1;
             tl[si] = r.x * lu - s * lv;
@@ -660,11 +698,45 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint(const double *__restrict_
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            double tsum = acc[p];
-            for (int d = 32; d > 0; d >>= 1) tsum += __shfl_xor(tsum, d, 64);
-            if (lane == 0 && tsum != 0.0) mine[tb + p] += tsum;
+            const double tsum = sec_wave_sum63(acc[p]);
+            if (lane == 63 && tsum != 0.0) mine[tb + p] += tsum;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    int ob = nops, oa = chunk_begin(nops), cb = 0;
+    if (oa < ob) {
+        fetch(oa, ob);
+        stash(wbuf);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    while (ob > 0) {
+        if (oa == ob) {   // one op with more pairs in this tile than a buffer holds: straight from memory
+            back_op(ob - 1, pairs, lop[ob - 1].p0, lop[ob].p0);
+            --ob;
+            if (ob > 0) {
+                oa = chunk_begin(ob);
+                if (oa < ob) {
+                    fetch(oa, ob);
+                    stash(wbuf + (size_t)cb * W);
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+            } else {
+                oa = 0;
+            }
+            continue;
+        }
+        const int nb = oa, na = nb > 0 ? chunk_begin(nb) : nb;
+        if (na < nb) fetch(na, nb);   // in flight while this chunk is processed
+        const uint32_t *wb = wbuf + (size_t)cb * W;
+        const uint32_t base = lop[oa].p0;
+        for (int o = ob - 1; o >= oa; --o) back_op(o, wb, lop[o].p0 - base, lop[o + 1].p0 - base);
+        if (na < nb) {
+            stash(wbuf + (size_t)(cb ^ 1) * W);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        cb ^= 1;
+        ob = nb;
+        oa = na;
     }
     __syncthreads();
     for (int r = threadIdx.x; r < nrot; r += NT) {
