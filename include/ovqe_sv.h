@@ -203,7 +203,10 @@ int ovqe_apply_exp_pauli_sum(ovqe_handle h, int64_t T, const uint64_t *x, const 
  * dE/dtheta_p = sum_{r: pidx_r = p} 2 c_r Im <lambda_r|P_r|psi_r> on the way — about three circuit executions for
  * ALL K derivatives, where the reference's BFGS (jac=None, ref:openvqe/ucc_family/get_energy_ucc.py:158-175) spends K+1
  * evaluations on forward differences (opt-in, because exact derivatives change the
- * optimiser's iterates at the 1e-8 level).  Streaming kernels, any n; the state buffer is left in |hf>. */
+ * optimiser's iterates at the 1e-8 level).  Streaming kernels, any n; the state buffer is left in |hf>.  A real-amplitude
+ * program with sector tables (option "sector") runs the whole pass on them from its second call on: forward circuit,
+ * lambda = H psi from a row-by-row copy of the materialised Hamiltonian (built at that call when it fits the table budget;
+ * "sector_rows" = 0 keeps the pair format and its scattered additions), backward sweeps over the pair lists. */
 int ovqe_energy_gradient(ovqe_handle h, const double *theta, int32_t K, double *energy, double *grad);
 
 /* ---- lowest eigenpair of the stored Hamiltonian (Lanczos on the device, two-pass: tridiagonal matrix, then the Ritz

@@ -358,7 +358,14 @@ __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ 
 // taken from its member with a clear pivot bit.  FILL = false: ccnt[e] / xcnt[e] = non-zero elements of entry e in the two
 // streams; FILL = true: they are written at cbase[e] / xbase[e] (entry-major: a wave of the evaluation kernel reads one
 // amplitude for a run of elements).  The coded stream is written with its values; k_sec_encode replaces them.
-template <bool FILL, int NT>
+// ROWS = true: the symmetric matrix row by row — every off-diagonal element under BOTH of its entries, explicit values
+// not doubled (the coded stream keeps the doubled magnitudes of the pair format so that the sweep's dictionary serves
+// both) — in SLICES of 64 consecutive entries of a tile: element q of the slice's row l sits at base + 64 q + l, rows padded
+// to the longest of the slice with null elements (value 0).  lambda = H psi then is one gather per element, a register
+// sum per row, coalesced loads, no scattered additions (k_sector_apply_rows).  cbase / xbase are per (tile, slice) then,
+// clen / xlen the slice lengths.
+constexpr int SEC_HSLICES = (SEC_HMAX_TILE + 64) / 64;   // slices per tile
+template <bool FILL, int NT, bool ROWS = false>
 __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ sup, const uint32_t *__restrict__ keys,
                                                    const uint32_t *__restrict__ cid, const uint32_t *__restrict__ off, int M,
                                                    uint32_t smask, const SecGroup *__restrict__ groups, int ngroups,
@@ -366,7 +373,8 @@ __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ 
                                                    uint32_t *__restrict__ xcnt, const uint32_t *__restrict__ cbase,
                                                    const uint32_t *__restrict__ xbase, uint32_t *__restrict__ cwords,
                                                    double *__restrict__ cvals, uint32_t *__restrict__ xwords,
-                                                   double *__restrict__ xvals) {
+                                                   double *__restrict__ xvals, const uint32_t *__restrict__ clen = nullptr,
+                                                   const uint32_t *__restrict__ xlen = nullptr) {
     extern __shared__ uint32_t sec_lk[];
     const uint32_t t = blockIdx.x, e0 = off[t];
     const int n = (int)(off[t + 1] - e0);
@@ -374,46 +382,91 @@ __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ 
     const uint32_t lmask = (1u << M) - 1u;
     for (int k = threadIdx.x; k < n; k += NT) sec_lk[k] = keys[e0 + k] & lmask;
     __syncthreads();
-    for (int k = threadIdx.x; k < n; k += NT) {
-        const uint64_t i = sup[cid[e0 + k]];
-        const uint32_t li = sec_lk[k];
+    const int nrows = (ROWS && FILL) ? ((n + 63) & ~63) : n;   // the lanes past the tile's last row write padding only
+    for (int k = threadIdx.x; k < nrows; k += NT) {
         uint32_t cc = 0, xc = 0;
-        const uint32_t cb = FILL ? cbase[e0 + k] : 0u, xb = FILL ? xbase[e0 + k] : 0u;
-        for (int g = 0; g < ngroups; ++g) {
-            const SecGroup gr = groups[g];
-            int sj = k;
-            if (gr.x) {
-                const uint64_t pbit = 1ull << (63 - __clzll((long long)gr.x));
-                if (i & pbit) continue;
-                sj = sec_find(sec_lk, n, li ^ sec_pext((uint32_t)gr.x, smask));
-                if (sj < 0) continue;
-            }
-            const uint64_t j = i ^ gr.x;
-            double d = 0.0;
-            for (int tt = gr.t0; tt < gr.t1; ++tt) {
-                const HTerm ht = terms[tt];
-                if (__popcll(gr.x & ht.z) & 1) continue;   // odd number of Y: <P> = 0 on a real state
-                d += parity64(j & ht.z) ? -ht.cr : ht.cr;
-            }
-            if (d == 0.0) continue;
-            const uint32_t word = (uint32_t)k | ((uint32_t)sj << SEC_HSLOT_BITS);
-            if (__popcll(gr.x) >= SEC_CODED_MIN_WEIGHT) {
-                if (FILL) {
-                    cwords[cb + cc] = word;
-                    cvals[cb + cc] = 2.0 * d;
+        const size_t sl = (size_t)t * SEC_HSLICES + (size_t)(k >> 6);
+        const uint32_t cstride = (ROWS && FILL) ? 64u : 1u;
+        uint32_t cb = 0, xb = 0;
+        if (FILL) {
+            cb = ROWS ? cbase[sl] + (uint32_t)(k & 63) : cbase[e0 + k];
+            xb = ROWS ? xbase[sl] + (uint32_t)(k & 63) : xbase[e0 + k];
+        }
+        if (k < n) {
+            const uint64_t i = sup[cid[e0 + k]];
+            const uint32_t li = sec_lk[k];
+            for (int g = 0; g < ngroups; ++g) {
+                const SecGroup gr = groups[g];
+                int sj = k;
+                uint64_t j = i;   // the pair's member with the pivot bit set: its index enters the signs
+                if (gr.x) {
+                    const uint64_t pbit = 1ull << (63 - __clzll((long long)gr.x));
+                    if (i & pbit) {
+                        if (!ROWS) continue;
+                    } else {
+                        j = i ^ gr.x;
+                    }
+                    sj = sec_find(sec_lk, n, li ^ sec_pext((uint32_t)gr.x, smask));
+                    if (sj < 0) continue;
                 }
-                ++cc;
-            } else {
-                if (FILL) {
-                    xwords[xb + xc] = word;
-                    xvals[xb + xc] = gr.x ? 2.0 * d : d;
+                double d = 0.0;
+                for (int tt = gr.t0; tt < gr.t1; ++tt) {
+                    const HTerm ht = terms[tt];
+                    if (__popcll(gr.x & ht.z) & 1) continue;   // odd number of Y: <P> = 0 on a real state
+                    d += parity64(j & ht.z) ? -ht.cr : ht.cr;
                 }
-                ++xc;
+                if (d == 0.0) continue;
+                const uint32_t word = (uint32_t)k | ((uint32_t)sj << SEC_HSLOT_BITS);
+                if (__popcll(gr.x) >= SEC_CODED_MIN_WEIGHT) {
+                    if (FILL) {
+                        cwords[cb + cc * cstride] = word;
+                        cvals[cb + cc * cstride] = 2.0 * d;
+                    }
+                    ++cc;
+                } else {
+                    if (FILL) {
+                        xwords[xb + xc * cstride] = word;
+                        xvals[xb + xc * cstride] = (gr.x && !ROWS) ? 2.0 * d : d;
+                    }
+                    ++xc;
+                }
             }
         }
         if (!FILL) {
             ccnt[e0 + k] = cc;
             xcnt[e0 + k] = xc;
+        } else if (ROWS) {   // pad the row to the slice's length
+            for (uint32_t q = cc; q < clen[sl]; ++q) {
+                cwords[cb + q * 64u] = 0u;
+                cvals[cb + q * 64u] = 0.0;
+            }
+            for (uint32_t q = xc; q < xlen[sl]; ++q) {
+                xwords[xb + q * 64u] = 0u;
+                xvals[xb + q * 64u] = 0.0;
+            }
+        }
+    }
+}
+// slice lengths of the row format: len[tile * SEC_HSLICES + s] = longest row of the slice (one wave per slice)
+__global__ __launch_bounds__(256) void k_sec_slice_len(const uint32_t *__restrict__ off, const uint32_t *__restrict__ ccnt,
+                                                       const uint32_t *__restrict__ xcnt, uint32_t *__restrict__ clen,
+                                                       uint32_t *__restrict__ xlen, uint32_t *__restrict__ cwords64,
+                                                       uint32_t *__restrict__ xwords64) {
+    const uint32_t t = blockIdx.x, e0 = off[t], n = off[t + 1] - e0;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t s = wave; s < (uint32_t)SEC_HSLICES; s += 4u) {
+        const uint32_t k = 64u * s + lane;
+        uint32_t c = k < n ? ccnt[e0 + k] : 0u, x = k < n ? xcnt[e0 + k] : 0u;
+        for (int o = 32; o > 0; o >>= 1) {
+            c = max(c, (uint32_t)__shfl_xor(c, o, 64));
+            x = max(x, (uint32_t)__shfl_xor(x, o, 64));
+        }
+        if (lane == 0) {
+            const size_t sl = (size_t)t * SEC_HSLICES + s;
+            clen[sl] = c;
+            xlen[sl] = x;
+            cwords64[sl] = 64u * c;   // words of the slice: input of the scan that lays the slices out
+            xwords64[sl] = 64u * x;
         }
     }
 }
@@ -427,6 +480,10 @@ __global__ __launch_bounds__(256) void k_sec_encode(uint32_t *__restrict__ words
     const uint32_t e = blockIdx.x * 256u + threadIdx.x;
     if (e >= n) return;
     const double v = vals[e];
+    if (v == 0.0) {   // padding of the row format: the zero magnitude appended to the dictionary
+        words[e] = (uint32_t)ndict << 21;
+        return;
+    }
     const uint64_t key = (uint64_t)__double_as_longlong(fabs(v));
     int lo = 0, hi = ndict - 1;
     while (lo < hi) {   // the key is in the dictionary
@@ -581,6 +638,71 @@ __global__ __launch_bounds__(NT) void k_sector_apply(const double *__restrict__ 
         }
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < n; k += NT) unsafeAtomicAdd(&lam_out[sw.src[e0 + k]], lam[k]);
+    }
+}
+// lambda = H psi from the row format: one wave per slice, lane = row; per element a coalesced word, the dictionary and
+// a_j from LDS, a register sum; the row's result goes straight to lambda in the circuit's final order (an f64 atomic: the
+// sweeps of the cover add up there).  Gradients use this when the row tables fit the budget, else k_sector_apply.
+struct SecHRows {
+    const uint32_t *src, *off;
+    const uint32_t *cbase, *clen, *cwords;   // [ntiles * SEC_HSLICES] slice bases / lengths; coded words
+    const double *cvals, *dict;              // cvals: sweeps without a dictionary
+    const uint32_t *xbase, *xlen, *xwords;
+    const double *xvals;
+    int32_t ndict, ntiles;
+};
+template <int NT>
+__global__ __launch_bounds__(NT) void k_sector_apply_rows(const double *__restrict__ state, const SecHRows *__restrict__ sweeps,
+                                                          double *__restrict__ lam_out) {
+    constexpr int NW = NT / 64;
+    __shared__ double tile[SEC_HMAX_TILE + 1];
+    __shared__ double dict[SEC_DICT_MAX + 1];
+    const SecHRows sw = sweeps[blockIdx.y];
+    for (int k = threadIdx.x; k < sw.ndict; k += NT) dict[k] = 0.5 * sw.dict[k];   // doubled magnitudes -> H_ij
+    if (threadIdx.x == 0) dict[sw.ndict] = 0.0;                                  // the null element
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t t = blockIdx.x; t < (uint32_t)sw.ntiles; t += gridDim.x) {
+        const uint32_t e0 = sw.off[t], n = sw.off[t + 1] - e0;
+        if (n == 0) continue;
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < n; k += NT) tile[k] = state[sw.src[e0 + k]];
+        __syncthreads();
+        for (uint32_t s = wave; 64u * s < n; s += NW) {
+            const size_t sl = (size_t)t * SEC_HSLICES + s;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            {
+                const uint32_t L = sw.clen[sl];
+                const uint32_t *wp = sw.cwords + sw.cbase[sl] + lane;
+                if (sw.ndict) {
+                    auto term = [&](uint32_t w) {
+                        const double v = dict[w >> 21] * tile[(w >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK];
+                        return (w & (1u << 20)) ? -v : v;
+                    };
+                    uint32_t q = 0;
+                    for (; q + 7u < L; q += 8u) {
+                        uint32_t w[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + 64u * (q + (uint32_t)u));
+                        a0 += term(w[0]) + term(w[4]);
+                        a1 += term(w[1]) + term(w[5]);
+                        a2 += term(w[2]) + term(w[6]);
+                        a3 += term(w[3]) + term(w[7]);
+                    }
+                    for (; q < L; ++q) a0 += term(wp[64u * q]);
+                } else {
+                    const double *vp = sw.cvals + sw.cbase[sl] + lane;
+                    for (uint32_t q = 0; q < L; ++q) a0 += 0.5 * vp[64u * q] * tile[(wp[64u * q] >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK];
+                }
+            }
+            {
+                const uint32_t L = sw.xlen[sl];
+                const uint32_t *wp = sw.xwords + sw.xbase[sl] + lane;
+                const double *vp = sw.xvals + sw.xbase[sl] + lane;
+                for (uint32_t q = 0; q < L; ++q) a1 += vp[64u * q] * tile[(wp[64u * q] >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK];
+            }
+            const uint32_t row = 64u * s + lane;
+            if (row < n) unsafeAtomicAdd(&lam_out[sw.src[e0 + row]], (a0 + a1) + (a2 + a3));
+        }
     }
 }
 // <a|b> over the compact state: partials per workgroup (fixed order)
