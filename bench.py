@@ -267,10 +267,17 @@ def gate_and_midsize_workloads(device):
         gates, K, _ = quccsd_gate_list(12, 5, 1, excitations=[op.terms[0].qbits for op in cluster_ops])
         sv.set_gate_program(gates, K, hfn)
         times = []
-        for _ in range(4):
+        for _ in range(6):
             t0 = time.perf_counter()
             e_q = sv.energy(theta_mp2)
             times.append(1e3 * (time.perf_counter() - t0))
+        calls = []
+        t0 = time.perf_counter()
+        resq = minimize(fun, np.array(theta_mp2), jac=True, method="L-BFGS-B", options={"maxiter": 100, "gtol": 1e-6, "ftol": 1e-14})
+        rown["quccsd_vqe_lbfgs_exact_gradient"] = {"energy": float(resq.fun), "iterations": int(resq.nit), "gradient_calls": len(calls),
+                                                   "max_abs_gradient": float(np.abs(resq.jac).max()),
+                                                   "wall_s": time.perf_counter() - t0,
+                                                   "ms_per_gradient_call_steady": 1e3 * float(np.median(calls[2:])) if len(calls) > 2 else None}
         rown["quccsd_gate_list_at_theta_mp2"] = {"literal_gates": len(gates), "energy": float(e_q), "ms_first_call": times[0],
                                                  "ms_steady_state": min(times[2:]), "program": sv.program_info()}
     out.append(rown)

@@ -91,13 +91,16 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * "compact" (1, default: compact cover — from the second evaluation of a (program, Hamiltonian) pair on, <H> of a
  * real-amplitude streaming energy runs over a compact copy of the state's support),
  * "sector" (1, default: sector path — from the second evaluation on, a real-amplitude program whose states occupy at most
- * 1/8 of the register runs entirely on that support: circuit over compact tiles from precomputed pair lists, <H> from the
+ * 1/4 of the register runs entirely on that support: circuit over compact tiles from precomputed pair lists, <H> from the
  * Hamiltonian materialised on the support; results equal the dense kernels' up to rounding; the tables live in device
  * memory next to the state), "sector_max_gb" (table budget, default 64, also capped at half of the free device memory;
  * beyond it the circuit stays on the sector path and <H> goes through the compact cover), "sector_h" (0: never materialise
  * <H>), "sector_dict" (0: explicit doubles instead of dictionary-coded matrix elements), "sector_bits" / "sector_h_bits"
  * (index bits per circuit / <H> tile, 0 = automatic), "sector_threads" (0 automatic, 64, 256, 512, 1024),
- * "sector_min_qubits" (default 18).  The state buffer holds unspecified data after an energy evaluation on this path. */
+ * "sector_min_qubits" (default 18), "sector_sparsity" (the support may fill at most 1/value of the register, default 4),
+ * "sector_tile_cap" (amplitudes per circuit tile, default 6500 so that gradients fit; up to 14000 for energies only),
+ * "sector_rows" (0: no row-format copy of the matrix for gradients).  The state buffer holds unspecified data after an
+ * energy evaluation on this path. */
 int ovqe_set_option(ovqe_handle h, const char *name, int64_t value);
 /* device pointer to the 2^n_local amplitudes (for RCCL exchange by the host layer) */
 int ovqe_state_ptr(ovqe_handle h, void **dev_ptr);

@@ -197,6 +197,8 @@ struct ovqe_sv {
     int opt_sector_h = 1;         // materialise <H> on the support when it fits the budget
     int opt_sector_h_bits = 0;    // index bits per <H> tile (0 = automatic: 300 .. 600 amplitudes per tile)
     int opt_sector_dict = 1;      // dictionary coding of the double-excitation-like matrix elements
+    int opt_sector_tile_cap = 6500;   // amplitudes per circuit tile (up to 14000 for energies; gradients on the tables hold two tiles in LDS: <= 6500)
+    int opt_sector_sparsity = 4;  // the support must be at most 1/this of the register
     int opt_sector_rows = 1;      // gradients: keep the matrix also row by row when it fits (lambda = H psi by gathers)
     int opt_sector_debug = 0;     // measurements only (1: circuit sweeps without their ops — wrong results)
     int opt_sector_h_groups = 128; // workgroups per <H> sweep (they share the sweep's tiles round robin)
@@ -2382,6 +2384,13 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "sector_h_groups") h->opt_sector_h_groups = (int)value;
     else if (k == "sector_debug") h->opt_sector_debug = (int)value;
     else if (k == "sector_rows") h->opt_sector_rows = (int)value;
+    else if (k == "sector_sparsity" || k == "sector_tile_cap") {
+        (k == "sector_sparsity" ? h->opt_sector_sparsity : h->opt_sector_tile_cap) = (int)value;
+        free_sector(h->sec);
+        h->sec.disabled = false;
+        h->sec.seen = 0;
+        h->sec.prog_version = -1;
+    }
     else if (k == "rot_variant") h->opt_rot_variant = (int)value;
     else if (k == "real_stream") h->opt_real_stream = (int)value;
     else if (k == "apply_min_tiles") h->opt_apply_min_tiles = (int)value;
@@ -3297,7 +3306,7 @@ extern "C" int ovqe_energy_gradient(ovqe_handle h, const double *theta, int32_t 
         // real-amplitude program on a sparse support: the whole adjoint pass on the sector tables
         rc = sector_prepare(h);
         if (rc) return rc;
-        if (h->sec.valid && h->sec.h_tables) {
+        if (h->sec.valid && h->sec.h_tables && sector_gradient_fits(h)) {   // (else: tiles sized for energies only, "sector_tile_cap")
             bool ok = false;
             rc = run_sector_gradient(h, theta, energy, grad, &ok);
             if (rc || ok) return rc;

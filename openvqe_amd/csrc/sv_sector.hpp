@@ -799,7 +799,8 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint(const double *__restrict_
     // one op backwards: gradient sums of its (at most few) patterns, then both states rotated back
     auto back_op = [&](int o, const uint32_t *words, uint32_t p0, uint32_t p1) {
         const int tb = lop[o].tab;
-        double acc[2] = {0.0, 0.0};
+        const int npat = (o + 1 < nops ? lop[o + 1].tab : nrot) - tb;   // the table entries of an op are consecutive
+        double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         for (uint32_t k = p0 + threadIdx.x; k < p1; k += NT) {
             const uint32_t pw = words[k];
             const uint32_t si = pw & mask, sj = (pw >> sb) & mask;
@@ -811,17 +812,23 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint(const double *__restrict_
             const double u1 = tp[si], v1 = tp[sj], lu = tl[si], lv = tl[sj];
             const double g = lu * v1 - lv * u1;
             const double gs = neg ? -g : g;
-            if (pat < 2) acc[pat] += gs;
-            else __hip_atomic_fetch_add(&mine[tb + pat], gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // rare
+            if (pat < 8) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) acc[p] += (pat == (uint32_t)p) ? gs : 0.0;
+            } else {
+                __hip_atomic_fetch_add(&mine[tb + pat], gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // rare
+            }
             tp[si] = r.x * u1 - s * v1;
             tp[sj] = r.x * v1 + s * u1;
             tl[si] = r.x * lu - s * lv;
             tl[sj] = r.x * lv + s * lu;
         }
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const double tsum = sec_wave_sum63(acc[p]);
-            if (lane == 63 && tsum != 0.0) mine[tb + p] += tsum;
+        for (int p = 0; p < 8; ++p) {
+            if (p < npat) {   // wave-uniform
+                const double tsum = sec_wave_sum63(acc[p]);
+                if (lane == 63 && tsum != 0.0) mine[tb + p] += tsum;
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };

@@ -10,11 +10,23 @@ mol = chem.molecule("N2-CCPVDZ"); e_rhf = mol.rhf()
 prob = chem.cas_problem(mol, 2, 12)
 ham = prob.jw_hamiltonian()
 size, _, spin_ops, theta_mp2, hf = prob.uccsd()
-method = sys.argv[1] if len(sys.argv) > 1 else "L-BFGS-B"
-maxit = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+method = args[0] if len(args) > 0 else "L-BFGS-B"
+maxit = int(args[1]) if len(args) > 1 else 60
+quccsd = "--quccsd" in sys.argv   # the reference's QUCCSD gate list (ref:openvqe/common_files/circuit.py) instead of UCCSD
 print(f"E_RHF={e_rhf:.10f} E_MP2(full space)={mol.mp2_energy():.10f} parameters={size}", flush=True)
 with Statevector(24) as sv:
-    sv.set_hamiltonian(ham); sv.set_ucc_program(spin_ops, hf)
+    for a in sys.argv[1:]:
+        if a.startswith("--opt="):
+            k, v = a[6:].split("="); sv.set_option(k, int(v))
+    sv.set_hamiltonian(ham)
+    if quccsd:
+        from openvqe_amd.common_files.circuit import quccsd_gate_list
+        cluster_ops = prob.uccsd()[1]
+        gates, K, _ = quccsd_gate_list(12, 5, 1, excitations=[op.terms[0].qbits for op in cluster_ops])
+        sv.set_gate_program(gates, K, hf)
+    else:
+        sv.set_ucc_program(spin_ops, hf)
     calls = []
     def fun(th):
         t = time.perf_counter(); e, g = sv.energy_gradient(th); calls.append(time.perf_counter() - t)
