@@ -312,3 +312,29 @@ def test_24_qubit_uccsd_vqe_on_n2_with_exact_gradients(gpu_lib):
     assert abs(res.fun - (-109.0745445341)) < 2e-8, res.fun                  # converged value of a 300-iteration run
     assert np.abs(res.jac).max() < 1e-5 and res.nit <= 40
     assert abs(e_opt - e_dense) < 1e-10 and np.abs(g_opt - g_dense).max() < 1e-10
+
+
+def test_24_qubit_quccsd_entry_point_on_n2(gpu_lib, capsys):
+    """the reference's QUCCSD entry point at configs[3]: EnergyUCC.get_energies (mirror of
+    ref:openvqe/ucc_family/get_energy_qucc.py:136-244: BFGS, tol 1e-5, from the MP2 guess and from the constant guess) on
+    N2 / cc-pVDZ (10e,12o), 1715 cluster operators, with the opt-in exact Jacobian: both runs reach the minimum that L-BFGS-B on
+    the C ABI finds (tools/exp_n2_vqe.py --quccsd: -109.0689753850), result schema and CNOT count as the reference's"""
+    from openvqe_amd import chem
+    from openvqe_amd.ucc_family.get_energy_qucc import EnergyUCC
+    mol = chem.molecule("N2-CCPVDZ")
+    mol.rhf()
+    prob = chem.cas_problem(mol, 2, 12)
+    ham = prob.jw_hamiltonian()
+    size, cluster_ops, _, theta_mp2, hf = prob.uccsd()
+    old = EnergyUCC.adjoint_gradient
+    EnergyUCC.adjoint_gradient = True
+    try:
+        iterations, result = EnergyUCC().get_energies(ham, cluster_ops, hf, list(theta_mp2), [0.01] * size, -109.0689753850)
+    finally:
+        EnergyUCC.adjoint_gradient = old
+    capsys.readouterr()
+    e1, e2 = iterations["minimum_energy_result1_guess"][0], iterations["minimum_energy_result2_guess"][0]
+    assert abs(e1 - (-109.0689753850)) < 1e-7 and abs(e2 - (-109.0689753850)) < 1e-7
+    assert result["len_op1"] == result["len_op2"] == 1715 and result["CNOT1"] == result["CNOT2"] == 39332
+    assert result["energies1_substracted_from_FCI"] < 1e-7 and len(result["energies_1"]) < 80
+    assert result["energies_1"][0] > -108.89                     # the templates at the MP2 amplitudes: above the RHF energy
