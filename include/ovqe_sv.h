@@ -221,6 +221,15 @@ int ovqe_energy_gradient(ovqe_handle h, const double *theta, int32_t K, double *
  * *residual = |H y - lambda y| measured afterwards, *iterations = Lanczos steps taken. */
 int ovqe_ground_state(ovqe_handle h, double tol, int max_iter, uint64_t seed, double *energy, double *residual,
                       int *iterations);
+/* ... and of the Hamiltonian RESTRICTED TO THE SUPPORT of the stored program's states (sector tables, option "sector";
+ * built by this call when they do not exist yet): for a particle-number / spin conserving ansatz on a Hartree-Fock
+ * determinant that is the full-CI energy of the determinant's symmetry sector — the `fci` argument the reference's
+ * drivers take from PySCF (ref:openvqe/common_files/molecule_factory.py:120-125, `info["FCI"]`), here for active spaces the dense
+ * routines cannot reach (N2/cc-pVDZ (10e,12o): 627 264 determinants, 538 M matrix elements).  Two-pass Lanczos on
+ * vectors of |support| doubles, H v from the materialised matrix.  OVQE_ERR_STATE when the program has no such tables
+ * (not a real-amplitude program, support denser than 1/sector_sparsity, tables beyond sector_max_gb). */
+int ovqe_sector_ground_state(ovqe_handle h, double tol, int max_iter, uint64_t seed, double *energy, double *residual,
+                             int *iterations);
 
 /* ---- measurement support (bench.py): average device time in ms of `reps` back-to-back launches of
  * one Pauli-rotation sweep, bracketed by HIP events on the handle's stream */

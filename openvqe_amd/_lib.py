@@ -67,6 +67,8 @@ SIGNATURES = {
     "ovqe_energy_gradient": (_int, [_H, _f64p, ctypes.c_int32, ctypes.POINTER(_dbl), _f64p]),
     "ovqe_ground_state": (_int, [_H, _dbl, _int, _u64, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl),
                                  ctypes.POINTER(_int)]),
+    "ovqe_sector_ground_state": (_int, [_H, _dbl, _int, _u64, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl),
+                                        ctypes.POINTER(_int)]),
     "ovqe_program_info": (_int, [_H, ctypes.POINTER(ctypes.c_int64), _int]),
 }
 

@@ -274,6 +274,15 @@ class Statevector:
                                            ctypes.byref(r), ctypes.byref(it)))
         return e.value, r.value, it.value
 
+    def sector_ground_state(self, tol=1e-10, max_iter=1000, seed=20250227):
+        """lowest eigenpair of the stored Hamiltonian restricted to the support of the stored program's states (sector tables):
+        the FCI energy of the Hartree-Fock determinant's symmetry sector for a number- and spin-conserving ansatz.
+        -> (energy, residual |H y - E y|, iterations)"""
+        e, r, it = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        self._ck(self._L.ovqe_sector_ground_state(self._h, float(tol), int(max_iter), int(seed), ctypes.byref(e),
+                                                  ctypes.byref(r), ctypes.byref(it)))
+        return e.value, r.value, it.value
+
     def program_info(self):
         """shape of the compiled program: ops, rotations, literal gates, sweeps per evaluation, tiled sweeps,
         fused-kernel ops, support size (-1 = not analysed yet)"""

@@ -1372,6 +1372,8 @@ int run_program_streaming(ovqe_handle h, const double *theta, bool real = false)
     return OVQE_OK;
 }
 
+void tridiag_lowest(const std::vector<double> &a, const std::vector<double> &b, int m, double *lam, std::vector<double> &s);
+
 #include "sector_host.inc"
 
 // sector path: the tables of a (program, Hamiltonian) pair are built at its second evaluation (energy or gradient), so
@@ -3292,6 +3294,32 @@ extern "C" int ovqe_ground_state(ovqe_handle h, double tol, int max_iter, uint64
     if (iterations) *iterations = m;
     (void)est;
     return OVQE_OK;
+}
+
+// ---- lowest eigenpair inside the support of the stored program (sector tables) ------------------------------------
+extern "C" int ovqe_sector_ground_state(ovqe_handle h, double tol, int max_iter, uint64_t seed, double *energy, double *residual,
+                                        int *iterations) {
+    OVQE_ENTER(h);
+    if (!h || !energy || max_iter < 1 || !(tol > 0.0)) return OVQE_ERR_INVALID;
+    if (!h->prog_set) return fail(h, OVQE_ERR_STATE, "no program set (ovqe_set_program / ovqe_set_gate_program)");
+    if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
+    const bool real = h->opt_real_stream && h->prog_real_ok && h->n_global == 0 && tile_ok(h, true) && h->ham.groups.size() >= 3;
+    if (!real || !h->opt_sector) return fail(h, OVQE_ERR_STATE, "the stored program has no sector tables (real-amplitude program on one device needed)");
+    SectorEngine &E = h->sec;
+    if (E.prog_version != h->prog_version || E.ham_version != h->ham.version) {
+        free_sector(E);
+        E.disabled = false;
+        E.seen = 0;
+        E.prog_version = h->prog_version;
+        E.ham_version = h->ham.version;
+    }
+    if (!E.valid && !E.disabled) {   // built on demand here: this call is what the tables are for
+        int rc = build_sector(h);
+        if (rc) return rc;
+    }
+    if (!E.valid || !E.h_tables)
+        return fail(h, OVQE_ERR_STATE, "the stored program has no sector tables (support too dense, or the tables exceed sector_max_gb)");
+    return run_sector_ground_state(h, tol, max_iter, seed, energy, residual, iterations);
 }
 
 // ---- exact gradient by the adjoint method -------------------------------------------------------------------

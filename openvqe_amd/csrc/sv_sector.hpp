@@ -891,6 +891,45 @@ __global__ __launch_bounds__(256) void k_sec_reduce_w(const double *__restrict__
     w[r] = tsum;
 }
 
+// ---- Lanczos on the support (ovqe_sector_ground_state): vectors of K doubles in the circuit's final order --------------
+__global__ __launch_bounds__(256) void k_sec_randomize(double *__restrict__ v, uint32_t K, uint64_t seed, double2 *__restrict__ partials) {
+    __shared__ double2 red[4];
+    double acc = 0.0;
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < K; k += gridDim.x * 256u) {
+        uint64_t z = seed + 0x9e3779b97f4a7c15ull * (uint64_t)(k + 1u);   // splitmix64
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        z ^= z >> 31;
+        const double x = (double)(int64_t)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;   // [-1, 1)
+        v[k] = x;
+        acc += x * x;
+    }
+    const double2 t = block_sum<256>(make_double2(acc, 0.0), red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(256) void k_sec_scale(double *__restrict__ v, uint32_t K, double a) {
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < K; k += gridDim.x * 256u) v[k] *= a;
+}
+// y = a x (first) or y += a x
+__global__ __launch_bounds__(256) void k_sec_axpy(double *__restrict__ y, const double *__restrict__ x, double a, uint32_t K, int first) {
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < K; k += gridDim.x * 256u) y[k] = first ? a * x[k] : y[k] + a * x[k];
+}
+// w -= alpha v + beta vprev; partials = |w|^2
+__global__ __launch_bounds__(256) void k_sec_lanczos_update(double *__restrict__ w, const double *__restrict__ v,
+                                                            const double *__restrict__ vprev, double alpha, double beta, uint32_t K,
+                                                            double2 *__restrict__ partials) {
+    __shared__ double2 red[4];
+    double acc = 0.0;
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < K; k += gridDim.x * 256u) {
+        double x = w[k] - alpha * v[k];
+        if (vprev) x -= beta * vprev[k];
+        w[k] = x;
+        acc += x * x;
+    }
+    const double2 t = block_sum<256>(make_double2(acc, 0.0), red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
 // the compact state back in canonical (ascending index) order, e.g. for ovqe_get_state-like consumers and tests
 __global__ __launch_bounds__(256) void k_sec_scatter(const double *__restrict__ in, const uint32_t *__restrict__ cid, uint32_t K,
                                                      double *__restrict__ out) {

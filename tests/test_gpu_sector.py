@@ -272,3 +272,44 @@ def test_sector_on_the_reference_quccsd_templates(SV, m, o):
     for (e, g), (ed, gd), ew in zip(eg, eg_dense, want[1:]):
         assert abs(e - ew) < 1e-10 * max(1.0, l1) and abs(ed - ew) < 1e-10 * max(1.0, l1)
         assert np.abs(g - gd).max() < 1e-11 * max(1.0, l1)
+
+
+@pytest.mark.parametrize("m,o", [(7, 2), (7, 3), (8, 4)])
+def test_sector_ground_state_is_the_fci_energy_of_the_sector(SV, m, o):
+    """ovqe_sector_ground_state (Lanczos on the materialised Hamiltonian of the support) against the dense diagonalisation of
+    the Hamiltonian's block on the (o alpha, o beta) determinants (bit-mask oracle), and against ovqe_ground_state's
+    whole-register minimum (never above it... the sector may or may not hold the global minimum: >=)"""
+    import itertools
+    from openvqe_amd import fermion
+    from oracle import masks
+    n = 2 * m
+    ham, gens, hf = fermion.synthetic_molecule(m, o, seed=600 + m)
+    # the sector: o electrons on the even (alpha) and o on the odd (beta) qubits, qubit 0 = most significant bit
+    def strings(qubits):
+        return [sum(1 << (n - 1 - q) for q in c) for c in itertools.combinations(qubits, o)]
+    dets = np.array(sorted(a | b for a in strings(range(0, n, 2)) for b in strings(range(1, n, 2))), dtype=np.uint64)
+    assert hf in set(dets.tolist())
+    hx, hz, hc = ham.packed()
+    block = np.zeros((len(dets), len(dets)))
+    index = {int(d): k for k, d in enumerate(dets)}
+    for x, z, c in zip(hx.tolist(), hz.tolist(), hc.real.tolist()):     # <i|P|j> = i^ny (-1)^{|j & z|} delta(i, j ^ x)
+        ph = (1j) ** (bin(x & z).count("1") % 4)
+        for k, j in enumerate(dets.tolist()):
+            i = j ^ x
+            if i in index:
+                block[index[i], k] += (c * ph * (-1.0 if bin(j & z).count("1") & 1 else 1.0)).real
+    assert np.abs(block - block.T).max() < 1e-12
+    e_fci = float(np.linalg.eigvalsh(block)[0]) + ham.constant_coeff
+    with SV(n) as sv:
+        sv.set_option("force_path", 2)
+        sv.set_option("sector_min_qubits", 8)
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, hf)
+        e, res, its = sv.sector_ground_state(tol=1e-12)        # builds the tables itself
+        info = sv.program_info()
+        e_all, _, _ = sv.ground_state(tol=1e-10)
+        rng = np.random.default_rng(m)
+        e_var = sv.energy(rng.uniform(-0.3, 0.3, len(gens)))
+    assert info["sector_support"] == len(dets)
+    assert abs(e - e_fci) < 1e-9 and res < 1e-6, (e, e_fci, res, its)
+    assert e_all <= e + 1e-9 and e <= e_var + 1e-12            # global minimum <= sector minimum <= any ansatz energy

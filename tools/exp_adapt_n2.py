@@ -1,0 +1,35 @@
+"""fermionic ADAPT-VQE (mirror of ref:openvqe/adapt/fermionic_adapt_vqe.py) on N2 / cc-pVDZ (10e,12o) = 24 qubits with the UCCSD
+singlet singles-and-doubles pool (ref:openvqe/common_files/generator_excitations.py:274-359): a few macro-iterations, wall time per phase"""
+import os, sys, time, io, contextlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from openvqe_amd import chem
+from openvqe_amd import pools
+from openvqe_amd.adapt import fermionic_adapt_vqe as fav
+mol = chem.molecule("N2-CCPVDZ"); e_rhf = mol.rhf()
+prob = chem.cas_problem(mol, 2, 12)
+ham = prob.jw_hamiltonian()
+size, cluster_ops, spin_ops, theta_mp2, hf = prob.uccsd()
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+t = time.perf_counter(); pool_size, _, pool = pools.singlet_sd(10, 12); print(f'pool {pool_size} operators, built in {time.perf_counter()-t:.1f}s', flush=True)
+t0 = time.perf_counter()
+buf = io.StringIO()
+marks = []
+orig_screen = fav.return_signed_gradients
+def timed_screen(*a, **k):
+    t = time.perf_counter(); r = orig_screen(*a, **k); marks.append(("screen", time.perf_counter() - t)); return r
+fav.return_signed_gradients = timed_screen
+orig_action = fav.ucc_action
+def timed_action(*a, **k):
+    t = time.perf_counter(); r = orig_action(*a, **k); marks.append(("energy", time.perf_counter() - t)); return r
+fav.ucc_action = timed_action
+try:
+    with contextlib.redirect_stdout(buf):
+        trace, result = fav.fermionic_adapt_vqe(None, None, None, ham, pool, hf, 1, -109.0745445341, "COBYLA", 1e-6, "norm", 1e-3, iters)
+except Exception:
+    print(buf.getvalue()[-1500:]); raise
+wall = time.perf_counter() - t0
+scr = [d for k, d in marks if k == "screen"]; en = [d for k, d in marks if k == "energy"]
+print(f"wall={wall:.1f}s screens={len(scr)} ({np.mean(scr)*1e3:.0f} ms each) energy evaluations={len(en)} (median {np.median(en)*1e3:.2f} ms, total {sum(en):.2f}s)")
+print({k: v for k, v in result.items() if not isinstance(v, (list, dict))})
+print("energies", trace.get("energies", trace)[:10] if isinstance(trace, dict) else trace)

@@ -37,3 +37,7 @@ with Statevector(24) as sv:
     print(f"{method}: E={res.fun:.10f} iterations={res.nit} gradient calls={len(calls)} |g|inf={np.abs(res.jac).max():.2e} wall={wall:.2f}s "
           f"(first two calls {calls[0]:.2f}+{calls[1]:.2f}s, then {1e3*np.median(calls[2:]):.1f} ms each)  E(theta_MP2)={fun(np.array(theta_mp2))[0]:.10f}", flush=True)
     print(sv.program_info())
+    if not quccsd:
+        t0 = time.perf_counter(); e_fci, r, its = sv.sector_ground_state(tol=1e-10); t = time.perf_counter() - t0
+        print(f"FCI of the (5 alpha, 5 beta) sector (Lanczos on the sector tables): E={e_fci:.10f} residual={r:.1e} iterations={its} in {t:.2f}s; "
+              f"E_UCCSD - E_FCI = {res.fun - e_fci:.3e}")
