@@ -264,6 +264,11 @@ def gate_and_midsize_workloads(device):
                                                   "wall_s": time.perf_counter() - t0,
                                                   "ms_per_gradient_call_steady": 1e3 * float(np.median(calls[2:])) if len(calls) > 2 else None,
                                                   "program": sv.program_info()}
+        t0 = time.perf_counter()
+        e_fci, r_fci, it_fci = sv.sector_ground_state(tol=1e-10)
+        rown["fci_of_the_sector_lanczos"] = {"energy": e_fci, "residual": r_fci, "iterations": it_fci, "determinants": 792 ** 2,
+                                             "wall_s": time.perf_counter() - t0,
+                                             "uccsd_minus_fci": float(res.fun) - e_fci}
         gates, K, _ = quccsd_gate_list(12, 5, 1, excitations=[op.terms[0].qbits for op in cluster_ops])
         sv.set_gate_program(gates, K, hfn)
         times = []

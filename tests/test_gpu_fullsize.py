@@ -305,6 +305,7 @@ def test_24_qubit_uccsd_vqe_on_n2_with_exact_gradients(gpu_lib):
         res = minimize(fun, np.array(theta_mp2), jac=True, method="L-BFGS-B", options={"maxiter": 40, "gtol": 1e-6, "ftol": 1e-14})
         info = sv.program_info()
         e_opt, g_opt = sv.energy_gradient(res.x)
+        e_fci, fci_res, _ = sv.sector_ground_state(tol=1e-10)      # FCI of the (5 alpha, 5 beta) sector: 627 264 determinants
         sv.set_option("sector", 0)
         e_dense, g_dense = sv.energy_gradient(res.x)
     assert info["sector_support"] == 792 ** 2 and info["sector_h_elements"] > 10 ** 8
@@ -312,6 +313,9 @@ def test_24_qubit_uccsd_vqe_on_n2_with_exact_gradients(gpu_lib):
     assert abs(res.fun - (-109.0745445341)) < 2e-8, res.fun                  # converged value of a 300-iteration run
     assert np.abs(res.jac).max() < 1e-5 and res.nit <= 40
     assert abs(e_opt - e_dense) < 1e-10 and np.abs(g_opt - g_dense).max() < 1e-10
+    # variational ladder: FCI of the sector < UCCSD optimum < UCCSD at the MP2 amplitudes < RHF; UCCSD misses 2.0 mHa
+    assert fci_res < 1e-7 and abs(e_fci - (-109.0765315037)) < 1e-8
+    assert e_fci < res.fun < trace[0] < e_rhf and 1.5e-3 < res.fun - e_fci < 2.5e-3
 
 
 def test_24_qubit_quccsd_entry_point_on_n2(gpu_lib, capsys):
