@@ -552,6 +552,20 @@ def main():
             out["single_call_evals_per_s"] = h2o["single"]["evals_per_s"]
             out["fd_gradient_evals_per_s"] = h2o["fd_gradient"]["evals_per_s"]
             out["host_buffer_evals_per_s"] = h2o["batch4096"]["evals_per_s"]
+            # ... and the 24-qubit figures (BASELINE configs[3] on its molecule), lifted out the same way
+            m3 = next((r for r in out["extra_workloads"] if "M3" in r.get("workload", "")), None)
+            n2 = next((r for r in out["extra_workloads"] if "configs[3]" in r.get("workload", "")), None)
+            if m3 and n2:
+                out["summary_24_qubits"] = {
+                    "uccsd_evaluation_ms": m3["sector_path"]["ms_steady_state"],
+                    "uccsd_evaluation_ms_dense_state": m3["dense_state_compact_cover"]["ms_steady_state"],
+                    "uccsd_gradient_1715_parameters_ms": m3["sector_path"]["ms_gradient_all_parameters"],
+                    "uccsd_gradient_ms_dense_state": m3["dense_state_compact_cover"]["ms_gradient_all_parameters"],
+                    "n2_uccsd_vqe": {k: n2["uccsd_vqe_lbfgs_exact_gradient"][k] for k in ("energy", "iterations", "gradient_calls", "wall_s")},
+                    "n2_quccsd_vqe": {k: n2["quccsd_vqe_lbfgs_exact_gradient"][k] for k in ("energy", "iterations", "gradient_calls", "wall_s")},
+                    "n2_quccsd_evaluation_ms": n2["quccsd_gate_list_at_theta_mp2"]["ms_steady_state"],
+                    "n2_fci_627264_determinants": {k: n2["fci_of_the_sector_lanczos"][k] for k in ("energy", "iterations", "wall_s")},
+                }
         if not args.no_cpu and world == 1:
             cpu, cores = cpu_baseline_leg(ham, gens, hf, thetas_host[0], args.cpu_seconds)
             e_gpu0 = energy_check(ham, gens, hf, thetas_host[0, 0], local_rank)
