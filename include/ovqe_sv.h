@@ -93,7 +93,7 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * "sector" (1, default: sector path — from the second evaluation on, a real-amplitude program whose states occupy at most
  * 1/4 of the register runs entirely on that support: circuit over compact tiles from precomputed pair lists, <H> from the
  * Hamiltonian materialised on the support; results equal the dense kernels' up to rounding; the tables live in device
- * memory next to the state), "sector_max_gb" (table budget, default 64, also capped at half of the free device memory;
+ * memory next to the state), "sector_max_gb" (table budget, default 128, also capped at 60 % of the free device memory;
  * beyond it the circuit stays on the sector path and <H> goes through the compact cover), "sector_h" (0: never materialise
  * <H>), "sector_dict" (0: explicit doubles instead of dictionary-coded matrix elements), "sector_bits" / "sector_h_bits"
  * (index bits per circuit / <H> tile, 0 = automatic), "sector_threads" (0 automatic, 64, 256, 512, 1024),

@@ -191,7 +191,7 @@ struct ovqe_sv {
     SectorEngine sec;             // of (current program, stored Hamiltonian)
     int opt_sector = 1;           // allow the sector path (real-amplitude streaming energies on a sparse support)
     int opt_sector_bits = 0;      // index bits per tile (0 = automatic: n - 8, at most 16)
-    int opt_sector_max_gb = 64;   // table budget (also capped at half of the free device memory)
+    int opt_sector_max_gb = 128;  // table budget (also capped at 60 % of the free device memory)
     int opt_sector_threads = 0;   // workgroup size of the circuit sweeps (0 = automatic; 64: one wave per tile, no barriers)
     int opt_sector_min_qubits = 18;
     int opt_sector_h = 1;         // materialise <H> on the support when it fits the budget
