@@ -7,6 +7,7 @@ operator objects (``.terms[i].{coeff,op,qbits}``) into the mask 
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 
@@ -61,6 +62,12 @@ class Statevector:
             self._h = ctypes.c_void_p()
             _lib.check(rc, None)
         self._K = 0
+        # OVQE_OPTIONS="name=value,name=value": tuning knobs (ovqe_set_option) for handles created inside library code —
+        # the L1 mirrors and the qat stand-ins own their Statevector objects
+        for item in os.environ.get("OVQE_OPTIONS", "").split(","):
+            if "=" in item:
+                name, value = item.split("=", 1)
+                self.set_option(name.strip(), int(value))
 
     # -- lifecycle ------------------------------------------------------------------------------
     def close(self):

@@ -209,3 +209,31 @@ def test_fermionic_adapt_fidelity_with_device_ground_state(h2, monkeypatch):
     assert out["eigh"][1]["indices"] == out["lanczos"][1]["indices"]
     assert np.abs(np.array(out["eigh"][0]["fidelity"]) - np.array(out["lanczos"][0]["fidelity"])).max() < 1e-9
     assert out["lanczos"][0]["fidelity"][-1] > 0.9
+
+
+def test_fermionic_adapt_at_18_qubits_runs_its_energies_on_sector_tables(gpu_lib, monkeypatch):
+    """fermionic ADAPT on an 18-qubit molecule-shaped problem: every macro-iteration installs a new program, whose energies
+    move to the sector tables at their second evaluation (18+ qubits) — the trace equals the one of the same flow with the
+    sector path switched off (OVQE_OPTIONS: the mirrors own their handles)"""
+    from openvqe_amd.adapt.fermionic_adapt_vqe import fermionic_adapt_vqe
+    import openvqe_amd.evaluator as ev
+    ham, _, hf = fermion.synthetic_molecule(9, 3, seed=18)
+    full = fermion.uccsd_pool_antihermitian(9, 3)
+    pool = full[:8] + full[36:76]                            # a few singles, forty doubles
+    args = dict(n_max_grads=1, fci=-1.0, optimizer="COBYLA", tolerance=1e-7, type_conver="norm",
+                threshold_needed=1e-4, max_external_iterations=3)
+    out, infos = {}, {}
+    for label, options in (("sector", "sparse=0"), ("dense", "sparse=0,sector=0")):
+        monkeypatch.setenv("OVQE_OPTIONS", options)          # sparse=0: the small-support kernel would take these programs
+        with engine("hip"):
+            out[label] = fermionic_adapt_vqe(None, None, None, ham, pool, hf, **args)
+            infos[label] = [sv.program_info() for sv in ev._BACKENDS.values() if hasattr(sv, "program_info")]
+    (it_s, res_s), (it_d, res_d) = out["sector"], out["dense"]
+    assert len(it_s["energies"]) == len(it_d["energies"]) == 3 and res_s.keys() == res_d.keys()
+    assert it_s["energies"][2] < it_s["energies"][1] < it_s["energies"][0]
+    assert np.abs(np.array(it_s["energies"]) - np.array(it_d["energies"])).max() < 1e-10
+    # (COBYLA stops within its tolerance 1e-7 of the minimiser on either path: the screens of the next iteration see
+    # parameters that differ at that level)
+    assert np.abs(np.array(it_s["norms"]) - np.array(it_d["norms"])).max() < 1e-6
+    assert any(i.get("sector_support", 0) > 0 for i in infos["sector"]), infos["sector"]
+    assert all(i.get("sector_support", 0) == 0 for i in infos["dense"])
