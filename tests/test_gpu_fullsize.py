@@ -342,3 +342,31 @@ def test_24_qubit_quccsd_entry_point_on_n2(gpu_lib, capsys):
     assert result["len_op1"] == result["len_op2"] == 1715 and result["CNOT1"] == result["CNOT2"] == 39332
     assert result["energies1_substracted_from_FCI"] < 1e-7 and len(result["energies_1"]) < 80
     assert result["energies_1"][0] > -108.89                     # the templates at the MP2 amplitudes: above the RHF energy
+
+
+def test_26_qubit_uccsd_sector_path(gpu_lib):
+    """molecule-shaped UCCSD at 26 qubits (13 orbitals, 6 + 6 electrons: 2478 generators, 2 944 656 determinants in the sector,
+    3.65 G matrix elements = 22 GB of tables): sector-path energies against the dense-state kernels, E(0) against <hf|H|hf>
+    evaluated term by term on the host"""
+    from openvqe_amd import fermion
+    from openvqe_amd.backend import Statevector
+    m, o = 13, 6
+    ham, gens, hf = fermion.synthetic_molecule(m, o, seed=26)
+    rng = np.random.default_rng(26)
+    thetas = [rng.uniform(-0.1, 0.1, len(gens)), np.zeros(len(gens)), rng.uniform(-0.1, 0.1, len(gens))]
+    hx, hz, hc = ham.packed()
+    diag = hx == 0
+    e_hf = ham.constant_coeff + float(np.sum(hc[diag].real * (1.0 - 2.0 * (np.bitwise_count(hz[diag] & np.uint64(hf)) & 1))))
+    res = {}
+    for sector in (1, 0):
+        with Statevector(2 * m) as sv:
+            sv.set_option("sector", sector)
+            sv.set_hamiltonian(ham)
+            sv.set_ucc_program(gens, hf)
+            res[sector] = ([sv.energy(t) for t in thetas], sv.program_info())
+    info = res[1][1]
+    assert info["sector_support"] == 1716 ** 2 and info["sector_h_elements"] > 3 * 10 ** 9 and res[0][1]["sector_support"] == 0
+    l1 = float(np.abs(hc).sum())
+    for a, b in zip(res[1][0], res[0][0]):
+        assert abs(a - b) < 1e-10 * l1
+    assert abs(res[1][0][1] - e_hf) < 1e-10 * l1
