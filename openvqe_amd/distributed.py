@@ -121,6 +121,31 @@ class ShardedStatevector:
     #: pieces of one exchange: transfer k + 1 runs while piece k is unpacked into the shard / packed for sending
     EXCHANGE_PIECES = 8
 
+    def _post_pair(self, snd, rcv, partner, tag=0):
+        """post send + receive with ``partner`` -> object with ``wait()``.  RCCL takes the device tensors as they are.
+        gloo (tests; CPU engines) does not synchronise with the GPU and talks to raw pointers, so device tensors travel
+        through host copies there: sent from a host copy taken now, received into a host buffer that ``wait()`` copies
+        to the device."""
+        staged = snd.is_cuda and dist.get_backend(self.group) == "gloo"
+        s_buf = snd.cpu() if staged else snd
+        r_buf = torch.empty(rcv.shape, dtype=rcv.dtype, device="cpu") if staged else rcv
+        ops = [dist.P2POp(dist.isend, s_buf, partner, self.group, tag=tag), dist.P2POp(dist.irecv, r_buf, partner, self.group, tag=tag)]
+        if self.rank > partner:   # lower rank sends first in a pair (gloo needs an order)
+            ops.reverse()
+        works = dist.batch_isend_irecv(ops)
+
+        class _Pending:
+            def wait(_self):
+                for w in works:
+                    w.wait()
+                if staged:
+                    rcv.copy_(r_buf)
+                _self.keep = None
+
+        pending = _Pending()
+        pending.keep = (s_buf, r_buf)
+        return pending
+
     def _exchange(self, partner, make_send, recv_pieces, on_arrival):
         """piece p: ``make_send(p)`` (pack, on the compute stream) then its send / receive with ``partner`` is posted —
         RCCL orders each transfer behind the pack it depends on and runs the transfers in sequence on its own stream, so
@@ -130,13 +155,9 @@ class ShardedStatevector:
         for p, rcv in enumerate(recv_pieces):
             snd = make_send(p)
             keep.append(snd)
-            ops = [dist.P2POp(dist.isend, snd, partner, self.group), dist.P2POp(dist.irecv, rcv, partner, self.group)]
-            if self.rank > partner:
-                ops.reverse()
-            works.append(dist.batch_isend_irecv(ops))
-        for p, ws in enumerate(works):
-            for w in ws:
-                w.wait()
+            works.append(self._post_pair(snd, rcv, partner, tag=p))   # one tag per piece: gloo matches by tag
+        for p, w in enumerate(works):
+            w.wait()
             on_arrival(p)
 
     def _swap(self, gbit, lbit):
@@ -272,17 +293,12 @@ class ShardedStatevector:
 
         def post(k):
             partner = self.rank ^ partners[k]
-            ops = [dist.P2POp(dist.isend, self.engine.tensor, partner, self.group),
-                   dist.P2POp(dist.irecv, self._shard_bufs[k & 1][:size], partner, self.group)]
-            if self.rank > partner:
-                ops.reverse()
-            return dist.batch_isend_irecv(ops)
+            return self._post_pair(self.engine.tensor, self._shard_bufs[k & 1][:size], partner)
 
         pending = post(0)
         for k in range(len(partners)):
-            for w in pending:
-                w.wait()
-            pending = post(k + 1) if k + 1 < len(partners) else []
+            pending.wait()
+            pending = post(k + 1) if k + 1 < len(partners) else None
             self.stats["full_shard_reads"] += 1
             self.stats["bytes_sent"] += size * 16
             yield self._shard_bufs[k & 1][:size]

@@ -99,7 +99,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, seed, out):
+def _worker(rank, world, port, n, seed, out, engine="oracle"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -123,7 +123,9 @@ def _worker(rank, world, port, n, seed, out):
         hz = [int(v) for v in rng.integers(0, 1 << n, T)]
         hc = rng.normal(size=T)
         hf = int(rng.integers(0, 1 << n))
-        sv = ShardedStatevector(n, engine_factory=lambda nl, ng, r: OracleShardEngine(nl, ng, r))
+        # engine = "hip": the product engine, every rank's shard handle on device 0 (tests/test_gpu_distributed.py)
+        sv = (ShardedStatevector(n, device=0) if engine == "hip" else
+              ShardedStatevector(n, engine_factory=lambda nl, ng, r: OracleShardEngine(nl, ng, r)))
         e = sv.energy(hx, hz, hc, 0.25, xs, zs, phis, hf)
         full = sv.gather_state()
         n2 = sv.norm2()
@@ -164,7 +166,7 @@ def test_permute_mask():
     assert permute_mask(0b1011, [2, 0, 1, 3]) == 0b1101
 
 
-def _screen_worker(rank, world, port, n, seed, out):
+def _screen_worker(rank, world, port, n, seed, out, engine="oracle"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -191,7 +193,9 @@ def _screen_worker(rank, world, port, n, seed, out):
                          list(rng.normal(size=nt) + 1j * rng.normal(size=nt))))
         pool[2] = ([0], [int(rng.integers(1, 1 << n))], [1.0 + 0j])          # a diagonal operator
         hf = int(rng.integers(0, 1 << n))
-        sv = ShardedStatevector(n, engine_factory=lambda nl, ng, r: OracleShardEngine(nl, ng, r))
+        # engine = "hip": the product engine, every rank's shard handle on device 0 (tests/test_gpu_distributed.py)
+        sv = (ShardedStatevector(n, device=0) if engine == "hip" else
+              ShardedStatevector(n, engine_factory=lambda nl, ng, r: OracleShardEngine(nl, ng, r)))
         sv.init_basis(hf)
         sv.apply_pauli_rotations(xs, zs, phis)
         gf = sv.pool_gradients((hx, hz, hc, 0.3), pool, "fermionic")

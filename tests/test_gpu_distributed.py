@@ -1,0 +1,61 @@
+"""The sharded state on its PRODUCT engine at world size 2 and 4: one process per rank, every rank's shard handle on
+device 0 (the pool gives one GPU; RCCL refuses two ranks on one device, so the exchange runs over gloo, which moves the
+device tensors point to point).  Same workloads and checks as tests/test_distributed.py, where the shard arithmetic is the
+bit-mask oracle: here the HIP kernels do it — rotations with local x masks, pipelined half-shard exchanges for global
+ones, <H> with global-x groups against partner shards, sigma = H psi and the ADAPT pool contraction per partner shard."""
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from oracle import masks
+from tests.test_distributed import _free_port, _screen_worker, _worker
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world,n", [(2, 14), (4, 15), (2, 17)])
+def test_sharded_state_on_hip_shards(gpu_lib, world, n):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 4321 + n, out, "hip")) for r in range(world)]
+    for p in procs:
+        p.start()
+    e, full, n2, stats, (xs, zs, phis, hx, hz, hc, hf) = out.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    psi = np.zeros(1 << n, complex)
+    psi[hf] = 1
+    for x, z, p in zip(xs, zs, phis):
+        psi = masks.rotate(psi, x, z, p)
+    assert np.abs(np.asarray(full) - psi).max() < 1e-12
+    assert abs(n2 - 1.0) < 1e-12
+    assert abs(e - masks.expectation(psi, hx, hz, hc, 0.25)) < 1e-11
+    g = world.bit_length() - 1
+    assert 1 <= stats["swaps"] <= sum(1 for x in xs if x >> (n - g)) and stats["full_shard_reads"] >= 1
+
+
+@pytest.mark.parametrize("world,n", [(2, 13), (4, 14)])
+def test_sharded_adapt_screen_on_hip_shards(gpu_lib, world, n):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_screen_worker, args=(r, world, port, n, 77 + n, out, "hip")) for r in range(world)]
+    for p in procs:
+        p.start()
+    gf, gq, stats, (xs, zs, phis, hx, hz, hc, pool, hf) = out.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    psi = np.zeros(1 << n, complex)
+    psi[hf] = 1
+    for x, z, p in zip(xs, zs, phis):
+        psi = masks.rotate(psi, x, z, p)
+    sigma = 0.3 * psi
+    for x, z, c in zip(hx, hz, hc):
+        sigma = sigma + c * masks.pauli_apply(psi, int(x), int(z))
+    want = np.array([sum(c * np.vdot(sigma, masks.pauli_apply(psi, int(x), int(z))) for x, z, c in zip(*op)) for op in pool])
+    assert np.abs(np.asarray(gf) - 2.0 * want.real).max() < 1e-11
+    assert np.abs(np.asarray(gq) - 2.0 * np.abs(want)).max() < 1e-11
+    assert stats["full_shard_reads"] >= 2
