@@ -308,11 +308,19 @@ def lower_circuit(circuit, theta=None):
 
 
 class HipQPU:
-    """``get_default_qpu()`` stand-in: exact (nbshots=0) simulation on the MI355X backend."""
+    """``get_default_qpu()`` stand-in: exact (nbshots=0) simulation on the MI355X backend.
+
+    The reference rebuilds Program / Circuit / Job for every energy evaluation (ref:openvqe/ucc_family/get_energy_ucc.py:35-50).
+    A circuit made of Pauli evolutions of the SAME operator objects as the previous one (what an optimiser loop submits)
+    differs from it only in its angles: it is compiled once with symbolic angles and later submissions only pass the new
+    angle vector — so the compiled-program paths of the backend (table fusion, sector tables at 18+ qubits) serve the
+    unchanged reference code too.  Circuits with literal rotation gates are compiled per submission."""
 
     def __init__(self, device=0):
         self.device = device
         self._sv = {}
+        self._compiled = {}   # nbqbits -> (skeleton key, operator objects kept alive, n_params)
+        self._observable = {}  # nbqbits -> observable object uploaded last
 
     def _backend(self, n):
         from .backend import Statevector
@@ -320,7 +328,47 @@ class HipQPU:
             self._sv[n] = Statevector(n, device=self.device)
         return self._sv[n]
 
+    @staticmethod
+    def _skeleton(circuit):
+        """-> (key, angles, symbolic circuit items) for a circuit of leading X gates + Pauli evolutions with concrete angles,
+        else None"""
+        key, angles, items = [], [], []
+        for kind, what, qubits in circuit.items:
+            if kind == "gate":
+                if what.name != "X" or any(k[0] == "E" for k in key):
+                    return None
+                key.append(("X", tuple(qubits)))
+                items.append((kind, what, qubits))
+                continue
+            ops = list(what.operators)
+            thetas = list(what.thetas)[:len(ops)]          # zip truncation, as PauliEvolution.rotations
+            ops = ops[:len(thetas)]
+            if any(isinstance(t, AffineParam) for t in thetas):
+                return None
+            key.append(("E", tuple(id(op) for op in ops), what.init, tuple(qubits)))
+            sym = [AffineParam(len(angles) + k) for k in range(len(thetas))]
+            angles.extend(float(t) for t in thetas)
+            items.append((kind, PauliEvolution(ops, what.init, sym, what.arity), qubits))
+        return tuple(key), angles, items
+
     def _load(self, sv, circuit):
+        """-> angle vector to evaluate the handle's program with"""
+        n = circuit.nbqbits
+        sk = self._skeleton(circuit)
+        if sk is not None:
+            key, angles, items = sk
+            cached = self._compiled.get(n)
+            if cached is not None and cached[0] == key and cached[2] == len(angles):
+                return np.asarray(angles, dtype=float)
+            symbolic = Circuit(n, items)
+            hf, kind, payload = lower_circuit(symbolic)
+            if kind == "rotations":
+                xs, zs, sc, co, pi = payload
+                sv.set_rotation_program(xs, zs, sc, pi, len(angles), hf, phi0=co)
+                keep = [what.operators for kind_, what, _ in items if kind_ != "gate"]
+                self._compiled[n] = (key, keep, len(angles))
+                return np.asarray(angles, dtype=float)
+        self._compiled.pop(n, None)
         hf, kind, payload = lower_circuit(circuit)
         if kind == "gates":
             npar = 1 + max([g[4] for g in payload] + [-1])
@@ -332,15 +380,19 @@ class HipQPU:
             if len(pi) and pi.max() >= 0:
                 raise ValueError("circuit still has free parameters")
             sv.set_rotation_program(xs, zs, sc, pi, 0, hf, phi0=co)
+        return np.zeros(0)
 
     def submit(self, job):
         circ = job.circuit
-        sv = self._backend(circ.nbqbits)
-        self._load(sv, circ)
+        n = circ.nbqbits
+        sv = self._backend(n)
+        theta = self._load(sv, circ)
         if job.type == "OBS":
-            sv.set_hamiltonian(job.observable)
-            return Result(value=sv.energy(np.zeros(0)))
-        sv.prepare_state(np.zeros(0))
+            if self._observable.get(n) is not job.observable:
+                sv.set_hamiltonian(job.observable)
+                self._observable[n] = job.observable
+            return Result(value=sv.energy(theta))
+        sv.prepare_state(theta)
         psi = sv.get_state()
         nz = np.nonzero(psi)[0]
         return Result(samples=[Sample(int(i), psi[i], circ.nbqbits) for i in nz])

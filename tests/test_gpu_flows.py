@@ -237,3 +237,44 @@ def test_fermionic_adapt_at_18_qubits_runs_its_energies_on_sector_tables(gpu_lib
     assert np.abs(np.array(it_s["norms"]) - np.array(it_d["norms"])).max() < 1e-6
     assert any(i.get("sector_support", 0) > 0 for i in infos["sector"]), infos["sector"]
     assert all(i.get("sector_support", 0) == 0 for i in infos["dense"])
+
+
+def test_stand_in_qpu_compiles_a_repeated_circuit_once(gpu_lib, monkeypatch):
+    """route A of INTEGRATION.md: the reference's evaluation loop (Program -> build_ucc_ansatz per operator -> to_job("OBS") ->
+    get_default_qpu().submit, ref:openvqe/ucc_family/get_energy_ucc.py:35-50) submits the same circuit with new angles over and
+    over; the stand-in QPU compiles it once (symbolic angles) and then only passes the angle vector — energies equal the mirror's,
+    and at 18 qubits the repeated circuit reaches the sector tables"""
+    from openvqe_amd.backend import Statevector
+    from openvqe_amd.qat_compat import Program, build_ucc_ansatz, get_default_qpu
+    _reset()
+    ham, gens, hf = fermion.synthetic_molecule(9, 3, seed=99)
+    n = ham.nbqbits
+    calls = {"programs": 0, "hamiltonians": 0}
+    orig_p, orig_h = Statevector.set_rotation_program, Statevector.set_hamiltonian
+    monkeypatch.setattr(Statevector, "set_rotation_program", lambda self, *a, **k: (calls.__setitem__("programs", calls["programs"] + 1), orig_p(self, *a, **k))[1])
+    monkeypatch.setattr(Statevector, "set_hamiltonian", lambda self, *a, **k: (calls.__setitem__("hamiltonians", calls["hamiltonians"] + 1), orig_h(self, *a, **k))[1])
+    monkeypatch.setenv("OVQE_OPTIONS", "sparse=0")
+
+    def reference_style_energy(theta):                       # the body of the reference's ucc_action
+        prog = Program()
+        reg = prog.qalloc(n)
+        for k, (op, t) in enumerate(zip(gens, theta)):
+            prog.apply(build_ucc_ansatz([op], hf if k == 0 else 0, n_steps=1)([t]), reg)
+        return get_default_qpu().submit(prog.to_circ().to_job(job_type="OBS", observable=ham)).value
+
+    rng = np.random.default_rng(9)
+    thetas = [rng.uniform(-0.2, 0.2, len(gens)) for _ in range(4)]
+    got = [reference_style_energy(t) for t in thetas]
+    info = get_default_qpu()._sv[n].program_info()
+    assert calls == {"programs": 1, "hamiltonians": 1}, calls
+    assert info["sector_support"] > 0, info
+    got_short = reference_style_energy(thetas[0][:5])         # zip truncation: another circuit, compiled anew
+    assert calls["programs"] == 2
+    with Statevector(n) as sv:
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, hf)
+        want = [sv.energy(t) for t in thetas]
+        sv.set_ucc_program(gens[:5], hf)
+        want_short = sv.energy(thetas[0][:5])
+    _reset()
+    assert np.abs(np.array(got) - np.array(want)).max() < 1e-10 and abs(got_short - want_short) < 1e-10
