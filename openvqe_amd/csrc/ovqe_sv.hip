@@ -91,9 +91,7 @@ struct SectorHSweep {   // one sweep of the materialised <H>
     SectorLayout L;
     uint64_t nnz = 0;
     int ndict = 0;          // magnitudes in the sweep's dictionary (0: the coded stream keeps explicit values)
-    DevBuf d_cbase, d_cwords, d_cvals, d_dict, d_xbase, d_xwords, d_xvals;
-    // row format (gradients, built on demand): slice bases / lengths per (tile, slice), padded element streams
-    DevBuf d_rcbase, d_rclen, d_rcwords, d_rcvals, d_rxbase, d_rxlen, d_rxwords, d_rxvals;
+    DevBuf d_cbase, d_clen, d_cwords, d_cvals, d_dict, d_xbase, d_xlen, d_xwords, d_xvals, d_order;   // row format (sv_sector.hpp)
 };
 struct SectorEngine {
     bool valid = false, disabled = false;
@@ -109,10 +107,8 @@ struct SectorEngine {
     std::vector<SectorHSweep> hs;
     DevBuf d_sup, d_buf[2], d_hdesc, d_flag;
     DevBuf d_lam[2], d_w, d_wpart;   // adjoint gradient: lambda (ping-pong), per-entry sums, per-tile partials
-    std::vector<std::pair<uint64_t, std::vector<SecGroup>>> hplan;   // <H> cover: tile bit set + x-groups of every sweep
-    int rows_state = 0;           // row format of the matrix: 0 not tried, 1 built, -1 does not fit
-    size_t budget = 0, rows_bytes = 0;
-    DevBuf d_hrows;
+    size_t budget = 0;
+    int h_max_dict = 0;
 };
 
 }  // namespace
@@ -199,7 +195,6 @@ struct ovqe_sv {
     int opt_sector_dict = 1;      // dictionary coding of the double-excitation-like matrix elements
     int opt_sector_tile_cap = 6500;   // amplitudes per circuit tile (up to 14000 for energies; gradients on the tables hold two tiles in LDS: <= 6500)
     int opt_sector_sparsity = 4;  // the support must be at most 1/this of the register
-    int opt_sector_rows = 1;      // gradients: keep the matrix also row by row when it fits (lambda = H psi by gathers)
     int opt_sector_debug = 0;     // measurements only (1: circuit sweeps without their ops — wrong results)
     int opt_sector_h_groups = 128; // workgroups per <H> sweep (they share the sweep's tiles round robin)
     float last_batch_ms = 0.f;
@@ -2385,7 +2380,6 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     } else if (k == "sector_threads") h->opt_sector_threads = (value == 0 || value == 64 || value == 512 || value == 1024) ? (int)value : 256;
     else if (k == "sector_h_groups") h->opt_sector_h_groups = (int)value;
     else if (k == "sector_debug") h->opt_sector_debug = (int)value;
-    else if (k == "sector_rows") h->opt_sector_rows = (int)value;
     else if (k == "sector_sparsity" || k == "sector_tile_cap") {
         (k == "sector_sparsity" ? h->opt_sector_sparsity : h->opt_sector_tile_cap) = (int)value;
         free_sector(h->sec);

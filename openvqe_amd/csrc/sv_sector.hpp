@@ -16,9 +16,9 @@
 //     tile cover of the x-groups and every tile, the list of (slot_i, slot_j, H_ij) with H_ij != 0.  An evaluation streams
 //     that list once against the tile's amplitudes in LDS: HBM-bound, no Pauli arithmetic left.  The matrix elements of the
 //     x-groups with three or more mixing bits (double excitations: 96 % of the elements) take few distinct magnitudes per
-//     sweep, so they are stored as ONE 32-bit word (slot_i, slot_j, sign, index into the sweep's dictionary of magnitudes:
-//     4 bytes per element); the others (diagonal, single-excitation-like groups: occupation-dependent values) keep an
-//     explicit double (12 bytes).  <H> tiles are smaller than the circuit's (<= 1023 amplitudes: 10-bit slots).
+//     sweep, so they are stored as ONE 32-bit word (slot_j, sign, index into the sweep's dictionary of magnitudes: 4 bytes
+//     per element); the others (diagonal, single-excitation-like groups: occupation-dependent values) keep an explicit
+//     double (12 bytes).  Elements are kept row by row in slices of 64 entries (lane = row), see "ROW format" below.
 //
 // All tables are built on the device (radix sort of the permuted indices, binary search of partners inside a tile).
 #pragma once
@@ -45,24 +45,40 @@ struct SecGroup {     // x-group of the Hamiltonian, global masks
     uint64_t x;
     int32_t t0, t1;
 };
-constexpr int SEC_HSLOT_BITS = 10;
+// ---- materialised <H>: ROW format ---------------------------------------------------------------------------------------
+// Tiles of up to 8190 amplitudes (13-bit slots).  Every matrix element H_ij (i != j) is stored ONCE, under one of its two
+// entries (a hash bit of the pair decides which: rows come out equally long); diagonal elements under their own entry.
+// The rows of a tile are kept in SLICES of 64 rows — the tile's entries sorted by row length, so that the rows of a slice are
+// equally long but for a few percent; rows are padded to the slice's longest (a multiple of 4) with null elements.  Coded
+// element q of the slice's row l sits at base + 256 (q / 4) + 4 l + q % 4 — a lane reads four elements with one 16-byte
+// load, a wave 1 KB contiguous; explicit element q at base + 64 q + l.  A wave owns a slice, lane = row: a_i stays in a register,
+// loads are coalesced, per element one word + the dictionary + a_j from LDS.
+//   coded element (x-groups with >= 3 mixing bits): word = slot_j | sign << 13 | dictionary index << 14, value 2 H_ij =
+//     +- dict[index] (index == ndict: null, 0);
+//   explicit element (diagonal, single-excitation-like groups): word = slot_j, value H_ii or 2 H_ij (null: 0).
+constexpr int SEC_HSLOT_BITS = 13;
 constexpr uint32_t SEC_HSLOT_MASK = (1u << SEC_HSLOT_BITS) - 1u;
-constexpr uint32_t SEC_HMAX_TILE = SEC_HSLOT_MASK;   // entries per <H> tile
-constexpr int SEC_DICT_MAX = 2048;                   // magnitudes per sweep (11 bits of the coded word)
+constexpr uint32_t SEC_HMAX_TILE = SEC_HSLOT_MASK - 1u;   // entries per <H> tile
+constexpr int SEC_DICT_MAX = 4096;                   // magnitudes per sweep staged in LDS (the word has room for 2^18)
 constexpr int SEC_CODED_MIN_WEIGHT = 3;              // x-groups with at least this many mixing bits go through the dictionary
-// coded word: slot_i | slot_j << 10 | sign << 20 | dictionary index << 21;  explicit word: slot_i | slot_j << 10
+constexpr int SEC_HSLICES = (SEC_HMAX_TILE + 64) / 64;   // slices per tile
+constexpr uint32_t SEC_HTILE_LDS_CAP = 7600;             // entries per <H> tile: the lambda kernel holds two tiles + the dictionary in LDS
 struct SecHSweep {    // one sweep of the materialised <H>: device pointers
     const uint32_t *src;    // [K] position of the entry in the circuit's final order
     const uint32_t *off;    // [ntiles + 1]
-    const uint32_t *cbase;  // [K + 1] first coded element of every entry
-    const uint32_t *cwords;
+    const uint16_t *order;  // [K] entry (slot) at every slice position of its tile: rows sorted by length
+    const uint32_t *cbase, *clen, *cwords;   // [ntiles * SEC_HSLICES] slice bases / lengths; coded words
     const double *cvals;    // the coded stream's values when the sweep has no dictionary (ndict == 0), else unused
     const double *dict;     // [ndict] magnitudes (ascending)
-    const uint32_t *xbase;  // [K + 1] first explicit element of every entry
-    const uint32_t *xwords;
-    const double *xvals;    // H_ii, or 2 H_ij (pair counted once)
+    const uint32_t *xbase, *xlen, *xwords;
+    const double *xvals;
     int32_t ndict, ntiles;
 };
+// which entry of an off-diagonal pair keeps its matrix element: a hash bit of the pair (lower index, x mask) — per pair, not
+// per entry, so that every row keeps about half of its elements
+__device__ __forceinline__ bool sec_low_owns(uint64_t low, uint64_t x) {
+    return (((low * 0x9e3779b97f4a7c15ull) ^ (x * 0xc2b2ae3d27d4eb4full)) >> 40) & 1ull;
+}
 
 __device__ __forceinline__ uint32_t sec_pext(uint32_t v, uint32_t mask) {  // mask is wave-uniform
     uint32_t r = 0;
@@ -353,28 +369,22 @@ __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ 
     if (bad) atomicOr(flag, 1);
 }
 
-// ---- materialised <H> -------------------------------------------------------------------------------------------------
-// One thread per entry of the tile; for every x-group of the sweep D_g(i) = sum_t c_t (-1)^{|j & z_t|}, j = i ^ x, the pair
-// taken from its member with a clear pivot bit.  FILL = false: ccnt[e] / xcnt[e] = non-zero elements of entry e in the two
-// streams; FILL = true: they are written at cbase[e] / xbase[e] (entry-major: a wave of the evaluation kernel reads one
-// amplitude for a run of elements).  The coded stream is written with its values; k_sec_encode replaces them.
-// ROWS = true: the symmetric matrix row by row — every off-diagonal element under BOTH of its entries, explicit values
-// not doubled (the coded stream keeps the doubled magnitudes of the pair format so that the sweep's dictionary serves
-// both) — in SLICES of 64 consecutive entries of a tile: element q of the slice's row l sits at base + 64 q + l, rows padded
-// to the longest of the slice with null elements (value 0).  lambda = H psi then is one gather per element, a register
-// sum per row, coalesced loads, no scattered additions (k_sector_apply_rows).  cbase / xbase are per (tile, slice) then,
-// clen / xlen the slice lengths.
-constexpr int SEC_HSLICES = (SEC_HMAX_TILE + 64) / 64;   // slices per tile
-template <bool FILL, int NT, bool ROWS = false>
+// ---- materialised <H>: construction ------------------------------------------------------------------------------------
+// One thread per entry of the tile; for every x-group of the sweep D_g = sum_t c_t (-1)^{|hi & z_t|} with hi = the pair's
+// member whose pivot bit is set, kept by the pair's owner.  FILL = false: ccnt[e] / xcnt[e] = elements of entry e in the
+// two streams; FILL = true: element q of the row goes to base[tile, slice] + 64 q + lane, the row is padded to the
+// slice's length (the lanes past the tile's last row only pad).  The coded stream is written with its values;
+// k_sec_encode replaces them.
+template <bool FILL, int NT>
 __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ sup, const uint32_t *__restrict__ keys,
                                                    const uint32_t *__restrict__ cid, const uint32_t *__restrict__ off, int M,
                                                    uint32_t smask, const SecGroup *__restrict__ groups, int ngroups,
                                                    const HTerm *__restrict__ terms, uint32_t *__restrict__ ccnt,
                                                    uint32_t *__restrict__ xcnt, const uint32_t *__restrict__ cbase,
-                                                   const uint32_t *__restrict__ xbase, uint32_t *__restrict__ cwords,
-                                                   double *__restrict__ cvals, uint32_t *__restrict__ xwords,
-                                                   double *__restrict__ xvals, const uint32_t *__restrict__ clen = nullptr,
-                                                   const uint32_t *__restrict__ xlen = nullptr) {
+                                                   const uint32_t *__restrict__ xbase, const uint32_t *__restrict__ clen,
+                                                   const uint32_t *__restrict__ xlen, const uint16_t *__restrict__ rank,
+                                                   uint32_t *__restrict__ cwords, double *__restrict__ cvals,
+                                                   uint32_t *__restrict__ xwords, double *__restrict__ xvals) {
     extern __shared__ uint32_t sec_lk[];
     const uint32_t t = blockIdx.x, e0 = off[t];
     const int n = (int)(off[t + 1] - e0);
@@ -382,30 +392,25 @@ __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ 
     const uint32_t lmask = (1u << M) - 1u;
     for (int k = threadIdx.x; k < n; k += NT) sec_lk[k] = keys[e0 + k] & lmask;
     __syncthreads();
-    const int nrows = (ROWS && FILL) ? ((n + 63) & ~63) : n;   // the lanes past the tile's last row write padding only
+    const int nrows = FILL ? ((n + 63) & ~63) : n;
     for (int k = threadIdx.x; k < nrows; k += NT) {
         uint32_t cc = 0, xc = 0;
-        const size_t sl = (size_t)t * SEC_HSLICES + (size_t)(k >> 6);
-        const uint32_t cstride = (ROWS && FILL) ? 64u : 1u;
-        uint32_t cb = 0, xb = 0;
-        if (FILL) {
-            cb = ROWS ? cbase[sl] + (uint32_t)(k & 63) : cbase[e0 + k];
-            xb = ROWS ? xbase[sl] + (uint32_t)(k & 63) : xbase[e0 + k];
-        }
+        const uint32_t pos = (FILL && k < n) ? rank[e0 + k] : (uint32_t)k;   // the row's place in its tile's slices
+        const size_t sl = (size_t)t * SEC_HSLICES + (size_t)(pos >> 6);
+        const uint32_t cb = FILL ? cbase[sl] + 4u * (pos & 63u) : 0u, xb = FILL ? xbase[sl] + (pos & 63u) : 0u;
         if (k < n) {
             const uint64_t i = sup[cid[e0 + k]];
             const uint32_t li = sec_lk[k];
             for (int g = 0; g < ngroups; ++g) {
                 const SecGroup gr = groups[g];
                 int sj = k;
-                uint64_t j = i;   // the pair's member with the pivot bit set: its index enters the signs
+                uint64_t hi = i;
                 if (gr.x) {
                     const uint64_t pbit = 1ull << (63 - __clzll((long long)gr.x));
-                    if (i & pbit) {
-                        if (!ROWS) continue;
-                    } else {
-                        j = i ^ gr.x;
-                    }
+                    const bool is_low = !(i & pbit);
+                    const uint64_t low = is_low ? i : i ^ gr.x;
+                    if (sec_low_owns(low, gr.x) != is_low) continue;   // the other member keeps this element
+                    hi = low ^ gr.x;
                     sj = sec_find(sec_lk, n, li ^ sec_pext((uint32_t)gr.x, smask));
                     if (sj < 0) continue;
                 }
@@ -413,20 +418,19 @@ __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ 
                 for (int tt = gr.t0; tt < gr.t1; ++tt) {
                     const HTerm ht = terms[tt];
                     if (__popcll(gr.x & ht.z) & 1) continue;   // odd number of Y: <P> = 0 on a real state
-                    d += parity64(j & ht.z) ? -ht.cr : ht.cr;
+                    d += parity64(hi & ht.z) ? -ht.cr : ht.cr;
                 }
                 if (d == 0.0) continue;
-                const uint32_t word = (uint32_t)k | ((uint32_t)sj << SEC_HSLOT_BITS);
                 if (__popcll(gr.x) >= SEC_CODED_MIN_WEIGHT) {
                     if (FILL) {
-                        cwords[cb + cc * cstride] = word;
-                        cvals[cb + cc * cstride] = 2.0 * d;
+                        cwords[cb + 256u * (cc >> 2) + (cc & 3u)] = (uint32_t)sj;
+                        cvals[cb + 256u * (cc >> 2) + (cc & 3u)] = 2.0 * d;
                     }
                     ++cc;
                 } else {
                     if (FILL) {
-                        xwords[xb + xc * cstride] = word;
-                        xvals[xb + xc * cstride] = (gr.x && !ROWS) ? 2.0 * d : d;
+                        xwords[xb + 64u * xc] = (uint32_t)sj;
+                        xvals[xb + 64u * xc] = gr.x ? 2.0 * d : d;
                     }
                     ++xc;
                 }
@@ -435,20 +439,56 @@ __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ 
         if (!FILL) {
             ccnt[e0 + k] = cc;
             xcnt[e0 + k] = xc;
-        } else if (ROWS) {   // pad the row to the slice's length
+        } else {   // pad the row to the slice's length
             for (uint32_t q = cc; q < clen[sl]; ++q) {
-                cwords[cb + q * 64u] = 0u;
-                cvals[cb + q * 64u] = 0.0;
+                cwords[cb + 256u * (q >> 2) + (q & 3u)] = 0u;
+                cvals[cb + 256u * (q >> 2) + (q & 3u)] = 0.0;
             }
             for (uint32_t q = xc; q < xlen[sl]; ++q) {
-                xwords[xb + q * 64u] = 0u;
-                xvals[xb + q * 64u] = 0.0;
+                xwords[xb + 64u * q] = 0u;
+                xvals[xb + 64u * q] = 0.0;
             }
         }
     }
 }
-// slice lengths of the row format: len[tile * SEC_HSLICES + s] = longest row of the slice (one wave per slice)
-__global__ __launch_bounds__(256) void k_sec_slice_len(const uint32_t *__restrict__ off, const uint32_t *__restrict__ ccnt,
+// order[e0 + p] = the entry at slice position p of its tile, rank = the inverse: entries sorted by row length (descending;
+// ties by slot, so the layout is reproducible) with a bitonic sort of (65535 - length) << 16 | slot in LDS
+template <int NT>
+__global__ __launch_bounds__(NT) void k_sec_row_order(const uint32_t *__restrict__ off, const uint32_t *__restrict__ ccnt,
+                                                      const uint32_t *__restrict__ xcnt, uint16_t *__restrict__ order,
+                                                      uint16_t *__restrict__ rank) {
+    extern __shared__ uint32_t sec_lk[];
+    const uint32_t t = blockIdx.x, e0 = off[t], n = off[t + 1] - e0;
+    if (n == 0) return;
+    uint32_t P = 64;
+    while (P < n) P <<= 1;
+    for (uint32_t k = threadIdx.x; k < P; k += NT)
+        sec_lk[k] = k < n ? ((65535u - min(ccnt[e0 + k] + xcnt[e0 + k], 65535u)) << 16) | k : 0xffffffffu;
+    __syncthreads();
+    for (uint32_t size = 2; size <= P; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t k = threadIdx.x; k < P / 2; k += NT) {
+                const uint32_t i = 2u * k - (k & (stride - 1u)), j = i + stride;
+                const bool up = !(i & size);
+                const uint32_t a = sec_lk[i], b = sec_lk[j];
+                if ((a > b) == up) {
+                    sec_lk[i] = b;
+                    sec_lk[j] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t p = threadIdx.x; p < n; p += NT) {
+        const uint32_t row = sec_lk[p] & 0xffffu;
+        order[e0 + p] = (uint16_t)row;
+        rank[e0 + row] = (uint16_t)p;
+    }
+}
+// slice lengths: len[tile * SEC_HSLICES + s] = longest row of the slice (one wave per slice); words64 = 64 len, the input of
+// the scan that lays the slices out
+__global__ __launch_bounds__(256) void k_sec_slice_len(const uint32_t *__restrict__ off, const uint16_t *__restrict__ order,
+                                                       const uint32_t *__restrict__ ccnt,
                                                        const uint32_t *__restrict__ xcnt, uint32_t *__restrict__ clen,
                                                        uint32_t *__restrict__ xlen, uint32_t *__restrict__ cwords64,
                                                        uint32_t *__restrict__ xwords64) {
@@ -456,16 +496,18 @@ __global__ __launch_bounds__(256) void k_sec_slice_len(const uint32_t *__restric
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t s = wave; s < (uint32_t)SEC_HSLICES; s += 4u) {
         const uint32_t k = 64u * s + lane;
-        uint32_t c = k < n ? ccnt[e0 + k] : 0u, x = k < n ? xcnt[e0 + k] : 0u;
+        const uint32_t row = k < n ? order[e0 + k] : 0u;
+        uint32_t c = k < n ? ccnt[e0 + row] : 0u, x = k < n ? xcnt[e0 + row] : 0u;
         for (int o = 32; o > 0; o >>= 1) {
             c = max(c, (uint32_t)__shfl_xor(c, o, 64));
             x = max(x, (uint32_t)__shfl_xor(x, o, 64));
         }
         if (lane == 0) {
             const size_t sl = (size_t)t * SEC_HSLICES + s;
+            c = (c + 3u) & ~3u;   // a lane reads its coded elements four at a time
             clen[sl] = c;
             xlen[sl] = x;
-            cwords64[sl] = 64u * c;   // words of the slice: input of the scan that lays the slices out
+            cwords64[sl] = 64u * c;
             xwords64[sl] = 64u * x;
         }
     }
@@ -480,8 +522,8 @@ __global__ __launch_bounds__(256) void k_sec_encode(uint32_t *__restrict__ words
     const uint32_t e = blockIdx.x * 256u + threadIdx.x;
     if (e >= n) return;
     const double v = vals[e];
-    if (v == 0.0) {   // padding of the row format: the zero magnitude appended to the dictionary
-        words[e] = (uint32_t)ndict << 21;
+    if (v == 0.0) {   // padding: the null element
+        words[e] = (uint32_t)ndict << 14;
         return;
     }
     const uint64_t key = (uint64_t)__double_as_longlong(fabs(v));
@@ -490,112 +532,131 @@ __global__ __launch_bounds__(256) void k_sec_encode(uint32_t *__restrict__ words
         const int mid = (lo + hi) >> 1;
         if (dict[mid] < key) lo = mid + 1; else hi = mid;
     }
-    words[e] |= (v < 0.0 ? 1u << 20 : 0u) | ((uint32_t)lo << 21);
+    words[e] |= (v < 0.0 ? 1u << SEC_HSLOT_BITS : 0u) | ((uint32_t)lo << 14);
 }
 
-// E = sum over the sweeps and tiles of sum_e H_e a[slot_i] a[slot_j]: blockIdx.y = sweep; the workgroups of a sweep share
-// its tiles round robin (the dictionary is staged once per workgroup, the amplitudes of the next tile are in flight while
-// the elements of the current one stream)
-template <int NT>
-__global__ __launch_bounds__(NT) void k_sector_expect(const double *__restrict__ state, const SecHSweep *__restrict__ sweeps,
-                                                      double2 *__restrict__ partials) {
-    constexpr int PER = (SEC_HMAX_TILE + NT) / NT;   // amplitudes of a tile per thread
-    __shared__ double tile[SEC_HMAX_TILE + 1];
-    __shared__ double dict[SEC_DICT_MAX];
-    __shared__ double2 red[NT / 64];
-    const SecHSweep sw = sweeps[blockIdx.y];
-    const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    for (int k = threadIdx.x; k < sw.ndict; k += NT) dict[k] = sw.dict[k];
-    double nxt[PER];
-    uint32_t e0 = 0, n = 0;
-    auto fetch = [&](uint32_t t) {
-        e0 = sw.off[t];
-        n = sw.off[t + 1] - e0;
+// ---- materialised <H>: evaluation --------------------------------------------------------------------------------------
+// The sum over the elements of the lane's row: sum_e value_e a[slot_j]  (APPLY: also lambda[slot_j] += H_ij a_i for the
+// off-diagonal elements, f64 LDS atomics on scattered slots)
+template <bool APPLY>
+__device__ __forceinline__ double sec_row_sum(const SecHSweep &sw, size_t sl, uint32_t lane, uint32_t row, double ai,
+                                              const double *tile, const double *dict, double *lam) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    {
+        const uint32_t L = sw.clen[sl];   // a multiple of 4
+        const uint32_t *wp = sw.cwords + sw.cbase[sl] + 4u * lane;
+        if (sw.ndict) {
+            auto term = [&](uint32_t w) {
+                const uint32_t sj = w & SEC_HSLOT_MASK;
+                double v = dict[w >> 14];
+                if (w & (1u << SEC_HSLOT_BITS)) v = -v;
+                if (APPLY && (w >> 14) != (uint32_t)sw.ndict)
+                    __hip_atomic_fetch_add(&lam[sj], 0.5 * v * ai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return v * tile[sj];
+            };
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            uint32_t q = 0;
+            for (; q + 15u < L; q += 16u) {
+                u32x4 w[4];
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const uint32_t k = threadIdx.x + (uint32_t)q * NT;
-            nxt[q] = k < n ? state[sw.src[e0 + k]] : 0.0;
-        }
-    };
-    uint32_t t = blockIdx.x;
-    if (t < (uint32_t)sw.ntiles) fetch(t);
-    for (; t < (uint32_t)sw.ntiles; t += gridDim.x) {
-        const uint32_t ce0 = e0, cn = n;
-        __syncthreads();   // the previous tile's elements are done with the LDS copy
+                for (int u = 0; u < 4; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wp + 64u * (q + 4u * (uint32_t)u)));
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const uint32_t k = threadIdx.x + (uint32_t)q * NT;
-            if (k < cn) tile[k] = nxt[q];
-        }
-        __syncthreads();
-        if (t + gridDim.x < (uint32_t)sw.ntiles) fetch(t + gridDim.x);
-        if (cn == 0) continue;
-        {
-            const uint32_t b1 = sw.cbase[ce0 + cn];
-            uint32_t e = sw.cbase[ce0] + threadIdx.x;
-            if (sw.ndict) {
-                auto term = [&](uint32_t w) {
-                    const double v = dict[w >> 21] * tile[w & SEC_HSLOT_MASK] * tile[(w >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK];
-                    return (w & (1u << 20)) ? -v : v;
-                };
-                for (; e + 7u * NT < b1; e += 8u * NT) {
-                    uint32_t w[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) w[q] = __builtin_nontemporal_load(&sw.cwords[e + q * NT]);
-                    acc0 += term(w[0]) + term(w[4]);
-                    acc1 += term(w[1]) + term(w[5]);
-                    acc2 += term(w[2]) + term(w[6]);
-                    acc3 += term(w[3]) + term(w[7]);
-                }
-                for (; e < b1; e += NT) acc0 += term(sw.cwords[e]);
-            } else {
-                for (; e < b1; e += NT) {
-                    const uint32_t w = sw.cwords[e];
-                    acc0 += sw.cvals[e] * tile[w & SEC_HSLOT_MASK] * tile[(w >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK];
+                for (int u = 0; u < 4; ++u) {
+                    a0 += term(w[u].x);
+                    a1 += term(w[u].y);
+                    a2 += term(w[u].z);
+                    a3 += term(w[u].w);
                 }
             }
-        }
-        {
-            const uint32_t b1 = sw.xbase[ce0 + cn];
-            uint32_t e = sw.xbase[ce0] + threadIdx.x;
-            for (; e + NT < b1; e += 2u * NT) {
-                const uint32_t w0 = sw.xwords[e], w1 = sw.xwords[e + NT];
-                const double v0 = sw.xvals[e], v1 = sw.xvals[e + NT];
-                acc1 += v0 * tile[w0 & SEC_HSLOT_MASK] * tile[(w0 >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK];
-                acc2 += v1 * tile[w1 & SEC_HSLOT_MASK] * tile[(w1 >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK];
+            for (; q < L; q += 4u) {
+                const u32x4 w = *reinterpret_cast<const u32x4 *>(wp + 64u * q);
+                a0 += term(w.x);
+                a1 += term(w.y);
+                a2 += term(w.z);
+                a3 += term(w.w);
             }
-            for (; e < b1; e += NT) {
-                const uint32_t w0 = sw.xwords[e];
-                acc3 += sw.xvals[e] * tile[w0 & SEC_HSLOT_MASK] * tile[(w0 >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK];
+        } else {
+            const double *vp = sw.cvals + sw.cbase[sl] + 4u * lane;
+            for (uint32_t q = 0; q < L; ++q) {
+                const uint32_t at = 256u * (q >> 2) + (q & 3u);
+                const uint32_t sj = wp[at] & SEC_HSLOT_MASK;
+                const double v = vp[at];
+                if (APPLY && v != 0.0) __hip_atomic_fetch_add(&lam[sj], 0.5 * v * ai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                a0 += v * tile[sj];
             }
         }
     }
+    double diag = 0.0;   // APPLY: H_ii a_i enters lambda_i once, the off-diagonal parts with H_ij = value / 2
+    {
+        const uint32_t L = sw.xlen[sl];
+        const uint32_t *wp = sw.xwords + sw.xbase[sl] + lane;
+        const double *vp = sw.xvals + sw.xbase[sl] + lane;
+        for (uint32_t q = 0; q < L; ++q) {
+            const uint32_t sj = wp[64u * q] & SEC_HSLOT_MASK;
+            const double v = vp[64u * q];
+            if (sj == row) {
+                diag += v * ai;
+            } else {
+                if (APPLY && v != 0.0) __hip_atomic_fetch_add(&lam[sj], 0.5 * v * ai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                a1 += v * tile[sj];
+            }
+        }
+    }
+    const double offd = (a0 + a1) + (a2 + a3);
+    return APPLY ? 0.5 * offd + diag : offd + diag;
+}
+
+// E = sum over the sweeps and tiles of sum_rows a_i (sum_e value_e a_j): blockIdx.y = sweep; the workgroups of a sweep
+// share its tiles round robin; one wave per slice of a tile
+template <int NT>
+__global__ __launch_bounds__(NT) void k_sector_expect(const double *__restrict__ state, const SecHSweep *__restrict__ sweeps,
+                                                      double2 *__restrict__ partials, uint32_t tile_cap) {
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
+    double *tile = reinterpret_cast<double *>(sec_smem);
+    double *dict = tile + ((tile_cap + 1u) & ~1u);
+    __shared__ double2 red[NW];
+    const SecHSweep sw = sweeps[blockIdx.y];
+    const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    for (int k = threadIdx.x; k < sw.ndict; k += NT) dict[k] = sw.dict[k];
+    if (threadIdx.x == 0) dict[sw.ndict] = 0.0;   // the null element
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    double acc = 0.0;
+    for (uint32_t t = blockIdx.x; t < (uint32_t)sw.ntiles; t += gridDim.x) {
+        const uint32_t e0 = sw.off[t], n = sw.off[t + 1] - e0;
+        if (n == 0) continue;
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < n; k += NT) tile[k] = state[sw.src[e0 + k]];
+        __syncthreads();
+        for (uint32_t s = wave; 64u * s < n; s += NW) {
+            const uint32_t p = 64u * s + lane;
+            const uint32_t row = p < n ? sw.order[e0 + p] : SEC_HSLOT_MASK;
+            const double ai = p < n ? tile[row] : 0.0;
+            acc += ai * sec_row_sum<false>(sw, (size_t)t * SEC_HSLICES + s, lane, row, ai, tile, dict, nullptr);
+        }
+    }
     __syncthreads();
-    const double2 tsum = block_sum<NT>(make_double2((acc0 + acc1) + (acc2 + acc3), 0.0), red);
+    const double2 tsum = block_sum<NT>(make_double2(acc, 0.0), red);
     if (threadIdx.x == 0) partials[slot] = tsum;
 }
 
 // ---- exact gradient on the sector tables (adjoint method) ----------------------------------------------------------------
-// lambda = H psi restricted to the support, from the same element streams as k_sector_expect: an off-diagonal element
-// (pair counted once, value 2 H_ij) adds H_ij a_j to lambda_i and H_ij a_i to lambda_j — two f64 LDS atomics per element on
-// an LDS copy of the tile (the lanes of a wave mostly share slot_i in entry-major order: the LDS unit serialises those);
+// lambda = H psi restricted to the support from the same tables: the lane's row sum is lambda_i's part from the elements
+// its entry owns (a register sum), the partner's part lambda_j += H_ij a_i is an f64 LDS atomic on an LDS copy of the tile;
 // the tile's result is added to lambda in the circuit's final order with f64 atomics.  The order of these additions is not
 // fixed: the gradient reproduces to rounding, not bit for bit.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_sector_apply(const double *__restrict__ state, const SecHSweep *__restrict__ sweeps,
-                                                     double *__restrict__ lam_out) {
-    __shared__ double tile[SEC_HMAX_TILE + 1];
-    __shared__ double lam[SEC_HMAX_TILE + 1];
-    __shared__ double dict[SEC_DICT_MAX];
+                                                     double *__restrict__ lam_out, uint32_t tile_cap) {
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
+    double *tile = reinterpret_cast<double *>(sec_smem);
+    double *lam = tile + ((tile_cap + 1u) & ~1u);
+    double *dict = lam + ((tile_cap + 1u) & ~1u);
     const SecHSweep sw = sweeps[blockIdx.y];
     for (int k = threadIdx.x; k < sw.ndict; k += NT) dict[k] = sw.dict[k];
-    auto add = [&](uint32_t w, double hv) {   // hv = H_ij (off-diagonal) or H_ii
-        const uint32_t si = w & SEC_HSLOT_MASK, sj = (w >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK;
-        const double ai = tile[si], aj = tile[sj];
-        __hip_atomic_fetch_add(&lam[si], hv * aj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (si != sj) __hip_atomic_fetch_add(&lam[sj], hv * ai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
+    if (threadIdx.x == 0) dict[sw.ndict] = 0.0;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t t = blockIdx.x; t < (uint32_t)sw.ntiles; t += gridDim.x) {
         const uint32_t e0 = sw.off[t], n = sw.off[t + 1] - e0;
         if (n == 0) continue;
@@ -605,104 +666,15 @@ __global__ __launch_bounds__(NT) void k_sector_apply(const double *__restrict__ 
             lam[k] = 0.0;
         }
         __syncthreads();
-        {
-            const uint32_t b1 = sw.cbase[e0 + n];
-            uint32_t e = sw.cbase[e0] + threadIdx.x;
-            if (sw.ndict) {
-                for (; e + 3u * NT < b1; e += 4u * NT) {
-                    uint32_t w[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) w[q] = __builtin_nontemporal_load(&sw.cwords[e + q * NT]);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const double v = 0.5 * dict[w[q] >> 21];
-                        add(w[q], (w[q] & (1u << 20)) ? -v : v);
-                    }
-                }
-                for (; e < b1; e += NT) {
-                    const uint32_t w = sw.cwords[e];
-                    const double v = 0.5 * dict[w >> 21];
-                    add(w, (w & (1u << 20)) ? -v : v);
-                }
-            } else {
-                for (; e < b1; e += NT) add(sw.cwords[e], 0.5 * sw.cvals[e]);
-            }
-        }
-        {
-            const uint32_t b1 = sw.xbase[e0 + n];
-            for (uint32_t e = sw.xbase[e0] + threadIdx.x; e < b1; e += NT) {
-                const uint32_t w = sw.xwords[e];
-                const bool diag = (w & SEC_HSLOT_MASK) == ((w >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK);
-                add(w, diag ? sw.xvals[e] : 0.5 * sw.xvals[e]);
-            }
+        for (uint32_t s = wave; 64u * s < n; s += NW) {
+            const uint32_t p = 64u * s + lane;
+            const uint32_t row = p < n ? sw.order[e0 + p] : SEC_HSLOT_MASK;
+            const double ai = p < n ? tile[row] : 0.0;
+            const double ci = sec_row_sum<true>(sw, (size_t)t * SEC_HSLICES + s, lane, row, ai, tile, dict, lam);
+            if (p < n) __hip_atomic_fetch_add(&lam[row], ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < n; k += NT) unsafeAtomicAdd(&lam_out[sw.src[e0 + k]], lam[k]);
-    }
-}
-// lambda = H psi from the row format: one wave per slice, lane = row; per element a coalesced word, the dictionary and
-// a_j from LDS, a register sum; the row's result goes straight to lambda in the circuit's final order (an f64 atomic: the
-// sweeps of the cover add up there).  Gradients use this when the row tables fit the budget, else k_sector_apply.
-struct SecHRows {
-    const uint32_t *src, *off;
-    const uint32_t *cbase, *clen, *cwords;   // [ntiles * SEC_HSLICES] slice bases / lengths; coded words
-    const double *cvals, *dict;              // cvals: sweeps without a dictionary
-    const uint32_t *xbase, *xlen, *xwords;
-    const double *xvals;
-    int32_t ndict, ntiles;
-};
-template <int NT>
-__global__ __launch_bounds__(NT) void k_sector_apply_rows(const double *__restrict__ state, const SecHRows *__restrict__ sweeps,
-                                                          double *__restrict__ lam_out) {
-    constexpr int NW = NT / 64;
-    __shared__ double tile[SEC_HMAX_TILE + 1];
-    __shared__ double dict[SEC_DICT_MAX + 1];
-    const SecHRows sw = sweeps[blockIdx.y];
-    for (int k = threadIdx.x; k < sw.ndict; k += NT) dict[k] = 0.5 * sw.dict[k];   // doubled magnitudes -> H_ij
-    if (threadIdx.x == 0) dict[sw.ndict] = 0.0;                                  // the null element
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    for (uint32_t t = blockIdx.x; t < (uint32_t)sw.ntiles; t += gridDim.x) {
-        const uint32_t e0 = sw.off[t], n = sw.off[t + 1] - e0;
-        if (n == 0) continue;
-        __syncthreads();
-        for (uint32_t k = threadIdx.x; k < n; k += NT) tile[k] = state[sw.src[e0 + k]];
-        __syncthreads();
-        for (uint32_t s = wave; 64u * s < n; s += NW) {
-            const size_t sl = (size_t)t * SEC_HSLICES + s;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            {
-                const uint32_t L = sw.clen[sl];
-                const uint32_t *wp = sw.cwords + sw.cbase[sl] + lane;
-                if (sw.ndict) {
-                    auto term = [&](uint32_t w) {
-                        const double v = dict[w >> 21] * tile[(w >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK];
-                        return (w & (1u << 20)) ? -v : v;
-                    };
-                    uint32_t q = 0;
-                    for (; q + 7u < L; q += 8u) {
-                        uint32_t w[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + 64u * (q + (uint32_t)u));
-                        a0 += term(w[0]) + term(w[4]);
-                        a1 += term(w[1]) + term(w[5]);
-                        a2 += term(w[2]) + term(w[6]);
-                        a3 += term(w[3]) + term(w[7]);
-                    }
-                    for (; q < L; ++q) a0 += term(wp[64u * q]);
-                } else {
-                    const double *vp = sw.cvals + sw.cbase[sl] + lane;
-                    for (uint32_t q = 0; q < L; ++q) a0 += 0.5 * vp[64u * q] * tile[(wp[64u * q] >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK];
-                }
-            }
-            {
-                const uint32_t L = sw.xlen[sl];
-                const uint32_t *wp = sw.xwords + sw.xbase[sl] + lane;
-                const double *vp = sw.xvals + sw.xbase[sl] + lane;
-                for (uint32_t q = 0; q < L; ++q) a1 += vp[64u * q] * tile[(wp[64u * q] >> SEC_HSLOT_BITS) & SEC_HSLOT_MASK];
-            }
-            const uint32_t row = 64u * s + lane;
-            if (row < n) unsafeAtomicAdd(&lam_out[sw.src[e0 + row]], (a0 + a1) + (a2 + a3));
-        }
     }
 }
 // <a|b> over the compact state: partials per workgroup (fixed order)

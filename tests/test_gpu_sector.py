@@ -195,9 +195,8 @@ def test_sector_table_budget(SV):
         assert abs(e - ew) < 1e-10 * max(1.0, float(np.abs(ham.packed()[2]).sum()))
 
 
-@pytest.mark.parametrize("m,o,bits,coded,rows", [(7, 3, 0, 1, 1), (8, 3, 9, 1, 1), (9, 4, 0, 1, 1), (10, 4, 0, 1, 1), (8, 4, 0, 0, 1),
-                                                  (9, 3, 0, 1, 0), (8, 3, 0, 0, 0)])
-def test_sector_adjoint_gradient(SV, m, o, bits, coded, rows):
+@pytest.mark.parametrize("m,o,bits,coded", [(7, 3, 0, 1), (8, 3, 9, 1), (9, 4, 0, 1), (10, 4, 0, 1), (8, 4, 0, 0), (9, 3, 10, 0)])
+def test_sector_adjoint_gradient(SV, m, o, bits, coded):
     """ovqe_energy_gradient on the sector tables (forward circuit, lambda = H psi on the support, one backward pass):
     against the dense-state adjoint pass of the same handle and central differences of the C oracle's energy"""
     from openvqe_amd import fermion
@@ -212,7 +211,6 @@ def test_sector_adjoint_gradient(SV, m, o, bits, coded, rows):
         sv.set_option("sector_min_qubits", 8)
         sv.set_option("sector_bits", bits)
         sv.set_option("sector_dict", coded)        # 0: explicit doubles for every matrix element
-        sv.set_option("sector_rows", rows)         # 0: lambda = H psi from the pair format (scattered f64 LDS additions)
         sv.set_hamiltonian(ham)
         sv.set_ucc_program(gens, hf)
         e1, g1 = sv.energy_gradient(th1)          # dense states (first evaluation of the pair)
