@@ -98,9 +98,8 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * <H>), "sector_dict" (0: explicit doubles instead of dictionary-coded matrix elements), "sector_bits" / "sector_h_bits"
  * (index bits per circuit / <H> tile, 0 = automatic), "sector_threads" (0 automatic, 64, 256, 512, 1024),
  * "sector_min_qubits" (default 18), "sector_sparsity" (the support may fill at most 1/value of the register, default 4),
- * "sector_tile_cap" (amplitudes per circuit tile, default 6500 so that gradients fit; up to 14000 for energies only),
- * "sector_rows" (0: no row-format copy of the matrix for gradients).  The state buffer holds unspecified data after an
- * energy evaluation on this path. */
+ * "sector_tile_cap" (amplitudes per circuit tile, default 6500 so that gradients fit; up to 14000 for energies only).
+ * The state buffer holds unspecified data after an energy evaluation on this path. */
 int ovqe_set_option(ovqe_handle h, const char *name, int64_t value);
 /* device pointer to the 2^n_local amplitudes (for RCCL exchange by the host layer) */
 int ovqe_state_ptr(ovqe_handle h, void **dev_ptr);
@@ -208,8 +207,7 @@ int ovqe_apply_exp_pauli_sum(ovqe_handle h, int64_t T, const uint64_t *x, const 
  * evaluations on forward differences (opt-in, because exact derivatives change the
  * optimiser's iterates at the 1e-8 level).  Streaming kernels, any n; the state buffer is left in |hf>.  A real-amplitude
  * program with sector tables (option "sector") runs the whole pass on them from its second call on: forward circuit,
- * lambda = H psi from a row-by-row copy of the materialised Hamiltonian (built at that call when it fits the table budget;
- * "sector_rows" = 0 keeps the pair format and its scattered additions), backward sweeps over the pair lists. */
+ * lambda = H psi from the materialised Hamiltonian, backward sweeps over the pair lists. */
 int ovqe_energy_gradient(ovqe_handle h, const double *theta, int32_t K, double *energy, double *grad);
 
 /* ---- lowest eigenpair of the stored Hamiltonian (Lanczos on the device, two-pass: tridiagonal matrix, then the Ritz
