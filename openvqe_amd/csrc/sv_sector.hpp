@@ -178,7 +178,7 @@ __device__ __forceinline__ int sec_find(const uint32_t *lk, int n, uint32_t key)
 // poff[tile * (nops + 1) + o], in ascending slot order (a fixed order: results are reproducible).  A member of an active
 // pair whose partner is not in the support is recorded with the all-ones slot: its amplitude is structurally zero at that point of
 // the circuit (otherwise the partner would have been populated at the probe parameters) and the sweep checks just that.
-template <bool FILL, int NT>
+template <bool FILL, int NT, bool DENSE>
 __global__ __launch_bounds__(NT) void k_sec_pairs(const uint32_t *__restrict__ sup, const uint32_t *__restrict__ keys,
                                                   const uint32_t *__restrict__ cid, const uint32_t *__restrict__ off, int M,
                                                   uint32_t smask, const SecBuildOp *__restrict__ ops, int nops,
@@ -195,8 +195,22 @@ __global__ __launch_bounds__(NT) void k_sec_pairs(const uint32_t *__restrict__ s
         return;
     }
     const uint32_t lmask = (1u << M) - 1u;
-    for (int k = threadIdx.x; k < n; k += NT) sec_lk[k] = keys[e0 + k] & lmask;
+    uint16_t *slot_of = reinterpret_cast<uint16_t *>(sec_lk);   // DENSE: local key -> slot (see k_sec_hbuild)
+    if (DENSE) {
+        for (uint32_t k = threadIdx.x; k < (1u << M) / 2u; k += NT) sec_lk[k] = 0xffffffffu;
+        __syncthreads();
+        for (int k = threadIdx.x; k < n; k += NT) slot_of[keys[e0 + k] & lmask] = (uint16_t)k;
+    } else {
+        for (int k = threadIdx.x; k < n; k += NT) sec_lk[k] = keys[e0 + k] & lmask;
+    }
     __syncthreads();
+    auto find = [&](uint32_t key) -> int {
+        if (DENSE) {
+            const uint32_t v = slot_of[key];
+            return v == 0xffffu ? -1 : (int)v;
+        }
+        return sec_find(sec_lk, n, key);
+    };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int o = 0; o < nops; ++o) {
         const SecBuildOp op = ops[o];
@@ -209,18 +223,19 @@ __global__ __launch_bounds__(NT) void k_sec_pairs(const uint32_t *__restrict__ s
             uint32_t word = 0;
             if (k < n) {
                 const uint64_t i = sup[cid[e0 + k]];
+                const uint32_t lk = keys[e0 + k] & lmask;
                 for (int p = 0; p < op.npat; ++p) {
                     const SecPat pt = pats[op.pat0 + p];
                     const uint64_t bits = i & pt.pm;
                     if (bits == pt.pv) {
-                        const int sj = sec_find(sec_lk, n, sec_lk[k] ^ xl);
+                        const int sj = find(lk ^ xl);
                         const uint32_t sign = (uint32_t)(parity64(i & op.zs) ^ op.flip);
                         word = (uint32_t)k | ((sj < 0 ? orphan : (uint32_t)sj) << sb) | (sign << (2 * sb)) | ((uint32_t)p << (2 * sb + 1));
                         emit = true;
                         break;
                     }
                     if (bits == (pt.pv ^ (op.x & pt.pm))) {   // second member: only its orphans are recorded
-                        if (sec_find(sec_lk, n, sec_lk[k] ^ xl) < 0) {
+                        if (find(lk ^ xl) < 0) {
                             word = (uint32_t)k | (orphan << sb) | ((uint32_t)p << (2 * sb + 1));
                             emit = true;
                         }
@@ -375,7 +390,9 @@ __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ 
 // two streams; FILL = true: element q of the row goes to base[tile, slice] + 64 q + lane, the row is padded to the
 // slice's length (the lanes past the tile's last row only pad).  The coded stream is written with its values;
 // k_sec_encode replaces them.
-template <bool FILL, int NT>
+// DENSE: the partner's slot comes from a dense LDS map local key -> slot (2 bytes x 2^M: M <= 16) instead of a binary
+// search in the tile's sorted keys (13 dependent LDS reads per pair: the construction was bound by them).
+template <bool FILL, int NT, bool DENSE>
 __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ sup, const uint32_t *__restrict__ keys,
                                                    const uint32_t *__restrict__ cid, const uint32_t *__restrict__ off, int M,
                                                    uint32_t smask, const SecGroup *__restrict__ groups, int ngroups,
@@ -386,11 +403,18 @@ __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ 
                                                    uint32_t *__restrict__ cwords, double *__restrict__ cvals,
                                                    uint32_t *__restrict__ xwords, double *__restrict__ xvals) {
     extern __shared__ uint32_t sec_lk[];
+    uint16_t *slot_of = reinterpret_cast<uint16_t *>(sec_lk);
     const uint32_t t = blockIdx.x, e0 = off[t];
     const int n = (int)(off[t + 1] - e0);
     if (n == 0) return;
     const uint32_t lmask = (1u << M) - 1u;
-    for (int k = threadIdx.x; k < n; k += NT) sec_lk[k] = keys[e0 + k] & lmask;
+    if (DENSE) {
+        for (uint32_t k = threadIdx.x; k < (1u << M) / 2u; k += NT) sec_lk[k] = 0xffffffffu;
+        __syncthreads();
+        for (int k = threadIdx.x; k < n; k += NT) slot_of[keys[e0 + k] & lmask] = (uint16_t)k;
+    } else {
+        for (int k = threadIdx.x; k < n; k += NT) sec_lk[k] = keys[e0 + k] & lmask;
+    }
     __syncthreads();
     const int nrows = FILL ? ((n + 63) & ~63) : n;
     for (int k = threadIdx.x; k < nrows; k += NT) {
@@ -400,7 +424,7 @@ __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ 
         const uint32_t cb = FILL ? cbase[sl] + 4u * (pos & 63u) : 0u, xb = FILL ? xbase[sl] + (pos & 63u) : 0u;
         if (k < n) {
             const uint64_t i = sup[cid[e0 + k]];
-            const uint32_t li = sec_lk[k];
+            const uint32_t li = keys[e0 + k] & lmask;
             for (int g = 0; g < ngroups; ++g) {
                 const SecGroup gr = groups[g];
                 int sj = k;
@@ -411,7 +435,13 @@ __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ 
                     const uint64_t low = is_low ? i : i ^ gr.x;
                     if (sec_low_owns(low, gr.x) != is_low) continue;   // the other member keeps this element
                     hi = low ^ gr.x;
-                    sj = sec_find(sec_lk, n, li ^ sec_pext((uint32_t)gr.x, smask));
+                    const uint32_t lj = li ^ sec_pext((uint32_t)gr.x, smask);
+                    if (DENSE) {
+                        const uint32_t v = slot_of[lj];
+                        sj = v == 0xffffu ? -1 : (int)v;
+                    } else {
+                        sj = sec_find(sec_lk, n, lj);
+                    }
                     if (sj < 0) continue;
                 }
                 double d = 0.0;
