@@ -300,20 +300,19 @@ __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ 
     double2 *cs = reinterpret_cast<double2 *>(tile + ((tile_cap + 1u) & ~1u));
     SecOpLds *lop = reinterpret_cast<SecOpLds *>(cs + nrot);
     uint32_t *wbuf = reinterpret_cast<uint32_t *>(lop + nops + 2);
-    const uint32_t t = blockIdx.x, e0 = off[t];
-    const int n = (int)(off[t + 1] - e0);
-    if (n == 0) return;
+    // Order of the prologue: everything that depends only on the tile number first (op table, cos/sin, tile bounds), then
+    // — one round trip later — the first chunk of pair words AND the gather indices together, then the gather itself; the
+    // pair words used to wait for the gather (one more dependent trip to memory per sweep).
+    const uint32_t t = blockIdx.x;
     const uint32_t *po = poff + (size_t)t * (nops + 1);
     for (int o = threadIdx.x; o <= nops; o += NT) lop[o] = SecOpLds{po[o], o < nops ? tab0[o] - rot0 : 0};
     for (int r = threadIdx.x; r < nrot; r += NT) {
         const RotParam rr = rp[rot0 + r];
         cs[r] = make_double2(rr.c, rr.s);
     }
-    if (src) {
-        for (int k = threadIdx.x; k < n; k += NT) tile[k] = in[src[e0 + k]];
-    } else {
-        for (int k = threadIdx.x; k < n; k += NT) tile[k] = (e0 + (uint32_t)k == hf_pos) ? 1.0 : 0.0;
-    }
+    const uint32_t e0 = off[t];
+    const int n = (int)(off[t + 1] - e0);
+    if (n == 0) return;
     __syncthreads();
     auto chunk_end = [&](int oa) {   // ops [oa, ob) whose pair words fit one buffer (ob == oa: op oa alone is larger)
         int ob = oa;
@@ -337,11 +336,14 @@ __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ 
     bool bad = false;
     int oa = 0, ob = chunk_end(0), cb = 0;
     if (dbg == 1) oa = ob = nops;   // measurement only: the sweep without its ops
-    if (ob > oa) {
-        fetch(oa, ob);
-        stash(wbuf);
+    if (ob > oa) fetch(oa, ob);
+    if (src) {
+        for (int k = threadIdx.x; k < n; k += NT) tile[k] = in[src[e0 + k]];
+    } else {
+        for (int k = threadIdx.x; k < n; k += NT) tile[k] = (e0 + (uint32_t)k == hf_pos) ? 1.0 : 0.0;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ob > oa) stash(wbuf);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     while (oa < nops) {
         if (ob == oa) {   // one op with more pairs in this tile than a buffer holds: straight from memory
             const uint32_t p0 = lop[oa].p0, p1 = lop[oa + 1].p0;
@@ -768,11 +770,7 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint(const double *__restrict_
         cs[r] = make_double2(rr.c, rr.s);
     }
     for (int r = threadIdx.x; r < NW * nrot; r += NT) wacc[r] = 0.0;
-    for (int k = threadIdx.x; k < n; k += NT) {
-        tp[k] = psi_in[e0 + k];
-        tl[k] = lam_in[e0 + k];
-    }
-    __syncthreads();
+    __syncthreads();   // (the tile loads follow the first chunk's pair-word loads below: one round trip for both)
     const uint32_t mask = (1u << sb) - 1u;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *mine = wacc + (size_t)wave * nrot;
@@ -835,11 +833,13 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint(const double *__restrict_
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     int ob = nops, oa = chunk_begin(nops), cb = 0;
-    if (oa < ob) {
-        fetch(oa, ob);
-        stash(wbuf);
+    if (oa < ob) fetch(oa, ob);
+    for (int k = threadIdx.x; k < n; k += NT) {
+        tp[k] = psi_in[e0 + k];
+        tl[k] = lam_in[e0 + k];
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (oa < ob) stash(wbuf);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     while (ob > 0) {
         if (oa == ob) {   // one op with more pairs in this tile than a buffer holds: straight from memory
             back_op(ob - 1, pairs, lop[ob - 1].p0, lop[ob].p0);
