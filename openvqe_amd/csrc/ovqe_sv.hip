@@ -86,6 +86,7 @@ struct SectorSeg {      // one sweep of the circuit
     uint32_t hf_pos = 0;
     uint64_t npairs = 0;
     DevBuf d_tab0, d_poff, d_pairs;
+    DevBuf d_srcpad;              // gather indices of the sweep, tile-padded (k_sec_pad_src)
 };
 struct SectorHSweep {   // one sweep of the materialised <H>
     SectorLayout L;

@@ -154,6 +154,13 @@ __global__ __launch_bounds__(256) void k_sec_compose(const uint32_t *__restrict_
     const uint32_t e = blockIdx.x * 256u + threadIdx.x;
     if (e < K) src[e] = inv_prev[cid[e]];
 }
+// src in tile-padded form: srcpad[tile * cap + k] = src[off[tile] + k], 0xffffffff beyond the tile's entries — a sweep can
+// then read its gather indices before it knows its tile's bounds
+__global__ __launch_bounds__(256) void k_sec_pad_src(const uint32_t *__restrict__ src, const uint32_t *__restrict__ off, uint32_t cap,
+                                                     uint32_t *__restrict__ srcpad) {
+    const uint32_t t = blockIdx.x, e0 = off[t], n = off[t + 1] - e0;
+    for (uint32_t k = threadIdx.x; k < cap; k += 256u) srcpad[(size_t)t * cap + k] = k < n ? src[e0 + k] : 0xffffffffu;
+}
 // per-tile maximum of the entry counts, as one number
 __global__ __launch_bounds__(256) void k_sec_max_tile(const uint32_t *__restrict__ off, uint32_t ntiles, uint32_t *__restrict__ out) {
     uint32_t m = 0;
@@ -310,6 +317,14 @@ __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ 
         const RotParam rr = rp[rot0 + r];
         cs[r] = make_double2(rr.c, rr.s);
     }
+    constexpr int PF = 4;   // gather indices per thread read before the tile's bounds are known (tile-padded array)
+    uint32_t gidx[PF];
+    const uint32_t *sp = src ? src + (size_t)t * tile_cap : nullptr;
+#pragma unroll
+    for (int r = 0; r < PF; ++r) {
+        const uint32_t k = threadIdx.x + (uint32_t)r * NT;
+        gidx[r] = (sp && k < tile_cap) ? sp[k] : 0xffffffffu;
+    }
     const uint32_t e0 = off[t];
     const int n = (int)(off[t + 1] - e0);
     if (n == 0) return;
@@ -338,7 +353,12 @@ __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ 
     if (dbg == 1) oa = ob = nops;   // measurement only: the sweep without its ops
     if (ob > oa) fetch(oa, ob);
     if (src) {
-        for (int k = threadIdx.x; k < n; k += NT) tile[k] = in[src[e0 + k]];
+#pragma unroll
+        for (int r = 0; r < PF; ++r) {
+            const int k = (int)threadIdx.x + r * NT;
+            if (k < n) tile[k] = in[gidx[r]];
+        }
+        for (int k = (int)threadIdx.x + PF * NT; k < n; k += NT) tile[k] = in[sp[k]];
     } else {
         for (int k = threadIdx.x; k < n; k += NT) tile[k] = (e0 + (uint32_t)k == hf_pos) ? 1.0 : 0.0;
     }
