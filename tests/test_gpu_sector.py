@@ -26,10 +26,11 @@ def _oracle_energies(n, gens, hf, H, thetas):
 
 
 @pytest.mark.parametrize("m,o,bits,threads", [(7, 2, 0, 256), (7, 3, 8, 256), (8, 3, 0, 64), (8, 4, 10, 256), (9, 4, 0, 256),
-                                              (10, 4, 12, 256), (10, 5, 0, 256)])
+                                              (10, 4, 12, 256), (10, 5, 0, 256), (10, 4, 18, 0)])
 def test_sector_uccsd_matches_c_oracle(SV, m, o, bits, threads):
     """molecule-shaped UCCSD (JW generators in table-fused form, a JW two-body Hamiltonian): the support is the
-    (o alpha, o beta) sector; energies of the sector path == oracle == dense kernels"""
+    (o alpha, o beta) sector; energies of the sector path == oracle == dense kernels.  bits = 18 at 20 qubits: tiles of 17
+    index bits (8 tiles of ~5500 amplitudes), beyond the dense slot maps of the table construction (binary-search path)"""
     from openvqe_amd import fermion
     n = 2 * m
     ham, gens, hf = fermion.synthetic_molecule(m, o, seed=100 + m)
