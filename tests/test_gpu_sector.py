@@ -315,3 +315,13 @@ def test_sector_ground_state_is_the_fci_energy_of_the_sector(SV, m, o):
     assert info["sector_support"] == len(dets)
     assert abs(e - e_fci) < 1e-9 and res < 1e-6, (e, e_fci, res, its)
     assert e_all <= e + 1e-9 and e <= e_var + 1e-12            # global minimum <= sector minimum <= any ansatz energy
+
+
+def test_problem_fci_energy_on_h2o(SV):
+    """chem.Problem.fci_energy (Lanczos on the sector tables of the problem's UCCSD program) against the determinant-space
+    FCI of the SCF front-end, H2O / STO-3G (14 qubits, 441 determinants in the (5 alpha, 5 beta) sector)"""
+    from openvqe_amd import chem
+    mol = chem.molecule("H2O")
+    mol.rhf()
+    e_fci = mol.ci_ground_state()[0]
+    assert abs(mol.problem(active=False).fci_energy() - e_fci) < 1e-9
