@@ -13,14 +13,16 @@
 //     precomputed pair lists (slot_i, slot_j, sign, pattern) in LDS and writes the tile back contiguously.  Compact tiles are
 //     small, so M is 16 where the dense tiles stop at 12-13: a third of the sweeps, and 27x less data per sweep.
 //   * <H>: the Hamiltonian restricted to the support is MATERIALISED once per (program, Hamiltonian): for every sweep of a
-//     tile cover of the x-groups and every tile, the list of (slot_i, slot_j, H_ij) with H_ij != 0.  An evaluation streams
+//     tile cover of the x-groups and every tile, the matrix elements H_ij != 0 between its entries.  An evaluation streams
 //     that list once against the tile's amplitudes in LDS: HBM-bound, no Pauli arithmetic left.  The matrix elements of the
 //     x-groups with three or more mixing bits (double excitations: 96 % of the elements) take few distinct magnitudes per
 //     sweep, so they are stored as ONE 32-bit word (slot_j, sign, index into the sweep's dictionary of magnitudes: 4 bytes
 //     per element); the others (diagonal, single-excitation-like groups: occupation-dependent values) keep an explicit
 //     double (12 bytes).  Elements are kept row by row in slices of 64 entries (lane = row), see "ROW format" below.
 //
-// All tables are built on the device (radix sort of the permuted indices, binary search of partners inside a tile).
+// All tables are built on the device (radix sort of the permuted indices; partners inside a tile from a dense LDS map
+// local key -> slot, or a binary search in the tile's sorted keys when the tile's index bits exceed 16).
+// The same tables serve ovqe_energy_gradient (lambda = H psi + backward sweeps) and ovqe_sector_ground_state (Lanczos).
 #pragma once
 #include "sv_kernels.hpp"
 
