@@ -213,6 +213,23 @@ def gate_and_midsize_workloads(device):
             if sector:
                 row24["ms_steady_state"] = min(times[2:])
                 row24[label]["table_GB"] = info["sector_bytes"] / 1e9
+                # the path's two kernels under HIP events (on the handle's stream): circuit sweeps, <H> table stream
+                sv.set_option("sector_profile", 1)
+                circ_us, exp_us = [], []
+                for _ in range(5):
+                    sv.energy(th24)
+                    pi = sv.program_info()
+                    circ_us.append(pi["sector_circuit_us"])
+                    exp_us.append(pi["sector_expect_us"])
+                sv.set_option("sector_profile", 0)
+                hb = sv.program_info()["sector_h_stream_bytes"]
+                t_exp = 1e-6 * float(np.mean(exp_us))
+                row24[label]["roofline_expect_kernel"] = {
+                    "bound": "hbm", "kernel": "k_sector_expect (materialised <H>: one pass over the table per evaluation)",
+                    "achieved": hb / t_exp / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / t_exp / 1e9 / HBM_PEAK_GBS,
+                    "bytes_per_launch": hb, "avg_launch_ms": 1e3 * t_exp,
+                    "traffic_source": "profiles/r2_sector/pmc_summary.txt (FETCH_SIZE x2)"}
+                row24[label]["circuit_sweeps_ms"] = 1e-3 * float(np.mean(circ_us))
             # exact gradient of all parameters (adjoint method; on the sector tables when they exist)
             tg = []
             for _ in range(2):
@@ -558,6 +575,9 @@ def main():
             if m3 and n2:
                 out["summary_24_qubits"] = {
                     "uccsd_evaluation_ms": m3["sector_path"]["ms_steady_state"],
+                    "uccsd_evaluation_hamiltonian_kernel": {k: m3["sector_path"]["roofline_expect_kernel"][k]
+                                                            for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")},
+                    "uccsd_evaluation_circuit_sweeps_ms": m3["sector_path"]["circuit_sweeps_ms"],
                     "uccsd_evaluation_ms_dense_state": m3["dense_state_compact_cover"]["ms_steady_state"],
                     "uccsd_gradient_1715_parameters_ms": m3["sector_path"]["ms_gradient_all_parameters"],
                     "uccsd_gradient_ms_dense_state": m3["dense_state_compact_cover"]["ms_gradient_all_parameters"],

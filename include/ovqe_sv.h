@@ -244,7 +244,9 @@ int ovqe_last_batch_ms(ovqe_handle h, double *ms);
  *   [12] 1 when streaming energies of this program keep the state as 2^n real amplitudes
  *   [13..15] support-compacted program: ops, active pairs per evaluation, entries of the restricted Hamiltonian
  *   [16..21] sector path (0 until its tables exist): support size, circuit sweeps, active pairs per evaluation, <H> sweeps
- *   (0: circuit only, <H> by the compact cover), matrix elements of the materialised Hamiltonian, table bytes */
+ *   (0: circuit only, <H> by the compact cover), matrix elements of the materialised Hamiltonian (padding included), table
+ *   bytes  [22..24] with option "sector_profile" = 1: HIP-event time in microseconds of the circuit sweeps and of the <H>
+ *   kernel of the most recent sector evaluation; bytes that kernel reads per evaluation */
 int ovqe_program_info(ovqe_handle h, int64_t *info, int count);
 
 #ifdef __cplusplus

@@ -110,6 +110,9 @@ struct SectorEngine {
     DevBuf d_lam[2], d_w, d_wpart;   // adjoint gradient: lambda (ping-pong), per-entry sums, per-tile partials
     size_t budget = 0;
     int h_max_dict = 0;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // option "sector_profile": start / after the sweeps / after <H>
+    float last_circuit_ms = 0.f, last_expect_ms = 0.f;
+    size_t h_stream_bytes = 0;    // bytes k_sector_expect reads per evaluation (elements + index arrays)
 };
 
 }  // namespace
@@ -196,6 +199,7 @@ struct ovqe_sv {
     int opt_sector_dict = 1;      // dictionary coding of the double-excitation-like matrix elements
     int opt_sector_tile_cap = 6500;   // amplitudes per circuit tile (up to 14000 for energies; gradients on the tables hold two tiles in LDS: <= 6500)
     int opt_sector_sparsity = 4;  // the support must be at most 1/this of the register
+    int opt_sector_profile = 0;   // 1: HIP events around the circuit and the <H> kernel of every sector evaluation (program_info)
     int opt_sector_debug = 0;     // measurements only (1: circuit sweeps without their ops — wrong results)
     int opt_sector_h_groups = 128; // workgroups per <H> sweep (they share the sweep's tiles round robin)
     float last_batch_ms = 0.f;
@@ -2381,6 +2385,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     } else if (k == "sector_threads") h->opt_sector_threads = (value == 0 || value == 64 || value == 512 || value == 1024) ? (int)value : 256;
     else if (k == "sector_h_groups") h->opt_sector_h_groups = (int)value;
     else if (k == "sector_debug") h->opt_sector_debug = (int)value;
+    else if (k == "sector_profile") h->opt_sector_profile = (int)value;
     else if (k == "sector_sparsity" || k == "sector_tile_cap") {
         (k == "sector_sparsity" ? h->opt_sector_sparsity : h->opt_sector_tile_cap) = (int)value;
         free_sector(h->sec);
@@ -3445,9 +3450,11 @@ int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
     for (const SmallOp &op : h->ops) v[2] += (op.kind == OP_X || op.kind == OP_H || op.kind == OP_CNOT);
     for (int i = 0; i < count && i < 16; ++i) info[i] = v[i];
     const SectorEngine &E = h->sec;
-    const int64_t sv[6] = {E.valid ? (int64_t)E.K : 0, E.valid ? (int64_t)E.segs.size() : 0, E.valid ? (int64_t)E.npairs : 0,
-                           E.valid ? (int64_t)E.hs.size() : 0, E.valid ? (int64_t)E.nnz : 0, E.valid ? (int64_t)E.bytes : 0};
-    for (int i = 16; i < count && i < 22; ++i) info[i] = sv[i - 16];
+    const int64_t sv[9] = {E.valid ? (int64_t)E.K : 0, E.valid ? (int64_t)E.segs.size() : 0, E.valid ? (int64_t)E.npairs : 0,
+                           E.valid ? (int64_t)E.hs.size() : 0, E.valid ? (int64_t)E.nnz : 0, E.valid ? (int64_t)E.bytes : 0,
+                           E.valid ? (int64_t)(1e3 * E.last_circuit_ms) : 0, E.valid ? (int64_t)(1e3 * E.last_expect_ms) : 0,
+                           E.valid ? (int64_t)E.h_stream_bytes : 0};
+    for (int i = 16; i < count && i < 25; ++i) info[i] = sv[i - 16];
     return OVQE_OK;
 }
 
