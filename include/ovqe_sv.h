@@ -206,7 +206,8 @@ int ovqe_apply_exp_pauli_sum(ovqe_handle h, int64_t T, const uint64_t *x, const 
  * ALL K derivatives, where the reference's BFGS (jac=None, ref:openvqe/ucc_family/get_energy_ucc.py:158-175) spends K+1
  * evaluations on forward differences (opt-in, because exact derivatives change the
  * optimiser's iterates at the 1e-8 level).  Streaming kernels, any n; the state buffer is left in |hf>.  A real-amplitude
- * program with sector tables (option "sector") runs the whole pass on them from its second call on: forward circuit,
+ * program with sector tables (option "sector"; built by the first gradient call when they do not exist yet) runs the whole
+ * pass on them: forward circuit,
  * lambda = H psi from the materialised Hamiltonian, backward sweeps over the pair lists. */
 int ovqe_energy_gradient(ovqe_handle h, const double *theta, int32_t K, double *energy, double *grad);
 

@@ -214,8 +214,8 @@ def test_sector_adjoint_gradient(SV, m, o, bits, coded):
         sv.set_option("sector_dict", coded)        # 0: explicit doubles for every matrix element
         sv.set_hamiltonian(ham)
         sv.set_ucc_program(gens, hf)
-        e1, g1 = sv.energy_gradient(th1)          # dense states (first evaluation of the pair)
-        e2, g2 = sv.energy_gradient(th1)          # builds the tables, runs on them
+        e1, g1 = sv.energy_gradient(th1)          # the first gradient call builds the tables and runs on them
+        e2, g2 = sv.energy_gradient(th1)
         e3, g3 = sv.energy_gradient(th2)
         e3b = sv.energy(th2)
         info = sv.program_info()
