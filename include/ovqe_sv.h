@@ -90,7 +90,7 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * instead of over all pairs; skipped work is multiplication by exact zeros; default 4, 0 = never),
  * "compact" (1, default: compact cover — from the second evaluation of a (program, Hamiltonian) pair on, <H> of a
  * real-amplitude streaming energy runs over a compact copy of the state's support),
- * "sector" (1, default: sector path — from the second evaluation on, a real-amplitude program whose states occupy at most
+ * "sector" (1, default: sector path — from the second energy evaluation (or the first gradient call) on, a real-amplitude program whose states occupy at most
  * 1/4 of the register runs entirely on that support: circuit over compact tiles from precomputed pair lists, <H> from the
  * Hamiltonian materialised on the support; results equal the dense kernels' up to rounding; the tables live in device
  * memory next to the state), "sector_max_gb" (table budget, default 128, also capped at 60 % of the free device memory;
