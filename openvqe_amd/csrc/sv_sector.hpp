@@ -905,14 +905,18 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint(const double *__restrict_
         }
     }
 }
-// w[r] = sum over the tiles of wpart[tile][r] (fixed order), r over the whole angle table
+// w[r] = sum over the tiles of wpart[tile][r] (fixed order), r over the whole angle table: 64 entries per workgroup, the
+// tiles dealt to its four waves, the four partial sums added in wave order
 __global__ __launch_bounds__(256) void k_sec_reduce_w(const double *__restrict__ wpart, uint32_t ntiles, int nrot,
                                                       double *__restrict__ w) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= nrot) return;
+    __shared__ double part[4][64];
+    const int r = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     double tsum = 0.0;
-    for (uint32_t t = 0; t < ntiles; ++t) tsum += wpart[(size_t)t * nrot + r];
-    w[r] = tsum;
+    if (r < nrot)
+        for (uint32_t t = g; t < ntiles; t += 4u) tsum += wpart[(size_t)t * nrot + r];
+    part[g][threadIdx.x & 63] = tsum;
+    __syncthreads();
+    if (g == 0 && r < nrot) w[r] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 // ---- Lanczos on the support (ovqe_sector_ground_state): vectors of K doubles in the circuit's final order --------------
