@@ -82,7 +82,9 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * keeps the amplitudes real; streaming energies (n >= 15) then store the state as 2^n doubles: half the HBM bytes per
  * sweep, one more mixing bit per LDS tile; ovqe_prepare_state always delivers the complex state),
  * "apply_min_tiles" (sigma = H psi uses the tile cover from this many tiles on, default 256; the gather
- * kernel below), "clifford_frame" (read by the NEXT ovqe_set_gate_program: 0 = execute the literal gate list; 1 (default) = when
+ * kernel below), "lanczos_keep_gb" (ovqe_ground_state keeps its Lanczos vectors in HBM up to this many GB — and never more than half
+ * of the free memory — so that one pass of the recurrence gives the Ritz vector; default 96; 0, or vectors that do not fit: the
+ * recurrence is run twice), "clifford_frame" (read by the NEXT ovqe_set_gate_program: 0 = execute the literal gate list; 1 (default) = when
  * the Clifford part of the list — X, H, CNOT, quarter-turn rotations — multiplies to the identity, run the
  * algebraically identical sequence of Pauli rotations with conjugated strings instead; 2 = always, Clifford part
  * appended literally), "expect_sparse" (tiled <H>: a tile in which at most 1/value of the amplitudes are non-zero — the

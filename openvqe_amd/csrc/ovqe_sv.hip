@@ -197,6 +197,7 @@ struct ovqe_sv {
     int opt_sector_h = 1;         // materialise <H> on the support when it fits the budget
     int opt_sector_h_bits = 0;    // index bits per <H> tile (0 = automatic: 300 .. 600 amplitudes per tile)
     int opt_sector_dict = 1;      // dictionary coding of the double-excitation-like matrix elements
+    int opt_lanczos_keep_gb = 96;     // ovqe_ground_state keeps its Lanczos vectors in HBM up to this many GB (one pass); 0 = always two passes
     int opt_sector_tile_cap = 6500;   // amplitudes per circuit tile (up to 14000 for energies; gradients on the tables hold two tiles in LDS: <= 6500)
     int opt_sector_sparsity = 4;  // the support must be at most 1/this of the register
     int opt_sector_profile = 0;   // 1: HIP events around the circuit and the <H> kernel of every sector evaluation (program_info)
@@ -2395,6 +2396,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
         h->sec.seen = 0;
         h->sec.prog_version = -1;
     }
+    else if (k == "lanczos_keep_gb") h->opt_lanczos_keep_gb = (int)value;
     else if (k == "rot_variant") h->opt_rot_variant = (int)value;
     else if (k == "real_stream") h->opt_real_stream = (int)value;
     else if (k == "apply_min_tiles") h->opt_apply_min_tiles = (int)value;
@@ -3229,6 +3231,23 @@ extern "C" int ovqe_ground_state(ovqe_handle h, double tol, int max_iter, uint64
     std::vector<double> alpha, beta, s;
     double lam = 0.0, est = 0.0;
     int m = 0;
+    // One pass while the Lanczos vectors fit in HBM (24 qubits: 256 MiB each, 150 of them = 40 GB of the 288): v_0..v_j stay
+    // where they were written and the Ritz vector is their combination.  Beyond the budget ("lanczos_keep_gb", and never more
+    // than half of the free memory) the kept vectors are dropped and the recurrence is run a second time for the Ritz vector.
+    std::vector<amp_t *> kept;
+    size_t keep_budget = 0;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            keep_budget = std::min<size_t>((size_t)std::max(h->opt_lanczos_keep_gb, 0) << 30, free_b / 2);
+    }
+    const size_t vec_bytes = h->namps * sizeof(amp_t);
+    bool keeping = keep_budget >= 8 * vec_bytes;
+    auto drop_kept = [&]() {
+        for (amp_t *v : kept) (void)hipFree(v);
+        kept.clear();
+        keeping = false;
+    };
     auto recurrence = [&](bool accumulate) -> int {
         amp_t *A = h->scratch[0], *B = h->scratch[1], *C = tmp;  // v_{j-1}, v_j, w
         int r = L.start(B, seed);
@@ -3261,6 +3280,23 @@ extern "C" int ovqe_ground_state(ovqe_handle h, double tol, int max_iter, uint64
                 beta.push_back(bj);
             }
             hipLaunchKernelGGL(k_scale, dim3(L.nb), dim3(256), 0, h->stream, C, h->namps, 1.0 / bj);
+            if (!accumulate && keeping) {
+                // v_j (B) has served as v_{j-1}'s successor: it stays in `kept` from here on; the three working buffers are
+                // re-filled from fresh allocations as long as the budget lasts.  A (v_{j-1}) is already kept or is a work buffer.
+                amp_t *fresh = nullptr;
+                if ((kept.size() + 1) * vec_bytes <= keep_budget && hipMalloc((void **)&fresh, vec_bytes) == hipSuccess) {
+                    // keep a copy of v_j: device-to-device copy at HBM rate (0.1 ms at 24 qubits) next to a 40 ms H psi
+                    if (hipMemcpyAsync(fresh, B, vec_bytes, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) {
+                        (void)hipFree(fresh);
+                        drop_kept();
+                    } else {
+                        kept.push_back(fresh);
+                    }
+                } else {
+                    (void)hipGetLastError();
+                    drop_kept();
+                }
+            }
             amp_t *t = A;
             A = B;
             B = C;
@@ -3272,7 +3308,21 @@ extern "C" int ovqe_ground_state(ovqe_handle h, double tol, int max_iter, uint64
         return OVQE_OK;
     };
     rc = recurrence(false);       // pass 1: the tridiagonal matrix
-    if (!rc) rc = recurrence(true);  // pass 2: the Ritz vector, same recurrence
+    if (!rc && keeping && (int)kept.size() == m - 1) {
+        // kept = v_0..v_{m-2}; v_{m-1} is the vector the last step multiplied, still in its work buffer: scratch[(m-1) % 3 ...]
+        // (the rotation A <- B <- C <- A moves one buffer per step, starting from B = scratch[1])
+        amp_t *ring[3] = {h->scratch[1], tmp, h->scratch[0]};
+        const amp_t *vlast = ring[(m - 1) % 3];
+        for (int j = 0; j < m; ++j)
+            hipLaunchKernelGGL(k_axpy_real, dim3(L.nb), dim3(256), 0, h->stream, h->state, j < m - 1 ? (const amp_t *)kept[j] : vlast,
+                               s[j], h->namps, j == 0 ? 1 : 0);
+        if (hipGetLastError() != hipSuccess) rc = fail(h, OVQE_ERR_HIP, "ground_state: launch failed");
+    } else if (!rc) {
+        drop_kept();
+        rc = recurrence(true);  // pass 2: the Ritz vector, same recurrence
+    }
+    if (hipStreamSynchronize(h->stream) != hipSuccess && !rc) rc = fail(h, OVQE_ERR_HIP, "ground_state: sync failed");
+    drop_kept();
     double true_res = 0.0;
     if (!rc) {
         // normalise, Rayleigh quotient and true residual |H y - lambda y|

@@ -502,6 +502,26 @@ def test_ground_state_lanczos(SV, n, kind):
         assert abs(overlap - 1.0) < 1e-8, overlap
 
 
+def test_ground_state_one_pass_and_two_pass_agree(SV):
+    """ovqe_ground_state with its Lanczos vectors kept in HBM (one pass, default) and with the recurrence run twice
+    ("lanczos_keep_gb" = 0): same tridiagonal matrix, same Ritz vector"""
+    from openvqe_amd import fermion
+    H, _, _ = fermion.synthetic_molecule(8, 4, seed=5)
+    out = []
+    for keep in (96, 0):
+        with SV(16) as sv:
+            sv.set_option("lanczos_keep_gb", keep)
+            sv.set_hamiltonian(H)
+            e, res, its = sv.ground_state(tol=1e-11)
+            out.append((e, res, its, sv.get_state()))
+    (e1, r1, i1, v1), (e2, r2, i2, v2) = out
+    assert i1 == i2 and i1 > 8
+    assert abs(e1 - e2) < 1e-11
+    assert max(r1, r2) < 1e-6
+    assert abs(abs(np.vdot(v1, v2)) - 1.0) < 1e-10
+    assert np.max(np.abs(v1 - v2)) < 1e-9
+
+
 def _fd_gradient(fun, theta, step=1e-5):
     g = np.zeros_like(theta)
     for k in range(len(theta)):

@@ -23,6 +23,13 @@ orig_action = fav.ucc_action
 def timed_action(*a, **k):
     t = time.perf_counter(); r = orig_action(*a, **k); marks.append(("energy", time.perf_counter() - t)); return r
 fav.ucc_action = timed_action
+def _timed(name):
+    orig = getattr(fav, name)
+    def wrapper(*a, **k):
+        t = time.perf_counter(); r = orig(*a, **k); marks.append((name, time.perf_counter() - t)); return r
+    setattr(fav, name, wrapper)
+for name in ("_ground_space", "fun_fidelity", "prepare_adapt_state", "prepare_state_ansatz", "hf_energy"):
+    _timed(name)
 try:
     with contextlib.redirect_stdout(buf):
         trace, result = fav.fermionic_adapt_vqe(None, None, None, ham, pool, hf, 1, -109.0745445341, "COBYLA", 1e-6, "norm", 1e-3, iters)
@@ -31,5 +38,8 @@ except Exception:
 wall = time.perf_counter() - t0
 scr = [d for k, d in marks if k == "screen"]; en = [d for k, d in marks if k == "energy"]
 print(f"wall={wall:.1f}s screens={len(scr)} ({np.mean(scr)*1e3:.0f} ms each) energy evaluations={len(en)} (median {np.median(en)*1e3:.2f} ms, total {sum(en):.2f}s)")
+for name in ("_ground_space", "fun_fidelity", "prepare_adapt_state", "prepare_state_ansatz", "hf_energy"):
+    d = [x for k, x in marks if k == name]
+    print(f"  {name}: {len(d)} calls, {sum(d):.2f}s")
 print({k: v for k, v in result.items() if not isinstance(v, (list, dict))})
 print("energies", trace.get("energies", trace)[:10] if isinstance(trace, dict) else trace)

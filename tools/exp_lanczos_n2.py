@@ -1,0 +1,17 @@
+"""device Lanczos over the whole 24-qubit register for N2 / cc-pVDZ (10e,12o) (the fun_fidelity reference vector of the ADAPT
+mirrors, ref:openvqe/adapt/fermionic_adapt_vqe.py:474): iterations, wall time, time per H psi"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from openvqe_amd import chem
+from openvqe_amd.backend import Statevector
+mol = chem.molecule("N2-CCPVDZ"); mol.rhf()
+prob = chem.cas_problem(mol, 2, 12)
+ham = prob.jw_hamiltonian()
+tol = float(sys.argv[1]) if len(sys.argv) > 1 else 1e-10
+sv = Statevector(ham.nbqbits)
+t = time.perf_counter(); sv.set_hamiltonian(ham); print(f"set_hamiltonian {time.perf_counter()-t:.2f}s", flush=True)
+for rep in range(2):
+    t = time.perf_counter(); e, r, it = sv.ground_state(tol=tol); dt = time.perf_counter() - t
+    print(f"ground_state tol={tol:g}: E={e:.10f} residual={r:.2e} iterations={it} wall={dt:.2f}s -> {dt/(2*it)*1e3:.2f} ms per step", flush=True)
+print(sv.program_info() if False else "")
