@@ -262,6 +262,12 @@ class Statevector:
         self._ck(self._L.ovqe_last_batch_ms(self._h, ctypes.byref(out)))
         return out.value
 
+    def last_screen_support(self):
+        """non-zero amplitudes the last ``pool_gradients`` call walked instead of the register (-1: the register)"""
+        out = ctypes.c_int64()
+        self._ck(self._L.ovqe_last_screen_support(self._h, ctypes.byref(out)))
+        return out.value
+
     def energy_gradient(self, theta):
         """E(theta) and the exact gradient dE/dtheta by the adjoint method (one forward + one backward pass over the
         program for all K derivatives) -> (energy, grad[K])"""

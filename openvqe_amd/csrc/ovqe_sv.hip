@@ -168,6 +168,9 @@ struct ovqe_sv {
     DevBuf d_sp_ops, d_sp_pairs, d_sp_entries;
     // device copy of the ADAPT pool of the last ovqe_pool_gradients call (+ its host image for the change test)
     DevBuf d_pg_off, d_pg_xs, d_pg_terms, d_pg_out, d_pg_part;
+    DevBuf d_nz_cnt, d_nz_start, d_nz_idx, d_nz_val;  // support list of the screened state (k_pool_grad_nz)
+    int opt_screen_sparse = 16;   // the ADAPT screen walks the support of psi when it is at most 1/this of the register (0 = never)
+    int64_t last_screen_support = -1;  // support size seen by the last ovqe_pool_gradients call (-1: register walked)
     std::vector<int64_t> pg_off;
     std::vector<uint64_t> pg_xs;
     std::vector<HTerm> pg_terms;
@@ -2328,7 +2331,7 @@ int ovqe_destroy(ovqe_handle h) {
                                   &h->d_stream,
                                   &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups, &h->d_eterms, &h->d_echunks,
                                   &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries, &h->d_pg_off, &h->d_pg_xs, &h->d_pg_terms,
-                                  &h->d_pg_out, &h->d_pg_part, &h->cc.d_sup, &h->cc.d_psic, &h->cc.d_loc, &h->cc.d_cid, &h->cc.d_off, &h->cc.d_sweeps};
+                                  &h->d_pg_out, &h->d_pg_part, &h->d_nz_cnt, &h->d_nz_start, &h->d_nz_idx, &h->d_nz_val, &h->cc.d_sup, &h->cc.d_psic, &h->cc.d_loc, &h->cc.d_cid, &h->cc.d_off, &h->cc.d_sweeps};
     for (TilePlan *tp : {&h->tp, &h->tp_adhoc, &h->tp_real}) bufs.insert(bufs.end(), {&tp->d_tops, &tp->d_trots});
     for (HamDev *H : {&h->ham, &h->ham_adhoc, &h->ham_real})
         bufs.insert(bufs.end(), {&H->d_groups, &H->d_terms, &H->d_tchunks, &H->d_tgroups, &H->d_tterms, &H->d_tflats,
@@ -2397,6 +2400,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
         h->sec.prog_version = -1;
     }
     else if (k == "lanczos_keep_gb") h->opt_lanczos_keep_gb = (int)value;
+    else if (k == "screen_sparse") h->opt_screen_sparse = (int)std::max<int64_t>(0, value);
     else if (k == "rot_variant") h->opt_rot_variant = (int)value;
     else if (k == "real_stream") h->opt_real_stream = (int)value;
     else if (k == "apply_min_tiles") h->opt_apply_min_tiles = (int)value;
@@ -3047,8 +3051,41 @@ int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, co
             h->pg_terms.swap(terms);
             h->pg_valid = true;
         }
+        // the support of psi, when it is a small part of the register (exact zeros outside: ovqe_apply_exp_pauli_sum and the
+        // rotation sweeps never write an amplitude they do not reach)
+        uint64_t support = 0;
+        bool on_support = false;
+        h->last_screen_support = -1;
+        if (h->opt_screen_sparse > 0 && h->n_global == 0 && h->namps >= 4096) {
+            const uint64_t per_block = 256ull * NZ_PER_THREAD;
+            const unsigned nbk = (unsigned)((h->namps + per_block - 1) / per_block);
+            rc = ensure(h, h->d_nz_cnt, (size_t)nbk * sizeof(uint32_t));
+            if (!rc) rc = ensure(h, h->d_nz_start, (size_t)nbk * sizeof(uint64_t));
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_nz_count, dim3(nbk), dim3(256), 0, h->stream, (const amp_t *)h->state, h->namps, (uint32_t *)h->d_nz_cnt.p);
+            std::vector<uint32_t> cnt(nbk);
+            hipError_t e = hipMemcpyAsync(cnt.data(), h->d_nz_cnt.p, (size_t)nbk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) return fail(h, OVQE_ERR_HIP, std::string("pool_gradients: ") + hipGetErrorString(e));
+            std::vector<uint64_t> start(nbk);
+            for (unsigned b = 0; b < nbk; ++b) {
+                start[b] = support;
+                support += cnt[b];
+            }
+            if (support > 0 && support * (uint64_t)h->opt_screen_sparse <= h->namps) {
+                rc = upload(h, h->d_nz_start, start.data(), (size_t)nbk * sizeof(uint64_t));
+                if (!rc) rc = ensure(h, h->d_nz_idx, support * sizeof(uint64_t));
+                if (!rc) rc = ensure(h, h->d_nz_val, support * sizeof(amp_t));
+                if (rc) return rc;
+                hipLaunchKernelGGL(k_nz_fill, dim3(nbk), dim3(256), 0, h->stream, (const amp_t *)h->state, h->namps,
+                                   (const uint64_t *)h->d_nz_start.p, (uint64_t *)h->d_nz_idx.p, (amp_t *)h->d_nz_val.p);
+                on_support = true;
+                h->last_screen_support = (int64_t)support;
+            }
+        }
         // one workgroup per operator while the state re-streams from L2/MALL; above that 2^16 amplitudes per workgroup
-        const int nchunks = h->n_local <= 22 ? 1 : (int)(h->namps >> 16);
+        const int nchunks = on_support ? (int)std::min<uint64_t>(256, (support + 65535) >> 16)
+                                       : h->n_local <= 22 ? 1 : (int)(h->namps >> 16);
         const int64_t ops_per_launch = 32768;
         rc = ensure(h, h->d_pg_out, n_ops * sizeof(double2));
         if (!rc && nchunks > 1)
@@ -3058,10 +3095,16 @@ int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, co
             const int64_t cnt = std::min<int64_t>(ops_per_launch, n_ops - op0);
             double2 *out = (double2 *)h->d_pg_out.p + op0;
             double2 *part = nchunks > 1 ? (double2 *)h->d_pg_part.p : out;
-            hipLaunchKernelGGL(k_pool_grad, dim3((unsigned)nchunks, (unsigned)cnt), dim3(256), 0, h->stream,
-                               (const amp_t *)sig, (const amp_t *)h->state, h->namps, h->base,
-                               (const int64_t *)h->d_pg_off.p, (const uint64_t *)h->d_pg_xs.p,
-                               (const HTerm *)h->d_pg_terms.p, op0, part);
+            if (on_support)
+                hipLaunchKernelGGL(k_pool_grad_nz, dim3((unsigned)nchunks, (unsigned)cnt), dim3(256), 0, h->stream,
+                                   (const amp_t *)sig, (const uint64_t *)h->d_nz_idx.p, (const amp_t *)h->d_nz_val.p, support,
+                                   h->base, (const int64_t *)h->d_pg_off.p, (const uint64_t *)h->d_pg_xs.p,
+                                   (const HTerm *)h->d_pg_terms.p, op0, part);
+            else
+                hipLaunchKernelGGL(k_pool_grad, dim3((unsigned)nchunks, (unsigned)cnt), dim3(256), 0, h->stream,
+                                   (const amp_t *)sig, (const amp_t *)h->state, h->namps, h->base,
+                                   (const int64_t *)h->d_pg_off.p, (const uint64_t *)h->d_pg_xs.p,
+                                   (const HTerm *)h->d_pg_terms.p, op0, part);
             if (nchunks > 1)
                 hipLaunchKernelGGL(k_reduce_rows2, dim3((unsigned)cnt), dim3(256), 0, h->stream, (const double2 *)part,
                                    nchunks, out);
@@ -3507,6 +3550,13 @@ int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
                            E.valid ? (int64_t)(1e3 * E.last_circuit_ms) : 0, E.valid ? (int64_t)(1e3 * E.last_expect_ms) : 0,
                            E.valid ? (int64_t)E.h_stream_bytes : 0};
     for (int i = 16; i < count && i < 25; ++i) info[i] = sv[i - 16];
+    return OVQE_OK;
+}
+
+int ovqe_last_screen_support(ovqe_handle h, int64_t *support) {
+    OVQE_ENTER(h);
+    if (!h || !support) return OVQE_ERR_INVALID;
+    *support = h->last_screen_support;
     return OVQE_OK;
 }
 

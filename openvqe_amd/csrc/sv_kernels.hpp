@@ -481,6 +481,87 @@ __global__ __launch_bounds__(256) void k_pool_grad(const amp_t *__restrict__ sig
     if (threadIdx.x == 0) partials[(size_t)(op - op0) * gridDim.x + blockIdx.x] = t;
 }
 
+// ---- the same screen over the SUPPORT of psi -------------------------------------------------------------------------
+// An ADAPT state of a few operators occupies a few determinants of the register (at most the particle-number / spin sector
+// of the reference determinant): val_k only has contributions from kets j with psi_j != 0.  The support is listed once per
+// screen (ascending indices, so the summation order is fixed) and every operator walks the list instead of the register.
+constexpr int NZ_PER_THREAD = 8;
+__global__ __launch_bounds__(256) void k_nz_count(const amp_t *__restrict__ st, uint64_t namps, uint32_t *__restrict__ counts) {
+    __shared__ uint32_t w[4];
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * NZ_PER_THREAD;
+    uint32_t c = 0;
+    for (int k = 0; k < NZ_PER_THREAD; ++k)
+        if (i0 + k < namps) {
+            const amp_t a = st[i0 + k];
+            if (a.x != 0.0 || a.y != 0.0) ++c;
+        }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+// ascending indices and amplitudes of the non-zero entries; start[b] = exclusive sum of counts
+__global__ __launch_bounds__(256) void k_nz_fill(const amp_t *__restrict__ st, uint64_t namps, const uint64_t *__restrict__ start,
+                                                 uint64_t *__restrict__ idx, amp_t *__restrict__ val) {
+    __shared__ uint32_t w[4];
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * NZ_PER_THREAD;
+    amp_t a[NZ_PER_THREAD];
+    uint32_t c = 0;
+    for (int k = 0; k < NZ_PER_THREAD; ++k) {
+        a[k] = i0 + k < namps ? st[i0 + k] : make_double2(0.0, 0.0);
+        if (a[k].x != 0.0 || a[k].y != 0.0) ++c;
+    }
+    uint32_t incl = c;   // inclusive scan inside the wave
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if ((int)(threadIdx.x & 63) >= o) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t pos = start[blockIdx.x] + incl - c;
+    for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) pos += w[k];
+    for (int k = 0; k < NZ_PER_THREAD; ++k)
+        if (a[k].x != 0.0 || a[k].y != 0.0) {
+            idx[pos] = i0 + k;
+            val[pos++] = a[k];
+        }
+}
+
+// block (chunk c, operator k): the slice [c, c+1) * count / gridDim.x of the support list; same value as k_pool_grad
+__global__ __launch_bounds__(256) void k_pool_grad_nz(const amp_t *__restrict__ sig, const uint64_t *__restrict__ idx,
+                                                      const amp_t *__restrict__ val, uint64_t count, uint64_t base,
+                                                      const int64_t *__restrict__ offsets, const uint64_t *__restrict__ xs,
+                                                      const HTerm *__restrict__ terms, int64_t op0, double2 *__restrict__ partials) {
+    __shared__ double2 red[4];
+    const int64_t op = op0 + blockIdx.y;
+    const uint64_t e0 = count * blockIdx.x / gridDim.x, e1 = count * (blockIdx.x + 1ull) / gridDim.x;
+    double2 acc = make_double2(0.0, 0.0);
+    const int64_t t1 = offsets[op + 1];
+    for (int64_t t = offsets[op]; t < t1;) {
+        const uint64_t x = xs[t];
+        int64_t te = t + 1;
+        while (te < t1 && xs[te] == x) ++te;
+        for (uint64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+            const uint64_t jl = idx[e];
+            const amp_t k = val[e], b = sig[jl ^ x];
+            double cr = 0.0, ci = 0.0;
+            for (int64_t u = t; u < te; ++u) {
+                const HTerm ht = terms[u];
+                const bool neg = parity64((base | jl) & ht.z);
+                cr += neg ? -ht.cr : ht.cr;
+                ci += neg ? -ht.ci : ht.ci;
+            }
+            const double vx = b.x * k.x + b.y * k.y;
+            const double vy = b.x * k.y - b.y * k.x;
+            acc.x += cr * vx - ci * vy;
+            acc.y += cr * vy + ci * vx;
+        }
+        t = te;
+    }
+    double2 t = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) partials[(size_t)(op - op0) * gridDim.x + blockIdx.x] = t;
+}
+
 // out[row] = sum of the row's `count` double2 partials (fixed order)
 __global__ __launch_bounds__(256) void k_reduce_rows2(const double2 *__restrict__ partials, int count,
                                                       double2 *__restrict__ out) {

@@ -727,6 +727,25 @@ __global__ __launch_bounds__(NT) void k_tile_apply(const amp_t *__restrict__ in,
         acc[j] = make_double2(0.0, 0.0);
         tile[tile_swz_v(threadIdx.x + j * NT)] = self[j];
     }
+    {
+        // a tile of zeros contributes nothing (the ADAPT state of a few operators, a UCC state's particle-number sector:
+        // most tiles of the register): the sweep then costs this tile its read only
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < TRIPS; ++j) any |= self[j].x != 0.0 || self[j].y != 0.0;
+        if (!__syncthreads_or(any)) {
+            if (first) {
+#pragma unroll
+                for (int j = 0; j < TRIPS; ++j) {
+                    v2d r;
+                    r.x = 0.0;
+                    r.y = 0.0;
+                    q[tb | glow | spread_bits((uint32_t)j, sw.mask_hi)] = r;
+                }
+            }
+            return;
+        }
+    }
     for (int ch = sw.a0; ch < sw.a1; ++ch) {
         const ExChunkT ck = chunks[ch];
         __syncthreads();

@@ -188,6 +188,48 @@ def test_pool_gradients_and_exact_exponential(SV, n):
         assert np.abs(sv.get_state() - ref).max() < 1e-11
 
 
+@pytest.mark.parametrize("n,nnz", [(12, 1), (14, 37), (16, 3000), (16, 5000)])
+def test_pool_gradients_on_the_support_of_psi(SV, n, nnz):
+    """ovqe_pool_gradients over the list of non-zero amplitudes ("screen_sparse": the ADAPT state of a few operators) against
+    the pass over the register and against the bit-mask oracle; complex amplitudes, complex pool coefficients, both modes"""
+    from openvqe_amd.operators import Hamiltonian, Term, pack_terms
+    from oracle import masks
+    rng = np.random.default_rng(900 + n + nnz)
+    H = random_hamiltonian(rng, n, 40)
+    pool = []
+    for _ in range(23):
+        terms = []
+        for _ in range(int(rng.integers(1, 9))):
+            op, qs = random_string(rng, n)
+            terms.append(Term(complex(rng.normal(), rng.normal()), op, qs))
+        pool.append(Hamiltonian(n, terms, do_clean_up=False))
+    psi = np.zeros(1 << n, complex)
+    where = rng.choice(1 << n, size=nnz, replace=False)
+    psi[where] = rng.normal(size=nnz) + 1j * rng.normal(size=nnz)
+    psi /= np.linalg.norm(psi)
+    hx, hz, hc = H.packed()
+    sigma = masks.apply_pauli_sum(psi, hx, hz, hc) + H.constant_coeff * psi
+    vals = []
+    for op in pool:
+        px, pz, pc = pack_terms(n, op.terms)
+        vals.append(np.vdot(sigma, masks.apply_pauli_sum(psi, px, pz, pc)))
+    vals = np.array(vals)
+    scale = max(1.0, np.abs(hc).sum()) * max(np.abs(pack_terms(n, op.terms)[2]).sum() for op in pool)
+    with SV(n) as sv:
+        sv.set_hamiltonian(H)
+        sv.set_state(psi)
+        got = {}
+        for den in (16, 0):
+            sv.set_option("screen_sparse", den)
+            got[den] = (np.array(sv.pool_gradients(pool, 0)), np.array(sv.pool_gradients(pool, 1)))
+            expect_list = den > 0 and nnz * den <= (1 << n)
+            assert sv.last_screen_support() == (nnz if expect_list else -1)
+    for den in (16, 0):
+        assert np.abs(got[den][0] - 2.0 * vals.real).max() < 1e-12 * scale
+        assert np.abs(got[den][1] - 2.0 * np.abs(vals)).max() < 1e-12 * scale
+    assert np.abs(got[16][0] - got[0][0]).max() < 1e-13 * scale
+
+
 def test_errors_are_reported(SV):
     from openvqe_amd._lib import BackendError
     with SV(3) as sv:
