@@ -84,7 +84,8 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * "apply_min_tiles" (sigma = H psi uses the tile cover from this many tiles on, default 256; the gather
  * kernel below), "screen_sparse" (ovqe_pool_gradients: when at most 1/value of the amplitudes of psi are non-zero — an ADAPT state of a few
  * operators lives on a few determinants — the bilinear forms <sigma|A_i|psi> are summed over the list of those amplitudes (ascending
- * index, fixed order) instead of over the register; default 16, 0 = never), "lanczos_keep_gb" (ovqe_ground_state keeps its Lanczos vectors in HBM up to this many GB — and never more than half
+ * index, fixed order) instead of over the register; ovqe_apply_exp_pauli_sum: the Taylor steps run over the closure of that list
+ * under the operator's x-groups while it stays within the same bound, bit-identical amplitudes; default 16, 0 = never), "lanczos_keep_gb" (ovqe_ground_state keeps its Lanczos vectors in HBM up to this many GB — and never more than half
  * of the free memory — so that one pass of the recurrence gives the Ritz vector; default 96; 0, or vectors that do not fit: the
  * recurrence is run twice), "clifford_frame" (read by the NEXT ovqe_set_gate_program: 0 = execute the literal gate list; 1 (default) = when
  * the Clifford part of the list — X, H, CNOT, quarter-turn rotations — multiplies to the identity, run the
@@ -241,9 +242,10 @@ int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, 
 /* device time in ms of the most recent ovqe_energy_batch launch (HIP events) */
 int ovqe_last_batch_ms(ovqe_handle h, double *ms);
 
-/* number of non-zero amplitudes the last ovqe_pool_gradients call walked instead of the register ("screen_sparse"), or -1 when
- * it walked the register (dense state, sharded register, option off) */
-int ovqe_last_screen_support(ovqe_handle h, int64_t *support);
+/* amplitudes the last ovqe_pool_gradients call (which = 0) or ovqe_apply_exp_pauli_sum call (which = 1) walked instead of the
+ * register ("screen_sparse"): the support of psi, resp. its closure under the operator's x-groups; -1 when the call walked the
+ * register (dense state, sharded register, option off) */
+int ovqe_last_support(ovqe_handle h, int32_t which, int64_t *support);
 /* shape of the compiled program (diagnostics / tests), up to `count` entries of:
  *   [0] ops of the sequential program  [1] Pauli rotations  [2] literal X/H/CNOT ops  [3] streaming sweeps per
  *   evaluation  [4] of those, LDS-tiled multi-op sweeps  [5] ops of the fused-kernel program

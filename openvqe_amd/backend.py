@@ -265,7 +265,13 @@ class Statevector:
     def last_screen_support(self):
         """non-zero amplitudes the last ``pool_gradients`` call walked instead of the register (-1: the register)"""
         out = ctypes.c_int64()
-        self._ck(self._L.ovqe_last_screen_support(self._h, ctypes.byref(out)))
+        self._ck(self._L.ovqe_last_support(self._h, 0, ctypes.byref(out)))
+        return out.value
+
+    def last_exp_support(self):
+        """amplitudes the Taylor steps of the last ``apply_exp_pauli_sum`` call ran over (-1: the register)"""
+        out = ctypes.c_int64()
+        self._ck(self._L.ovqe_last_support(self._h, 1, ctypes.byref(out)))
         return out.value
 
     def energy_gradient(self, theta):

@@ -168,8 +168,9 @@ struct ovqe_sv {
     DevBuf d_sp_ops, d_sp_pairs, d_sp_entries;
     // device copy of the ADAPT pool of the last ovqe_pool_gradients call (+ its host image for the change test)
     DevBuf d_pg_off, d_pg_xs, d_pg_terms, d_pg_out, d_pg_part;
-    DevBuf d_nz_cnt, d_nz_start, d_nz_idx, d_nz_val;  // support list of the screened state (k_pool_grad_nz)
+    DevBuf d_nz_cnt, d_nz_start, d_nz_idx, d_nz_val, d_nz_bitmap;  // support list of the screened state (k_pool_grad_nz)
     int opt_screen_sparse = 16;   // the ADAPT screen walks the support of psi when it is at most 1/this of the register (0 = never)
+    int64_t last_exp_support = -1;     // amplitudes the last ovqe_apply_exp_pauli_sum call's Taylor steps ran over (-1: the register)
     int64_t last_screen_support = -1;  // support size seen by the last ovqe_pool_gradients call (-1: register walked)
     std::vector<int64_t> pg_off;
     std::vector<uint64_t> pg_xs;
@@ -2331,7 +2332,7 @@ int ovqe_destroy(ovqe_handle h) {
                                   &h->d_stream,
                                   &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups, &h->d_eterms, &h->d_echunks,
                                   &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries, &h->d_pg_off, &h->d_pg_xs, &h->d_pg_terms,
-                                  &h->d_pg_out, &h->d_pg_part, &h->d_nz_cnt, &h->d_nz_start, &h->d_nz_idx, &h->d_nz_val, &h->cc.d_sup, &h->cc.d_psic, &h->cc.d_loc, &h->cc.d_cid, &h->cc.d_off, &h->cc.d_sweeps};
+                                  &h->d_pg_out, &h->d_pg_part, &h->d_nz_cnt, &h->d_nz_start, &h->d_nz_idx, &h->d_nz_val, &h->d_nz_bitmap, &h->cc.d_sup, &h->cc.d_psic, &h->cc.d_loc, &h->cc.d_cid, &h->cc.d_off, &h->cc.d_sweeps};
     for (TilePlan *tp : {&h->tp, &h->tp_adhoc, &h->tp_real}) bufs.insert(bufs.end(), {&tp->d_tops, &tp->d_trots});
     for (HamDev *H : {&h->ham, &h->ham_adhoc, &h->ham_real})
         bufs.insert(bufs.end(), {&H->d_groups, &H->d_terms, &H->d_tchunks, &H->d_tgroups, &H->d_tterms, &H->d_tflats,
@@ -2995,6 +2996,41 @@ int ovqe_energy(ovqe_handle h, const double *theta, int32_t K, double *energy) {
     return ovqe_energy_batch(h, 1, theta, K, energy);
 }
 
+// Ascending list of the non-zero amplitudes of the state (d_nz_idx, d_nz_val) when they are at most 1/"screen_sparse" of the
+// register; capacity: room for this many indices (0 = the support itself).
+static int list_support(ovqe_handle h, uint64_t *support, bool *listed, uint64_t capacity) {
+    *support = 0;
+    *listed = false;
+    if (h->opt_screen_sparse <= 0 || h->n_global != 0 || h->namps < 4096) return OVQE_OK;
+    const uint64_t per_block = 256ull * NZ_PER_THREAD;
+    const unsigned nbk = (unsigned)((h->namps + per_block - 1) / per_block);
+    int rc = ensure(h, h->d_nz_cnt, (size_t)nbk * sizeof(uint32_t));
+    if (!rc) rc = ensure(h, h->d_nz_start, (size_t)nbk * sizeof(uint64_t));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_nz_count, dim3(nbk), dim3(256), 0, h->stream, (const amp_t *)h->state, h->namps, (uint32_t *)h->d_nz_cnt.p);
+    std::vector<uint32_t> cnt(nbk);
+    hipError_t e = hipMemcpyAsync(cnt.data(), h->d_nz_cnt.p, (size_t)nbk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail(h, OVQE_ERR_HIP, std::string("support list: ") + hipGetErrorString(e));
+    std::vector<uint64_t> start(nbk);
+    uint64_t total = 0;
+    for (unsigned b = 0; b < nbk; ++b) {
+        start[b] = total;
+        total += cnt[b];
+    }
+    *support = total;
+    if (total == 0 || total * (uint64_t)h->opt_screen_sparse > h->namps) return OVQE_OK;
+    rc = upload(h, h->d_nz_start, start.data(), (size_t)nbk * sizeof(uint64_t));
+    if (!rc) rc = ensure(h, h->d_nz_idx, std::max(total, capacity) * sizeof(uint64_t));
+    if (!rc) rc = ensure(h, h->d_nz_val, total * sizeof(amp_t));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_nz_fill, dim3(nbk), dim3(256), 0, h->stream, (const amp_t *)h->state, h->namps,
+                       (const uint64_t *)h->d_nz_start.p, (uint64_t *)h->d_nz_idx.p, (amp_t *)h->d_nz_val.p);
+    HIPC(h, hipGetLastError());
+    *listed = true;
+    return OVQE_OK;
+}
+
 // ---- ADAPT --------------------------------------------------------------------------------------
 int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, const uint64_t *x, const uint64_t *z,
                         const double *coeff_re, const double *coeff_im, int mode, double *grads) {
@@ -3056,33 +3092,9 @@ int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, co
         uint64_t support = 0;
         bool on_support = false;
         h->last_screen_support = -1;
-        if (h->opt_screen_sparse > 0 && h->n_global == 0 && h->namps >= 4096) {
-            const uint64_t per_block = 256ull * NZ_PER_THREAD;
-            const unsigned nbk = (unsigned)((h->namps + per_block - 1) / per_block);
-            rc = ensure(h, h->d_nz_cnt, (size_t)nbk * sizeof(uint32_t));
-            if (!rc) rc = ensure(h, h->d_nz_start, (size_t)nbk * sizeof(uint64_t));
-            if (rc) return rc;
-            hipLaunchKernelGGL(k_nz_count, dim3(nbk), dim3(256), 0, h->stream, (const amp_t *)h->state, h->namps, (uint32_t *)h->d_nz_cnt.p);
-            std::vector<uint32_t> cnt(nbk);
-            hipError_t e = hipMemcpyAsync(cnt.data(), h->d_nz_cnt.p, (size_t)nbk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-            if (e != hipSuccess) return fail(h, OVQE_ERR_HIP, std::string("pool_gradients: ") + hipGetErrorString(e));
-            std::vector<uint64_t> start(nbk);
-            for (unsigned b = 0; b < nbk; ++b) {
-                start[b] = support;
-                support += cnt[b];
-            }
-            if (support > 0 && support * (uint64_t)h->opt_screen_sparse <= h->namps) {
-                rc = upload(h, h->d_nz_start, start.data(), (size_t)nbk * sizeof(uint64_t));
-                if (!rc) rc = ensure(h, h->d_nz_idx, support * sizeof(uint64_t));
-                if (!rc) rc = ensure(h, h->d_nz_val, support * sizeof(amp_t));
-                if (rc) return rc;
-                hipLaunchKernelGGL(k_nz_fill, dim3(nbk), dim3(256), 0, h->stream, (const amp_t *)h->state, h->namps,
-                                   (const uint64_t *)h->d_nz_start.p, (uint64_t *)h->d_nz_idx.p, (amp_t *)h->d_nz_val.p);
-                on_support = true;
-                h->last_screen_support = (int64_t)support;
-            }
-        }
+        rc = list_support(h, &support, &on_support, 0);
+        if (rc) return rc;
+        if (on_support) h->last_screen_support = (int64_t)support;
         // one workgroup per operator while the state re-streams from L2/MALL; above that 2^16 amplitudes per workgroup
         const int nchunks = on_support ? (int)std::min<uint64_t>(256, (support + 65535) >> 16)
                                        : h->n_local <= 22 ? 1 : (int)(h->namps >> 16);
@@ -3149,17 +3161,65 @@ int ovqe_apply_exp_pauli_sum(ovqe_handle h, int64_t T, const uint64_t *x, const 
     rc = upload(h, dg, groups.data(), groups.size() * sizeof(HGroup));
     if (!rc) rc = upload(h, dt, terms.data(), terms.size() * sizeof(HTerm));
     const int nb = reduce_blocks(h->namps);
+    // A state of a few determinants (the ADAPT state while the ansatz is short): the series only reaches the closure of its
+    // support under the operator's x-groups.  The closure is listed once ("screen_sparse" bounds it) and every Taylor step
+    // runs over the list; amplitudes equal the pass over the register bit for bit.
+    uint64_t reach = 0;
+    bool listed = false;
+    h->last_exp_support = -1;
+    if (!rc && h->opt_screen_sparse > 0) {
+        const uint64_t cap = h->namps / (uint64_t)h->opt_screen_sparse;
+        rc = list_support(h, &reach, &listed, cap);
+        if (!rc && listed) {
+            const size_t words = (size_t)std::max<uint64_t>(1, h->namps >> 5);
+            rc = ensure(h, h->d_nz_bitmap, words * sizeof(uint32_t) + 16);
+            unsigned long long *d_total = nullptr;
+            if (!rc) {
+                d_total = (unsigned long long *)((char *)h->d_nz_bitmap.p + words * sizeof(uint32_t) + (8 - (words * sizeof(uint32_t)) % 8) % 8);
+                unsigned long long t0 = reach;
+                hipError_t e = hipMemsetAsync(h->d_nz_bitmap.p, 0, words * sizeof(uint32_t), h->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(d_total, &t0, sizeof(t0), hipMemcpyHostToDevice, h->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                if (e != hipSuccess) rc = fail(h, OVQE_ERR_HIP, "exp_pauli_sum: support bitmap");
+            }
+            if (!rc) {
+                hipLaunchKernelGGL(k_support_mark, dim3((unsigned)((reach + 255) / 256)), dim3(256), 0, h->stream,
+                                   (const uint64_t *)h->d_nz_idx.p, reach, (uint32_t *)h->d_nz_bitmap.p);
+                uint64_t first = 0, last = reach;
+                for (int round = 0; round < 4096 && !rc && listed && first < last; ++round) {
+                    hipLaunchKernelGGL(k_support_expand, dim3((unsigned)((last - first + 255) / 256)), dim3(256), 0, h->stream,
+                                       (uint64_t *)h->d_nz_idx.p, first, last, cap, h->base, (const HGroup *)dg.p, (int)groups.size(),
+                                       (const HTerm *)dt.p, (uint32_t *)h->d_nz_bitmap.p, d_total);
+                    unsigned long long total = 0;
+                    hipError_t e = hipMemcpyAsync(&total, d_total, sizeof(total), hipMemcpyDeviceToHost, h->stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                    if (e != hipSuccess) rc = fail(h, OVQE_ERR_HIP, std::string("exp_pauli_sum: ") + hipGetErrorString(e));
+                    if (total > cap) listed = false;   // the series fills too much of the register: walk it
+                    first = last;
+                    last = total;
+                }
+                reach = last;
+            }
+        }
+    }
+    if (!rc && listed) h->last_exp_support = (int64_t)reach;
     for (int s = 0; s < steps && !rc; ++s) {
         amp_t *va = h->scratch[0], *vb = h->scratch[1];
         hipError_t e = hipMemcpyAsync(va, h->state, h->namps * sizeof(amp_t), hipMemcpyDeviceToDevice, h->stream);
+        if (e == hipSuccess && listed && s == 0) e = hipMemsetAsync(vb, 0, h->namps * sizeof(amp_t), h->stream);
         if (e != hipSuccess) {
             rc = fail(h, OVQE_ERR_HIP, "exp_pauli_sum: copy failed");
             break;
         }
         for (int m = 1; m <= M; ++m) {
-            hipLaunchKernelGGL(k_apply_sum, dim3(nb), dim3(256), 0, h->stream, vb, (const amp_t *)va, h->state, h->namps,
-                               h->base, (const HGroup *)dg.p, (int)groups.size(), (const HTerm *)dt.p, tau / m, 0.0, 0.0,
-                               0.0);
+            if (listed)
+                hipLaunchKernelGGL(k_apply_sum_list, dim3((unsigned)((reach + 255) / 256)), dim3(256), 0, h->stream, vb,
+                                   (const amp_t *)va, h->state, (const uint64_t *)h->d_nz_idx.p, reach, h->base,
+                                   (const HGroup *)dg.p, (int)groups.size(), (const HTerm *)dt.p, tau / m, 0.0);
+            else
+                hipLaunchKernelGGL(k_apply_sum, dim3(nb), dim3(256), 0, h->stream, vb, (const amp_t *)va, h->state, h->namps,
+                                   h->base, (const HGroup *)dg.p, (int)groups.size(), (const HTerm *)dt.p, tau / m, 0.0, 0.0,
+                                   0.0);
             std::swap(va, vb);
         }
         if (hipGetLastError() != hipSuccess) rc = fail(h, OVQE_ERR_HIP, "exp_pauli_sum: launch failed");
@@ -3553,10 +3613,10 @@ int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
     return OVQE_OK;
 }
 
-int ovqe_last_screen_support(ovqe_handle h, int64_t *support) {
+int ovqe_last_support(ovqe_handle h, int32_t which, int64_t *support) {
     OVQE_ENTER(h);
-    if (!h || !support) return OVQE_ERR_INVALID;
-    *support = h->last_screen_support;
+    if (!h || !support || which < 0 || which > 1) return OVQE_ERR_INVALID;
+    *support = which == 0 ? h->last_screen_support : h->last_exp_support;
     return OVQE_OK;
 }
 

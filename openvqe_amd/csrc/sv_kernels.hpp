@@ -408,6 +408,78 @@ __global__ __launch_bounds__(256) void k_apply_sum(amp_t *__restrict__ out, cons
     }
 }
 
+// The same step for the listed output indices only (Taylor steps of exp(theta A) on a state of a few determinants: every
+// index the series can reach is in the list, k_support_expand; the buffers hold zeros elsewhere).  Same arithmetic, same
+// order: the listed amplitudes equal k_apply_sum's bit for bit.
+__global__ __launch_bounds__(256) void k_apply_sum_list(amp_t *__restrict__ out, const amp_t *__restrict__ in,
+                                                        amp_t *__restrict__ acc, const uint64_t *__restrict__ idx,
+                                                        uint64_t count, uint64_t base, const HGroup *__restrict__ groups,
+                                                        int ngroups, const HTerm *__restrict__ terms, double scale_re,
+                                                        double scale_im) {
+    const uint64_t e = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (e >= count) return;
+    const uint64_t i = idx[e];
+    double sx = 0.0, sy = 0.0;
+    for (int g = 0; g < ngroups; ++g) {
+        const HGroup gr = groups[g];
+        const uint64_t jl = i ^ gr.x;
+        const amp_t k = in[jl];
+        const uint64_t gj = base | jl;
+        double dr = 0.0, di = 0.0;
+        for (int t = gr.t0; t < gr.t1; ++t) {
+            const HTerm ht = terms[t];
+            const bool neg = parity64(gj & ht.z);
+            dr += neg ? -ht.cr : ht.cr;
+            di += neg ? -ht.ci : ht.ci;
+        }
+        sx += dr * k.x - di * k.y;
+        sy += dr * k.y + di * k.x;
+    }
+    amp_t r;
+    r.x = scale_re * sx - scale_im * sy;
+    r.y = scale_re * sy + scale_im * sx;
+    out[i] = r;
+    if (acc) {
+        amp_t a = acc[i];
+        a.x += r.x;
+        a.y += r.y;
+        acc[i] = a;
+    }
+}
+
+// bitmap of the listed indices
+__global__ __launch_bounds__(256) void k_support_mark(const uint64_t *__restrict__ idx, uint64_t count, uint32_t *__restrict__ bitmap) {
+    const uint64_t e = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (e < count) atomicOr(&bitmap[idx[e] >> 5], 1u << (idx[e] & 31));
+}
+// one round of the closure of the list under the operator's x-groups: ket j = idx[e], e in [first, last), reaches j ^ x_g when
+// D_g(j) != 0; indices not yet in the bitmap are appended behind position *total (capacity cap: *total may run past it, the
+// host then falls back to the pass over the register)
+__global__ __launch_bounds__(256) void k_support_expand(uint64_t *__restrict__ idx, uint64_t first, uint64_t last, uint64_t cap,
+                                                        uint64_t base, const HGroup *__restrict__ groups, int ngroups,
+                                                        const HTerm *__restrict__ terms, uint32_t *__restrict__ bitmap,
+                                                        unsigned long long *__restrict__ total) {
+    const uint64_t e = first + (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (e >= last) return;
+    const uint64_t jl = idx[e], gj = base | jl;
+    for (int g = 0; g < ngroups; ++g) {
+        const HGroup gr = groups[g];
+        double dr = 0.0, di = 0.0;
+        for (int t = gr.t0; t < gr.t1; ++t) {
+            const HTerm ht = terms[t];
+            const bool neg = parity64(gj & ht.z);
+            dr += neg ? -ht.cr : ht.cr;
+            di += neg ? -ht.ci : ht.ci;
+        }
+        if (dr == 0.0 && di == 0.0) continue;
+        const uint64_t i = jl ^ gr.x;
+        const uint32_t bit = 1u << (i & 31);
+        if (atomicOr(&bitmap[i >> 5], bit) & bit) continue;
+        const unsigned long long pos = atomicAdd(total, 1ull);
+        if (pos < cap) idx[pos] = i;
+    }
+}
+
 // out_i (+)= sum_g D_g(jbase_g | (i ^ x_g)) in_{i ^ x_g}: a Pauli sum applied to an explicit ket buffer that may be ANOTHER
 // shard of a distributed register (jbase = the global index bits of that shard); accumulate = 0 overwrites out
 __global__ __launch_bounds__(256) void k_apply_terms(amp_t *__restrict__ out, const amp_t *__restrict__ in, uint64_t namps,

@@ -230,6 +230,44 @@ def test_pool_gradients_on_the_support_of_psi(SV, n, nnz):
     assert np.abs(got[16][0] - got[0][0]).max() < 1e-13 * scale
 
 
+@pytest.mark.parametrize("m,o", [(6, 3), (8, 4)])
+def test_exact_exponentials_on_the_reachable_support(SV, m, o):
+    """ovqe_apply_exp_pauli_sum with its Taylor steps over the closure of the support ("screen_sparse") against the pass over
+    the register: bit-identical states; the chain of spin-adapted generators from the Hartree-Fock determinant (the
+    prepare_adapt_state of the ADAPT mirrors, ref:openvqe/adapt/fermionic_adapt_vqe.py:12-38) stays inside the particle-number
+    sector, and matches scipy's expm_multiply on the oracle's matrices at the smaller size"""
+    from openvqe_amd import fermion, pools
+    n = 2 * m
+    _, _, hf = fermion.synthetic_molecule(m, o, seed=3)
+    _, _, pool = pools.singlet_sd(2 * o, m)
+    rng = np.random.default_rng(m)
+    picks = rng.choice(len(pool), size=6, replace=False)
+    thetas = rng.uniform(-0.8, 0.8, len(picks))
+    states, reach = {}, {}
+    for den in (16, 0):
+        with SV(n) as sv:
+            sv.set_option("screen_sparse", den)
+            sv.init_basis(hf)
+            reach[den] = []
+            for k, th in zip(picks, thetas):
+                sv.apply_exp_pauli_sum(pool[k], th)
+                reach[den].append(sv.last_exp_support())
+            states[den] = sv.get_state()
+    assert all(r == -1 for r in reach[0])
+    assert all(0 < r <= (1 << n) // 16 for r in reach[16]), reach[16]
+    assert reach[16][0] <= 16 and reach[16][-1] >= reach[16][0]
+    assert np.array_equal(states[16], states[0])
+    assert abs(np.linalg.norm(states[16]) - 1.0) < 1e-12
+    occupied = np.flatnonzero(np.abs(states[16]) > 1e-13)   # (rounding residues of cancelling coefficients aside)
+    assert all(bin(int(i)).count("1") == 2 * o for i in occupied)
+    if n <= 12:
+        mats = [dense.operator_matrix(pool[k], sparse=True, with_constant=False) for k in picks]
+        psi0 = np.zeros(1 << n, complex)
+        psi0[hf] = 1.0
+        ref = dense.exact_exp_state(psi0, mats, list(thetas))
+        assert np.abs(states[16] - ref).max() < 1e-11
+
+
 def test_errors_are_reported(SV):
     from openvqe_amd._lib import BackendError
     with SV(3) as sv:
