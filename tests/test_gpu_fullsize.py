@@ -370,3 +370,50 @@ def test_26_qubit_uccsd_sector_path(gpu_lib):
     for a, b in zip(res[1][0], res[0][0]):
         assert abs(a - b) < 1e-10 * l1
     assert abs(res[1][0][1] - e_hf) < 1e-10 * l1
+
+
+def test_24_qubit_adapt_screens_and_qubit_adapt_on_n2(gpu_lib, capsys):
+    """configs[3]'s molecule through the ADAPT side of the path: the screen state prod_k exp(theta_k A_k)|HF> of
+    five spin-adapted generators and both screens (fermionic 2 Re, qubit 2 |.|) over the support of psi against the passes over the
+    whole 2^24 register (bit-identical state, screens to 1e-12); then three macro-iterations of the qubit-ADAPT mirror
+    (ref:openvqe/adapt/qubit_adapt_vqe.py:310-605): energies fall monotonically from the RHF energy and stay above FCI"""
+    from openvqe_amd import chem, pools
+    from openvqe_amd.adapt import qubit_adapt_vqe as qav
+    from openvqe_amd.backend import GRAD_FERMIONIC, GRAD_QUBIT, Statevector
+    mol = chem.molecule("N2-CCPVDZ")
+    e_rhf = mol.rhf()
+    prob = chem.cas_problem(mol, 2, 12)
+    ham = prob.jw_hamiltonian()
+    _, _, spin_ops, _, hf = prob.uccsd()
+    _, _, singlets = pools.singlet_sd(10, 12)
+    _, strings = pools.generate_pool_from_cluster("full_without_Z", spin_ops, 24)
+    capsys.readouterr()
+    picks, thetas = [3, 200, 411, 77, 640], [0.2, -0.15, 0.1, 0.3, -0.25]
+    out = {}
+    for den in (16, 0):
+        with Statevector(24) as sv:
+            sv.set_option("screen_sparse", den)
+            sv.set_hamiltonian(ham)
+            sv.init_basis(hf)
+            reach = []
+            for k, th in zip(picks, thetas):
+                sv.apply_exp_pauli_sum(singlets[k], th)
+                reach.append(sv.last_exp_support())
+            g_f = np.array(sv.pool_gradients(singlets, GRAD_FERMIONIC))
+            walked = sv.last_screen_support()
+            g_q = np.array(sv.pool_gradients(strings[::7], GRAD_QUBIT))
+            out[den] = (reach, walked, g_f, g_q, sv.norm2(), sv.expectation(ham))
+    assert all(r == -1 for r in out[0][0]) and out[0][1] == -1
+    assert all(0 < r < 4096 for r in out[16][0]) and 1 < out[16][1] <= out[16][0][-1]
+    l1 = float(np.abs(ham.packed()[2]).sum())
+    assert np.abs(out[16][2] - out[0][2]).max() < 1e-12 * l1
+    assert np.abs(out[16][3] - out[0][3]).max() < 1e-12 * l1
+    assert np.abs(out[16][2]).max() > 1e-3                       # a live screen, not zeros against zeros
+    assert abs(out[16][4] - 1.0) < 1e-12 and out[16][4] == out[0][4]
+    assert out[16][5] == out[0][5]                               # same state bit for bit: same <H>
+    trace, _, result, _ = qav.qubit_adapt_vqe(ham, None, None, 24, strings, hf, -109.0765315037, n_max_grads=1, adapt_maxiter=3,
+                                              method_sim="BFGS")
+    capsys.readouterr()
+    energies = [float(e) for e in trace["energies"]]
+    assert len(energies) == 3
+    assert e_rhf - 1e-9 > energies[0] > energies[1] > energies[2] > -109.0765315037
