@@ -40,6 +40,15 @@ __device__ __forceinline__ uint64_t insert_zero(uint64_t k, int p) {
     return ((k & ~low) << 1) | (k & low);
 }
 __device__ __forceinline__ int parity64(uint64_t v) { return __popcll(v) & 1; }
+// (-1)^popcount as a double, from the parity bit by integer arithmetic (bit 0 of the count shifted into the sign of 1.0):
+// accumulating fma(c, sign, acc) is the same exactly-rounded sum as acc += parity ? -c : c at half the VALU instructions
+// (no compare / 64-bit select)
+__device__ __forceinline__ double parity_sign(uint32_t v) {
+    return __hiloint2double((int)(((uint32_t)__popc(v) << 31) | 0x3FF00000u), 0);
+}
+__device__ __forceinline__ double parity_sign64(uint64_t v) {
+    return __hiloint2double((int)(((uint32_t)__popcll(v) << 31) | 0x3FF00000u), 0);
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -294,9 +303,9 @@ __global__ __launch_bounds__(256) void k_bilinear(const amp_t *__restrict__ bra,
             double dr = 0.0, di = 0.0;
             for (int t = gr.t0; t < gr.t1; ++t) {
                 const HTerm ht = terms[t];
-                const bool neg = parity64(gj & ht.z);
-                dr += neg ? -ht.cr : ht.cr;
-                di += neg ? -ht.ci : ht.ci;
+                const double sg = parity_sign64(gj & ht.z);
+                dr = fma(ht.cr, sg, dr);
+                di = fma(ht.ci, sg, di);
             }
             // v = conj(b) * k
             const double vx = b.x * k.x + b.y * k.y;
@@ -341,9 +350,9 @@ __global__ __launch_bounds__(256) void k_expect_pairs(const amp_t *__restrict__ 
                 double dr = 0.0, di = 0.0;
                 for (int t = gr.t0; t < gr.t1; ++t) {
                     const HTerm ht = terms[t];
-                    const bool neg = parity64(gj & ht.z);
-                    dr += neg ? -ht.cr : ht.cr;
-                    di += neg ? -ht.ci : ht.ci;
+                    const double sg = parity_sign64(gj & ht.z);
+                    dr = fma(ht.cr, sg, dr);
+                    di = fma(ht.ci, sg, di);
                 }
                 const double vx = a.x * c.x + a.y * c.y;  // conj(a_i) a_j
                 const double vy = a.x * c.y - a.y * c.x;
@@ -388,9 +397,9 @@ __global__ __launch_bounds__(256) void k_apply_sum(amp_t *__restrict__ out, cons
             double dr = 0.0, di = 0.0;
             for (int t = gr.t0; t < gr.t1; ++t) {
                 const HTerm ht = terms[t];
-                const bool neg = parity64(gj & ht.z);
-                dr += neg ? -ht.cr : ht.cr;
-                di += neg ? -ht.ci : ht.ci;
+                const double sg = parity_sign64(gj & ht.z);
+                dr = fma(ht.cr, sg, dr);
+                di = fma(ht.ci, sg, di);
             }
             sx += dr * k.x - di * k.y;
             sy += dr * k.y + di * k.x;
@@ -428,9 +437,9 @@ __global__ __launch_bounds__(256) void k_apply_sum_list(amp_t *__restrict__ out,
         double dr = 0.0, di = 0.0;
         for (int t = gr.t0; t < gr.t1; ++t) {
             const HTerm ht = terms[t];
-            const bool neg = parity64(gj & ht.z);
-            dr += neg ? -ht.cr : ht.cr;
-            di += neg ? -ht.ci : ht.ci;
+            const double sg = parity_sign64(gj & ht.z);
+            dr = fma(ht.cr, sg, dr);
+            di = fma(ht.ci, sg, di);
         }
         sx += dr * k.x - di * k.y;
         sy += dr * k.y + di * k.x;
@@ -467,9 +476,9 @@ __global__ __launch_bounds__(256) void k_support_expand(uint64_t *__restrict__ i
         double dr = 0.0, di = 0.0;
         for (int t = gr.t0; t < gr.t1; ++t) {
             const HTerm ht = terms[t];
-            const bool neg = parity64(gj & ht.z);
-            dr += neg ? -ht.cr : ht.cr;
-            di += neg ? -ht.ci : ht.ci;
+            const double sg = parity_sign64(gj & ht.z);
+            dr = fma(ht.cr, sg, dr);
+            di = fma(ht.ci, sg, di);
         }
         if (dr == 0.0 && di == 0.0) continue;
         const uint64_t i = jl ^ gr.x;
@@ -496,9 +505,9 @@ __global__ __launch_bounds__(256) void k_apply_terms(amp_t *__restrict__ out, co
             double dr = 0.0, di = 0.0;
             for (int t = gr.t0; t < gr.t1; ++t) {
                 const HTerm ht = terms[t];
-                const bool neg = parity64(gj & ht.z);
-                dr += neg ? -ht.cr : ht.cr;
-                di += neg ? -ht.ci : ht.ci;
+                const double sg = parity_sign64(gj & ht.z);
+                dr = fma(ht.cr, sg, dr);
+                di = fma(ht.ci, sg, di);
             }
             sx += dr * k.x - di * k.y;
             sy += dr * k.y + di * k.x;
@@ -538,9 +547,9 @@ __global__ __launch_bounds__(256) void k_pool_grad(const amp_t *__restrict__ sig
             double cr = 0.0, ci = 0.0;
             for (int64_t u = t; u < te; ++u) {
                 const HTerm ht = terms[u];
-                const bool neg = parity64((base | jl) & ht.z);
-                cr += neg ? -ht.cr : ht.cr;
-                ci += neg ? -ht.ci : ht.ci;
+                const double sg = parity_sign64((base | jl) & ht.z);
+                cr = fma(ht.cr, sg, cr);
+                ci = fma(ht.ci, sg, ci);
             }
             const double vx = b.x * k.x + b.y * k.y;
             const double vy = b.x * k.y - b.y * k.x;
@@ -619,9 +628,9 @@ __global__ __launch_bounds__(256) void k_pool_grad_nz(const amp_t *__restrict__ 
             double cr = 0.0, ci = 0.0;
             for (int64_t u = t; u < te; ++u) {
                 const HTerm ht = terms[u];
-                const bool neg = parity64((base | jl) & ht.z);
-                cr += neg ? -ht.cr : ht.cr;
-                ci += neg ? -ht.ci : ht.ci;
+                const double sg = parity_sign64((base | jl) & ht.z);
+                cr = fma(ht.cr, sg, cr);
+                ci = fma(ht.ci, sg, ci);
             }
             const double vx = b.x * k.x + b.y * k.y;
             const double vy = b.x * k.y - b.y * k.x;

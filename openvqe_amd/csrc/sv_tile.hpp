@@ -532,16 +532,16 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
                 for (int t = 0; t < nt; ++t) {
                     const ExTermLds l = gt[t];
 #pragma unroll
-                    for (int m = 0; m < PP; ++m) dr[m] += (__popc(jj[m] & l.zin) & 1) ? -l.cr : l.cr;
+                    for (int m = 0; m < PP; ++m) dr[m] = fma(l.cr, parity_sign(jj[m] & l.zin), dr[m]);
                 }
             } else {
                 for (int t = 0; t < nt; ++t) {
                     const ExTermLds l = gt[t];
 #pragma unroll
                     for (int m = 0; m < PP; ++m) {
-                        const bool neg = __popc(jj[m] & l.zin) & 1;
-                        dr[m] += neg ? -l.cr : l.cr;
-                        di[m] += neg ? -l.ci : l.ci;
+                        const double sg = parity_sign(jj[m] & l.zin);
+                        dr[m] = fma(l.cr, sg, dr[m]);
+                        di[m] = fma(l.ci, sg, di[m]);
                     }
                 }
             }
@@ -779,9 +779,11 @@ __global__ __launch_bounds__(NT) void k_tile_apply(const amp_t *__restrict__ in,
                 const ExTermLds l = lt[t];
 #pragma unroll
                 for (int j = 0; j < TRIPS; ++j) {
-                    const bool neg = __popc(je[j] & l.zin) & 1;
-                    dr[j] += neg ? -l.cr : l.cr;
-                    di[j] += neg ? -l.ci : l.ci;
+                    // +-1.0 from the parity bit (3 integer ops), then one exact FMA per component: half the VALU work of
+                    // compare + select + add
+                    const double sg = parity_sign(je[j] & l.zin);
+                    dr[j] = fma(l.cr, sg, dr[j]);
+                    di[j] = fma(l.ci, sg, di[j]);
                 }
             }
 #pragma unroll
