@@ -628,6 +628,9 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
                         aterms.push_back(et);
                     }
                     ag.t1 = (int32_t)aterms.size();
+                    ag.pad = 1;   // bit 0: every folded coefficient of the piece is real (a real-symmetric H: all of them)
+                    for (int32_t t = ag.t0; t < ag.t1; ++t)
+                        if (aterms[t].ci != 0.0) ag.pad = 0;
                     agroups.push_back(ag);
                 }
             }

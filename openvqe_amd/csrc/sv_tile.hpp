@@ -775,6 +775,19 @@ __global__ __launch_bounds__(NT) void k_tile_apply(const amp_t *__restrict__ in,
                 dr[j] = 0.0;
                 di[j] = 0.0;
             }
+            if (__builtin_amdgcn_readfirstlane(gr.pad) & 1) {   // real coefficients only (every group of a real-symmetric H)
+                for (int t = t0; t < t1; ++t) {
+                    const ExTermLds l = lt[t];
+#pragma unroll
+                    for (int j = 0; j < TRIPS; ++j) dr[j] = fma(l.cr, parity_sign(je[j] & l.zin), dr[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < TRIPS; ++j) {
+                    acc[j].x += dr[j] * k[j].x;
+                    acc[j].y += dr[j] * k[j].y;
+                }
+                continue;
+            }
             for (int t = t0; t < t1; ++t) {
                 const ExTermLds l = lt[t];
 #pragma unroll
