@@ -302,6 +302,35 @@ def gate_and_midsize_workloads(device):
                                                    "ms_per_gradient_call_steady": 1e3 * float(np.median(calls[2:])) if len(calls) > 2 else None}
         rown["quccsd_gate_list_at_theta_mp2"] = {"literal_gates": len(gates), "energy": float(e_q), "ms_first_call": times[0],
                                                  "ms_steady_state": min(times[2:]), "program": sv.program_info()}
+    # the ADAPT side of the same molecule: screen state of five spin-adapted generators (exact exponentials), the screen
+    # over the 665-operator singlet pool, and sigma = H psi / the fun_fidelity reference vector over the whole register
+    from openvqe_amd import pools
+    from openvqe_amd.backend import GRAD_FERMIONIC
+    _, _, singlets = pools.singlet_sd(10, 12)
+    with Statevector(prob.nbqbits, device=device) as sv:
+        sv.set_hamiltonian(hamn)
+        adapt = {"pool_operators": len(singlets)}
+        for label, den in (("support", 16), ("register", 0)):
+            sv.set_option("screen_sparse", den)
+            t_exp, t_scr = [], []
+            for rep in range(3):
+                sv.init_basis(hfn)
+                t0 = time.perf_counter()
+                for k, th in zip((3, 200, 411, 77, 640), (0.2, -0.15, 0.1, 0.3, -0.25)):
+                    sv.apply_exp_pauli_sum(singlets[k], th)
+                sv.norm2()
+                t_exp.append(1e3 * (time.perf_counter() - t0) / 5)
+                t0 = time.perf_counter()
+                g = sv.pool_gradients(singlets, GRAD_FERMIONIC)
+                t_scr.append(1e3 * (time.perf_counter() - t0))
+            adapt[label] = {"exact_exponential_ms_per_operator": min(t_exp), "screen_ms": min(t_scr),
+                            "amplitudes_walked_by_the_screen": sv.last_screen_support(),
+                            "largest_gradient": float(np.abs(g).max())}
+        t0 = time.perf_counter()
+        e_g, r_g, it_g = sv.ground_state(tol=1e-10)
+        adapt["reference_vector_lanczos_whole_register"] = {"energy": e_g, "residual": r_g, "iterations": it_g,
+                                                            "wall_s": time.perf_counter() - t0}
+        rown["fermionic_adapt_phases"] = adapt
     out.append(rown)
     return out
 
