@@ -117,6 +117,12 @@ int ovqe_adopt_state(ovqe_handle h, void *dev_ptr);
  *  ref:openvqe/adapt/fermionic_adapt_vqe.py:183-213 prepare_hf_state) */
 int ovqe_init_basis(ovqe_handle h, uint64_t index);
 int ovqe_set_state(ovqe_handle h, const double *amps_re_im);       /* 2*2^n_local doubles */
+
+/* The state as the list of its non-zero amplitudes, ascending index (what iterating a myQLM Result of a state-vector job yields,
+ * ref:openvqe/adapt/fermionic_adapt_vqe.py:309-328 get_statevector): *count = number of non-zero amplitudes; indices[0..*count) and
+ * amps[0..2 * *count) (re, im) are filled when *count <= capacity (else only the count is returned: call again, or ovqe_get_state).
+ * *count = -1 on registers below 12 qubits and on shards of a distributed register (use ovqe_get_state there). */
+int ovqe_get_support(ovqe_handle h, int64_t capacity, uint64_t *indices, double *amps, int64_t *count);
 /* full-statevector read-back (ref:openvqe/adapt/fermionic_adapt_vqe.py:309-328 get_statevector) */
 int ovqe_get_state(ovqe_handle h, double *amps_re_im);
 int ovqe_get_amplitudes(ovqe_handle h, int64_t count, const uint64_t *local_indices, double *amps_re_im);

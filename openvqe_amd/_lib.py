@@ -64,6 +64,7 @@ SIGNATURES = {
     "ovqe_apply_exp_pauli_sum": (_int, [_H, _i64, _u64p, _u64p, _f64p, _OptF64, _dbl]),
     "ovqe_time_pauli_rotation": (_int, [_H, _u64, _u64, _dbl, _int, _int, ctypes.POINTER(_dbl)]),
     "ovqe_last_batch_ms": (_int, [_H, ctypes.POINTER(_dbl)]),
+    "ovqe_get_support": (_int, [_H, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
     "ovqe_last_support": (_int, [_H, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]),
     "ovqe_energy_gradient": (_int, [_H, _f64p, ctypes.c_int32, ctypes.POINTER(_dbl), _f64p]),
     "ovqe_ground_state": (_int, [_H, _dbl, _int, _u64, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl),

@@ -262,6 +262,19 @@ class Statevector:
         self._ck(self._L.ovqe_last_batch_ms(self._h, ctypes.byref(out)))
         return out.value
 
+    def get_support(self, capacity=None):
+        """(indices, amplitudes) of the non-zero amplitudes, ascending index, listed on the device — or None when the
+        list is not available (register below 12 qubits, shard of a distributed register) or longer than ``capacity``
+        (default: 1/8 of the register)"""
+        cap = int(capacity if capacity is not None else max(1, (1 << self.n_local) // 8))
+        idx = np.empty(cap, np.uint64)
+        amp = np.empty(cap, np.complex128)
+        count = ctypes.c_int64()
+        self._ck(self._L.ovqe_get_support(self._h, cap, idx.ctypes.data, amp.ctypes.data, ctypes.byref(count)))
+        if count.value < 0 or count.value > cap:
+            return None
+        return idx[:count.value].copy(), amp[:count.value].copy()
+
     def last_screen_support(self):
         """non-zero amplitudes the last ``pool_gradients`` call walked instead of the register (-1: the register)"""
         out = ctypes.c_int64()

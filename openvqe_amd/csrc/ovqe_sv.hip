@@ -3233,6 +3233,27 @@ int ovqe_apply_exp_pauli_sum(ovqe_handle h, int64_t T, const uint64_t *x, const 
     return rc;
 }
 
+// ---- the state as a list of its non-zero amplitudes ---------------------------------------------------------------
+int ovqe_get_support(ovqe_handle h, int64_t capacity, uint64_t *indices, double *amps, int64_t *count) {
+    OVQE_ENTER(h);
+    if (!h || !count || capacity < 0 || (capacity && (!indices || !amps))) return OVQE_ERR_INVALID;
+    *count = -1;
+    if (h->n_global != 0 || h->namps < 4096) return OVQE_OK;   // small or sharded registers: ovqe_get_state
+    const int keep = h->opt_screen_sparse;
+    h->opt_screen_sparse = 1;   // list whatever the density
+    uint64_t support = 0;
+    bool listed = false;
+    const int rc = list_support(h, &support, &listed, 0);
+    h->opt_screen_sparse = keep;
+    if (rc) return rc;
+    *count = (int64_t)support;
+    if (!listed || (int64_t)support > capacity) return OVQE_OK;   // (support = 0: nothing to copy)
+    HIPC(h, hipMemcpyAsync(indices, h->d_nz_idx.p, support * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipMemcpyAsync(amps, h->d_nz_val.p, support * sizeof(amp_t), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    return OVQE_OK;
+}
+
 // ---- ground state of the stored Hamiltonian: Lanczos on the device -------------------------------------------
 namespace {
 

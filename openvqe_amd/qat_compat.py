@@ -250,15 +250,29 @@ class Sample:
 
 
 class Result:
-    def __init__(self, value=None, samples=None):
+    """value of an observable job, or the samples of a state-vector job.  The samples of a large register are kept as
+    the arrays the device listed (``indices`` ascending, ``amplitudes``); Sample objects are made when somebody iterates."""
+
+    def __init__(self, value=None, samples=None, indices=None, amplitudes=None, nbqbits=None):
         self.value = value
-        self.raw_data = samples or []
+        self.indices = indices
+        self.amplitudes = amplitudes
+        self._nbqbits = nbqbits
+        self._samples = samples if samples is not None else ([] if indices is None else None)
+
+    @property
+    def raw_data(self):
+        if self._samples is None:
+            self._samples = [Sample(int(i), a, self._nbqbits) for i, a in zip(self.indices, self.amplitudes)]
+        return self._samples
 
     def __iter__(self):
-        return iter(self.raw_data)
+        if self._samples is None:   # one pass over a long list: no need to keep the objects
+            return (Sample(int(i), a, self._nbqbits) for i, a in zip(self.indices, self.amplitudes))
+        return iter(self._samples)
 
     def __len__(self):
-        return len(self.raw_data)
+        return len(self.indices) if self._samples is None else len(self._samples)
 
 
 # ------------------------------------------------------------------------------------ execution
@@ -393,6 +407,9 @@ class HipQPU:
                 self._observable[n] = job.observable
             return Result(value=sv.energy(theta))
         sv.prepare_state(theta)
+        listed = sv.get_support() if n >= 16 else None   # non-zero amplitudes listed on the device (ovqe_get_support)
+        if listed is not None:
+            return Result(indices=listed[0].astype(np.int64), amplitudes=listed[1], nbqbits=circ.nbqbits)
         psi = sv.get_state()
         nz = np.nonzero(psi)[0]
         return Result(samples=[Sample(int(i), psi[i], circ.nbqbits) for i in nz])

@@ -211,6 +211,43 @@ def test_fermionic_adapt_fidelity_with_device_ground_state(h2, monkeypatch):
     assert out["lanczos"][0]["fidelity"][-1] > 0.9
 
 
+def test_state_vector_job_as_listed_samples_and_fidelity_at_16_qubits(gpu_lib):
+    """a state-vector job of the stand-in QPU on 16+ qubits returns the samples as the arrays the device listed
+    (ovqe_get_support); iterating them gives the myQLM samples (get_statevector, ref:openvqe/adapt/fermionic_adapt_vqe.py:309-328)
+    and fun_fidelity's overlap over those samples equals the dense one"""
+    import openvqe_amd.adapt.fermionic_adapt_vqe as fa
+    from openvqe_amd.backend import Statevector
+    ham, _, hf = fermion.synthetic_molecule(8, 3, seed=16)
+    pool = fermion.uccsd_pool_antihermitian(8, 3)
+    gens = [1j * pool[k] for k in (2, 40, 77, 130)]
+    theta = [0.3, -0.2, 0.15, 0.4]
+    rng = np.random.default_rng(5)
+    ground = rng.normal(size=1 << 16) + 1j * rng.normal(size=1 << 16)
+    ground /= np.linalg.norm(ground)
+    with engine("hip"):
+        circ = fa.prepare_state_ansatz(gens, hf, theta)
+        res = fa.get_default_qpu().submit(circ.to_job())
+        assert res.indices is not None and 1 < len(res) <= 16 and len(res) == len(res.indices)
+        assert np.all(np.diff(res.indices) > 0)
+        dense = fa.get_statevector(res, 16)
+        assert abs(np.linalg.norm(dense) - 1.0) < 1e-12
+        assert [s.state.int for s in res] == [int(i) for i in res.indices]
+        assert len(res.raw_data) == len(res.indices) and res.raw_data[0].probability == abs(res.amplitudes[0]) ** 2
+        fid = fa.fun_fidelity(circ, np.array([0.0]), ground.reshape(-1, 1), 16)
+    assert abs(fid - abs(np.vdot(ground, dense)) ** 2) < 1e-14
+    with Statevector(16) as sv:                                # the list itself against the whole state
+        psi = np.zeros(1 << 16, complex)
+        where = rng.choice(1 << 16, size=700, replace=False)
+        psi[where] = rng.normal(size=700) + 1j * rng.normal(size=700)
+        sv.set_state(psi)
+        idx, amp = sv.get_support()
+        assert np.array_equal(idx, np.sort(where).astype(np.uint64)) and np.array_equal(amp, psi[np.sort(where)])
+        assert sv.get_support(capacity=699) is None
+    with Statevector(10) as sv:
+        sv.init_basis(3)
+        assert sv.get_support() is None
+
+
 def test_fermionic_adapt_at_18_qubits_runs_its_energies_on_sector_tables(gpu_lib, monkeypatch):
     """fermionic ADAPT on an 18-qubit molecule-shaped problem: every macro-iteration installs a new program, whose energies
     move to the sector tables at their second evaluation (18+ qubits) — the trace equals the one of the same flow with the

@@ -300,3 +300,18 @@ def test_qubit_adapt_mirror_and_reference(oracle_engine, h2):
         assert np.abs(np.array(it_r["energies"]) - np.array(it["energies"])).max() < 1e-9
         assert np.abs(np.array(it_r["norms"]) - np.array(it["norms"])).max() < 1e-8
         assert it_r["CNOTs"] == it["CNOTs"]
+
+
+def test_result_of_a_state_vector_job_keeps_arrays_and_yields_samples():
+    """qat stand-in Result: samples given as (indices, amplitudes) arrays are turned into Sample objects on iteration"""
+    from openvqe_amd.qat_compat import Result, Sample
+    idx = np.array([3, 5, 12], dtype=np.int64)
+    amp = np.array([0.6, 0.8j, 0.0 + 0.0j])
+    res = Result(indices=idx, amplitudes=amp, nbqbits=4)
+    assert len(res) == 3
+    got = [(s.state.int, s.amplitude, s.probability) for s in res]
+    assert got == [(3, 0.6 + 0j, 0.36), (5, 0.8j, 0.6400000000000001), (12, 0j, 0.0)]
+    assert str(res.raw_data[1].state) == str(Sample(5, 0.8j, 4).state)
+    assert len(Result(value=1.5)) == 0 and Result(value=1.5).indices is None
+    legacy = Result(samples=[Sample(1, 1.0, 2)])
+    assert [s.state.int for s in legacy] == [1] and legacy.indices is None
