@@ -81,12 +81,13 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * whose rotation strings all have an odd number of Y — every UCC / ADAPT generator, the QUCCSD templates in frame form —
  * keeps the amplitudes real; streaming energies (n >= 15) then store the state as 2^n doubles: half the HBM bytes per
  * sweep, one more mixing bit per LDS tile; ovqe_prepare_state always delivers the complex state),
- * "apply_min_tiles" (sigma = H psi uses the tile cover from this many tiles on, default 256; the gather
+ * "ham_tile_low" (lowest index bits forced into every tile of the Hamiltonian's cover, default 2; -1 = "tile_low"; fewer forced bits =
+ * fewer sweeps per H psi / tiled <H>), "apply_min_tiles" (sigma = H psi uses the tile cover from this many tiles on, default 256; the gather
  * kernel below), "screen_sparse" (ovqe_pool_gradients: when at most 1/value of the amplitudes of psi are non-zero — an ADAPT state of a few
  * operators lives on a few determinants — the bilinear forms <sigma|A_i|psi> are summed over the list of those amplitudes (ascending
  * index, fixed order) instead of over the register; ovqe_apply_exp_pauli_sum: the Taylor steps run over the closure of that list
- * under the operator's x-groups while it stays within the same bound, bit-identical amplitudes; default 16, 0 = never), "lanczos_keep_gb" (ovqe_ground_state keeps its Lanczos vectors in HBM up to this many GB — and never more than half
- * of the free memory — so that one pass of the recurrence gives the Ritz vector; default 96; 0, or vectors that do not fit: the
+ * under the operator's x-groups while it stays within the same bound, bit-identical amplitudes; default 16, 0 = never), "lanczos_keep_gb" (ovqe_ground_state keeps its Lanczos vectors in HBM up to this many GB — and never more than 60 %
+ * of the free memory — so that one pass of the recurrence gives the Ritz vector; default 160; 0, or vectors that do not fit: the
  * recurrence is run twice), "clifford_frame" (read by the NEXT ovqe_set_gate_program: 0 = execute the literal gate list; 1 (default) = when
  * the Clifford part of the list — X, H, CNOT, quarter-turn rotations — multiplies to the identity, run the
  * algebraically identical sequence of Pauli rotations with conjugated strings instead; 2 = always, Clifford part

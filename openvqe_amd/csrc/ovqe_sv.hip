@@ -201,7 +201,7 @@ struct ovqe_sv {
     int opt_sector_h = 1;         // materialise <H> on the support when it fits the budget
     int opt_sector_h_bits = 0;    // index bits per <H> tile (0 = automatic: 300 .. 600 amplitudes per tile)
     int opt_sector_dict = 1;      // dictionary coding of the double-excitation-like matrix elements
-    int opt_lanczos_keep_gb = 96;     // ovqe_ground_state keeps its Lanczos vectors in HBM up to this many GB (one pass); 0 = always two passes
+    int opt_lanczos_keep_gb = 160;    // ovqe_ground_state keeps its Lanczos vectors in HBM up to this many GB (one pass); 0 = always two passes
     int opt_sector_tile_cap = 6500;   // amplitudes per circuit tile (up to 14000 for energies; gradients on the tables hold two tiles in LDS: <= 6500)
     int opt_sector_sparsity = 4;  // the support must be at most 1/this of the register
     int opt_sector_profile = 0;   // 1: HIP events around the circuit and the <H> kernel of every sector evaluation (program_info)
@@ -227,6 +227,8 @@ struct ovqe_sv {
     double2 init_amp = make_double2(1.0, 0.0);  // amplitude of |hf> (global phase of a folded Clifford part)
     int opt_clifford_frame = 1;   // gate programs: 0 literal, 1 Clifford-frame form when the frame closes, 2 forced
     int opt_tile_low = 4;         // lowest index bits always inside the tile (contiguous 16 B << low chunks)
+    int opt_ham_tile_low = 2;     // the same for the tile cover of the Hamiltonian (-1: opt_tile_low): fewer forced bits = fewer
+                                  // sweeps per H psi / <H> (N2/cc-pVDZ at 24 qubits: 102 sweeps at 4; 25.4 ms per H psi at 2, 30.1 at 4)
     TilePlan tp;                  // of the stored program
     TilePlan tp_real;             // same program on a real-amplitude state (built on first use)
     bool tp_real_built = false;
@@ -506,6 +508,12 @@ inline bool tile_ok(ovqe_handle h, bool real) {
            h->opt_tile_low <= 8;
 }
 
+// lowest index bits forced into every tile of the Hamiltonian's cover
+inline int ham_tile_low(ovqe_handle h, bool real) {
+    const int l = h->opt_ham_tile_low >= 0 ? h->opt_ham_tile_low : h->opt_tile_low;
+    return std::min(8, std::max(l, real ? 1 : 0));   // (a real amplitude is 8 bytes: at least 16-byte chunks)
+}
+
 inline uint32_t extract_bits(uint64_t v, uint64_t mask) {  // pext
     uint32_t r = 0;
     int k = 0;
@@ -521,7 +529,7 @@ static int achunks_g0(const std::vector<ExChunkT> &a, int a0, const ExChunkT &cu
 static int achunks_t0(const std::vector<ExChunkT> &a, int a0, const ExChunkT &cur) { return a0 < (int)a.size() ? a[a0].t0 : cur.t0; }
 
 int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
-    const int M = tile_bits(h, real), L = h->opt_tile_low;
+    const int M = tile_bits(h, real), L = ham_tile_low(h, real);
     H.tile_bits = M;
     H.tile_low = L;
     H.tile_real = real;
@@ -805,7 +813,7 @@ int launch_tile_expect(ovqe_handle h, const HamDev &H, const ExSweep &sw, double
 // <state|H|state> of the stored Hamiltonian through the tile cover; *used = false when there is no cover
 int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bool real = false) {
     *used = false;
-    if (H.tile_bits != tile_bits(h, real) || H.tile_low != h->opt_tile_low || H.tile_real != real) {
+    if (H.tile_bits != tile_bits(h, real) || H.tile_low != ham_tile_low(h, real) || H.tile_real != real) {
         int rc = build_ham_tiles(h, H, real);
         if (rc) return rc;
     }
@@ -1084,7 +1092,7 @@ int launch_tile_apply(ovqe_handle h, const HamDev &H, const ExSweep &sw, const a
 
 int apply_hamiltonian(ovqe_handle h, amp_t *out, const amp_t *in, double ident) {
     HamDev &H = h->ham;
-    if (H.tile_bits != tile_bits(h, false) || H.tile_low != h->opt_tile_low || H.tile_real) {
+    if (H.tile_bits != tile_bits(h, false) || H.tile_low != ham_tile_low(h, false) || H.tile_real) {
         int rc = build_ham_tiles(h, H, false);
         if (rc) return rc;
     }
@@ -2409,6 +2417,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "real_stream") h->opt_real_stream = (int)value;
     else if (k == "apply_min_tiles") h->opt_apply_min_tiles = (int)value;
     else if (k == "clifford_frame") h->opt_clifford_frame = (int)value;  // applies to the next ovqe_set_gate_program
+    else if (k == "ham_tile_low") h->opt_ham_tile_low = (int)value;
     else if (k == "tile_bits" || k == "tile_low") {
         (k == "tile_bits" ? h->opt_tile_bits : h->opt_tile_low) = (int)value;
         h->tp_real_built = false;  // the real-amplitude plan follows on its next use
@@ -2912,7 +2921,7 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
             // compact cover: built at the second evaluation of a (program, Hamiltonian) pair — one-shot callers never pay
             HamDev &R = h->ham_real;
             CompactCover &C = h->cc;
-            if (R.tile_bits != tile_bits(h, true) || R.tile_low != h->opt_tile_low || !R.tile_real) {
+            if (R.tile_bits != tile_bits(h, true) || R.tile_low != ham_tile_low(h, true) || !R.tile_real) {
                 rc = build_ham_tiles(h, R, true);
                 if (rc) return rc;
             }
@@ -3360,13 +3369,13 @@ extern "C" int ovqe_ground_state(ovqe_handle h, double tol, int max_iter, uint64
     int m = 0;
     // One pass while the Lanczos vectors fit in HBM (24 qubits: 256 MiB each, 150 of them = 40 GB of the 288): v_0..v_j stay
     // where they were written and the Ritz vector is their combination.  Beyond the budget ("lanczos_keep_gb", and never more
-    // than half of the free memory) the kept vectors are dropped and the recurrence is run a second time for the Ritz vector.
+    // than 60 % of the free memory) the kept vectors are dropped and the recurrence is run a second time for the Ritz vector.
     std::vector<amp_t *> kept;
     size_t keep_budget = 0;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            keep_budget = std::min<size_t>((size_t)std::max(h->opt_lanczos_keep_gb, 0) << 30, free_b / 2);
+            keep_budget = std::min<size_t>((size_t)std::max(h->opt_lanczos_keep_gb, 0) << 30, free_b / 5 * 3);
     }
     const size_t vec_bytes = h->namps * sizeof(amp_t);
     bool keeping = keep_budget >= 8 * vec_bytes;

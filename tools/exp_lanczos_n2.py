@@ -5,12 +5,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from openvqe_amd import chem
 from openvqe_amd.backend import Statevector
-mol = chem.molecule("N2-CCPVDZ"); mol.rhf()
-prob = chem.cas_problem(mol, 2, 12)
-ham = prob.jw_hamiltonian()
+if "--synthetic" in sys.argv:      # --synthetic m o: molecule-shaped random integrals on 2 m qubits instead
+    from openvqe_amd import fermion
+    k = sys.argv.index("--synthetic")
+    ham, _, _ = fermion.synthetic_molecule(int(sys.argv[k + 1]), int(sys.argv[k + 2]), seed=24)
+    del sys.argv[k:k + 3]
+else:
+    mol = chem.molecule("N2-CCPVDZ"); mol.rhf()
+    prob = chem.cas_problem(mol, 2, 12)
+    ham = prob.jw_hamiltonian()
 tol = float(sys.argv[1]) if len(sys.argv) > 1 else 1e-10
 sv = Statevector(ham.nbqbits)
 t = time.perf_counter(); sv.set_hamiltonian(ham); print(f"set_hamiltonian {time.perf_counter()-t:.2f}s", flush=True)
-for rep in range(2):
+for rep in range(1):
     t = time.perf_counter(); e, r, it = sv.ground_state(tol=tol); dt = time.perf_counter() - t
     print(f"ground_state tol={tol:g}: E={e:.10f} residual={r:.2e} iterations={it} wall={dt:.2f}s -> {dt/it*1e3:.2f} ms per Lanczos step", flush=True)
