@@ -168,7 +168,8 @@ struct ovqe_sv {
     DevBuf d_sp_ops, d_sp_pairs, d_sp_entries;
     // device copy of the ADAPT pool of the last ovqe_pool_gradients call (+ its host image for the change test)
     DevBuf d_pg_off, d_pg_xs, d_pg_terms, d_pg_out, d_pg_part;
-    DevBuf d_nz_cnt, d_nz_start, d_nz_idx, d_nz_val, d_nz_bitmap;  // support list of the screened state (k_pool_grad_nz)
+    DevBuf d_nz_cnt, d_nz_start, d_nz_idx, d_nz_val, d_nz_bitmap;
+    DevBuf d_tile_smasks, d_tile_lists, d_tile_counts;   // non-empty tiles per sweep of H psi on a listed state (k_tile_lists)  // support list of the screened state (k_pool_grad_nz)
     int opt_screen_sparse = 16;   // the ADAPT screen walks the support of psi when it is at most 1/this of the register (0 = never)
     int64_t last_exp_support = -1;     // amplitudes the last ovqe_apply_exp_pauli_sum call's Taylor steps ran over (-1: the register)
     int64_t last_screen_support = -1;  // support size seen by the last ovqe_pool_gradients call (-1: register walked)
@@ -1064,7 +1065,8 @@ int run_expectation_compact(ovqe_handle h, HamDev &H, double2 *out, bool *ok, bo
 // kernel.  in / out: complex states of this handle's size, out != in.
 template <int M>
 int launch_tile_apply(ovqe_handle h, const HamDev &H, const ExSweep &sw, const amp_t *in, amp_t *out, int first,
-                      double ident) {
+                      double ident, const uint32_t *tile_list = nullptr, const uint32_t *tile_count = nullptr,
+                      unsigned listed_grid = 0) {
     constexpr int NT = 1 << TILE_EXPECT_LOG_NT;  // the sweeps' thread / trip masks are laid out for this group size
     const size_t smem = ((size_t)16 << M) + TILE_TERM_CAP * sizeof(ExTermLds) + TILE_APPLY_GROUPS * sizeof(ExAGroupT);
     static bool attr_done_dev[64] = {};  // function attributes are per device
@@ -1076,21 +1078,24 @@ int launch_tile_apply(ovqe_handle h, const HamDev &H, const ExSweep &sw, const a
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done = true;
     }
-    const unsigned grid = (unsigned)(h->namps >> M);
+    const unsigned grid = tile_list ? listed_grid : (unsigned)(h->namps >> M);
     if (h->n_local >= 25) {
         hipLaunchKernelGGL((k_tile_apply<M, NT, true>), dim3(grid), dim3(NT), smem, h->stream, in, out, h->base, sw,
                            (const ExChunkT *)H.d_achunks.p, (const ExAGroupT *)H.d_agroups.p,
-                           (const ExTermT *)H.d_aterms.p, first, ident);
+                           (const ExTermT *)H.d_aterms.p, first, ident, tile_list, tile_count);
     } else {
         hipLaunchKernelGGL((k_tile_apply<M, NT, false>), dim3(grid), dim3(NT), smem, h->stream, in, out, h->base, sw,
                            (const ExChunkT *)H.d_achunks.p, (const ExAGroupT *)H.d_agroups.p,
-                           (const ExTermT *)H.d_aterms.p, first, ident);
+                           (const ExTermT *)H.d_aterms.p, first, ident, tile_list, tile_count);
     }
     HIPC(h, hipGetLastError());
     return OVQE_OK;
 }
 
-int apply_hamiltonian(ovqe_handle h, amp_t *out, const amp_t *in, double ident) {
+// in_idx / in_count: the ascending list of the non-zero amplitudes of `in` when the caller has it (the ADAPT screen of a
+// state of a few determinants): every sweep then only visits the tiles that hold one of them
+int apply_hamiltonian(ovqe_handle h, amp_t *out, const amp_t *in, double ident, const uint64_t *in_idx = nullptr,
+                      uint64_t in_count = 0) {
     HamDev &H = h->ham;
     if (H.tile_bits != tile_bits(h, false) || H.tile_low != ham_tile_low(h, false) || H.tile_real) {
         int rc = build_ham_tiles(h, H, false);
@@ -1104,16 +1109,39 @@ int apply_hamiltonian(ovqe_handle h, amp_t *out, const amp_t *in, double ident) 
         HIPC(h, hipGetLastError());
         return OVQE_OK;
     }
+    const uint32_t *lists = nullptr, *counts = nullptr;
+    const uint64_t ntiles = h->namps >> H.tile_bits;
+    uint32_t cap = 0;
+    if (in_idx && in_count > 0 && ntiles <= (1u << 19) && in_count * 4 <= ntiles) {
+        const size_t nsw = H.tsweeps.size();
+        cap = (uint32_t)std::min<uint64_t>(in_count, ntiles);
+        std::vector<uint64_t> smasks(nsw);
+        for (size_t k = 0; k < nsw; ++k) smasks[k] = H.tsweeps[k].smask;
+        int rc = upload(h, h->d_tile_smasks, smasks.data(), nsw * sizeof(uint64_t));
+        if (!rc) rc = ensure(h, h->d_tile_lists, nsw * (size_t)cap * sizeof(uint32_t));
+        if (!rc) rc = ensure(h, h->d_tile_counts, nsw * sizeof(uint32_t));
+        if (rc) return rc;
+        HIPC(h, hipMemsetAsync(out, 0, h->namps * sizeof(amp_t), h->stream));
+        hipLaunchKernelGGL(k_tile_lists, dim3((unsigned)nsw), dim3(256), (size_t)((ntiles + 31) / 32) * sizeof(uint32_t), h->stream,
+                           in_idx, in_count, (const uint64_t *)h->d_tile_smasks.p, h->n_local, (uint32_t)ntiles, cap,
+                           (uint32_t *)h->d_tile_lists.p, (uint32_t *)h->d_tile_counts.p);
+        HIPC(h, hipGetLastError());
+        lists = (const uint32_t *)h->d_tile_lists.p;
+        counts = (const uint32_t *)h->d_tile_counts.p;
+    }
     int first = 1;
+    size_t k = 0;
     for (const ExSweep &sw : H.tsweeps) {
+        const uint32_t *tl = lists ? lists + k * cap : nullptr, *tc = lists ? counts + k : nullptr;
         int rc;
         switch (H.tile_bits) {
-        case 10: rc = launch_tile_apply<10>(h, H, sw, in, out, first, ident); break;
-        case 11: rc = launch_tile_apply<11>(h, H, sw, in, out, first, ident); break;
-        default: rc = launch_tile_apply<12>(h, H, sw, in, out, first, ident); break;
+        case 10: rc = launch_tile_apply<10>(h, H, sw, in, out, first, ident, tl, tc, cap); break;
+        case 11: rc = launch_tile_apply<11>(h, H, sw, in, out, first, ident, tl, tc, cap); break;
+        default: rc = launch_tile_apply<12>(h, H, sw, in, out, first, ident, tl, tc, cap); break;
         }
         if (rc) return rc;
         first = 0;
+        ++k;
     }
     return OVQE_OK;
 }
@@ -2343,7 +2371,7 @@ int ovqe_destroy(ovqe_handle h) {
                                   &h->d_stream,
                                   &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups, &h->d_eterms, &h->d_echunks,
                                   &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries, &h->d_pg_off, &h->d_pg_xs, &h->d_pg_terms,
-                                  &h->d_pg_out, &h->d_pg_part, &h->d_nz_cnt, &h->d_nz_start, &h->d_nz_idx, &h->d_nz_val, &h->d_nz_bitmap, &h->cc.d_sup, &h->cc.d_psic, &h->cc.d_loc, &h->cc.d_cid, &h->cc.d_off, &h->cc.d_sweeps};
+                                  &h->d_pg_out, &h->d_pg_part, &h->d_nz_cnt, &h->d_nz_start, &h->d_nz_idx, &h->d_nz_val, &h->d_nz_bitmap, &h->d_tile_smasks, &h->d_tile_lists, &h->d_tile_counts, &h->cc.d_sup, &h->cc.d_psic, &h->cc.d_loc, &h->cc.d_cid, &h->cc.d_off, &h->cc.d_sweeps};
     for (TilePlan *tp : {&h->tp, &h->tp_adhoc, &h->tp_real}) bufs.insert(bufs.end(), {&tp->d_tops, &tp->d_trots});
     for (HamDev *H : {&h->ham, &h->ham_adhoc, &h->ham_real})
         bufs.insert(bufs.end(), {&H->d_groups, &H->d_terms, &H->d_tchunks, &H->d_tgroups, &H->d_tterms, &H->d_tflats,
@@ -3059,8 +3087,16 @@ int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, co
     if (rc) return rc;
     amp_t *sig = h->scratch[0];
     const int nb = reduce_blocks(h->namps);
+    // the support of psi, when it is a small part of the register (exact zeros outside: ovqe_apply_exp_pauli_sum and the
+    // rotation sweeps never write an amplitude they do not reach)
+    uint64_t support = 0;
+    bool on_support = false;
+    h->last_screen_support = -1;
+    rc = list_support(h, &support, &on_support, 0);
+    if (rc) return rc;
+    if (on_support) h->last_screen_support = (int64_t)support;
     // sigma = H psi (constant included)
-    rc = apply_hamiltonian(h, sig, h->state, h->ham.constant);
+    rc = apply_hamiltonian(h, sig, h->state, h->ham.constant, on_support ? (const uint64_t *)h->d_nz_idx.p : nullptr, support);
     if (rc) return rc;
     std::vector<double2> vals(n_ops);
     {
@@ -3099,14 +3135,6 @@ int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, co
             h->pg_terms.swap(terms);
             h->pg_valid = true;
         }
-        // the support of psi, when it is a small part of the register (exact zeros outside: ovqe_apply_exp_pauli_sum and the
-        // rotation sweeps never write an amplitude they do not reach)
-        uint64_t support = 0;
-        bool on_support = false;
-        h->last_screen_support = -1;
-        rc = list_support(h, &support, &on_support, 0);
-        if (rc) return rc;
-        if (on_support) h->last_screen_support = (int64_t)support;
         // one workgroup per operator while the state re-streams from L2/MALL; above that 2^16 amplitudes per workgroup
         const int nchunks = on_support ? (int)std::min<uint64_t>(256, (support + 65535) >> 16)
                                        : h->n_local <= 22 ? 1 : (int)(h->namps >> 16);

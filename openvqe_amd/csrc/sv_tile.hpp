@@ -692,6 +692,42 @@ __global__ __launch_bounds__(NT) void k_tile_expect_compact(const typename Amp<R
     }
 }
 
+// ---- the non-empty tiles of every sweep, for a state given as the list of its non-zero amplitudes ----------------------
+// Block s: bitmap (LDS) of the tiles of sweep s that hold a listed index, then their numbers into lists[s * cap ..) and
+// counts[s].  A tile's number is its index bits outside the sweep's tile set, packed in ascending order (the blockIdx -> tile
+// map of the tile kernels).
+__global__ __launch_bounds__(256) void k_tile_lists(const uint64_t *__restrict__ idx, uint64_t count,
+                                                    const uint64_t *__restrict__ smasks, int nbits, uint32_t ntiles, uint32_t cap,
+                                                    uint32_t *__restrict__ lists, uint32_t *__restrict__ counts) {
+    extern __shared__ uint32_t tl_bitmap[];
+    __shared__ uint32_t found;
+    const uint32_t words = (ntiles + 31u) >> 5;
+    const uint64_t sm = smasks[blockIdx.x];
+    for (uint32_t w = threadIdx.x; w < words; w += 256) tl_bitmap[w] = 0u;
+    if (threadIdx.x == 0) found = 0u;
+    __syncthreads();
+    for (uint64_t e = threadIdx.x; e < count; e += 256) {
+        const uint64_t i = idx[e];
+        uint32_t t = 0u;
+        int pos = 0;
+        for (int b = 0; b < nbits; ++b)
+            if (!((sm >> b) & 1ull)) t |= (uint32_t)((i >> b) & 1ull) << pos++;
+        atomicOr(&tl_bitmap[t >> 5], 1u << (t & 31u));
+    }
+    __syncthreads();
+    for (uint32_t w = threadIdx.x; w < words; w += 256) {
+        uint32_t v = tl_bitmap[w];
+        while (v) {
+            const uint32_t b = (uint32_t)__ffs((int)v) - 1u;
+            v &= v - 1u;
+            const uint32_t pos = atomicAdd(&found, 1u);
+            if (pos < cap) lists[(size_t)blockIdx.x * cap + pos] = (w << 5) + b;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = min(found, cap);
+}
+
 // ---- out = ident * in + H in on tiles ------------------------------------------------------------------------
 // Same cover as k_tile_expect, operator-application form (sigma = H psi of the ADAPT screens and of the adjoint
 // gradient, the Lanczos matrix-vector product): a thread OWNS its output amplitudes (registers), walks the sweep's
@@ -704,7 +740,9 @@ template <int M, int NT, bool NTL>
 __global__ __launch_bounds__(NT) void k_tile_apply(const amp_t *__restrict__ in, amp_t *__restrict__ out, uint64_t base,
                                                    ExSweep sw, const ExChunkT *__restrict__ chunks,
                                                    const ExAGroupT *__restrict__ groups,
-                                                   const ExTermT *__restrict__ terms, int first, double ident) {
+                                                   const ExTermT *__restrict__ terms, int first, double ident,
+                                                   const uint32_t *__restrict__ tile_list,
+                                                   const uint32_t *__restrict__ tile_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t NEL = 1u << M;
     constexpr int TRIPS = NEL / NT;
@@ -715,6 +753,10 @@ __global__ __launch_bounds__(NT) void k_tile_apply(const amp_t *__restrict__ in,
     v2d *q = reinterpret_cast<v2d *>(out);
 
     uint64_t tb = blockIdx.x;
+    if (tile_list) {   // only the tiles of this sweep that hold a non-zero input amplitude (k_tile_lists); out was zeroed
+        if (blockIdx.x >= *tile_count) return;
+        tb = tile_list[blockIdx.x];
+    }
     for (uint64_t mk = sw.smask; mk; mk &= mk - 1ull) tb = insert_zero(tb, __ffsll((long long)mk) - 1);
     const uint64_t glow = spread_bits(threadIdx.x, sw.mask_lo);
     const uint64_t gbase = base | tb;

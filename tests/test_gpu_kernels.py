@@ -188,7 +188,7 @@ def test_pool_gradients_and_exact_exponential(SV, n):
         assert np.abs(sv.get_state() - ref).max() < 1e-11
 
 
-@pytest.mark.parametrize("n,nnz", [(12, 1), (14, 37), (16, 3000), (16, 5000)])
+@pytest.mark.parametrize("n,nnz", [(12, 1), (14, 37), (16, 3000), (16, 5000), (20, 60), (20, 1)])
 def test_pool_gradients_on_the_support_of_psi(SV, n, nnz):
     """ovqe_pool_gradients over the list of non-zero amplitudes ("screen_sparse": the ADAPT state of a few operators) against
     the pass over the register and against the bit-mask oracle; complex amplitudes, complex pool coefficients, both modes"""
