@@ -569,11 +569,13 @@ __global__ __launch_bounds__(256) void k_pool_grad(const amp_t *__restrict__ sig
 constexpr int NZ_PER_THREAD = 8;
 __global__ __launch_bounds__(256) void k_nz_count(const amp_t *__restrict__ st, uint64_t namps, uint32_t *__restrict__ counts) {
     __shared__ uint32_t w[4];
-    const uint64_t i0 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * NZ_PER_THREAD;
+    // the block's 256 * NZ_PER_THREAD amplitudes, consecutive lanes on consecutive amplitudes (only the count matters here)
+    const uint64_t i0 = (uint64_t)blockIdx.x * 256u * NZ_PER_THREAD + threadIdx.x;
     uint32_t c = 0;
+#pragma unroll
     for (int k = 0; k < NZ_PER_THREAD; ++k)
-        if (i0 + k < namps) {
-            const amp_t a = st[i0 + k];
+        if (i0 + 256u * k < namps) {
+            const amp_t a = st[i0 + 256u * k];
             if (a.x != 0.0 || a.y != 0.0) ++c;
         }
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
