@@ -37,6 +37,9 @@ except Exception:
     print(buf.getvalue()[-1500:]); raise
 wall = time.perf_counter() - t0
 scr = [d for k, d in marks if k == "screen"]; en = [d for k, d in marks if k == "energy"]
+slow = sorted(en, reverse=True)
+print(f"energy evaluations: {sum(1 for d in en if d > 5e-3)} above 5 ms totalling {sum(d for d in en if d > 5e-3):.2f}s; largest {[round(1e3*d,1) for d in slow[:6]]} ms; "
+      f"quartiles {[round(1e3*float(q),3) for q in np.percentile(en, [25, 50, 75, 95])]} ms")
 print(f"wall={wall:.1f}s screens={len(scr)} ({np.mean(scr)*1e3:.0f} ms each) energy evaluations={len(en)} (median {np.median(en)*1e3:.2f} ms, total {sum(en):.2f}s)")
 for name in ("_ground_space", "fun_fidelity", "prepare_adapt_state", "prepare_state_ansatz", "hf_energy"):
     d = [x for k, x in marks if k == name]
