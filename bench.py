@@ -470,9 +470,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    host_energies = torch.empty((B,), dtype=torch.float64).pin_memory()   # where the optimiser reads them: no staging copy
+
     def step(k):
         sv.energy_batch_device(B, thetas_dev[k].data_ptr(), energies_dev[k].data_ptr())
-        return energies_dev[k].cpu()
+        host_energies.copy_(energies_dev[k])   # blocking device-to-host copy: the step ends with the energies on the host
+        return host_energies
 
     def timed_steps(first, count):
         sync_all()
@@ -494,7 +497,7 @@ def main():
         elapsed = float(t.item())
     total_evals = world * B * args.steps
     value = total_evals / elapsed
-    e = e.numpy()
+    e = e.numpy().copy()
 
     # the same steps on the dense LDS statevector kernel (support compaction off), rank 0, for the record
     dense = None
