@@ -104,7 +104,11 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * <H>), "sector_dict" (0: explicit doubles instead of dictionary-coded matrix elements), "sector_bits" / "sector_h_bits"
  * (index bits per circuit / <H> tile, 0 = automatic), "sector_threads" (0 automatic, 64, 256, 512, 1024),
  * "sector_min_qubits" (default 18), "sector_sparsity" (the support may fill at most 1/value of the register, default 4),
- * "sector_tile_cap" (amplitudes per circuit tile, default 6500 so that gradients fit; up to 14000 for energies only).
+ * "sector_tile_cap" (amplitudes per circuit tile, default 6500 so that gradients fit; up to 14000 for energies only),
+ * "sector_debug" (2: report on stderr why a program was left to the dense kernels or its tables dropped; 1: measurement only).
+ * When an evaluation meets a non-zero amplitude whose partner is outside the probed support (generators whose strings share a
+ * parameter can pass through determinants their final states do not hold) it is redone by the dense kernels and the tables are
+ * rebuilt once from a probe with an independent angle per rotation (a superset of the support; still exact).
  * The state buffer holds unspecified data after an energy evaluation on this path. */
 int ovqe_set_option(ovqe_handle h, const char *name, int64_t value);
 /* device pointer to the 2^n_local amplitudes (for RCCL exchange by the host layer) */

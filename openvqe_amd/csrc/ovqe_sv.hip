@@ -99,6 +99,7 @@ struct SectorEngine {
     bool h_tables = false;        // the materialised <H> is part of the engine (else: circuit only, <H> by the compact cover)
     int prog_version = -1, ham_version = -1;
     int seen = 0;                 // evaluations of this (program, Hamiltonian) pair before the tables are built
+    int probe_mode = 0;           // 0: support probed with one angle per PARAMETER; 1: one per rotation (sector_orphaned)
     uint32_t K = 0, max_tile = 0, h_max_tile = 0;
     int M = 0, Mh = 0;            // index bits per tile: circuit sweeps, <H> sweeps
     int sb = 13;                  // slot bits of the pair words
@@ -194,6 +195,7 @@ struct ovqe_sv {
     int opt_compact_cpp = 1;      // host chunks (512 terms each) staged in LDS per pass of the compact-cover kernel
     int prog_version = 0;
     SectorEngine sec;             // of (current program, stored Hamiltonian)
+    bool probe_independent = false;  // resolve_angles: one quasi-random angle per ROTATION (support probe, second attempt)
     int opt_sector = 1;           // allow the sector path (real-amplitude streaming energies on a sparse support)
     int opt_sector_bits = 0;      // index bits per tile (0 = automatic: n - 8, at most 16)
     int opt_sector_max_gb = 128;  // table budget (also capped at 60 % of the free device memory)
@@ -1325,6 +1327,24 @@ int resolve_angles(ovqe_handle h, const double *theta) {
     rc = ensure_rp(h, std::max<size_t>(S + R, 1));
     if (rc) return rc;
     static_assert(sizeof(RotSpec) == sizeof(SmallRot), "RotSpec mirrors SmallRot");
+    if (h->probe_independent) {
+        auto probe = [](const SmallRot &sr, size_t r) {
+            const double f = 0.6180339887498949 * (double)(r + 1);
+            const double phi = 0.4 + 0.7 * (f - std::floor(f));
+            RotParam rp;
+            rp.z = sr.z;
+            rp.c = std::cos(phi);
+            rp.s = (sr.ny & 2) ? -std::sin(phi) : std::sin(phi);
+            rp.odd = sr.ny & 1;
+            rp.pad = 0;
+            return rp;
+        };
+        for (size_t r = 0; r < S; ++r) h->h_rp[r] = probe(h->srots[r], r);
+        for (size_t r = 0; r < R; ++r) h->h_rp[S + r] = probe(h->rots[r], S + r);
+        if (S + R)
+            HIPC(h, hipMemcpyAsync(h->d_rp.p, h->h_rp, (S + R) * sizeof(RotParam), hipMemcpyHostToDevice, h->stream));
+        return OVQE_OK;
+    }
     if (S + R >= 256 && (size_t)h->K <= ovqe_sv::IO_DOUBLES && mapped_io(h, 1)) {
         // angles resolved on the device from the parameter vector (read through the pinned, mapped buffer): no host
         // trigonometry and no table upload on the evaluation path
@@ -1429,6 +1449,7 @@ int sector_prepare(ovqe_handle h, bool eager = false) {
         free_sector(E);
         E.disabled = false;
         E.seen = 0;
+        E.probe_mode = 0;
         E.prog_version = h->prog_version;
         E.ham_version = h->ham.version;
     }
@@ -1436,6 +1457,24 @@ int sector_prepare(ovqe_handle h, bool eager = false) {
     // 0.26 s), and whoever asks for gradients evaluates many times
     if (!E.valid && !E.disabled && (++E.seen >= 2 || eager)) return build_sector(h);
     return OVQE_OK;
+}
+
+// An evaluation found a non-zero amplitude whose partner is outside the probed support.  The support was taken from the FINAL
+// probe state; rotations that share a parameter (the strings of a spin-adapted generator) can pass through determinants whose
+// amplitudes cancel again by the end of the program — absent from the list, present in between.  Second attempt: probe with an
+// independent angle per rotation (nothing cancels: every determinant the program can touch is listed; a superset is still exact).
+// A program that fails that too is left to the dense kernels.
+void sector_orphaned(ovqe_handle h) {
+    SectorEngine &E = h->sec;
+    const int mode = E.probe_mode;
+    free_sector(E);
+    if (mode == 0) {
+        E.probe_mode = 1;
+        E.disabled = false;
+        E.seen = 1;   // rebuilt at the next evaluation
+    } else {
+        E.disabled = true;
+    }
 }
 
 // commuting-run fusion analysis of one same-x run (see sv_small.hpp OP_TAB); returns false when the run
@@ -2940,8 +2979,7 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
                     energies[b] = res.x + h->ham.constant;
                     continue;
                 }
-                free_sector(E);   // a structurally-zero amplitude was not: the tables do not describe this program
-                E.disabled = true;
+                sector_orphaned(h);   // a structurally-zero amplitude was not: these tables do not describe this program
             }
         }
         bool use_cc = false;
@@ -2980,8 +3018,7 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
                 energies[b] = res.x + h->ham.constant;
                 continue;
             }
-            free_sector(h->sec);
-            h->sec.disabled = true;
+            sector_orphaned(h);
         }
         rc = run_program_streaming(h, theta + b * (int64_t)K, real);
         if (rc) return rc;
@@ -3554,8 +3591,16 @@ extern "C" int ovqe_energy_gradient(ovqe_handle h, const double *theta, int32_t 
             bool ok = false;
             rc = run_sector_gradient(h, theta, energy, grad, &ok);
             if (rc || ok) return rc;
-            free_sector(h->sec);
-            h->sec.disabled = true;
+            sector_orphaned(h);
+            if (!h->sec.disabled) {   // second attempt: support probed with independent angles
+                rc = sector_prepare(h, true);
+                if (rc) return rc;
+                if (h->sec.valid && h->sec.h_tables && sector_gradient_fits(h)) {
+                    rc = run_sector_gradient(h, theta, energy, grad, &ok);
+                    if (rc || ok) return rc;
+                    sector_orphaned(h);
+                }
+            }
         }
     }
     rc = run_program_streaming(h, theta);  // psi = U(theta)|hf>; angle table: original rotations at offset S

@@ -417,3 +417,44 @@ def test_24_qubit_adapt_screens_and_qubit_adapt_on_n2(gpu_lib, capsys):
     energies = [float(e) for e in trace["energies"]]
     assert len(energies) == 3
     assert e_rhf - 1e-9 > energies[0] > energies[1] > energies[2] > -109.0765315037
+
+
+def test_24_qubit_spin_adapted_ansatz_gets_its_tables_from_the_second_probe(gpu_lib):
+    """28 spin-adapted singlet generators on N2 / cc-pVDZ (10e,12o) (an ADAPT ansatz of that length, Trotterised: the strings of a
+    generator share its parameter): states of this program reach determinants that the final state of the first support probe
+    (one angle per parameter) does not hold, the orphan check drops those tables at the first evaluation, and the second probe
+    (one angle per rotation: nothing cancels) lists a superset on which the tables are exact — energies and the gradient equal the
+    dense kernels', and evaluations stay on the tables afterwards"""
+    from openvqe_amd import chem, pools
+    from openvqe_amd.backend import Statevector
+    mol = chem.molecule("N2-CCPVDZ")
+    mol.rhf()
+    prob = chem.cas_problem(mol, 2, 12)
+    ham = prob.jw_hamiltonian()
+    _, _, _, _, hf = prob.uccsd()
+    _, _, singlets = pools.singlet_sd(10, 12)
+    order = np.random.default_rng(3).permutation(len(singlets))
+    gens = [1j * singlets[k] for k in order[:28]]
+    rng = np.random.default_rng(28)
+    thetas = [rng.uniform(-0.2, 0.2, 28) for _ in range(5)]
+    out = {}
+    for sector in (1, 0):
+        with Statevector(24) as sv:
+            sv.set_option("sector", sector)
+            sv.set_hamiltonian(ham)
+            sv.set_ucc_program(gens, hf)
+            es, supports = [], []
+            for t in thetas:
+                es.append(sv.energy(t))
+                supports.append(sv.program_info()["sector_support"])
+            eg, g = sv.energy_gradient(thetas[0])
+            out[sector] = (es, supports, eg, g)
+    l1 = float(np.abs(ham.packed()[2]).sum())
+    for a, b in zip(out[1][0], out[0][0]):
+        assert abs(a - b) < 1e-11 * l1
+    assert abs(out[1][2] - out[0][2]) < 1e-11 * l1 and np.abs(out[1][3] - out[0][3]).max() < 1e-9 * l1
+    sup = out[1][1]
+    assert sup[0] == 0                                        # first evaluation: dense kernels
+    assert sup[-1] > 792 ** 2                                 # tables of the second probe: beyond the (5 alpha, 5 beta) sector
+    assert 0 in sup[1:-1] or sup[1] != sup[-1]               # ... after the first probe's tables were dropped
+    assert out[0][1] == [0] * 5
