@@ -335,6 +335,121 @@ def gate_and_midsize_workloads(device):
     return out
 
 
+XGMI_LINK_GBS = 153.0  # one xGMI link, one direction (task brief / MI355X platform: 7 links x ~153 GB/s per GPU)
+
+
+def two_body_string(rng, n):
+    """(x, z) of a JW double-excitation-like string: X/Y on 4 random qubits, Z chains between the pairs (index-bit masks)"""
+    q = sorted(rng.choice(n, 4, replace=False).tolist())
+    x = sum(1 << (n - 1 - k) for k in q)
+    z = 0
+    for lo, hi in ((q[0], q[1]), (q[2], q[3])):
+        for k in range(lo + 1, hi):
+            z |= 1 << (n - 1 - k)
+    ys = rng.choice(4, int(rng.choice([1, 3])), replace=False)
+    for k in ys:
+        z |= 1 << (n - 1 - q[k])
+    return x, z
+
+
+def sharded_workload(n, rotations=64, terms=1000, seed=34):
+    """configs[4]: `rotations` JW two-body Pauli rotations and a `terms`-term random JW Hamiltonian
+    (30 % diagonal strings, even number of Y: real symmetric) on n qubits -> (xs, zs, phis, hx, hz, hc)"""
+    rng = np.random.default_rng(seed)
+    rots = [two_body_string(rng, n) for _ in range(rotations)]
+    xs, zs = [r[0] for r in rots], [r[1] for r in rots]
+    phis = rng.uniform(-0.2, 0.2, rotations)
+    hx, hz = [], []
+    for _ in range(terms):
+        x, z = two_body_string(rng, n)
+        if rng.random() < 0.3:
+            x = 0  # diagonal term
+        else:
+            z ^= x & z if rng.random() < 0.5 else 0
+            if bin(x & z).count("1") & 1:   # keep H real-symmetric: even number of Y
+                z ^= x & -x
+        hx.append(x); hz.append(z)
+    hc = rng.normal(size=terms)
+    return xs, zs, phis, hx, hz, hc
+
+
+SHARDED_SEED = 20250227
+
+
+def sharded_leg(n, local_rank, world, rank, rotations=64, terms=1000, barrier=None):
+    """One pass of configs[4] over the index-bit-partitioned register (openvqe_amd.distributed): the synthetic state
+    (recomputable on the host per global index, openvqe_amd/synth.py) -> `rotations` Pauli rotations (half-shard
+    exchanges over RCCL for X/Y on global qubits) -> <H> (partner-shard reads for global-x groups).  World size 1 runs
+    the same code on one shard.  -> dict (identical on every rank up to the timings, which are this rank's)."""
+    import torch
+    from openvqe_amd.distributed import ShardedStatevector
+    g = world.bit_length() - 1
+    xs, zs, phis, hx, hz, hc = sharded_workload(n, rotations, terms)
+    sv = ShardedStatevector(n, device=local_rank)
+    sv.randomize(SHARDED_SEED)
+
+    def fence():
+        torch.cuda.synchronize()
+        if barrier is not None:
+            barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    sv.apply_pauli_rotations(xs, zs, phis)
+    fence()
+    t_rot = time.perf_counter() - t0
+    st = dict(sv.stats)
+    t0 = time.perf_counter()
+    e = sv.expectation(hx, hz, hc, 0.0)
+    fence()
+    t_exp = time.perf_counter() - t0
+    n2 = sv.norm2()
+    st2 = dict(sv.stats)
+    groups = len(set(hx))
+    swap_bytes = st["bytes_sent"]
+    read_bytes = st2["bytes_sent"] - st["bytes_sent"]
+    t_local = max(t_rot - st["swap_s"], 1e-9)
+    out = {
+        "workload": f"{rotations} JW two-body rotations + {terms}-term random JW Hamiltonian ({groups} x-groups) on the "
+                    f"synthetic {n}-qubit state, index-bit partition over {world} GPU(s)",
+        "n_qubits": n, "n_gpus": world, "shard_GiB": 16.0 * 2 ** (n - g) / 2 ** 30,
+        "rotations_s": t_rot, "ms_per_rotation": 1e3 * t_rot / rotations,
+        "local_sweeps_s": t_local, "exchange_s": st["swap_s"],
+        "swaps": st["swaps"], "exchange_pieces": st["pieces"], "exchanged_GiB_per_rank": swap_bytes / 2 ** 30,
+        "xgmi_link_GBs_exchange": (swap_bytes / st["swap_s"] / 1e9) if st["swap_s"] > 0 else None,
+        "xgmi_link_frac_of_153": (swap_bytes / st["swap_s"] / 1e9 / XGMI_LINK_GBS) if st["swap_s"] > 0 else None,
+        "local_sweep_GBs_aggregate": 32.0 * 2 ** n * rotations / t_local / 1e9,
+        "rotations_GBs_aggregate_incl_exchange": 32.0 * 2 ** n * rotations / t_rot / 1e9,
+        "expectation_s": t_exp, "full_shard_reads": st2["full_shard_reads"],
+        "shard_read_GiB_per_rank": read_bytes / 2 ** 30,
+        "xgmi_link_GBs_shard_reads": (read_bytes / st2["shard_read_s"] / 1e9) if st2["shard_read_s"] > 0 else None,
+        "expectation_GBs_aggregate": 16.0 * 2 ** n * groups / t_exp / 1e9,
+        "energy": e, "norm2": n2,
+    }
+    del sv
+    torch.cuda.empty_cache()
+    return out
+
+
+def sharded_block(args, local_rank, world, rank, barrier):
+    """the `sharded` object of the JSON line: configs[4]'s weak curve (n = base + log2 N: the shard keeps its size) and
+    strong curve (n = base) through the same code; at N = 1 both are the one-shard run"""
+    g = world.bit_length() - 1
+    if (1 << g) != world:
+        return {"skipped": f"index-bit partition needs a power-of-two world size, got {world}"}
+    base = args.sharded_qubits
+    block = {"qubits_per_gpu_weak": base, "qubits_strong": base, "seed": SHARDED_SEED,
+             "xgmi_link_peak_GBs": XGMI_LINK_GBS,
+             "note": "energy of the strong run must not depend on the number of GPUs (same synthetic state and operators)"}
+    block["weak"] = sharded_leg(base + g, local_rank, world, rank, args.sharded_rotations, args.sharded_terms, barrier)
+    if g and base - g >= 6:
+        block["strong"] = sharded_leg(base, local_rank, world, rank, args.sharded_rotations, args.sharded_terms, barrier)
+    else:
+        block["strong"] = block["weak"]
+    return block
+
+
 def pmc_traffic_per_launch():
     """HBM bytes per launch of the pair-sweep kernel from the newest committed PMC summary (profiles/*/pmc_summary.csv,
     produced by tools/profile_bench.sh with separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).
@@ -415,6 +530,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the H2 / LiH / H2O latency and small-batch side figures")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-sharded", action="store_true", help="skip the index-bit-partitioned configs[4] block")
+    ap.add_argument("--sharded-qubits", type=int, default=int(os.environ.get("OVQE_BENCH_SHARDED_QUBITS", "31")),
+                    help="configs[4]: qubits per GPU of the weak curve = register of the strong curve (31: 32-GiB shards)")
+    ap.add_argument("--sharded-rotations", type=int, default=64)
+    ap.add_argument("--sharded-terms", type=int, default=1000)
     args = ap.parse_args()
 
     import torch
@@ -499,6 +619,11 @@ def main():
     value = total_evals / elapsed
     e = e.numpy().copy()
 
+    # configs[4]: the index-bit-partitioned register through the same launch (every rank takes part; outside the timed steps)
+    sharded = None
+    if not args.no_sharded:
+        sharded = sharded_block(args, local_rank, world, rank, dist.barrier if use_dist else None)
+
     # the same steps on the dense LDS statevector kernel (support compaction off), rank 0, for the record
     dense = None
     if rank == 0:
@@ -538,6 +663,8 @@ def main():
             "parallelism": f"batch-replicas x{world}",
         },
     }
+    if sharded is not None:
+        out["sharded"] = sharded
     if rank == 0:
         e_last = float(e[0])
         # kernel-only figures of the timed region (HIP events around the fused launch)

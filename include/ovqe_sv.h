@@ -237,7 +237,10 @@ int ovqe_energy_gradient(ovqe_handle h, const double *theta, int32_t K, double *
 int ovqe_ground_state(ovqe_handle h, double tol, int max_iter, uint64_t seed, double *energy, double *residual,
                       int *iterations);
 /* ... and of the Hamiltonian RESTRICTED TO THE SUPPORT of the stored program's states (sector tables, option "sector";
- * built by this call when they do not exist yet): for a particle-number / spin conserving ansatz on a Hartree-Fock
+ * built by this call when they do not exist yet), inside the BLOCK OF THE REFERENCE DETERMINANT: the determinants that the
+ * non-zero matrix elements connect to |hf> are found first and the Lanczos vectors live on them alone, so tables on a superset
+ * of the symmetry sector (the one-angle-per-rotation probe of spin-adapted ansaetze lists several particle-number sectors)
+ * give the same number as tables on the sector itself.  For a particle-number / spin conserving ansatz on a Hartree-Fock
  * determinant that is the full-CI energy of the determinant's symmetry sector — the `fci` argument the reference's
  * drivers take from PySCF (ref:openvqe/common_files/molecule_factory.py:120-125, `info["FCI"]`), here for active spaces the dense
  * routines cannot reach (N2/cc-pVDZ (10e,12o): 627 264 determinants, 538 M matrix elements).  Two-pass Lanczos on
@@ -268,7 +271,8 @@ int ovqe_last_support(ovqe_handle h, int32_t which, int64_t *support);
  *   [16..21] sector path (0 until its tables exist): support size, circuit sweeps, active pairs per evaluation, <H> sweeps
  *   (0: circuit only, <H> by the compact cover), matrix elements of the materialised Hamiltonian (padding included), table
  *   bytes  [22..24] with option "sector_profile" = 1: HIP-event time in microseconds of the circuit sweeps and of the <H>
- *   kernel of the most recent sector evaluation; bytes that kernel reads per evaluation */
+ *   kernel of the most recent sector evaluation; bytes that kernel reads per evaluation
+ *   [25] determinants of the block of H (restricted to the support) that the last ovqe_sector_ground_state diagonalised */
 int ovqe_program_info(ovqe_handle h, int64_t *info, int count);
 
 #ifdef __cplusplus

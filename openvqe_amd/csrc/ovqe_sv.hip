@@ -86,7 +86,10 @@ struct SectorSeg {      // one sweep of the circuit
     uint32_t hf_pos = 0;
     uint64_t npairs = 0;
     DevBuf d_tab0, d_poff, d_pairs;
-    DevBuf d_srcpad;              // gather indices of the sweep, tile-padded (k_sec_pad_src)
+    DevBuf d_srcpad;              // gather indices of the sweep, tile-padded (k_sec_pad_src): first form of the sweep kernel
+    DevBuf d_dstpad;              // scatter indices into the next sweep's tile-padded order (k_sector_sweep2)
+    DevBuf d_wide, d_rounds;      // 64-bit pair words, rounds per (tile, chunk) (k_sec_widen)
+    uint32_t maxchunks = 0;
 };
 struct SectorHSweep {   // one sweep of the materialised <H>
     SectorLayout L;
@@ -101,10 +104,14 @@ struct SectorEngine {
     int seen = 0;                 // evaluations of this (program, Hamiltonian) pair before the tables are built
     int probe_mode = 0;           // 0: support probed with one angle per PARAMETER; 1: one per rotation (sector_orphaned)
     uint32_t K = 0, max_tile = 0, h_max_tile = 0;
+    uint32_t hf_final = 0;        // position of |hf> in the final circuit order (= the order of the <H> tables' vectors)
+    uint32_t last_fci_block = 0;  // determinants of the block ovqe_sector_ground_state diagonalised last
     int M = 0, Mh = 0;            // index bits per tile: circuit sweeps, <H> sweeps
     int sb = 13;                  // slot bits of the pair words
     uint64_t npairs = 0, nnz = 0;
     size_t bytes = 0;
+    size_t pad_elems = 0;         // doubles of a state buffer in tile-padded form (largest sweep; 0: no dst tables)
+    uint32_t chunk = 2048;        // pair words per chunk of the 64-bit tables (k_sec_widen)
     std::vector<SectorSeg> segs;
     std::vector<SectorHSweep> hs;
     DevBuf d_sup, d_buf[2], d_hdesc, d_flag;
@@ -209,7 +216,11 @@ struct ovqe_sv {
     int opt_sector_sparsity = 4;  // the support must be at most 1/this of the register
     int opt_sector_profile = 0;   // 1: HIP events around the circuit and the <H> kernel of every sector evaluation (program_info)
     int opt_sector_debug = 0;     // measurements only (1: circuit sweeps without their ops — wrong results)
+    int opt_sector_sweep = 2;     // circuit sweep kernel: 2 = scatter-on-write, pair words in registers (k_sector_sweep2); 1 = first form
+    int opt_sector_chunk = 2048;  // k_sector_sweep2: pair words per chunk = threads x words per thread (1024, 2048, 4096)
+    int opt_sector_sweep_dbg = 0; // measurements only, k_sector_sweep2: 1 no ops, 2 empty kernel, 3 loads only — wrong results
     int opt_sector_h_groups = 128; // workgroups per <H> sweep (they share the sweep's tiles round robin)
+    int opt_sector_h_threads = 512; // threads per workgroup of k_sector_expect (512 or 1024)
     float last_batch_ms = 0.f;
     const double *cur_theta = nullptr;  // device pointers of the batch being evaluated
     double *cur_energies = nullptr;
@@ -2469,7 +2480,11 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
         h->sec.prog_version = -1;
     } else if (k == "sector_threads") h->opt_sector_threads = (value == 0 || value == 64 || value == 512 || value == 1024) ? (int)value : 256;
     else if (k == "sector_h_groups") h->opt_sector_h_groups = (int)value;
+    else if (k == "sector_h_threads") h->opt_sector_h_threads = value == 1024 ? 1024 : 512;
     else if (k == "sector_debug") h->opt_sector_debug = (int)value;
+    else if (k == "sector_sweep") h->opt_sector_sweep = value == 1 ? 1 : 2;
+    else if (k == "sector_sweep_dbg") h->opt_sector_sweep_dbg = (int)value;
+    else if (k == "sector_chunk") h->opt_sector_chunk = (value == 1024 || value == 4096) ? (int)value : 2048;
     else if (k == "sector_profile") h->opt_sector_profile = (int)value;
     else if (k == "sector_sparsity" || k == "sector_tile_cap") {
         (k == "sector_sparsity" ? h->opt_sector_sparsity : h->opt_sector_tile_cap) = (int)value;
@@ -2774,6 +2789,11 @@ int ovqe_apply_pauli_sum(ovqe_handle h, const void *ket_dev, void *out_dev, int6
     if (!h || !out_dev || T < 0 || (T && (!x || !z || !coeff_re))) return OVQE_ERR_INVALID;
     const amp_t *ket = ket_dev ? (const amp_t *)ket_dev : h->state;
     if ((const void *)ket == out_dev) return fail(h, OVQE_ERR_INVALID, "ovqe_apply_pauli_sum: out must differ from the ket");
+    if (T == 0) {   // the empty sum: out = 0, or out unchanged when accumulating
+        if (!accumulate) HIPC(h, hipMemsetAsync(out_dev, 0, (size_t)h->namps * sizeof(amp_t), h->stream));
+        HIPC(h, hipStreamSynchronize(h->stream));
+        return OVQE_OK;
+    }
     std::vector<HGroup> groups;
     std::vector<HTerm> terms;
     int rc = build_groups(h, T, x, z, coeff_re, coeff_im, /*allow_global_x=*/ket_dev != nullptr, groups, terms);
@@ -2797,6 +2817,10 @@ int ovqe_bilinear_batch(ovqe_handle h, const void *bra_dev, const void *ket_dev,
     if (n_ops == 0) return OVQE_OK;
     const int64_t T = offsets[n_ops];
     if (T < 0 || (T && (!x || !z || !coeff_re))) return OVQE_ERR_INVALID;
+    if (T == 0) {   // operators without terms: every bilinear form is 0
+        std::fill(out_re_im, out_re_im + 2 * n_ops, 0.0);
+        return OVQE_OK;
+    }
     const uint64_t lmask = local_mask(h);
     std::vector<HTerm> terms(T);
     std::vector<uint64_t> xs(T);
@@ -3563,6 +3587,7 @@ extern "C" int ovqe_sector_ground_state(ovqe_handle h, double tol, int max_iter,
         free_sector(E);
         E.disabled = false;
         E.seen = 0;
+        E.probe_mode = 0;
         E.prog_version = h->prog_version;
         E.ham_version = h->ham.version;
     }
@@ -3711,11 +3736,11 @@ int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
     for (const SmallOp &op : h->ops) v[2] += (op.kind == OP_X || op.kind == OP_H || op.kind == OP_CNOT);
     for (int i = 0; i < count && i < 16; ++i) info[i] = v[i];
     const SectorEngine &E = h->sec;
-    const int64_t sv[9] = {E.valid ? (int64_t)E.K : 0, E.valid ? (int64_t)E.segs.size() : 0, E.valid ? (int64_t)E.npairs : 0,
+    const int64_t sv[10] = {E.valid ? (int64_t)E.K : 0, E.valid ? (int64_t)E.segs.size() : 0, E.valid ? (int64_t)E.npairs : 0,
                            E.valid ? (int64_t)E.hs.size() : 0, E.valid ? (int64_t)E.nnz : 0, E.valid ? (int64_t)E.bytes : 0,
                            E.valid ? (int64_t)(1e3 * E.last_circuit_ms) : 0, E.valid ? (int64_t)(1e3 * E.last_expect_ms) : 0,
-                           E.valid ? (int64_t)E.h_stream_bytes : 0};
-    for (int i = 16; i < count && i < 25; ++i) info[i] = sv[i - 16];
+                           E.valid ? (int64_t)E.h_stream_bytes : 0, E.valid ? (int64_t)E.last_fci_block : 0};
+    for (int i = 16; i < count && i < 26; ++i) info[i] = sv[i - 16];
     return OVQE_OK;
 }
 

@@ -408,6 +408,187 @@ __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ 
     if (bad) atomicOr(flag, 1);
 }
 
+// ---- one sweep of the circuit, second form (round 3) -------------------------------------------------------------------
+// What the first form spends outside its rotations is a chain of dependent trips to memory and LDS: tile bounds / op table ->
+// gather indices + first pair words -> gather -> [per op: op bounds -> staged pair word -> cos/sin + amplitudes] -> store
+// (rocprofv3: 9 us of the 24 us per sweep without the ops, 0.4 us = 840 cycles per op).  Here
+//  (a) the PREVIOUS sweep scatters its tile into this sweep's order (dst indices; tile-padded layout in[tile * cap + k]), so
+//      tile, cos/sin table, first pair words and dst indices are addressed by the tile number alone and arrive in ONE trip,
+//      loaded in unrolled batches (a load -> LDS-store loop is compiled to one memory round trip per iteration);
+//  (b) pair words are 64 bits wide and carry everything a thread needs to act without looking anything up:
+//        slot_i | slot_j << 16 | sign << 32 | cos/sin entry of the sweep << 33 (12 bits) | round << 45 (12 bits)
+//      (slot_j = 0xffff: partner outside the support).  They never pass through LDS: chunk c of the tile's list is the words
+//      [c CH, (c + 1) CH), thread t keeps words t, t + NT, ... of the current chunk in registers with their cos/sin values
+//      (the next chunk's loads already in flight).  A ROUND is the part of one op inside one chunk — pairs of an op are
+//      disjoint, so an op cut by a chunk boundary is applied in two rounds; rounds are numbered from 0 inside every chunk at
+//      build time (k_sec_widen), ops without pairs in the tile have no round;
+//  (c) per round that leaves: compare -> two LDS reads -> rotate -> two writes -> barrier.
+// blockIdx.y = state of a batch (own in / out slices and angle tables).
+constexpr uint32_t SEC_CHUNK = 4096;            // pair words per chunk (k_sector_sweep2: NT x WPT), option "sector_chunk"
+constexpr uint32_t SEC_NO_ROUND = 0xfffu;
+__device__ __forceinline__ uint64_t sec_word64(uint32_t si, uint32_t sj, uint32_t sign, uint32_t csidx, uint32_t round) {
+    return (uint64_t)si | ((uint64_t)sj << 16) | ((uint64_t)sign << 32) | ((uint64_t)csidx << 33) | ((uint64_t)round << 45);
+}
+// 32-bit pair words of one sweep -> 64-bit words + rounds per (tile, chunk); one workgroup per tile
+__global__ __launch_bounds__(256) void k_sec_widen(const uint32_t *__restrict__ pairs, const uint32_t *__restrict__ poff,
+                                                   const int32_t *__restrict__ tab0, int nops, int rot0, int sb, uint32_t maxchunks,
+                                                   uint32_t chunk, uint64_t *__restrict__ wide, uint16_t *__restrict__ rounds) {
+    const uint32_t t = blockIdx.x;
+    const uint32_t *po = poff + (size_t)t * (nops + 1);
+    const uint32_t pbase = po[0];
+    const uint32_t mask = (1u << sb) - 1u;
+    uint32_t cur_chunk = 0, cur_round = 0;
+    for (int o = 0; o < nops; ++o) {
+        uint32_t a = po[o] - pbase;
+        const uint32_t b = po[o + 1] - pbase;
+        const uint32_t tab = (uint32_t)(tab0[o] - rot0);
+        while (a < b) {   // the op's part inside chunk a / CH
+            const uint32_t c = a / chunk, e = min(b, (c + 1u) * chunk);
+            if (c != cur_chunk) {
+                if (threadIdx.x == 0) rounds[(size_t)t * maxchunks + cur_chunk] = (uint16_t)cur_round;
+                cur_chunk = c;
+                cur_round = 0;
+            }
+            for (uint32_t k = a + threadIdx.x; k < e; k += 256u) {
+                const uint32_t pw = pairs[(size_t)pbase + k];
+                const uint32_t si = pw & mask, sj = (pw >> sb) & mask;
+                wide[(size_t)pbase + k] = sec_word64(si, sj == mask ? 0xffffu : sj, (pw >> (2 * sb)) & 1u, tab + (pw >> (2 * sb + 1)), cur_round);
+            }
+            ++cur_round;
+            a = e;
+        }
+    }
+    if (threadIdx.x == 0) {
+        rounds[(size_t)t * maxchunks + cur_chunk] = (uint16_t)cur_round;
+        for (uint32_t c = cur_chunk + 1u; c < maxchunks; ++c) rounds[(size_t)t * maxchunks + c] = 0;
+    }
+}
+template <int NT, int WPT>
+__global__ __launch_bounds__(NT) void k_sector_sweep2(const double *__restrict__ in, double *__restrict__ out, size_t in_stride,
+                                                      size_t out_stride, const uint32_t *__restrict__ dstpad,
+                                                      const uint32_t *__restrict__ off, const uint32_t *__restrict__ poff, int nops,
+                                                      const uint64_t *__restrict__ wide, const uint16_t *__restrict__ rounds,
+                                                      uint32_t maxchunks, const RotParam *__restrict__ rp, size_t rp_stride, int rot0,
+                                                      int nrot, uint32_t tile_cap, uint32_t hf_pos, int *__restrict__ flag, int dbg) {
+    constexpr uint32_t CH = (uint32_t)NT * WPT;   // = the chunk size the tables were built for (host checks)
+    extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
+    double *tile = reinterpret_cast<double *>(sec_smem);
+    const uint32_t spare = tile_cap;     // one slot behind the tile (see the orphan words below); tile_cap < 0xffff
+    double2 *cs = reinterpret_cast<double2 *>(tile + ((tile_cap + 2u) & ~1u));
+    uint32_t *dst = reinterpret_cast<uint32_t *>(cs + nrot);
+    uint32_t *nround = dst + tile_cap;   // [maxchunks]
+    const uint32_t t = blockIdx.x, b = blockIdx.y;
+    if (dbg == 4) return;
+    const uint32_t e0 = off[t];
+    const uint32_t n = off[t + 1] - e0;
+    if (n == 0) return;
+    const uint32_t pbase = poff[(size_t)t * (nops + 1)], ptot = poff[(size_t)t * (nops + 1) + nops] - pbase;
+    // dbg: measurements only (1: no ops, 2: scalar loads only, 3: loads only, 4: empty, 5: rounds = barriers only, 6: rounds without barriers)
+    const uint32_t nchunks = (dbg >= 1 && dbg <= 4) ? 0u : (ptot + CH - 1u) / CH;
+    if (dbg == 2) return;
+    in += (size_t)b * in_stride;
+    out += (size_t)b * out_stride;
+    rp += (size_t)b * rp_stride;
+    const size_t tbase = (size_t)t * tile_cap;
+    const uint64_t *wp = wide + pbase;
+    uint64_t wa[WPT], wb[WPT];
+    // ---- one trip to memory: words of chunk 0, tile, dst indices, cos/sin (clamped addresses, no branches around the loads;
+    // words past the tile's list are recognised by their index when the chunk is decoded — nothing here consumes a loaded value)
+#pragma unroll
+    for (int r = 0; r < WPT; ++r) wa[r] = wp[min(threadIdx.x + (uint32_t)r * NT, ptot ? ptot - 1u : 0u)];
+    constexpr int TB = 8;
+    for (uint32_t k0 = threadIdx.x; k0 < n; k0 += TB * NT) {
+        uint32_t d[TB];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) d[j] = dstpad[tbase + min(k0 + (uint32_t)j * NT, n - 1u)];
+        if (in) {
+            double v[TB];
+#pragma unroll
+            for (int j = 0; j < TB; ++j) v[j] = in[tbase + min(k0 + (uint32_t)j * NT, n - 1u)];
+#pragma unroll
+            for (int j = 0; j < TB; ++j)
+                if (k0 + (uint32_t)j * NT < n) tile[k0 + (uint32_t)j * NT] = v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < TB; ++j)
+                if (k0 + (uint32_t)j * NT < n) tile[k0 + (uint32_t)j * NT] = (e0 + k0 + (uint32_t)j * NT == hf_pos) ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+            if (k0 + (uint32_t)j * NT < n) dst[k0 + (uint32_t)j * NT] = d[j];
+    }
+    for (int r0 = threadIdx.x; r0 < nrot; r0 += 2 * NT) {
+        const RotParam ra = rp[rot0 + r0], rb = rp[rot0 + min(r0 + NT, nrot - 1)];
+        cs[r0] = make_double2(ra.c, ra.s);
+        if (r0 + NT < nrot) cs[r0 + NT] = make_double2(rb.c, rb.s);
+    }
+    if (threadIdx.x < maxchunks) nround[threadIdx.x] = rounds[(size_t)t * maxchunks + threadIdx.x];
+    if (threadIdx.x == 0) tile[spare] = 0.0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (dbg == 3) return;
+    bool bad = false;
+    const uint64_t tm0 = dbg == 7 ? __builtin_amdgcn_s_memtime() : 0, tr0 = dbg == 7 ? __builtin_amdgcn_s_memrealtime() : 0;
+    uint32_t rtot = 0;
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        // the next chunk's words: in flight while this chunk is applied
+        const uint32_t nbeg = (c + 1u) * CH;
+#pragma unroll
+        for (int r = 0; r < WPT; ++r) wb[r] = wp[min(nbeg + threadIdx.x + (uint32_t)r * NT, ptot - 1u)];
+        // the thread's words of this chunk, decoded once: slots, round, cos, signed sin.  A word whose partner is outside the
+        // support rotates its amplitude against the spare slot behind the tile by the identity (branch-free) and reports a
+        // non-zero amplitude.  (A queue with one compare per round and a register shift per rotation was measured: no faster.)
+        uint32_t qs[WPT], qr[WPT];
+        double qc[WPT], qn[WPT];
+#pragma unroll
+        for (int r = 0; r < WPT; ++r) {
+            const double2 cr = cs[(uint32_t)(wa[r] >> 33) & 0xfffu];
+            const bool live = c * CH + threadIdx.x + (uint32_t)r * NT < ptot;
+            const bool orphan = ((uint32_t)(wa[r] >> 16) & 0xffffu) == 0xffffu;
+            qs[r] = orphan ? (((uint32_t)wa[r] & 0xffffu) | (spare << 16)) : (uint32_t)wa[r];
+            qr[r] = live ? (((uint32_t)(wa[r] >> 45) & 0xfffu) | (orphan ? 0x1000u : 0u)) : SEC_NO_ROUND;
+            qc[r] = orphan ? 1.0 : cr.x;
+            qn[r] = orphan ? 0.0 : (((uint32_t)(wa[r] >> 32) & 1u) ? -cr.y : cr.y);
+        }
+        const uint32_t R = nround[c];
+        rtot += R;
+        for (uint32_t q = 0; q < R; ++q) {
+#pragma unroll
+            for (int r = 0; r < WPT; ++r) {
+                if ((qr[r] & 0xfffu) == q && dbg != 5) {
+                    const uint32_t si = qs[r] & 0xffffu, sj = qs[r] >> 16;
+                    const double u = tile[si], v = tile[sj];
+                    tile[si] = qc[r] * u + qn[r] * v;
+                    tile[sj] = qc[r] * v - qn[r] * u;
+                    bad |= (qr[r] & 0x1000u) && u != 0.0;
+                }
+            }
+            if (dbg != 6) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+#pragma unroll
+        for (int r = 0; r < WPT; ++r) wa[r] = wb[r];
+    }
+    if (dbg == 7 && threadIdx.x == 0 && (t % 37u) == 5u) {   // measurement: shader clock and time inside the rounds
+        const uint64_t tm1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
+        printf("tile %u n %u pairs %u chunks %u rounds %u: %.2f us in the chunk loop, clock %.0f MHz\n", t, n, ptot, nchunks, rtot,
+               (double)(tr1 - tr0) / 100.0, (double)(tm1 - tm0) / (double)(tr1 - tr0) * 100.0);
+    }
+    for (uint32_t k = threadIdx.x; k < n; k += NT) out[dst[k]] = tile[k];
+    if (bad) atomicOr(flag, 1);
+}
+// scatter indices of a sweep: where every entry of its order sits in the NEXT sweep's tile-padded order
+// (dstc[p], p = position in this sweep's order; src_next / off_next / cap_next describe the next sweep) ...
+__global__ __launch_bounds__(256) void k_sec_dst_compact(const uint32_t *__restrict__ src_next, const uint32_t *__restrict__ off_next,
+                                                         uint32_t cap_next, uint32_t *__restrict__ dstc) {
+    const uint32_t t = blockIdx.x, e0 = off_next[t], n = off_next[t + 1] - e0;
+    for (uint32_t k = threadIdx.x; k < n; k += 256u) dstc[src_next[e0 + k]] = t * cap_next + k;
+}
+// ... in this sweep's own tile-padded form (dstc == nullptr: the last sweep writes its order contiguously)
+__global__ __launch_bounds__(256) void k_sec_dst_pad(const uint32_t *__restrict__ dstc, const uint32_t *__restrict__ off, uint32_t cap,
+                                                     uint32_t *__restrict__ dstpad) {
+    const uint32_t t = blockIdx.x, e0 = off[t], n = off[t + 1] - e0;
+    for (uint32_t k = threadIdx.x; k < cap; k += 256u) dstpad[(size_t)t * cap + k] = k < n ? (dstc ? dstc[e0 + k] : e0 + k) : 0xffffffffu;
+}
+
 // ---- materialised <H>: construction ------------------------------------------------------------------------------------
 // One thread per entry of the tile; for every x-group of the sweep D_g = sum_t c_t (-1)^{|hi & z_t|} with hi = the pair's
 // member whose pivot bit is set, kept by the pair's owner.  FILL = false: ccnt[e] / xcnt[e] = elements of entry e in the
@@ -920,17 +1101,43 @@ __global__ __launch_bounds__(256) void k_sec_reduce_w(const double *__restrict__
 }
 
 // ---- Lanczos on the support (ovqe_sector_ground_state): vectors of K doubles in the circuit's final order --------------
-__global__ __launch_bounds__(256) void k_sec_randomize(double *__restrict__ v, uint32_t K, uint64_t seed, double2 *__restrict__ partials) {
+__device__ __forceinline__ double sec_unit_pm1(uint64_t seed, uint32_t k) {
+    uint64_t z = seed + 0x9e3779b97f4a7c15ull * (uint64_t)(k + 1u);   // splitmix64
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return (double)(int64_t)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;   // [-1, 1)
+}
+// start vector: seeded noise on the entries whose `reach` value is non-zero (the block of H that holds the reference
+// determinant, k_sec_reach_step), exact zeros elsewhere — H never leaves that block, so neither do the Lanczos vectors
+__global__ __launch_bounds__(256) void k_sec_randomize(double *__restrict__ v, const double *__restrict__ reach, uint32_t K, uint64_t seed,
+                                                       double2 *__restrict__ partials) {
     __shared__ double2 red[4];
     double acc = 0.0;
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < K; k += gridDim.x * 256u) {
-        uint64_t z = seed + 0x9e3779b97f4a7c15ull * (uint64_t)(k + 1u);   // splitmix64
-        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-        z ^= z >> 31;
-        const double x = (double)(int64_t)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;   // [-1, 1)
+        const double x = reach[k] != 0.0 ? sec_unit_pm1(seed, k) : 0.0;
         v[k] = x;
         acc += x * x;
+    }
+    const double2 t = block_sum<256>(make_double2(acc, 0.0), red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+// reachability from the reference determinant through the non-zero elements of the materialised Hamiltonian: r = e_hf, then
+// r <- positive noise on {r != 0 or (H r) != 0} until the set stops growing (positive, irrational-ish values: a sum of elements
+// of mixed sign vanishes on a null set only).  partials.x = members.
+__global__ __launch_bounds__(256) void k_sec_reach_init(double *__restrict__ r, uint32_t K, uint32_t hf_pos) {
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < K; k += gridDim.x * 256u) r[k] = k == hf_pos ? 1.5 : 0.0;
+}
+__global__ __launch_bounds__(256) void k_sec_reach_step(double *__restrict__ r, const double *__restrict__ w, uint32_t K, uint64_t salt,
+                                                        double thresh, double2 *__restrict__ partials) {
+    __shared__ double2 red[4];
+    double acc = 0.0;
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < K; k += gridDim.x * 256u) {
+        // thresh: rounding residues of cancelling strings (the XX and YY coefficients of a hopping term agree to an ulp, not
+        // exactly: <N + 2| H |N> ~ 1e-17) are not connections
+        const bool in = r[k] != 0.0 || fabs(w[k]) > thresh;
+        r[k] = in ? 1.5 + 0.5 * sec_unit_pm1(salt, k) : 0.0;   // [1, 2)
+        acc += in ? 1.0 : 0.0;
     }
     const double2 t = block_sum<256>(make_double2(acc, 0.0), red);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
@@ -942,15 +1149,17 @@ __global__ __launch_bounds__(256) void k_sec_scale(double *__restrict__ v, uint3
 __global__ __launch_bounds__(256) void k_sec_axpy(double *__restrict__ y, const double *__restrict__ x, double a, uint32_t K, int first) {
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < K; k += gridDim.x * 256u) y[k] = first ? a * x[k] : y[k] + a * x[k];
 }
-// w -= alpha v + beta vprev; partials = |w|^2
+// w -= alpha v + beta vprev; partials = |w|^2.  mask (optional): entries with mask[k] == 0 are projected out (the operator
+// is P H P, P = the block of the reference determinant)
 __global__ __launch_bounds__(256) void k_sec_lanczos_update(double *__restrict__ w, const double *__restrict__ v,
                                                             const double *__restrict__ vprev, double alpha, double beta, uint32_t K,
-                                                            double2 *__restrict__ partials) {
+                                                            double2 *__restrict__ partials, const double *__restrict__ mask = nullptr) {
     __shared__ double2 red[4];
     double acc = 0.0;
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < K; k += gridDim.x * 256u) {
         double x = w[k] - alpha * v[k];
         if (vprev) x -= beta * vprev[k];
+        if (mask && mask[k] == 0.0) x = 0.0;
         w[k] = x;
         acc += x * x;
     }

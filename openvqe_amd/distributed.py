@@ -26,6 +26,8 @@ collective exists on the data path.
 """
 from __future__ import annotations
 
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -53,6 +55,15 @@ class HipShardEngine:
         self.tensor = torch.zeros(1 << n_local, dtype=torch.complex128, device=self.device)
         self.sv = Statevector(n_local, device=device, n_global=n_global, shard_index=rank)
         self.sv.adopt_state(self.tensor.data_ptr())
+        # RCCL's Work.wait() orders torch's CURRENT stream behind a transfer, nothing else: the handle's kernels must run
+        # on that very stream, or a contraction could read a partner shard before it has arrived
+        self.stream = torch.cuda.current_stream(self.device)
+        self.sv.set_stream(self.stream.cuda_stream)
+
+    def check_stream(self):
+        if torch.cuda.current_stream(self.device).cuda_stream != self.stream.cuda_stream:
+            raise RuntimeError("ShardedStatevector was created under another torch stream: its shard kernels would not be "
+                               "ordered behind RCCL transfers waited for on this one")
 
     def new_buffer(self, count):
         return torch.empty(count, dtype=torch.complex128, device=self.device)
@@ -101,7 +112,8 @@ class ShardedStatevector:
             dev = device if device is not None else torch.cuda.current_device()
             engine_factory = lambda nl, ng, r: HipShardEngine(nl, ng, r, dev)  # noqa: E731
         self.engine = engine_factory(self.n_local, self.g, self.rank)
-        self.stats = {"swaps": 0, "bytes_sent": 0, "full_shard_reads": 0}
+        self._dist = dist.is_initialized()
+        self.stats = {"swaps": 0, "bytes_sent": 0, "full_shard_reads": 0, "pieces": 0, "swap_s": 0.0, "shard_read_s": 0.0}
         self._tmp = None
         self._shard_bufs = None
         self._sigma = None
@@ -127,6 +139,8 @@ class ShardedStatevector:
         through host copies there: sent from a host copy taken now, received into a host buffer that ``wait()`` copies
         to the device."""
         staged = snd.is_cuda and dist.get_backend(self.group) == "gloo"
+        if snd.is_cuda and not staged and hasattr(self.engine, "check_stream"):
+            self.engine.check_stream()
         s_buf = snd.cpu() if staged else snd
         r_buf = torch.empty(rcv.shape, dtype=rcv.dtype, device="cpu") if staged else rcv
         ops = [dist.P2POp(dist.isend, s_buf, partner, self.group, tag=tag), dist.P2POp(dist.irecv, r_buf, partner, self.group, tag=tag)]
@@ -171,16 +185,19 @@ class ShardedStatevector:
         mine_out = t[:, 1 - alpha, :]          # (A, B): the half this rank gives away / receives into
         A, B = mine_out.shape
         half = A * B
-        P = max(1, min(self.EXCHANGE_PIECES, half))
+        P = self.EXCHANGE_PIECES
         recv = self._tmp_buffer(half)
-        if A >= P:                              # pieces = row blocks (strided rows of length B)
+        if A >= P or A >= B:                    # pieces = row blocks (strided rows of length B)
+            P = max(1, min(P, A))               # never a zero-length piece: an empty send/recv pair is still a group launch
             views = [mine_out[(A * p) // P:(A * (p + 1)) // P, :] for p in range(P)]
         else:                                   # few long rows: cut the columns
+            P = max(1, min(P, B))
             views = [mine_out[:, (B * p) // P:(B * (p + 1)) // P] for p in range(P)]
         sizes = [v.numel() for v in views]
         starts = [sum(sizes[:p]) for p in range(P)]
         recv_pieces = [recv[starts[p]:starts[p] + sizes[p]] for p in range(P)]
         self.engine.sync()
+        t_swap = time.perf_counter()
 
         def pack(p):
             v = views[p]
@@ -191,12 +208,13 @@ class ShardedStatevector:
 
         self._exchange(partner, pack, recv_pieces, unpack)
         self.engine.sync()
+        self.stats["swap_s"] += time.perf_counter() - t_swap
         # the logical qubits living on these two physical bits trade places
         la, lb = self.perm.index(gbit), self.perm.index(lbit)
         self.perm[la], self.perm[lb] = lbit, gbit
         self.stats["swaps"] += 1
         self.stats["bytes_sent"] += half * 16
-        self.stats["pieces"] = self.stats.get("pieces", 0) + P
+        self.stats["pieces"] += P
 
     def _localise(self, x_logical_seq, r):
         """make every X/Y qubit of rotation r local; victims by farthest next X/Y use"""
@@ -233,14 +251,14 @@ class ShardedStatevector:
         self.perm = list(range(self.n))
         self.engine.randomize(seed, 1.0)
         n2 = torch.tensor([self.engine.norm2()], dtype=torch.float64, device=self.engine.tensor.device)
-        if self.world > 1:
+        if self._dist:
             dist.all_reduce(n2, group=self.group)
         self.engine.tensor.mul_(1.0 / float(n2.item()) ** 0.5)
         return float(n2.item())
 
     def norm2(self):
         n2 = torch.tensor([self.engine.norm2()], dtype=torch.float64, device=self.engine.tensor.device)
-        if self.world > 1:
+        if self._dist:
             dist.all_reduce(n2, group=self.group)
         return float(n2.item())
 
@@ -297,7 +315,11 @@ class ShardedStatevector:
 
         pending = post(0)
         for k in range(len(partners)):
+            t0 = time.perf_counter()
             pending.wait()
+            if hasattr(self.engine, "stream"):
+                self.engine.stream.synchronize()      # the transfer itself, for the per-link rate of the bench line
+            self.stats["shard_read_s"] += time.perf_counter() - t0
             pending = post(k + 1) if k + 1 < len(partners) else None
             self.stats["full_shard_reads"] += 1
             self.stats["bytes_sent"] += size * 16
@@ -319,7 +341,7 @@ class ShardedStatevector:
                                           np.array([t[1] for t in terms], np.uint64),
                                           np.array([t[2] for t in terms], np.complex128), ket)
         val = torch.tensor([total.real], dtype=torch.float64, device=self.engine.tensor.device)
-        if self.world > 1:
+        if self._dist:
             dist.all_reduce(val, group=self.group)
         return float(val.item()) + float(np.real(constant))
 
@@ -380,7 +402,7 @@ class ShardedStatevector:
         for (xg, terms), ket in zip(remote, self._partner_shards([xg for xg, _ in remote])):
             contract(terms, ket)
         buf = torch.from_numpy(np.stack([vals.real, vals.imag])).to(self.engine.tensor.device)
-        if self.world > 1:
+        if self._dist:
             dist.all_reduce(buf, group=self.group)
         v = buf[0].cpu().numpy() + 1j * buf[1].cpu().numpy()
         return 2.0 * v.real if mode == "fermionic" else 2.0 * np.abs(v)

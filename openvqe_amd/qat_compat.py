@@ -334,13 +334,24 @@ class HipQPU:
         self.device = device
         self._sv = {}
         self._compiled = {}   # nbqbits -> (skeleton key, operator objects kept alive, n_params)
-        self._observable = {}  # nbqbits -> observable object uploaded last
+        self._observable = {}  # nbqbits -> (observable object uploaded last, its content fingerprint)
 
     def _backend(self, n):
         from .backend import Statevector
         if n not in self._sv:
             self._sv[n] = Statevector(n, device=self.device)
         return self._sv[n]
+
+    @staticmethod
+    def _fingerprint(op):
+        """cheap content check of an operator object next to its identity: callers of the reference may mutate an operator
+        or an observable in place between submissions (it rebuilds everything per submit); term count, constant, the
+        coefficient sum and a sample of whole terms catch an edited / appended term at a cost far below the submission's"""
+        terms = op.terms
+        acc = sum([t.coeff for t in terms])                                   # one pass, ~20 us per 1000 terms
+        step = max(1, len(terms) // 8)
+        chars = tuple((t.op, tuple(t.qbits), t.coeff) for t in terms[::step])  # ... and a few whole terms
+        return (len(terms), complex(getattr(op, "constant_coeff", 0.0)), acc, chars)
 
     @staticmethod
     def _skeleton(circuit):
@@ -359,7 +370,7 @@ class HipQPU:
             ops = ops[:len(thetas)]
             if any(isinstance(t, AffineParam) for t in thetas):
                 return None
-            key.append(("E", tuple(id(op) for op in ops), what.init, tuple(qubits)))
+            key.append(("E", tuple(id(op) for op in ops), tuple(HipQPU._fingerprint(op) for op in ops), what.init, tuple(qubits)))
             sym = [AffineParam(len(angles) + k) for k in range(len(thetas))]
             angles.extend(float(t) for t in thetas)
             items.append((kind, PauliEvolution(ops, what.init, sym, what.arity), qubits))
@@ -402,9 +413,11 @@ class HipQPU:
         sv = self._backend(n)
         theta = self._load(sv, circ)
         if job.type == "OBS":
-            if self._observable.get(n) is not job.observable:
+            seen = self._observable.get(n)
+            fp = self._fingerprint(job.observable)
+            if seen is None or seen[0] is not job.observable or seen[1] != fp:
                 sv.set_hamiltonian(job.observable)
-                self._observable[n] = job.observable
+                self._observable[n] = (job.observable, fp)
             return Result(value=sv.energy(theta))
         sv.prepare_state(theta)
         listed = sv.get_support() if n >= 16 else None   # non-zero amplitudes listed on the device (ovqe_get_support)

@@ -35,3 +35,41 @@ def test_two_process_replica_bench_line(gpu_lib):
     assert "workload" in out["config"] and out["config"]["parallelism"].endswith("x2")
     # whole-job aggregate: both ranks' batches over the max-over-ranks time
     assert abs(out["value"] - 2 * 2048 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+
+
+def test_two_process_sharded_block_against_oracle(gpu_lib):
+    """configs[4] through the driver's own command at a size the oracle holds: `bench.py --gpus 2` (gloo, both ranks on
+    device 0) must add the `sharded` block — weak run at n = 16 (one global qubit), strong run at n = 15 — and both energies
+    must equal the bit-mask oracle's on the host-recomputed synthetic state."""
+    import numpy as np
+
+    import bench
+    from openvqe_amd import synth
+    from oracle import masks
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, OVQE_BENCH_BACKEND="gloo", OVQE_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "1024", "--no-roofline", "--no-cpu", "--no-extra", "--sharded-qubits", "15", "--sharded-rotations", "24",
+           "--sharded-terms", "80"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    sh = json.loads(lines[0])["sharded"]
+    assert sh["weak"]["n_qubits"] == 16 and sh["strong"]["n_qubits"] == 15
+    for leg in (sh["weak"], sh["strong"]):
+        n = leg["n_qubits"]
+        xs, zs, phis, hx, hz, hc = bench.sharded_workload(n, 24, 80)
+        psi = synth.amplitudes(bench.SHARDED_SEED, np.arange(1 << n, dtype=np.uint64))
+        psi = psi / np.linalg.norm(psi)
+        for x, z, p in zip(xs, zs, phis):
+            psi = masks.rotate(psi, x, z, p)
+        want = masks.expectation(psi, hx, hz, hc, 0.0)
+        assert abs(leg["energy"] - want) < 1e-11 * np.abs(hc).sum(), (n, leg["energy"], want)
+        assert abs(leg["norm2"] - 1.0) < 1e-12
+        assert leg["n_gpus"] == 2 and leg["swaps"] >= 1 and leg["exchanged_GiB_per_rank"] > 0
+        assert leg["xgmi_link_GBs_exchange"] > 0 and leg["full_shard_reads"] >= 1

@@ -449,10 +449,24 @@ def test_24_qubit_spin_adapted_ansatz_gets_its_tables_from_the_second_probe(gpu_
                 supports.append(sv.program_info()["sector_support"])
             eg, g = sv.energy_gradient(thetas[0])
             out[sector] = (es, supports, eg, g)
+            if sector:
+                # the `fci` number from tables that list determinants of SEVERAL particle-number sectors: Lanczos stays inside
+                # the block of H connected to |hf>; a lower eigenvalue of another sector must not come back
+                fci = sv.sector_ground_state(tol=1e-10)
+                fci_block = sv.program_info()["sector_fci_block"]
+                # ... and a fresh program on the same handle starts from the one-angle-per-parameter probe again
+                sv.set_ucc_program(gens[:3], hf)
+                fci3 = sv.sector_ground_state(tol=1e-10)
+                sup3 = sv.program_info()["sector_support"]
     l1 = float(np.abs(ham.packed()[2]).sum())
     for a, b in zip(out[1][0], out[0][0]):
         assert abs(a - b) < 1e-11 * l1
     assert abs(out[1][2] - out[0][2]) < 1e-11 * l1 and np.abs(out[1][3] - out[0][3]).max() < 1e-9 * l1
+    # variational bracket: the block is a subspace of the determinant's symmetry sector (never below the sector's FCI energy,
+    # DESIGN.md section 4) that holds every state of the ansatz (never above its energies)
+    assert -109.0765315037 - 1e-9 <= fci[0] <= min(out[1][0]) + 1e-9 and fci[1] < 1e-6, fci
+    assert fci_block <= 792 ** 2 < out[1][1][-1]
+    assert sup3 <= 792 ** 2 and fci3[0] >= fci[0] - 1e-9    # a three-generator support: a subspace of the sector
     sup = out[1][1]
     assert sup[0] == 0                                        # first evaluation: dense kernels
     assert sup[-1] > 792 ** 2                                 # tables of the second probe: beyond the (5 alpha, 5 beta) sector

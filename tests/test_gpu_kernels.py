@@ -719,3 +719,24 @@ def test_shard_screen_primitives_against_oracle(gpu_lib, n_local, n_global, shar
         ref = [sum(c * np.vdot(sigma, apply_ref(partner, pbase, x, z)) for x, z, c in
                    zip(xs[a:b], zs[a:b], cs[a:b])) for a, b in zip(offsets[:-1], offsets[1:])]
         assert np.abs(got - np.array(ref)).max() < 1e-10 * np.sqrt(dim)
+
+
+def test_empty_pauli_sums(gpu_lib):
+    """ovqe_apply_pauli_sum with T = 0 (out = 0, or untouched when accumulating) and ovqe_bilinear_batch over operators without
+    any term (all zeros): the empty host vectors must never reach an upload"""
+    import torch
+    from openvqe_amd.backend import Statevector
+    n = 9
+    rng = np.random.default_rng(9)
+    fill = torch.from_numpy(rng.normal(size=1 << n) + 1j * rng.normal(size=1 << n)).cuda()
+    out = fill.clone()
+    with Statevector(n) as sv:
+        sv.randomize(5)
+        sv.apply_pauli_sum([], [], [], out.data_ptr(), None, accumulate=True)
+        torch.cuda.synchronize()
+        assert torch.equal(out, fill)
+        sv.apply_pauli_sum([], [], [], out.data_ptr(), None, accumulate=False)
+        torch.cuda.synchronize()
+        assert float(out.abs().max()) == 0.0
+        got = sv.bilinear_batch(np.zeros(4, np.int64), [], [], [], bra_ptr=fill.data_ptr())
+        assert got.shape == (3,) and np.all(got == 0)

@@ -315,3 +315,21 @@ def test_result_of_a_state_vector_job_keeps_arrays_and_yields_samples():
     assert len(Result(value=1.5)) == 0 and Result(value=1.5).indices is None
     legacy = Result(samples=[Sample(1, 1.0, 2)])
     assert [s.state.int for s in legacy] == [1] and legacy.indices is None
+
+
+def test_qpu_cache_keys_follow_operator_contents():
+    """HipQPU skips recompilation / re-upload for the SAME operator objects only while their contents are unchanged: the
+    reference rebuilds everything per submission, so in-place edits between submissions are legal there"""
+    from openvqe_amd.operators import Hamiltonian, Term
+    from openvqe_amd.qat_compat import HipQPU
+    ham = Hamiltonian(4, [Term(0.1 * (k + 1), "XZ", [k % 3, 3]) for k in range(40)], 0.5, do_clean_up=False)
+    f0 = HipQPU._fingerprint(ham)
+    assert HipQPU._fingerprint(ham) == f0 == HipQPU._fingerprint(ham.copy())
+    ham.terms[17].coeff *= 2
+    f1 = HipQPU._fingerprint(ham)
+    assert f1 != f0
+    ham.terms.append(Term(0.0, "Z", [0]))
+    f2 = HipQPU._fingerprint(ham)
+    assert f2 != f1
+    ham.constant_coeff = 0.25
+    assert HipQPU._fingerprint(ham) != f2
