@@ -230,6 +230,15 @@ def gate_and_midsize_workloads(device):
                     "bytes_per_launch": hb, "avg_launch_ms": 1e3 * t_exp,
                     "traffic_source": "profiles/r2_sector/pmc_summary.txt (FETCH_SIZE x2)"}
                 row24[label]["circuit_sweeps_ms"] = 1e-3 * float(np.mean(circ_us))
+            if sector:
+                # batched evaluations on the tables (what a finite-difference gradient of the reference's BFGS submits)
+                thb = rng.uniform(-0.1, 0.1, (64, len(gens24)))
+                sv.energy_batch(thb)
+                t0 = time.perf_counter()
+                eb = sv.energy_batch(thb)
+                dtb = (time.perf_counter() - t0) / 64
+                row24[label]["batch_64"] = {"ms_per_evaluation": 1e3 * dtb, "x_serial_rate": min(times[2:]) * 1e-3 / dtb,
+                                            "max_abs_diff_vs_single": float(max(abs(eb[k] - sv.energy(thb[k])) for k in (0, 63)))}
             # exact gradient of all parameters (adjoint method; on the sector tables when they exist)
             tg = []
             for _ in range(2):
@@ -448,6 +457,48 @@ def sharded_block(args, local_rank, world, rank, barrier):
     else:
         block["strong"] = block["weak"]
     return block
+
+
+def mirror_leg():
+    """what a caller of the reference's entry points gets (Route B): H2O/STO-3G UCCSD through
+    openvqe_amd.ucc_family.get_energy_ucc.EnergyUCC — `ucc_action` one evaluation per call, and the whole `get_energies`
+    (two BFGS runs at tol 1e-4, ref:openvqe/ucc_family/get_energy_ucc.py:92-206) with the reference's default jac=None,
+    with the opt-in batched forward-difference Jacobian and with the opt-in exact Jacobian"""
+    import contextlib
+    import io
+    from openvqe_amd import chem
+    from openvqe_amd.ucc_family.get_energy_ucc import EnergyUCC
+    mol = chem.molecule("H2O")
+    mol.rhf()
+    prob = mol.problem(active=False)
+    ham = prob.jw_hamiltonian()
+    size, _, spin_ops, theta_mp2, hf = prob.uccsd()
+    e_fci = mol.ci_ground_state()[0]
+    out = {"workload": f"H2O/STO-3G UCCSD, {size} cluster operators (reference operator order), MP2 guess", "E_FCI": e_fci}
+    ucc = EnergyUCC()
+    th = np.array(theta_mp2)
+    energies = []
+    ucc.ucc_action(th, ham, spin_ops, hf, energies)
+    reps = 300
+    t0 = time.perf_counter()
+    for k in range(reps):
+        ucc.ucc_action(th + 1e-3 * k, ham, spin_ops, hf, energies)
+    dt = (time.perf_counter() - t0) / reps
+    out["ucc_action"] = {"us_per_call": 1e6 * dt, "evals_per_s": 1.0 / dt, "energy_at_theta_mp2": float(energies[0])}
+    for label, flags in (("default_fd_jacobian_by_scipy", {}), ("batched_gradient", {"batched_gradient": True}),
+                         ("adjoint_gradient", {"adjoint_gradient": True})):
+        u = EnergyUCC()
+        for k, v in flags.items():
+            setattr(u, k, v)
+        sink = io.StringIO()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(sink):
+            it, res = u.get_energies(ham, spin_ops, spin_ops, hf, list(theta_mp2), [0.0] * size, e_fci)
+        out["get_energies_" + label] = {"wall_s": time.perf_counter() - t0, "evaluations": len(res["energies_1"]) + len(res["energies_2"]),
+                                        "E1": float(it["minimum_energy_result1_guess"][0]),
+                                        "E2": float(it["minimum_energy_result2_guess"][0]),
+                                        "E1_minus_FCI": float(res["energies1_substracted_from_FCI"])}
+    return out
 
 
 def pmc_traffic_per_launch():
@@ -711,8 +762,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                # PMC counters need their own rocprofv3 passes (no counters inside this run): the number below is read from the
+                # newest COMMITTED profile of this same command and says so
                 "traffic": (pmc_traffic_per_launch() or (None, None))[0] if nq == 30 else None,
-                "traffic_source": (pmc_traffic_per_launch() or (None, None))[1] if nq == 30 else None,
+                "traffic_source": ("committed profile: " + pmc_traffic_per_launch()[1]) if nq == 30 and pmc_traffic_per_launch() else None,
                 "bytes_per_launch": 32.0 * (1 << nq),
                 "avg_launch_ms": mean_ms,
                 "worst_string": worst,
@@ -728,12 +781,18 @@ def main():
             out["single_call_evals_per_s"] = h2o["single"]["evals_per_s"]
             out["fd_gradient_evals_per_s"] = h2o["fd_gradient"]["evals_per_s"]
             out["host_buffer_evals_per_s"] = h2o["batch4096"]["evals_per_s"]
+            # ... and through the mirrors of the reference's entry points (what north_star names)
+            mir = mirror_leg()
+            out["mirror"] = mir
+            out["mirror_ucc_action_evals_per_s"] = mir["ucc_action"]["evals_per_s"]
+            out["mirror_get_energies_wall_s"] = {k[len("get_energies_"):]: v["wall_s"] for k, v in mir.items() if k.startswith("get_energies_")}
             # ... and the 24-qubit figures (BASELINE configs[3] on its molecule), lifted out the same way
             m3 = next((r for r in out["extra_workloads"] if "M3" in r.get("workload", "")), None)
             n2 = next((r for r in out["extra_workloads"] if "configs[3]" in r.get("workload", "")), None)
             if m3 and n2:
                 out["summary_24_qubits"] = {
                     "uccsd_evaluation_ms": m3["sector_path"]["ms_steady_state"],
+                    "uccsd_evaluation_ms_in_batches_of_64": m3["sector_path"]["batch_64"]["ms_per_evaluation"],
                     "uccsd_evaluation_hamiltonian_kernel": {k: m3["sector_path"]["roofline_expect_kernel"][k]
                                                             for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")},
                     "uccsd_evaluation_circuit_sweeps_ms": m3["sector_path"]["circuit_sweeps_ms"],

@@ -116,6 +116,7 @@ struct SectorEngine {
     std::vector<SectorHSweep> hs;
     DevBuf d_sup, d_buf[2], d_hdesc, d_flag;
     DevBuf d_lam[2], d_w, d_wpart;   // adjoint gradient: lambda (ping-pong), per-entry sums, per-tile partials
+    DevBuf d_bbuf[2], d_brp, d_benergies;   // batched evaluations: state slices (ping-pong), angle tables, energies
     size_t budget = 0;
     int h_max_dict = 0;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // option "sector_profile": start / after the sweeps / after <H>
@@ -221,6 +222,7 @@ struct ovqe_sv {
     int opt_sector_sweep_dbg = 0; // measurements only, k_sector_sweep2: 1 no ops, 2 empty kernel, 3 loads only — wrong results
     int opt_sector_h_groups = 128; // workgroups per <H> sweep (they share the sweep's tiles round robin)
     int opt_sector_h_threads = 512; // threads per workgroup of k_sector_expect (512 or 1024)
+    int opt_sector_batch = 1;     // ovqe_energy_batch on the sector tables: whole batches per pass (0: one evaluation at a time)
     float last_batch_ms = 0.f;
     const double *cur_theta = nullptr;  // device pointers of the batch being evaluated
     double *cur_energies = nullptr;
@@ -2481,6 +2483,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     } else if (k == "sector_threads") h->opt_sector_threads = (value == 0 || value == 64 || value == 512 || value == 1024) ? (int)value : 256;
     else if (k == "sector_h_groups") h->opt_sector_h_groups = (int)value;
     else if (k == "sector_h_threads") h->opt_sector_h_threads = value == 1024 ? 1024 : 512;
+    else if (k == "sector_batch") h->opt_sector_batch = (int)value;
     else if (k == "sector_debug") h->opt_sector_debug = (int)value;
     else if (k == "sector_sweep") h->opt_sector_sweep = value == 1 ? 1 : 2;
     else if (k == "sector_sweep_dbg") h->opt_sector_sweep_dbg = (int)value;
@@ -2958,6 +2961,15 @@ int ovqe_prepare_state(ovqe_handle h, const double *theta, int32_t K) {
     return run_program_streaming(h, theta);
 }
 
+// batched sector evaluations need the tables of the second sweep kernel (64-bit pair words) and the materialised <H>
+static bool sector_batch_ready(ovqe_handle h) {
+    const SectorEngine &E = h->sec;
+    const bool real = h->opt_real_stream && h->prog_real_ok && h->n_global == 0 && tile_ok(h, true) && h->ham.groups.size() >= 3;
+    return real && h->opt_sector && h->opt_sector_batch && E.valid && E.h_tables && E.pad_elems && !E.segs.empty() && E.segs[0].d_wide.p &&
+           E.prog_version == h->prog_version && E.ham_version == h->ham.version &&
+           sector_h_smem(E, SEC_BATCH_NB) <= 156 * 1024;
+}
+
 int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, double *energies) {
     OVQE_ENTER(h);
     if (!h || B < 0 || (B && !energies)) return OVQE_ERR_INVALID;
@@ -2977,7 +2989,19 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
     }
     if (use_small_path(h, B)) return run_small(h, B, theta, energies);
     HIPC(h, hipEventRecord(h->ev0, h->stream));
-    for (int64_t b = 0; b < B; ++b) {
+    int64_t b_first = 0;
+    if (B >= 4 && h->opt_sector_batch && h->opt_real_stream && h->prog_real_ok && h->n_global == 0 && tile_ok(h, true) &&
+        h->ham.groups.size() >= 3) {
+        rc = sector_prepare(h, true);   // a batch is worth the tables at once (a lone evaluation builds them at its second call)
+        if (rc) return rc;
+    }
+    if (B >= 2 && sector_batch_ready(h)) {   // the whole batch in one pass of the sector tables
+        bool ok = false;
+        rc = run_sector_energy_batch(h, B, theta, false, energies, &ok);
+        if (rc) return rc;
+        if (ok) b_first = B;
+    }
+    for (int64_t b = b_first; b < B; ++b) {
         // programs that keep the amplitudes real stream 8 bytes per amplitude (state left as 2^n doubles)
         const bool real = h->opt_real_stream && h->prog_real_ok && h->n_global == 0 && tile_ok(h, true) &&
                           h->ham.groups.size() >= 3;

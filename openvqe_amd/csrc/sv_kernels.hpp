@@ -744,6 +744,24 @@ __global__ __launch_bounds__(256) void k_resolve_rots(const RotSpec *__restrict_
     out[r] = rp;
 }
 
+// angle tables of a batch: out[b * count + r] from theta[b * K + .]  (blockIdx.y = b)
+__global__ __launch_bounds__(256) void k_resolve_rots_batch(const RotSpec *__restrict__ spec, int count, const double *__restrict__ theta,
+                                                            int K, RotParam *__restrict__ out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= count) return;
+    const RotSpec sr = spec[r];
+    const double phi = sr.phi0 + (sr.pidx >= 0 ? sr.coeff * theta[(size_t)blockIdx.y * K + sr.pidx] : 0.0);
+    double sn, c;
+    sincos(phi, &sn, &c);
+    RotParam rp;
+    rp.z = sr.z;
+    rp.c = c;
+    rp.s = (sr.ny & 2) ? -sn : sn;
+    rp.odd = sr.ny & 1;
+    rp.pad = 0;
+    out[(size_t)blockIdx.y * count + r] = rp;
+}
+
 // ---- real-amplitude state (2^n doubles): one-op sweeps for what does not fit a tile ----------------------------
 // run of odd-ny rotations sharing x: u' = c u + s_i v, v' = c v + s_j u
 __global__ __launch_bounds__(256) void k_rot_pairs_real(double *__restrict__ st, uint64_t npairs, int pivot, uint64_t x,

@@ -875,6 +875,123 @@ __global__ __launch_bounds__(NT) void k_sector_expect(const double *__restrict__
     if (threadIdx.x == 0) partials[slot] = tsum;
 }
 
+// <H> of NB states per pass over the table (batched evaluations, ovqe_energy_batch on the sector tables): the tile holds the NB
+// states interleaved (tile[slot * NB + s]), so an element's word, its dictionary value and its row serve NB states and the
+// table — the bytes that bound the single-state kernel — streams once for all of them.  blockIdx.z = group of NB states
+// (slices of `stride` doubles); partials[((z * sweeps + y) * groups + x) * NB + s].
+template <int NT, int NB>
+__global__ __launch_bounds__(NT) void k_sector_expect_batch(const double *__restrict__ states, size_t stride,
+                                                            const SecHSweep *__restrict__ sweeps, double *__restrict__ partials,
+                                                            uint32_t tile_cap) {
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
+    double *tile = reinterpret_cast<double *>(sec_smem);
+    double *dict = tile + (size_t)NB * ((tile_cap + 1u) & ~1u);
+    __shared__ double2 red[NW];
+    const SecHSweep sw = sweeps[blockIdx.y];
+    states += (size_t)blockIdx.z * NB * stride;
+    for (int k = threadIdx.x; k < sw.ndict; k += NT) dict[k] = sw.dict[k];
+    if (threadIdx.x == 0) dict[sw.ndict] = 0.0;   // the null element
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    double acc[NB];
+#pragma unroll
+    for (int s = 0; s < NB; ++s) acc[s] = 0.0;
+    for (uint32_t t = blockIdx.x; t < (uint32_t)sw.ntiles; t += gridDim.x) {
+        const uint32_t e0 = sw.off[t], n = sw.off[t + 1] - e0;
+        if (n == 0) continue;
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < n; k += NT) {
+            const uint32_t src = sw.src[e0 + k];
+#pragma unroll
+            for (int s = 0; s < NB; ++s) tile[(size_t)k * NB + s] = states[(size_t)s * stride + src];
+        }
+        __syncthreads();
+        for (uint32_t sl0 = wave; 64u * sl0 < n; sl0 += NW) {
+            const uint32_t p = 64u * sl0 + lane;
+            const uint32_t row = p < n ? sw.order[e0 + p] : 0u;
+            const size_t sl = (size_t)t * SEC_HSLICES + sl0;
+            double r[NB];
+#pragma unroll
+            for (int s = 0; s < NB; ++s) r[s] = 0.0;
+            {
+                const uint32_t L = sw.clen[sl];   // a multiple of 4
+                const uint32_t *wp = sw.cwords + sw.cbase[sl] + 4u * lane;
+                if (sw.ndict) {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    auto term = [&](uint32_t w) {
+                        const double *a = tile + (size_t)(w & SEC_HSLOT_MASK) * NB;
+                        double v = dict[w >> 14];
+                        if (w & (1u << SEC_HSLOT_BITS)) v = -v;
+#pragma unroll
+                        for (int s = 0; s < NB; ++s) r[s] += v * a[s];
+                    };
+                    uint32_t q = 0;
+                    for (; q + 7u < L; q += 8u) {
+                        u32x4 w[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wp + 64u * (q + 4u * (uint32_t)u)));
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            term(w[u].x);
+                            term(w[u].y);
+                            term(w[u].z);
+                            term(w[u].w);
+                        }
+                    }
+                    for (; q < L; q += 4u) {
+                        const u32x4 w = *reinterpret_cast<const u32x4 *>(wp + 64u * q);
+                        term(w.x);
+                        term(w.y);
+                        term(w.z);
+                        term(w.w);
+                    }
+                } else {
+                    const double *vp = sw.cvals + sw.cbase[sl] + 4u * lane;
+                    for (uint32_t q = 0; q < L; ++q) {
+                        const uint32_t at = 256u * (q >> 2) + (q & 3u);
+                        const double *a = tile + (size_t)(wp[at] & SEC_HSLOT_MASK) * NB;
+                        const double v = vp[at];
+#pragma unroll
+                        for (int s = 0; s < NB; ++s) r[s] += v * a[s];
+                    }
+                }
+            }
+            {
+                const uint32_t L = sw.xlen[sl];
+                const uint32_t *wp = sw.xwords + sw.xbase[sl] + lane;
+                const double *vp = sw.xvals + sw.xbase[sl] + lane;
+                for (uint32_t q = 0; q < L; ++q) {   // (a diagonal element reads the row's own amplitude: value * a_i)
+                    const double *a = tile + (size_t)(wp[64u * q] & SEC_HSLOT_MASK) * NB;
+                    const double v = vp[64u * q];
+#pragma unroll
+                    for (int s = 0; s < NB; ++s) r[s] += v * a[s];
+                }
+            }
+            if (p < n) {
+#pragma unroll
+                for (int s = 0; s < NB; ++s) acc[s] += tile[(size_t)row * NB + s] * r[s];
+            }
+        }
+    }
+    const size_t slot = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NB;
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+        __syncthreads();
+        const double2 tsum = block_sum<NT>(make_double2(acc[s], 0.0), red);
+        if (threadIdx.x == 0) partials[slot + s] = tsum.x;
+    }
+}
+// energies of a batch from the partial sums of k_sector_expect_batch: one workgroup per state, fixed order
+__global__ __launch_bounds__(256) void k_sec_reduce_batch(const double *__restrict__ partials, int nparts, int NB, double constant,
+                                                          double *__restrict__ energies) {
+    __shared__ double2 red[4];
+    const int b = blockIdx.x, z = b / NB, s = b % NB;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += partials[((size_t)z * nparts + i) * NB + s];
+    const double2 t = block_sum<256>(make_double2(acc, 0.0), red);
+    if (threadIdx.x == 0) energies[b] = t.x + constant;
+}
+
 // ---- exact gradient on the sector tables (adjoint method) ----------------------------------------------------------------
 // lambda = H psi restricted to the support from the same tables: the lane's row sum is lambda_i's part from the elements
 // its entry owns (a register sum), the partner's part lambda_j += H_ij a_i is an f64 LDS atomic on an LDS copy of the tile;

@@ -55,3 +55,34 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(dp, f)
                 assert "ovqe_oracle" not in text, os.path.join(dp, f)
+
+
+def test_cdef_header_for_cffi_is_current_and_preprocessor_free():
+    """include/ovqe_sv.cdef.h is what `cffi.FFI().cdef()` takes: no preprocessor line at all,
+    every declared entry point with the signature of the main header, the OVQE_* constants as one enum — and it is the
+    output of tools/make_cdef.py on the committed header.  Parsed with pycparser / cffi when they are importable."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_cdef", os.path.join(ROOT, "tools", "make_cdef.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    header = open(os.path.join(ROOT, "include", "ovqe_sv.h")).read()
+    cdef = open(os.path.join(ROOT, "include", "ovqe_sv.cdef.h")).read()
+    assert cdef == mk.generate(header), "run tools/make_cdef.py"
+    body = re.sub(r"/\*.*?\*/", "", cdef, flags=re.S)
+    assert "#" not in body and "extern" not in body
+    assert sorted(set(re.findall(r"\b(ovqe_[a-z0-9_]+)\s*\(", body))) == declared_symbols()
+    norm = lambda t: re.sub(r"\s+", " ", t).strip()
+    plain = norm(re.sub(r"/\*.*?\*/", "", header, flags=re.S))
+    for decl in re.findall(r"[^;{}]*\bovqe_[a-z0-9_]+\s*\([^;]*\);", body):
+        assert norm(decl) in plain, decl
+    for name, value in re.findall(r"#define\s+(OVQE_[A-Z_]+)\s+\(?(-?\d+)\)?", header):
+        if name != "OVQE_SV_H":
+            assert re.search(rf"\b{name} = {value},", body), name
+    try:
+        import cffi
+    except ImportError:
+        cffi = None
+    if cffi is not None:
+        ffi = cffi.FFI()
+        ffi.cdef(cdef)
+        assert ffi.typeof("ovqe_handle").kind == "pointer"

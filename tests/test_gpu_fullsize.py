@@ -279,6 +279,90 @@ def test_24_qubit_uccsd_sector_path_on_n2(gpu_lib):
     assert res[1][0][0] < e_rhf - 0.05                          # MP2 amplitudes recover correlation energy
 
 
+def test_24_qubit_sector_path_against_c_oracle(gpu_lib):
+    """The sector path at the size it is sold at, against the plain-C oracle (oracle/c, 256-MiB host state, fused mask sweeps +
+    x-grouped expectation): (1) the FULL N2 / cc-pVDZ (10e,12o) UCCSD program — 1715 generators = 13 300 rotations, 6464-term
+    Hamiltonian — at the MP2 amplitudes + noise; (2) every 8th generator: energy and sampled components of the exact gradient
+    against central differences of the oracle's energy."""
+    from openvqe_amd import chem
+    from openvqe_amd.backend import Statevector, compile_ucc_program
+    from oracle import cref
+    mol = chem.molecule("N2-CCPVDZ")
+    mol.rhf()
+    prob = chem.cas_problem(mol, 2, 12)
+    n = prob.nbqbits
+    ham = prob.jw_hamiltonian()
+    size, _, spin_ops, theta_mp2, hf = prob.uccsd()
+    hx, hz, hc = ham.packed()
+    hc = np.ascontiguousarray(hc.real)
+    l1 = float(np.abs(hc).sum())
+    rng = np.random.default_rng(2403)
+    theta = np.array(theta_mp2) + rng.uniform(-0.05, 0.05, size)
+    rx, rz, rc, pidx, K = compile_ucc_program(n, spin_ops)
+    assert K == size == 1715 and len(rx) == 13300
+    psi = np.empty(1 << n, dtype=np.complex128)
+    e_ref, _ = cref.ucc_energy(n, hf, rx, rz, rc, pidx, theta, hx, hz, hc, ham.constant_coeff, psi=psi)
+    with Statevector(n) as sv:
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(spin_ops, hf)
+        es = [sv.energy(theta) for _ in range(3)]
+        info = sv.program_info()
+    assert info["sector_support"] == 792 ** 2 and info["sector_h_elements"] > 10 ** 8
+    for e in es:                                                  # dense first call, table-building call, sector call
+        assert abs(e - e_ref) < 1e-10 * max(1.0, l1), (e, e_ref)
+    # thinned program: gradient components
+    gens8 = spin_ops[::8]
+    K8 = len(gens8)
+    th8 = theta[::8].copy()
+    rx, rz, rc, pidx, _ = compile_ucc_program(n, gens8)
+    e8_ref, _ = cref.ucc_energy(n, hf, rx, rz, rc, pidx, th8, hx, hz, hc, ham.constant_coeff, psi=psi)
+    with Statevector(n) as sv:
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens8, hf)
+        sv.energy(th8)
+        e8 = sv.energy(th8)
+        e8g, g8 = sv.energy_gradient(th8)
+        assert sv.program_info()["sector_support"] > 0
+    assert abs(e8 - e8_ref) < 1e-10 * max(1.0, l1) and abs(e8g - e8_ref) < 1e-10 * max(1.0, l1)
+    h = 1e-4
+    for k in (0, K8 // 3, K8 - 1):
+        tp, tm = th8.copy(), th8.copy()
+        tp[k] += h
+        tm[k] -= h
+        ep, _ = cref.ucc_energy(n, hf, rx, rz, rc, pidx, tp, hx, hz, hc, ham.constant_coeff, psi=psi)
+        em, _ = cref.ucc_energy(n, hf, rx, rz, rc, pidx, tm, hx, hz, hc, ham.constant_coeff, psi=psi)
+        assert abs(g8[k] - (ep - em) / (2 * h)) < 2e-7 * max(1.0, l1), (k, g8[k], (ep - em) / (2 * h))
+
+
+def test_22_qubit_full_program_sector_path_against_c_oracle(gpu_lib):
+    """molecule-shaped UCCSD at 22 qubits (11 orbitals, 5 + 5 electrons; full program, full Hamiltonian) on the sector tables
+    against the C oracle at two parameter vectors"""
+    from openvqe_amd import fermion
+    from openvqe_amd.backend import Statevector, compile_ucc_program
+    from oracle import cref
+    m, o = 11, 5
+    n = 2 * m
+    ham, gens, hf = fermion.synthetic_molecule(m, o, seed=22)
+    hx, hz, hc = ham.packed()
+    hc = np.ascontiguousarray(hc.real)
+    l1 = float(np.abs(hc).sum())
+    rx, rz, rc, pidx, K = compile_ucc_program(n, gens)
+    rng = np.random.default_rng(22)
+    thetas = [rng.uniform(-0.15, 0.15, K) for _ in range(2)]
+    psi = np.empty(1 << n, dtype=np.complex128)
+    want = [cref.ucc_energy(n, hf, rx, rz, rc, pidx, t, hx, hz, hc, ham.constant_coeff, psi=psi)[0] for t in thetas]
+    with Statevector(n) as sv:
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, hf)
+        sv.energy(thetas[0])
+        sv.energy(thetas[0])
+        got = [sv.energy(t) for t in thetas]
+        info = sv.program_info()
+    assert info["sector_support"] == 462 ** 2 and info["sector_h_elements"] > 0
+    for a, b in zip(got, want):
+        assert abs(a - b) < 1e-10 * max(1.0, l1), (a, b)
+
+
 def test_24_qubit_uccsd_vqe_on_n2_with_exact_gradients(gpu_lib):
     """BASELINE configs[3] as an optimisation: UCCSD-VQE of N2 / cc-pVDZ (10e, 12o), 1715 parameters, L-BFGS-B from the MP2
     amplitudes with ovqe_energy_gradient (sector tables from its second call on).  Checks: the energy falls monotonically

@@ -358,3 +358,41 @@ def test_spin_adapted_generators_on_sector_tables(SV):
     assert np.abs(out[1][2] - out[0][2]).max() < 1e-9 * l1
     assert info["sector_support"] > 0, info            # tables in use at the end (first or second probe)
     assert out[0][3]["sector_support"] == 0
+
+
+@pytest.mark.parametrize("m,o", [(8, 4), (9, 4), (10, 4)])
+def test_batched_evaluations_on_the_sector_tables_match_c_oracle(SV, m, o):
+    """ovqe_energy_batch at 16 - 20 qubits: B parameter vectors per pass of the sector tables (the sweeps with one workgroup per
+    (tile, state), <H> with two states per tile; ref:openvqe/ucc_family/get_energy_ucc.py:158-175 — BFGS with jac=None asks
+    for K + 1 evaluations per gradient) for B = 1, 3, 8, 141 — a first call on a fresh handle included, which builds the tables
+    at once — against the C oracle and against one evaluation at a time"""
+    from openvqe_amd import fermion
+    from openvqe_amd.backend import compile_ucc_program
+    from oracle import cref
+    n = 2 * m
+    ham, gens, hf = fermion.synthetic_molecule(m, o, seed=300 + m)
+    K = len(gens)
+    rng = np.random.default_rng(m * o)
+    thetas = rng.uniform(-0.3, 0.3, (141, K))
+    thetas[5] = 0.0
+    rx, rz, rc, pidx, _ = compile_ucc_program(n, gens)
+    hx, hz, hc = ham.packed()
+    want = cref.ucc_energy_batch(n, hf, rx, rz, rc, pidx, thetas, hx, hz, hc.real.copy(), ham.constant_coeff)
+    l1 = float(np.abs(hc).sum())
+    with SV(n) as sv:
+        sv.set_option("force_path", 2)
+        sv.set_option("sector_min_qubits", 8)
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, hf)
+        first = sv.energy_batch(thetas[:8])                  # fresh handle: the batch builds the tables itself
+        info = sv.program_info()
+        got = {B: sv.energy_batch(thetas[:B]) for B in (1, 3, 8, 141)}
+        serial = np.array([sv.energy(t) for t in thetas[:9]])
+        sv.set_option("sector_batch", 0)
+        unbatched = sv.energy_batch(thetas[:9])
+    assert info["sector_support"] == comb(m, o) ** 2
+    assert np.abs(first - want[:8]).max() < 1e-10 * max(1.0, l1)
+    for B, e in got.items():
+        assert e.shape == (B,) and np.abs(e - want[:B]).max() < 1e-10 * max(1.0, l1), B
+    assert np.abs(got[141][:9] - serial).max() < 1e-12 * max(1.0, l1)
+    assert np.abs(unbatched - serial).max() < 1e-13 * max(1.0, l1)
