@@ -72,6 +72,10 @@ int ovqe_destroy(ovqe_handle h);
 int ovqe_set_stream(ovqe_handle h, void *hip_stream);
 /* tuning knobs: "force_path" (0 auto, 1 fused small-register kernel, 2 streaming kernels, 3 support-compacted
  * kernel), "sparse" (1: allow the support-compacted kernel when the program has a small reachable support),
+ * "sparse_renumber" (1, default: the compact support is numbered so that the pairs of an op fall into distinct LDS banks),
+ * "sector_sweep" (2, default: circuit sweeps of the sector path scatter into the next sweep's order and keep 64-bit pair
+ * words in registers; 1: first form), "sector_chunk" (pair words per chunk of those sweeps: 1024, 2048 default, 4096),
+ * "sector_batch" (1, default: ovqe_energy_batch runs whole batches per pass of the sector tables),
  * "small_max_qubits", "small_batch_max_qubits", "unroll", "real_mode" (1: allow the real-amplitude
  * specialisation of the fused kernel when every rotation string has an odd number of Y),
  * "table_fusion" (1: commuting same-x runs become single sparse pair rotations in the fused kernel),
@@ -90,8 +94,11 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * of the free memory — so that one pass of the recurrence gives the Ritz vector; default 160; 0, or vectors that do not fit: the
  * recurrence is run twice), "clifford_frame" (read by the NEXT ovqe_set_gate_program: 0 = execute the literal gate list; 1 (default) = when
  * the Clifford part of the list — X, H, CNOT, quarter-turn rotations — multiplies to the identity, run the
- * algebraically identical sequence of Pauli rotations with conjugated strings instead; 2 = always, Clifford part
- * appended literally), "expect_sparse" (tiled <H>: a tile in which at most 1/value of the amplitudes are non-zero — the
+ * algebraically identical sequence of Pauli rotations with conjugated strings instead, and when it does NOT (an open
+ * frame: interleaved CNOT ladders, stray gates) run that rotation sequence too: energies and gradients then use the stored
+ * Hamiltonian conjugated by the net Clifford operator (<C phi|H|C phi> = <phi|C^+ H C|phi>, every term stays one Pauli
+ * string) and ovqe_prepare_state applies the Clifford gates behind the rotations; 2 = frame form always, Clifford part
+ * appended literally to the program; 3 = frame form only when the frame closes, literal list otherwise), "expect_sparse" (tiled <H>: a tile in which at most 1/value of the amplitudes are non-zero — the
  * particle-number / spin sector of a UCC-type state — is evaluated over the compacted list of its non-zero amplitudes
  * instead of over all pairs; skipped work is multiplication by exact zeros; default 4, 0 = never),
  * "compact" (1, default: compact cover — from the second evaluation of a (program, Hamiltonian) pair on, <H> of a
@@ -272,7 +279,9 @@ int ovqe_last_support(ovqe_handle h, int32_t which, int64_t *support);
  *   (0: circuit only, <H> by the compact cover), matrix elements of the materialised Hamiltonian (padding included), table
  *   bytes  [22..24] with option "sector_profile" = 1: HIP-event time in microseconds of the circuit sweeps and of the <H>
  *   kernel of the most recent sector evaluation; bytes that kernel reads per evaluation
- *   [25] determinants of the block of H (restricted to the support) that the last ovqe_sector_ground_state diagonalised */
+ *   [25] determinants of the block of H (restricted to the support) that the last ovqe_sector_ground_state diagonalised
+ *   [26..27] support-compacted program: colliding lane pairs per evaluation (LDS bank conflicts of the circuit's pair
+ *   rotations) with the support numbered in discovery order, and with the numbering in use (option "sparse_renumber") */
 int ovqe_program_info(ovqe_handle h, int64_t *info, int count);
 
 #ifdef __cplusplus

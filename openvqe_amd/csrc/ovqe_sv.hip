@@ -150,6 +150,18 @@ struct ovqe_sv {
     static constexpr size_t IO_DOUBLES = 131072;
 
     HamDev ham;
+    // Gate programs whose Clifford part does not close (compile_gate_program_frame): the compiled program is the Pauli-rotation
+    // sequence alone, energies are evaluated with the stored Hamiltonian conjugated by the net Clifford operator
+    // (<C phi|H|C phi> = <phi|C^+ H C|phi>: every term stays one Pauli string), ovqe_prepare_state applies the Clifford
+    // gates literally behind the rotations.  ham_conj takes ham's place for the duration of an energy / gradient call.
+    HamDev ham_conj;
+    bool frame_open = false;
+    std::vector<uint64_t> frame_img;          // images of X_q, Z_q under the net Clifford: (x, z, k) triples, 2 n of them
+    std::vector<int32_t> tail_gates;          // the Clifford gates in order: (opcode, b0, b1, quarter-turn sign) quadruples
+    std::vector<uint64_t> user_x, user_z;     // the stored Hamiltonian as the caller gave it
+    std::vector<double> user_c;
+    double user_const = 0.0;
+    int ham_versions = 0;                     // version numbers are unique over ham and ham_conj
     HamDev ham_adhoc;             // last Hermitian sum evaluated by ovqe_expectation / ovqe_bilinear on the own state
     std::vector<uint64_t> adhoc_x, adhoc_z;
     std::vector<double> adhoc_c;
@@ -173,6 +185,8 @@ struct ovqe_sv {
     // support-compacted program (sv_sparse.hpp): built lazily for the current (program, Hamiltonian)
     bool sp_tried = false, sp_valid = false;
     int sp_m = 0, sp_nops = 0, sp_nent = 0;
+    int sp_mp = 0, sp_hf = 0;     // slots of the compact state (support padded to a multiple of 32 when renumbered), slot of |hf>
+    int64_t sp_conflicts_before = 0, sp_conflicts_after = 0;   // colliding lane pairs per evaluation, discovery order / renumbered
     int64_t sp_npairs = 0;
     DevBuf d_sp_ops, d_sp_pairs, d_sp_entries;
     // device copy of the ADAPT pool of the last ovqe_pool_gradients call (+ its host image for the change test)
@@ -189,9 +203,12 @@ struct ovqe_sv {
     int opt_sparse = 1;           // allow the support-compacted path
     int opt_sparse_spw = 0;       // evaluations per wave (0 = automatic)
     int opt_sparse_dealias = 1;   // arrange the restricted-Hamiltonian entries against LDS bank conflicts
+    int opt_sparse_renumber = 1;  // number the compact support against LDS bank conflicts of the circuit's pairs
+    int opt_sparse_grad = 1;      // ovqe_energy_gradient on the compact support in one launch (n <= 16)
     // pair-index-space expectation tables of the fused kernel, built per (thread bits, real mode)
     DevBuf d_egroups, d_eterms, d_echunks, d_eflat;
     int exp_lbits = -1, exp_real = -1, exp_ngroups = 0, exp_nchunks = 0, exp_nflat = 0;
+    int exp_ham_version = -1;     // version of the Hamiltonian the fused kernel's expectation tables were built from
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // second stream of the tiled <H>: the compute-heavy sweeps (many x-groups) and the bandwidth-bound ones (few groups,
     // one read of the state each) run side by side
@@ -1722,6 +1739,45 @@ inline PauliRaw pauli_mul(const PauliRaw &a, const PauliRaw &b) {
     return PauliRaw{a.x ^ b.x, a.z ^ b.z, (a.k + b.k + 2 * __builtin_popcountll(a.z & b.x)) & 3};
 }
 
+int install_hamdev(ovqe_handle h, HamDev &H, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff, double constant) {
+    H.set = false;
+    int rc = build_groups(h, T, x, z, coeff, nullptr, false, H.groups, H.terms);
+    if (rc) return rc;
+    rc = upload(h, H.d_groups, H.groups.data(), H.groups.size() * sizeof(HGroup));
+    if (!rc) rc = upload(h, H.d_terms, H.terms.data(), H.terms.size() * sizeof(HTerm));
+    if (rc) return rc;
+    H.constant = constant;
+    H.set = true;
+    H.tile_bits = -1;  // tile cover rebuilt on first use
+    H.version = ++h->ham_versions;
+    return OVQE_OK;
+}
+
+// stored Hamiltonian through the open Clifford frame: P = i^{|x&z|} X^x Z^z -> product of the images of its X_q and Z_q
+int install_conjugated_hamiltonian(ovqe_handle h) {
+    h->ham_conj.set = false;
+    if (!h->frame_open || !h->ham.set) return OVQE_OK;
+    const int n = h->n_local;
+    const size_t T = h->user_x.size();
+    std::vector<uint64_t> cx(T), cz(T);
+    std::vector<double> cc(T);
+    auto img = [&](int idx) { return PauliRaw{h->frame_img[3 * idx], h->frame_img[3 * idx + 1], (int)h->frame_img[3 * idx + 2]}; };
+    for (size_t t = 0; t < T; ++t) {
+        const uint64_t x = h->user_x[t], z = h->user_z[t];
+        PauliRaw acc{0, 0, __builtin_popcountll(x & z) & 3};   // the i^{|x&z|} of the Hermitian string
+        for (int q = 0; q < n; ++q)
+            if ((x >> q) & 1) acc = pauli_mul(acc, img(q));
+        for (int q = 0; q < n; ++q)
+            if ((z >> q) & 1) acc = pauli_mul(acc, img(n + q));
+        const int rel = (acc.k - __builtin_popcountll(acc.x & acc.z)) & 3;
+        if (rel & 1) return fail(h, OVQE_ERR_INVALID, "internal: non-Hermitian conjugated Hamiltonian term");
+        cx[t] = acc.x;
+        cz[t] = acc.z;
+        cc[t] = rel ? -h->user_c[t] : h->user_c[t];
+    }
+    return install_hamdev(h, h->ham_conj, (int64_t)T, cx.data(), cz.data(), cc.data(), h->user_const);
+}
+
 int compile_gate_program_frame(ovqe_handle h, int64_t G, const int32_t *opcode, const int32_t *b0, const int32_t *b1,
                                const double *ascale, const double *aconst, const int32_t *pidx, bool *done) {
     *done = false;
@@ -1776,7 +1832,39 @@ int compile_gate_program_frame(ovqe_handle h, int64_t G, const int32_t *opcode, 
         closed = ix[q].x == (1ull << q) && ix[q].z == 0 && ix[q].k == 0 && iz[q].x == 0 && iz[q].z == (1ull << q) &&
                  iz[q].k == 0;
     const bool forced = h->opt_clifford_frame == 2;
-    if (!closed && !forced) return OVQE_OK;
+    if (!closed && !forced) {
+        // Open frame (e.g. interleaved CNOT ladders, which the reference's ladder code does not undo): the program is the
+        // rotation sequence; the net Clifford operator goes into the Hamiltonian for energies (install_conjugated_hamiltonian)
+        // and behind the rotations, gate by gate, for ovqe_prepare_state.  Option 3 keeps the literal program instead.
+        if (h->opt_clifford_frame == 3 || n > 63) return OVQE_OK;
+        h->prog_set = false;
+        h->ops.clear();
+        h->rots.clear();
+        h->init_amp = make_double2(1.0, 0.0);
+        for (const Emit &e : emitted) push_rotation(h, e.x, e.z, e.coeff, e.phi0, e.pidx);
+        h->frame_img.assign((size_t)6 * n, 0);
+        for (int q = 0; q < n; ++q) {
+            h->frame_img[3 * q] = ix[q].x;
+            h->frame_img[3 * q + 1] = ix[q].z;
+            h->frame_img[3 * q + 2] = (uint64_t)ix[q].k;
+            h->frame_img[3 * (n + q)] = iz[q].x;
+            h->frame_img[3 * (n + q) + 1] = iz[q].z;
+            h->frame_img[3 * (n + q) + 2] = (uint64_t)iz[q].k;
+        }
+        h->tail_gates.clear();
+        for (const int64_t g : tail) {
+            h->tail_gates.push_back(opcode[g]);
+            h->tail_gates.push_back(b0[g]);
+            h->tail_gates.push_back(b1[g]);
+            h->tail_gates.push_back(aconst[g] > 0 ? 1 : -1);
+        }
+        h->frame_open = true;
+        *done = true;
+        int rc = finish_program(h);
+        if (!rc) rc = install_conjugated_hamiltonian(h);
+        if (rc) h->frame_open = false;
+        return rc;
+    }
     bool drop_tail = false;
     double2 phase = make_double2(1.0, 0.0);
     h->init_amp = phase;
@@ -1858,7 +1946,7 @@ int launch_small(ovqe_handle h, const SmallArgs &A, int grid, size_t smem) {
 // sign of parity(x & z), i^ny and the pattern-dependent sign are folded into the coefficients, terms with
 // equal outside masks are merged, terms bucketed by the 3 free-index bits above the thread bits
 int build_exp_tables(ovqe_handle h, int lbits, bool real) {
-    if (h->exp_lbits == lbits && h->exp_real == (int)real) return OVQE_OK;
+    if (h->exp_lbits == lbits && h->exp_real == (int)real && h->exp_ham_version == h->ham.version) return OVQE_OK;
     std::vector<ExpGroup> eg;
     std::vector<ExpTerm> et;
     std::vector<FlatItem> flat;
@@ -2002,6 +2090,7 @@ int build_exp_tables(ovqe_handle h, int lbits, bool real) {
     if (!rc) rc = upload(h, h->d_eflat, flat.data(), flat.size() * sizeof(FlatItem));
     if (rc) return rc;
     h->exp_lbits = lbits;
+    h->exp_ham_version = h->ham.version;
     h->exp_real = (int)real;
     h->exp_ngroups = (int)eg.size();
     h->exp_nchunks = (int)chunks.size();
@@ -2190,6 +2279,130 @@ int build_sparse_program(ovqe_handle h) {
             if (entries.size() > (size_t)16 << 20) return OVQE_OK;
         }
     }
+    // ---- compact numbering against LDS bank conflicts in the circuit (round 3) ---------------------------------------------------
+    // The lanes of an evaluation rotate the (up to 32) pairs of an op with ONE ds_read_b64 per member: 32 lanes against 32
+    // bank pairs, bank = compact index mod 32.  In discovery order the members of an op collide (rocprofv3: 55 % of the LDS
+    // cycles of k_sparse_vqe were conflict replays).  The numbering is the host's to choose: residues mod 32 are assigned by
+    // a deterministic local search (swap two elements' residues, keep the swap when the sum over ops and sides of the
+    // colliding lane pairs does not grow, with a little annealing) and the support is padded to a multiple of 32 slots.
+    int mp = m, hf_slot = 0;
+    h->sp_conflicts_before = h->sp_conflicts_after = 0;
+    if (h->opt_sparse_renumber && m > 32 && m <= 4064 && !ops.empty()) {
+        const int nh = 2 * (int)ops.size();
+        const int rows = (m + 31) / 32;
+        std::vector<std::array<uint16_t, 32>> hist((size_t)nh);
+        for (auto &a : hist) a.fill(0);
+        std::vector<int> cap((size_t)nh);
+        std::vector<std::vector<int>> inc((size_t)m);
+        for (size_t o = 0; o < ops.size(); ++o) {
+            cap[2 * o] = cap[2 * o + 1] = (ops[o].npairs + 31) / 32;
+            for (int k = 0; k < ops[o].npairs; ++k) {
+                const uint32_t pw = pairs[(size_t)ops[o].first + k];
+                inc[pw & 0xfffu].push_back((int)(2 * o));
+                inc[(pw >> 12) & 0xfffu].push_back((int)(2 * o + 1));
+            }
+        }
+        std::vector<int> res((size_t)m), count(32, 0);
+        for (int k = 0; k < m; ++k) {
+            res[k] = k & 31;
+            ++count[k & 31];
+            for (int hid : inc[k]) ++hist[hid][k & 31];
+        }
+        auto excess = [](int n, int c) { return n > c ? (int64_t)(n - c) * (n - c + 1) / 2 : (int64_t)0; };
+        int64_t cost = 0;
+        for (int hid = 0; hid < nh; ++hid)
+            for (int r = 0; r < 32; ++r) cost += excess(hist[hid][r], cap[hid]);
+        h->sp_conflicts_before = cost;
+        auto move = [&](int e, int to) {   // -> change of the cost
+            const int from = res[e];
+            int64_t d = 0;
+            for (int hid : inc[e]) {
+                auto &hh = hist[hid];
+                d += excess(hh[from] - 1, cap[hid]) - excess(hh[from], cap[hid]) + excess(hh[to] + 1, cap[hid]) - excess(hh[to], cap[hid]);
+                --hh[from];
+                ++hh[to];
+            }
+            res[e] = to;
+            return d;
+        };
+        size_t total_inc = 0;
+        for (const auto &v : inc) total_inc += v.size();
+        const double avg_inc = std::max(1.0, (double)total_inc / m);
+        const int64_t proposals = cost ? (int64_t)std::min(400.0 * m, 6e7 / avg_inc) : 0;
+        uint64_t rng = 0x9e3779b97f4a7c15ull;
+        auto next = [&]() {
+            rng ^= rng << 13;
+            rng ^= rng >> 7;
+            rng ^= rng << 17;
+            return rng;
+        };
+        for (int64_t it = 0; it < proposals && cost > 0; ++it) {
+            const double temp = 0.6 * (1.0 - (double)it / (double)proposals) + 0.02;
+            const int a = (int)(next() % (uint64_t)m);
+            int64_t d;
+            int b = -1, ra = res[a], rb;
+            if ((next() & 3u) == 0) {                       // move into a residue class with a free slot
+                rb = (int)(next() & 31u);
+                if (rb == ra || count[rb] >= rows) continue;
+                d = move(a, rb);
+            } else {                                        // swap residues with another element
+                b = (int)(next() % (uint64_t)m);
+                rb = res[b];
+                if (rb == ra) continue;
+                d = move(a, rb);
+                d += move(b, ra);
+            }
+            const bool accept = d <= 0 || (double)(next() >> 11) * (1.0 / 9007199254740992.0) < std::exp(-(double)d / temp);
+            if (accept) {
+                cost += d;
+                if (b < 0) {
+                    --count[ra];
+                    ++count[rb];
+                }
+            } else {
+                move(a, ra);
+                if (b >= 0) move(b, rb);
+            }
+        }
+        h->sp_conflicts_after = cost;
+        // slots: residue + 32 * (rank inside the residue class, by discovery order)
+        std::vector<int> slot((size_t)m), fill(32, 0);
+        for (int k = 0; k < m; ++k) slot[k] = res[k] + 32 * fill[res[k]]++;
+        mp = 32 * rows;
+        hf_slot = slot[0];
+        for (uint32_t &pw : pairs)
+            pw = (pw & ~0xffffffu) | (uint32_t)slot[pw & 0xfffu] | ((uint32_t)slot[(pw >> 12) & 0xfffu] << 12);
+        for (SpEntry &e : entries) e.ij = (uint32_t)slot[e.ij & 0xfffu] | ((uint32_t)slot[(e.ij >> 12) & 0xfffu] << 12);
+        // ops with more than 32 pairs: chunks of 32 with distinct residues on both sides where the pairs allow it
+        for (const SpOp &so : ops) {
+            if (so.npairs <= 32) continue;
+            std::vector<uint32_t> left(pairs.begin() + so.first, pairs.begin() + so.first + so.npairs), out;
+            out.reserve(left.size());
+            while (!left.empty()) {
+                uint32_t ui = 0, uj = 0;
+                std::vector<uint32_t> rest;
+                size_t taken = 0;
+                for (uint32_t pw : left) {
+                    const uint32_t bi = pw & 31u, bj = (pw >> 12) & 31u;
+                    if (taken < 32 && !((ui >> bi) & 1u) && !((uj >> bj) & 1u)) {
+                        ui |= 1u << bi;
+                        uj |= 1u << bj;
+                        out.push_back(pw);
+                        ++taken;
+                    } else {
+                        rest.push_back(pw);
+                    }
+                }
+                while (taken < 32 && !rest.empty()) {   // pad the chunk so that later chunks stay aligned
+                    out.push_back(rest.back());
+                    rest.pop_back();
+                    ++taken;
+                }
+                left.swap(rest);
+            }
+            std::copy(out.begin(), out.end(), pairs.begin() + so.first);
+        }
+    }
     // LDS bank conflicts: a wave reads the two amplitudes of 64 consecutive entries at once (ds_read_b64 is served in two
     // 32-lane groups, bank = double slot mod 32).  The entries are a plain sum, so their order is free: they are
     // re-arranged greedily so that inside every aligned group of 32 the first indices are distinct mod 32 and so are the
@@ -2255,6 +2468,8 @@ int build_sparse_program(ovqe_handle h) {
     if (!rc) rc = upload(h, h->d_sp_entries, entries.data(), entries.size() * sizeof(SpEntry));
     if (rc) return rc;
     h->sp_m = m;
+    h->sp_mp = mp;
+    h->sp_hf = hf_slot;
     h->sp_nops = (int)ops.size();
     h->sp_nent = (int)entries.size();
     h->sp_npairs = (int64_t)pairs.size();
@@ -2299,8 +2514,9 @@ int run_sparse(ovqe_handle h, int64_t B, const double *theta, double *energies, 
     h->cur_theta = d_theta;
     h->cur_energies = d_energies;
     SparseArgs A;
-    A.m = h->sp_m;
-    A.mpad = (h->sp_m + 1) & ~1;
+    A.m = h->sp_mp;
+    A.mpad = (h->sp_mp + 1) & ~1;
+    A.hf = h->sp_hf;
     A.K = h->K;
     A.nops = h->sp_nops;
     A.ntab = (int)h->srots.size();
@@ -2336,6 +2552,77 @@ int run_sparse(ovqe_handle h, int64_t B, const double *theta, double *energies, 
         HIPC(h, hipMemcpyAsync(energies, h->cur_energies, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
     HIPC(h, hipEventElapsedTime(&h->last_batch_ms, h->ev0, h->ev1));
+    return OVQE_OK;
+}
+
+// E and all K derivatives of one parameter vector on the compact support, one launch (k_sparse_grad).  *done = false: the
+// program has no compact support or its tables do not fit one workgroup's LDS (the caller takes the other paths).
+int run_sparse_gradient(ovqe_handle h, const double *theta, double *energy, double *grad, bool *done) {
+    *done = false;
+    if (!(h->opt_force_path == 0 || h->opt_force_path == 3) || !h->opt_sparse_grad || h->n_local > 16) return OVQE_OK;
+    int rc = OVQE_OK;
+    if (!h->sp_tried) {
+        rc = build_sparse_program(h);
+        if (rc) return rc;
+    }
+    if (!h->sp_valid) return OVQE_OK;
+    SparseArgs A;
+    A.m = h->sp_mp;
+    A.mpad = (h->sp_mp + 1) & ~1;
+    A.hf = h->sp_hf;
+    A.K = h->K;
+    A.nops = h->sp_nops;
+    A.ntab = (int)h->srots.size();
+    A.nent = h->sp_nent;
+    A.npairs = (int)h->sp_npairs;
+    A.B = 1;
+    A.constant = h->ham.constant;
+    const size_t base = 2 * (size_t)A.mpad * sizeof(double) + (size_t)A.ntab * (sizeof(double2) + sizeof(double)) +
+                        (size_t)((A.K + 1) & ~1) * sizeof(double);
+    const size_t staged = base + (size_t)A.nops * sizeof(SpOp) + (size_t)A.npairs * sizeof(uint32_t);
+    if (base > 150 * 1024) return OVQE_OK;
+    const bool stage = staged <= 150 * 1024;
+    static bool attr_done_dev[64] = {};
+    bool &attr_done = attr_done_dev[h->device & 63];
+    if (!attr_done) {
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sparse_grad<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sparse_grad<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    const bool zero_copy = mapped_io(h, 2);   // theta [K] | energy | gradient [K] in the pinned, device-mapped buffer
+    const double *d_theta;
+    double *d_e, *d_g;
+    if (zero_copy) {
+        std::memcpy(h->h_io, theta, (size_t)h->K * sizeof(double));
+        d_theta = h->d_io;
+        d_e = h->d_io + h->K;
+        d_g = h->d_io + h->K + 1;
+    } else {
+        rc = ensure(h, h->d_theta, (size_t)std::max(1, h->K) * sizeof(double));
+        if (!rc) rc = ensure(h, h->d_energies, (size_t)(h->K + 1) * sizeof(double));
+        if (rc) return rc;
+        HIPC(h, hipMemcpyAsync(h->d_theta.p, theta, (size_t)h->K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        d_theta = (const double *)h->d_theta.p;
+        d_e = (double *)h->d_energies.p;
+        d_g = d_e + 1;
+    }
+    if (stage)
+        hipLaunchKernelGGL((k_sparse_grad<true>), dim3(1), dim3(64), staged, h->stream, A, d_theta, (const SmallRot *)h->d_rots.p,
+                           (const SpOp *)h->d_sp_ops.p, (const uint32_t *)h->d_sp_pairs.p, (const SpEntry *)h->d_sp_entries.p, d_e, d_g);
+    else
+        hipLaunchKernelGGL((k_sparse_grad<false>), dim3(1), dim3(64), base, h->stream, A, d_theta, (const SmallRot *)h->d_rots.p,
+                           (const SpOp *)h->d_sp_ops.p, (const uint32_t *)h->d_sp_pairs.p, (const SpEntry *)h->d_sp_entries.p, d_e, d_g);
+    HIPC(h, hipGetLastError());
+    if (zero_copy) {
+        HIPC(h, hipStreamSynchronize(h->stream));
+        *energy = h->h_io[h->K];
+        std::memcpy(grad, h->h_io + h->K + 1, (size_t)h->K * sizeof(double));
+    } else {
+        HIPC(h, hipMemcpyAsync(energy, d_e, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPC(h, hipMemcpyAsync(grad, d_g, (size_t)h->K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPC(h, hipStreamSynchronize(h->stream));
+    }
+    *done = true;
     return OVQE_OK;
 }
 
@@ -2510,6 +2797,11 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     }
     else if (k == "sparse_dealias") {
         h->opt_sparse_dealias = value ? 1 : 0;
+        h->sp_tried = false;
+    }
+    else if (k == "sparse_grad") h->opt_sparse_grad = value ? 1 : 0;
+    else if (k == "sparse_renumber") {
+        h->opt_sparse_renumber = value ? 1 : 0;
         h->sp_tried = false;
     }
     else if (k == "expect_sparse") h->opt_expect_sparse = (int)std::max<int64_t>(0, value);
@@ -2891,20 +3183,28 @@ int ovqe_set_hamiltonian(ovqe_handle h, int64_t T, const uint64_t *x, const uint
                          double constant) {
     OVQE_ENTER(h);
     if (!h || T < 0 || (T && (!x || !z || !coeff))) return OVQE_ERR_INVALID;
-    h->ham.set = false;
-    int rc = build_groups(h, T, x, z, coeff, nullptr, false, h->ham.groups, h->ham.terms);
+    int rc = install_hamdev(h, h->ham, T, x, z, coeff, constant);
     if (rc) return rc;
-    rc = upload(h, h->ham.d_groups, h->ham.groups.data(), h->ham.groups.size() * sizeof(HGroup));
-    if (!rc) rc = upload(h, h->ham.d_terms, h->ham.terms.data(), h->ham.terms.size() * sizeof(HTerm));
-    if (rc) return rc;
-    h->ham.constant = constant;
-    h->ham.set = true;
-    h->ham.tile_bits = -1;  // tile cover rebuilt on first use
-    h->ham.version++;
+    h->user_x.assign(x, x + T);
+    h->user_z.assign(z, z + T);
+    h->user_c.assign(coeff, coeff + T);
+    h->user_const = constant;
     h->exp_lbits = -1;
     h->sp_tried = false;
-    return OVQE_OK;
+    return install_conjugated_hamiltonian(h);
 }
+
+// energy-type entry points evaluate <phi|C^+ H C|phi> when the program's Clifford frame is open
+struct FrameHamGuard {
+    ovqe_handle h;
+    bool on;
+    explicit FrameHamGuard(ovqe_handle hh) : h(hh), on(hh && hh->frame_open && hh->ham_conj.set) {
+        if (on) std::swap(h->ham, h->ham_conj);
+    }
+    ~FrameHamGuard() {
+        if (on) std::swap(h->ham, h->ham_conj);
+    }
+};
 
 int ovqe_set_program(ovqe_handle h, int64_t R, const uint64_t *x, const uint64_t *z, const double *coeff,
                      const double *phi0, const int32_t *pidx, int32_t K, uint64_t hf_index) {
@@ -2924,6 +3224,7 @@ int ovqe_set_program(ovqe_handle h, int64_t R, const uint64_t *x, const uint64_t
     h->init_amp = make_double2(1.0, 0.0);
     h->K = K;
     h->hf = hf_index;
+    h->frame_open = false;
     for (int64_t r = 0; r < R; ++r) push_rotation(h, x[r], z[r], coeff[r], phi0 ? phi0[r] : 0.0, pidx[r]);
     return finish_program(h);
 }
@@ -2944,6 +3245,7 @@ int ovqe_set_gate_program(ovqe_handle h, int64_t G, const int32_t *opcode, const
     }
     h->K = K;
     h->hf = hf_index;
+    h->frame_open = false;
     if (h->opt_clifford_frame) {
         bool done = false;
         int rc = compile_gate_program_frame(h, G, opcode, b0, b1, ascale, aconst, pidx, &done);
@@ -2958,7 +3260,14 @@ int ovqe_prepare_state(ovqe_handle h, const double *theta, int32_t K) {
     if (!h) return OVQE_ERR_INVALID;
     int rc = check_theta(h, theta, K);
     if (rc) return rc;
-    return run_program_streaming(h, theta);
+    rc = run_program_streaming(h, theta);
+    if (rc || !h->frame_open) return rc;
+    for (size_t g = 0; g + 3 < h->tail_gates.size() && !rc; g += 4) {   // the Clifford part of an open frame, literally
+        const int op = h->tail_gates[g], t = h->tail_gates[g + 1], c = h->tail_gates[g + 2];
+        const double a = h->tail_gates[g + 3] > 0 ? M_PI_2 : -M_PI_2;
+        rc = ovqe_apply_gate(h, op, t, c, a);
+    }
+    return rc;
 }
 
 // batched sector evaluations need the tables of the second sweep kernel (64-bit pair words) and the materialised <H>
@@ -2973,6 +3282,7 @@ static bool sector_batch_ready(ovqe_handle h) {
 int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, double *energies) {
     OVQE_ENTER(h);
     if (!h || B < 0 || (B && !energies)) return OVQE_ERR_INVALID;
+    FrameHamGuard frame_guard(h);
     int rc = check_theta(h, theta, K);
     if (rc) return rc;
     if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
@@ -3098,6 +3408,7 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
 int ovqe_energy_batch_device(ovqe_handle h, int64_t B, const void *theta_dev, int32_t K, void *energies_dev) {
     OVQE_ENTER(h);
     if (!h || B < 0 || (B && (!theta_dev || !energies_dev))) return OVQE_ERR_INVALID;
+    FrameHamGuard frame_guard(h);
     if (!h->prog_set) return fail(h, OVQE_ERR_STATE, "no program set (ovqe_set_program / ovqe_set_gate_program)");
     if (K != h->K || K <= 0) return fail(h, OVQE_ERR_INVALID, "K does not match the program's parameter count");
     if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
@@ -3604,6 +3915,7 @@ extern "C" int ovqe_sector_ground_state(ovqe_handle h, double tol, int max_iter,
     if (!h || !energy || max_iter < 1 || !(tol > 0.0)) return OVQE_ERR_INVALID;
     if (!h->prog_set) return fail(h, OVQE_ERR_STATE, "no program set (ovqe_set_program / ovqe_set_gate_program)");
     if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
+    FrameHamGuard frame_guard(h);
     const bool real = h->opt_real_stream && h->prog_real_ok && h->n_global == 0 && tile_ok(h, true) && h->ham.groups.size() >= 3;
     if (!real || !h->opt_sector) return fail(h, OVQE_ERR_STATE, "the stored program has no sector tables (real-amplitude program on one device needed)");
     SectorEngine &E = h->sec;
@@ -3632,6 +3944,12 @@ extern "C" int ovqe_energy_gradient(ovqe_handle h, const double *theta, int32_t 
     if (rc) return rc;
     if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
     if (h->n_global) return fail(h, OVQE_ERR_INVALID, "ovqe_energy_gradient is single-device");
+    FrameHamGuard frame_guard(h);
+    {   // small registers: forward, H psi and the backward pass in one launch on the compact support
+        bool done = false;
+        rc = run_sparse_gradient(h, theta, energy, grad, &done);
+        if (rc || done) return rc;
+    }
     if (h->opt_real_stream && h->prog_real_ok && tile_ok(h, true) && h->ham.groups.size() >= 3) {
         // real-amplitude program on a sparse support: the whole adjoint pass on the sector tables
         rc = sector_prepare(h, true);
@@ -3760,11 +4078,12 @@ int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
     for (const SmallOp &op : h->ops) v[2] += (op.kind == OP_X || op.kind == OP_H || op.kind == OP_CNOT);
     for (int i = 0; i < count && i < 16; ++i) info[i] = v[i];
     const SectorEngine &E = h->sec;
-    const int64_t sv[10] = {E.valid ? (int64_t)E.K : 0, E.valid ? (int64_t)E.segs.size() : 0, E.valid ? (int64_t)E.npairs : 0,
+    const int64_t sv[12] = {E.valid ? (int64_t)E.K : 0, E.valid ? (int64_t)E.segs.size() : 0, E.valid ? (int64_t)E.npairs : 0,
                            E.valid ? (int64_t)E.hs.size() : 0, E.valid ? (int64_t)E.nnz : 0, E.valid ? (int64_t)E.bytes : 0,
                            E.valid ? (int64_t)(1e3 * E.last_circuit_ms) : 0, E.valid ? (int64_t)(1e3 * E.last_expect_ms) : 0,
-                           E.valid ? (int64_t)E.h_stream_bytes : 0, E.valid ? (int64_t)E.last_fci_block : 0};
-    for (int i = 16; i < count && i < 26; ++i) info[i] = sv[i - 16];
+                           E.valid ? (int64_t)E.h_stream_bytes : 0, E.valid ? (int64_t)E.last_fci_block : 0,
+                            h->sp_valid ? h->sp_conflicts_before : 0, h->sp_valid ? h->sp_conflicts_after : 0};
+    for (int i = 16; i < count && i < 28; ++i) info[i] = sv[i - 16];
     return OVQE_OK;
 }
 

@@ -41,6 +41,7 @@ struct SparseArgs {
     int ntab;
     int nent;
     int npairs;   // all active pairs of the program (STAGE: copied to LDS once per launch)
+    int hf;       // compact slot of |hf>
     int64_t B;
     double constant;
 };
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(64) void k_sparse_vqe(SparseArgs A, const double *_
     for (int64_t w = blockIdx.x; w < nwork; w += gridDim.x) {
         const int64_t b0 = w * SPW;
         // |HF> (compact index 0) and the cos/sin table of every active pattern, per evaluation
-        for (int i = lane; i < SPW * A.mpad; i += 64) st[i] = (i % A.mpad == 0) ? 1.0 : 0.0;
+        for (int i = lane; i < SPW * A.mpad; i += 64) st[i] = (i % A.mpad == A.hf) ? 1.0 : 0.0;
         {
             const int64_t b = b0 + s < A.B ? b0 + s : A.B - 1;
             const double *th = theta + b * A.K;
@@ -146,6 +147,118 @@ __global__ __launch_bounds__(64) void k_sparse_vqe(SparseArgs A, const double *_
             const double tot = wave_sum(acc[s]);
             if (lane == 0 && b0 + s < A.B) energies[b0 + s] = tot + A.constant;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// ---- exact gradient on the compact support (round 3) ---------------------------------------------------------------------
+// E(theta) and dE/dtheta_k for ALL K parameters of one parameter vector per wave, in ONE launch: forward circuit as above,
+// lambda = H psi from the restricted Hamiltonian's entries (f64 LDS atomics: lambda_i += H_ij a_j, lambda_j += H_ij a_i),
+// then the ops BACKWARDS on psi and lambda together — per pair g = lambda_i psi_j - lambda_j psi_i on the states after the op,
+// w[table entry] += +-g, both states rotated back — and dE/dtheta_k = sum over the table entries of parameter k of
+// 2 coeff w.  (The adjoint method of ovqe_energy_gradient's streaming and sector paths on the support: the streaming form
+// needs ~6 launches per generator — H2O: 1.6 ms for 140 derivatives.)  The order of the atomic additions is not fixed: the
+// gradient reproduces to rounding, the energy bit for bit.
+template <bool STAGE>
+__global__ __launch_bounds__(64) void k_sparse_grad(SparseArgs A, const double *__restrict__ theta, const SmallRot *__restrict__ tabrots,
+                                                    const SpOp *__restrict__ ops, const uint32_t *__restrict__ pairs,
+                                                    const SpEntry *__restrict__ entries, double *__restrict__ energies,
+                                                    double *__restrict__ grads) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *psi = reinterpret_cast<double *>(smem);                 // [mpad]
+    double *lam = psi + A.mpad;                                     // [mpad]
+    double2 *cs = reinterpret_cast<double2 *>(lam + A.mpad);        // [ntab]
+    double *w = reinterpret_cast<double *>(cs + A.ntab);            // [ntab]
+    double *gk = w + A.ntab;                                        // [K]
+    SpOp *lops = reinterpret_cast<SpOp *>(gk + ((A.K + 1) & ~1));   // [nops]   (STAGE)
+    uint32_t *lpairs = reinterpret_cast<uint32_t *>(lops + A.nops); // [npairs] (STAGE)
+    const int lane = threadIdx.x;
+    if constexpr (STAGE) {
+        for (int i = lane; i < A.nops; i += 64) lops[i] = ops[i];
+        for (int i = lane; i < A.npairs; i += 64) lpairs[i] = pairs[i];
+    }
+    const SpOp *opv = STAGE ? lops : ops;
+    const uint32_t *pv = STAGE ? lpairs : pairs;
+    for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+        const double *th = theta + b * A.K;
+        for (int i = lane; i < A.mpad; i += 64) {
+            psi[i] = i == A.hf ? 1.0 : 0.0;
+            lam[i] = 0.0;
+        }
+        for (int e = lane; e < A.ntab; e += 64) {
+            const SmallRot sr = tabrots[e];
+            double sn, c;
+            sincos(sr.coeff * th[sr.pidx], &sn, &c);
+            cs[e] = make_double2(c, sn);
+            w[e] = 0.0;
+        }
+        for (int k = lane; k < A.K; k += 64) gk[k] = 0.0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // forward
+        for (int o = 0; o < A.nops; ++o) {
+            SpOp op = opv[o];
+            op.first = __builtin_amdgcn_readfirstlane(op.first);
+            op.npairs = __builtin_amdgcn_readfirstlane(op.npairs);
+            op.tab0 = __builtin_amdgcn_readfirstlane(op.tab0);
+            for (int pe = lane; pe < op.npairs; pe += 64) {
+                const uint32_t pw = pv[op.first + pe];
+                const uint32_t ci = pw & 0xfffu, cj = (pw >> 12) & 0xfffu;
+                const double2 t = cs[op.tab0 + (int)(pw >> 25)];
+                const double sn = (pw & (1u << 24)) ? -t.y : t.y;
+                const double u = psi[ci], v = psi[cj];
+                psi[ci] = t.x * u + sn * v;
+                psi[cj] = t.x * v - sn * u;
+            }
+            asm volatile("" ::: "memory");   // a wave's DS instructions execute in issue order (see k_sparse_vqe)
+        }
+        // lambda = H psi, E = <psi|lambda>
+        double acc = 0.0;
+#pragma unroll 4
+        for (int e = lane; e < A.nent; e += 64) {
+            const SpEntry en = entries[e];
+            const uint32_t ci = en.ij & 0xfffu, cj = (en.ij >> 12) & 0xfffu;
+            const double ai = psi[ci], aj = psi[cj];
+            acc += en.c * ai * aj;
+            if (ci == cj) {
+                __hip_atomic_fetch_add(&lam[ci], en.c * ai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {   // c = 2 H_ij, the pair counted once
+                __hip_atomic_fetch_add(&lam[ci], 0.5 * en.c * aj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&lam[cj], 0.5 * en.c * ai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        const double etot = wave_sum(acc);
+        if (lane == 0) energies[b] = etot + A.constant;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // backward
+        for (int o = A.nops - 1; o >= 0; --o) {
+            SpOp op = opv[o];
+            op.first = __builtin_amdgcn_readfirstlane(op.first);
+            op.npairs = __builtin_amdgcn_readfirstlane(op.npairs);
+            op.tab0 = __builtin_amdgcn_readfirstlane(op.tab0);
+            for (int pe = lane; pe < op.npairs; pe += 64) {
+                const uint32_t pw = pv[op.first + pe];
+                const uint32_t ci = pw & 0xfffu, cj = (pw >> 12) & 0xfffu;
+                const int e = op.tab0 + (int)(pw >> 25);
+                const double2 t = cs[e];
+                const bool neg = (pw & (1u << 24)) != 0u;
+                const double sn = neg ? -t.y : t.y;
+                const double u1 = psi[ci], v1 = psi[cj], lu = lam[ci], lv = lam[cj];
+                const double g = lu * v1 - lv * u1;
+                __hip_atomic_fetch_add(&w[e], neg ? -g : g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                psi[ci] = t.x * u1 - sn * v1;
+                psi[cj] = t.x * v1 + sn * u1;
+                lam[ci] = t.x * lu - sn * lv;
+                lam[cj] = t.x * lv + sn * lu;
+            }
+            asm volatile("" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int e = lane; e < A.ntab; e += 64) {
+            const SmallRot sr = tabrots[e];
+            if (sr.pidx >= 0) __hip_atomic_fetch_add(&gk[sr.pidx], 2.0 * sr.coeff * w[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int k = lane; k < A.K; k += 64) grads[b * A.K + k] = gk[k];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }

@@ -740,3 +740,50 @@ def test_empty_pauli_sums(gpu_lib):
         assert float(out.abs().max()) == 0.0
         got = sv.bilinear_batch(np.zeros(4, np.int64), [], [], [], bra_ptr=fill.data_ptr())
         assert got.shape == (3,) and np.all(got == 0)
+
+
+@pytest.mark.parametrize("molecule", ["LIH", "H2O"])
+def test_fused_gradient_on_the_compact_support(SV, molecule):
+    """ovqe_energy_gradient below 17 qubits: forward circuit, lambda = H psi and the backward pass in ONE launch on the compact
+    support (k_sparse_grad) — against the streaming adjoint pass of the same handle (option sparse_grad = 0), against central
+    differences of the C oracle on sampled parameters, and the energy against ovqe_energy; also with the bank-aware numbering
+    of the support switched off (same numbers up to the order of the additions)"""
+    from openvqe_amd import chem, fermion
+    from openvqe_amd.backend import compile_ucc_program
+    from oracle import cref
+    mol = chem.molecule(molecule)
+    mol.rhf()
+    ham = mol.jw_hamiltonian()
+    n = ham.nbqbits
+    gens = fermion.uccsd_generators(mol.nao, mol.n_elec // 2)
+    hf = mol.hf_init()
+    K = len(gens)
+    rng = np.random.default_rng(K)
+    theta = rng.uniform(-0.2, 0.2, K)
+    out = {}
+    for label, opts in (("fused", {}), ("fused_discovery_order", {"sparse_renumber": 0}), ("streaming", {"sparse_grad": 0})):
+        with SV(n) as sv:
+            for k, v in opts.items():
+                sv.set_option(k, v)
+            sv.set_hamiltonian(ham)
+            sv.set_ucc_program(gens, hf)
+            e, g = sv.energy_gradient(theta)
+            out[label] = (e, g, sv.energy(theta), sv.program_info())
+    assert out["fused"][3]["support"] > 0 and out["fused"][3]["sp_conflicts"] <= out["fused"][3]["sp_conflicts_discovery_order"]
+    rx, rz, rc, pidx, _ = compile_ucc_program(n, gens)
+    hx, hz, hc = ham.packed()
+    scale = max(1.0, float(np.abs(hc).sum()))
+
+    def e_oracle(th):
+        return cref.ucc_energy(n, hf, rx, rz, rc, pidx, th, hx, hz, hc.real.copy(), ham.constant_coeff, 0)[0]
+
+    e_ref = e_oracle(theta)
+    for label, (e, g, e2, _) in out.items():
+        assert abs(e - e_ref) < 1e-10 * scale and abs(e2 - e_ref) < 1e-10 * scale, label
+        assert np.abs(g - out["streaming"][1]).max() < 1e-11 * scale, label
+    h = 1e-4
+    for k in (0, K // 2, K - 1):
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += h
+        tm[k] -= h
+        assert abs(out["fused"][1][k] - (e_oracle(tp) - e_oracle(tm)) / (2 * h)) < 2e-7 * scale

@@ -39,12 +39,26 @@ def test_tiled_gate_program_matches_c_oracle(SV, n, tile_bits, tile_low):
         sv.set_option("force_path", 2)
         sv.set_hamiltonian(H)
         for bits in (0, tile_bits):
+            sv.set_option("clifford_frame", 0)                # the literal list, gate by gate
             sv.set_option("tile_low", tile_low)
             sv.set_option("tile_bits", bits)
             sv.set_gate_program(gates, K, hf)
+            assert sv.program_info()["literal_gates"] > 0
             e = sv.energy(theta)
             sv.prepare_state(theta)
             out[bits] = (e, sv.get_amplitudes(idx), sv.norm2())
+        # default: the random gates leave the Clifford frame OPEN — the program is the Pauli-rotation sequence, energies use the
+        # Hamiltonian conjugated by the net Clifford operator, ovqe_prepare_state applies the Clifford gates behind the rotations
+        sv.set_option("clifford_frame", 1)
+        sv.set_gate_program(gates, K, hf)
+        info = sv.program_info()
+        e = sv.energy(theta)
+        eg, _ = sv.energy_gradient(theta)
+        sv.prepare_state(theta)
+        out["open_frame"] = (e, sv.get_amplitudes(idx), sv.norm2())
+        e_after = sv.energy(theta)                            # ... and the state calls leave the evaluation path intact
+    assert info["literal_gates"] == 0
+    assert abs(eg - e_ref) < 1e-10 * max(1.0, np.abs(hc).sum()) and abs(e_after - e_ref) < 1e-10 * max(1.0, np.abs(hc).sum())
     for bits, (e, amps, n2) in out.items():
         assert abs(e - e_ref) < 1e-10 * max(1.0, np.abs(hc).sum()), bits
         assert np.abs(amps - psi_ref[idx.astype(np.int64)]).max() < 1e-12, bits
