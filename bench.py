@@ -721,8 +721,8 @@ def main():
         # kernel-only figures of the timed region (HIP events around the fused launch)
         per_eval_bytes = 32.0 * (1 << n) * R + 16.0 * (1 << n) * G
         out["timed_kernel"] = {
-            "name": "k_sparse_vqe (support-compacted evaluation: the circuit's reachable support is 441 of 16384 "
-                    "amplitudes; exact, see DESIGN.md) — auto-selected by ovqe_energy_batch",
+            "name": "k_sparse_vqe_rows (support-compacted evaluation: the circuit's reachable support is 441 of 16384 "
+                    "amplitudes; exact, see DESIGN.md; flat rows of padded 64-bit pair words) — auto-selected by ovqe_energy_batch",
             "avg_launch_ms": kernel_ms / args.steps,
             "evals_per_s_kernel_only": B * args.steps / (kernel_ms * 1e-3),
             "algorithmic_GBs_if_streamed": per_eval_bytes * B * args.steps / (kernel_ms * 1e-3) / 1e9,
@@ -732,18 +732,19 @@ def main():
         }
         # the kernel behind `value` keeps its states in LDS: its roofline is the LDS array, not HBM.  Bytes per
         # evaluation from the compiled program: an active pair = 2 reads + 2 writes of 8-B amplitudes + one 16-B cos/sin
-        # entry + its 4-B pair word; a Hamiltonian entry = 2 amplitude reads (the 16-B entry record streams from L2).
+        # entry (its 8-B word streams from L2); a Hamiltonian entry = 2 amplitude reads (the 16-B entry record streams from L2).
         info = sv.program_info()
-        lds_bytes = 52.0 * info["sp_pairs"] + 16.0 * info["sp_h_entries"]
+        lds_bytes = 48.0 * info["sp_pairs"] + 16.0 * info["sp_h_entries"]
         lds_rate = lds_bytes * B * args.steps / (kernel_ms * 1e-3) / 1e9
         out["roofline_value_kernel"] = {
-            "bound": "lds", "kernel": "k_sparse_vqe<2>", "achieved": lds_rate, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+            "bound": "lds", "kernel": "k_sparse_vqe_rows<2>", "achieved": lds_rate, "peak": LDS_PEAK_GBS, "unit": "GB/s",
             "frac": lds_rate / LDS_PEAK_GBS, "lds_bytes_per_evaluation": lds_bytes,
             "active_pairs_per_evaluation": info["sp_pairs"], "hamiltonian_entries_per_evaluation": info["sp_h_entries"],
             "support": info["support"], "avg_launch_ms": kernel_ms / args.steps,
-            "note": "aggregate LDS read rate of MI355X_MICROARCH.md (ds_read_b64/b128, every CU streaming); the kernel is "
-                    "bound by the dependent chain pair word -> amplitudes -> rotate -> store of consecutive ops on one "
-                    "wave (latency / issue), see profiles/r1g/README.md",
+            "note": "aggregate LDS read rate of MI355X_MICROARCH.md (ds_read_b64/b128, every CU streaming); the kernel is NOT "
+                    "bound by the LDS array (rocprofv3 counters, profiles/r3a: LDS instructions active 6 % of the wave cycles, "
+                    "bank-conflict cycles cut by a third without any change in run time) but by instruction issue and the "
+                    "latency of the dependent chain amplitudes -> rotate -> store of consecutive rows on one wave",
         }
         if not args.no_roofline:
             sv.close()

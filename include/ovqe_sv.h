@@ -251,7 +251,8 @@ int ovqe_ground_state(ovqe_handle h, double tol, int max_iter, uint64_t seed, do
  * determinant that is the full-CI energy of the determinant's symmetry sector — the `fci` argument the reference's
  * drivers take from PySCF (ref:openvqe/common_files/molecule_factory.py:120-125, `info["FCI"]`), here for active spaces the dense
  * routines cannot reach (N2/cc-pVDZ (10e,12o): 627 264 determinants, 538 M matrix elements).  Two-pass Lanczos on
- * vectors of |support| doubles, H v from the materialised matrix.  OVQE_ERR_STATE when the program has no such tables
+ * vectors of |support| doubles, H v from the materialised matrix.  The normalised eigenvector is left in the handle's state
+ * buffer (zeros outside the support: ovqe_get_state / ovqe_get_support).  OVQE_ERR_STATE when the program has no such tables
  * (not a real-amplitude program, support denser than 1/sector_sparsity, tables beyond sector_max_gb). */
 int ovqe_sector_ground_state(ovqe_handle h, double tol, int max_iter, uint64_t seed, double *energy, double *residual,
                              int *iterations);

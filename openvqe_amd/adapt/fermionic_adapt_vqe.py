@@ -135,16 +135,34 @@ def fun_fidelity(circ, eigenvalues, eigenvectors, nbqbits):
     return abs(np.vdot(ee, get_statevector(res, nbqbits))) ** 2
 
 
-def _ground_space(hamiltonian_sp):
+#: opt-in: the `fun_fidelity` reference vector above the dense-eigh sizes from ``ovqe_sector_ground_state`` — Lanczos on the
+#: Hamiltonian restricted to the determinants the pool can reach from |hf> (its sector tables), inside the block connected to
+#: |hf>: N2/cc-pVDZ (10e,12o) 0.08 s instead of 4.5 s.  SEMANTICS: the reference's ``eigh`` column 0 (and the default below)
+#: is the minimum over the WHOLE register — every particle number and spin projection; this is the lowest state of the
+#: reference determinant's symmetry block, the state a number-conserving ansatz can reach.  They coincide when the neutral
+#: molecule's ground state is the global minimum of the qubit Hamiltonian; otherwise the reference reports fidelity 0.
+SECTOR_GROUND_SPACE = False
+
+
+def _ground_space(hamiltonian_sp, cluster_ops_sp=None, hf_init_sp=None):
     """dense eigh like the reference (fermionic_adapt_vqe.py:474) while it is feasible (its cost is O(8^n): 4 GiB and
     hours at the H2O size); above, the lowest eigenpair by Lanczos ON THE DEVICE (ovqe_ground_state: random start
-    vector, i.e. the minimum over the whole register like eigh's column 0) — returned in eigh's (values, vectors) shape"""
+    vector, i.e. the minimum over the whole register like eigh's column 0; or, with SECTOR_GROUND_SPACE, the sector's
+    ground state from the materialised Hamiltonian of the pool's support) — returned in eigh's (values, vectors) shape"""
     if hamiltonian_sp.nbqbits <= _DENSE_EIGH_MAX_QUBITS:
         return np.linalg.eigh(hamiltonian_sp.get_matrix())
     sv = _screen_backend(hamiltonian_sp.nbqbits)
     if getattr(sv, "_ham_token", None) is not hamiltonian_sp:
         sv.set_hamiltonian(hamiltonian_sp)
         sv._ham_token = hamiltonian_sp
+    if SECTOR_GROUND_SPACE and cluster_ops_sp is not None and hf_init_sp is not None:
+        from .._lib import BackendError
+        try:
+            sv.set_ucc_program([complex(0.0, 1.0) * op for op in cluster_ops_sp], hf_init_sp)
+            energy, _, _ = sv.sector_ground_state(tol=1e-10)
+            return np.array([energy]), sv.get_state().reshape(-1, 1)
+        except BackendError:
+            pass   # no sector tables for this pool (support too dense, not a real-amplitude program): the register
     energy, _, _ = sv.ground_state(tol=1e-10)
     return np.array([energy]), sv.get_state().reshape(-1, 1)
 
@@ -185,7 +203,7 @@ def fermionic_adapt_vqe(hamiltonian_sparse, cluster_ops_sparse, reference_ket, h
     trace = {key: [] for key in (*_FLAVOUR.trace_keys.values(), *_FLAVOUR.gate_keys)}
     result = {}
     _announce(threshold_needed, max_external_iterations, n_max_grads, optimizer, tolerance)
-    eigenvalues, eigenvectors = _ground_space(hamiltonian_sp)
+    eigenvalues, eigenvectors = _ground_space(hamiltonian_sp, cluster_ops_sp, hf_init_sp)
     hf_circuit = prepare_hf_state(hf_init_sp, cluster_ops_sp)
     ref_energy = hf_energy(hf_circuit, hamiltonian_sp)
     print(ref_energy)

@@ -185,6 +185,9 @@ struct ovqe_sv {
     // support-compacted program (sv_sparse.hpp): built lazily for the current (program, Hamiltonian)
     bool sp_tried = false, sp_valid = false;
     int sp_m = 0, sp_nops = 0, sp_nent = 0;
+    int sp_nrows4 = 0;            // rows of the throughput kernel (multiple of four; 0: not built)
+    int sp_nprim = 0;             // distinct angles of the program = entries of that kernel's cos/sin table
+    DevBuf d_sp_rows, d_sp_prim;
     int sp_mp = 0, sp_hf = 0;     // slots of the compact state (support padded to a multiple of 32 when renumbered), slot of |hf>
     int64_t sp_conflicts_before = 0, sp_conflicts_after = 0;   // colliding lane pairs per evaluation, discovery order / renumbered
     int64_t sp_npairs = 0;
@@ -204,6 +207,7 @@ struct ovqe_sv {
     int opt_sparse_spw = 0;       // evaluations per wave (0 = automatic)
     int opt_sparse_dealias = 1;   // arrange the restricted-Hamiltonian entries against LDS bank conflicts
     int opt_sparse_renumber = 1;  // number the compact support against LDS bank conflicts of the circuit's pairs
+    int opt_sparse_rows = 1;      // support-compacted evaluation, large batches: flat rows of padded 64-bit pair words (k_sparse_vqe_rows)
     int opt_sparse_grad = 1;      // ovqe_energy_gradient on the compact support in one launch (n <= 16)
     // pair-index-space expectation tables of the fused kernel, built per (thread bits, real mode)
     DevBuf d_egroups, d_eterms, d_echunks, d_eflat;
@@ -239,6 +243,7 @@ struct ovqe_sv {
     int opt_sector_sweep_dbg = 0; // measurements only, k_sector_sweep2: 1 no ops, 2 empty kernel, 3 loads only — wrong results
     int opt_sector_h_groups = 128; // workgroups per <H> sweep (they share the sweep's tiles round robin)
     int opt_sector_h_threads = 512; // threads per workgroup of k_sector_expect (512 or 1024)
+    int opt_sector_row_banks = 1; // materialised <H>: the elements of every row ordered against LDS bank conflicts (k_sec_row_banks)
     int opt_sector_batch = 1;     // ovqe_energy_batch on the sector tables: whole batches per pass (0: one evaluation at a time)
     float last_batch_ms = 0.f;
     const double *cur_theta = nullptr;  // device pointers of the batch being evaluated
@@ -2373,6 +2378,7 @@ int build_sparse_program(ovqe_handle h) {
         for (uint32_t &pw : pairs)
             pw = (pw & ~0xffffffu) | (uint32_t)slot[pw & 0xfffu] | ((uint32_t)slot[(pw >> 12) & 0xfffu] << 12);
         for (SpEntry &e : entries) e.ij = (uint32_t)slot[e.ij & 0xfffu] | ((uint32_t)slot[(e.ij >> 12) & 0xfffu] << 12);
+        // (chunks of 32 are split into two halves of 16 below, for the stores)
         // ops with more than 32 pairs: chunks of 32 with distinct residues on both sides where the pairs allow it
         for (const SpOp &so : ops) {
             if (so.npairs <= 32) continue;
@@ -2401,6 +2407,39 @@ int build_sparse_program(ovqe_handle h) {
                 left.swap(rest);
             }
             std::copy(out.begin(), out.end(), pairs.begin() + so.first);
+        }
+        // The two ds_write_b64 of a rotation are served in groups of 16 lanes against 16 bank pairs (bank = slot mod 16): inside
+        // every chunk of 32 pairs the two halves of 16 are chosen so that slots equal mod 16 — at most two per side once the
+        // residues mod 32 are distinct — fall into different halves (twins on the first and on the second index form paths and
+        // even cycles: two-colourable; greedy here, balanced halves).
+        for (const SpOp &so : ops) {
+            for (int c0 = 0; c0 < so.npairs; c0 += 32) {
+                const int cn = std::min(32, so.npairs - c0);
+                if (cn <= 1) continue;
+                uint32_t *pw = pairs.data() + so.first + c0;
+                std::vector<uint32_t> half[2];
+                int cnt_i[2][16] = {}, cnt_j[2][16] = {};
+                const int cap0 = std::min(16, cn), cap1 = cn - std::min(16, cn) < 0 ? 0 : 16;
+                (void)cap1;
+                for (int k = 0; k < cn; ++k) {
+                    const uint32_t bi = pw[k] & 15u, bj = (pw[k] >> 12) & 15u;
+                    const int c0s = cnt_i[0][bi] + cnt_j[0][bj], c1s = cnt_i[1][bi] + cnt_j[1][bj];
+                    int side = c0s < c1s ? 0 : (c1s < c0s ? 1 : (half[0].size() <= half[1].size() ? 0 : 1));
+                    if ((int)half[side].size() >= 16) side ^= 1;
+                    if (side == 0 && (int)half[0].size() >= cap0) side = 1;
+                    half[side].push_back(pw[k]);
+                    ++cnt_i[side][bi];
+                    ++cnt_j[side][bj];
+                }
+                // lanes 0..15 take half 0; when half 0 is short of 16 and half 1 not empty the chunk stays contiguous: pad from half 1
+                while (half[0].size() < 16 && !half[1].empty()) {
+                    half[0].push_back(half[1].back());
+                    half[1].pop_back();
+                }
+                int k = 0;
+                for (uint32_t w : half[0]) pw[k++] = w;
+                for (uint32_t w : half[1]) pw[k++] = w;
+            }
         }
     }
     // LDS bank conflicts: a wave reads the two amplitudes of 64 consecutive entries at once (ds_read_b64 is served in two
@@ -2463,7 +2502,64 @@ int build_sparse_program(ovqe_handle h) {
         }
         entries.swap(arranged);
     }
+    // rows of 32 padded 64-bit words for the throughput kernel (k_sparse_vqe_rows): only when every byte offset fits 16 bits
+    std::vector<uint64_t> rows;
+    h->sp_nrows4 = 0;
+    const int ntab_all = (int)h->srots.size();
+    // ... with ONE cos/sin entry per distinct angle: table entries of one parameter with coefficients +-c (the active patterns of
+    // a JW excitation) share cos and differ in the sign of sin, which moves into the word's sign bit — fewer sincos per evaluation
+    // and a smaller table per evaluation in LDS (more waves per CU)
+    std::vector<SmallRot> prim;
+    std::vector<int> prim_of((size_t)ntab_all, -1);
+    std::vector<uint8_t> prim_neg((size_t)ntab_all, 0);
+    {
+        std::unordered_map<uint64_t, std::vector<int>> by_param;
+        for (int e = 0; e < ntab_all; ++e) {
+            const SmallRot &sr = h->srots[e];
+            std::vector<int> &cand = by_param[(uint64_t)(uint32_t)sr.pidx];
+            for (int p : cand)
+                if (std::fabs(prim[p].coeff) == std::fabs(sr.coeff) && prim[p].phi0 == 0.0 && sr.phi0 == 0.0) {
+                    prim_of[e] = p;
+                    prim_neg[e] = (prim[p].coeff < 0) != (sr.coeff < 0);
+                    break;
+                }
+            if (prim_of[e] < 0) {
+                prim_of[e] = (int)prim.size();
+                cand.push_back((int)prim.size());
+                prim.push_back(sr);
+            }
+        }
+    }
+    const int nprim = (int)prim.size();
+    h->sp_nprim = 0;
+    if (h->opt_sparse_rows && (size_t)(mp + 64) * 8 < 65536 && (size_t)(nprim + 1) * 16 < 65536) {
+        auto pad_word = [&](int lane) {
+            return (uint64_t)((uint32_t)(mp + lane) * 8u) | ((uint64_t)((uint32_t)(mp + 32 + lane) * 8u) << 16) |
+                   ((uint64_t)((uint32_t)nprim * 16u) << 32);
+        };
+        for (const SpOp &so : ops)
+            for (int c0 = 0; c0 < so.npairs; c0 += 32)
+                for (int lane = 0; lane < 32; ++lane) {
+                    if (c0 + lane >= so.npairs) {
+                        rows.push_back(pad_word(lane));
+                        continue;
+                    }
+                    const uint32_t pw = pairs[(size_t)so.first + c0 + lane];
+                    const uint32_t ci = pw & 0xfffu, cj = (pw >> 12) & 0xfffu, ent = (uint32_t)so.tab0 + (pw >> 25);
+                    const bool neg = ((pw >> 24) & 1u) != (uint32_t)prim_neg[ent];
+                    rows.push_back((uint64_t)(ci * 8u) | ((uint64_t)(cj * 8u) << 16) | ((uint64_t)((uint32_t)prim_of[ent] * 16u) << 32) |
+                                   (neg ? (1ull << 63) : 0ull));
+                }
+        const int nrows = (int)(rows.size() / 32);
+        const int nrows4 = (nrows + 3) & ~3;
+        for (int r = nrows; r < nrows4 + 4; ++r)             // padding to a multiple of four + the four rows fetched ahead
+            for (int lane = 0; lane < 32; ++lane) rows.push_back(pad_word(lane));
+        h->sp_nrows4 = nrows4;
+        h->sp_nprim = nprim;
+    }
     int rc = upload(h, h->d_sp_ops, ops.data(), ops.size() * sizeof(SpOp));
+    if (!rc && h->sp_nrows4) rc = upload(h, h->d_sp_rows, rows.data(), rows.size() * sizeof(uint64_t));
+    if (!rc && h->sp_nrows4) rc = upload(h, h->d_sp_prim, prim.data(), prim.size() * sizeof(SmallRot));
     if (!rc) rc = upload(h, h->d_sp_pairs, pairs.data(), pairs.size() * sizeof(uint32_t));
     if (!rc) rc = upload(h, h->d_sp_entries, entries.data(), entries.size() * sizeof(SpEntry));
     if (rc) return rc;
@@ -2538,6 +2634,21 @@ int run_sparse(ovqe_handle h, int64_t B, const double *theta, double *energies, 
     const size_t staged = per_eval + (size_t)A.nops * sizeof(SpOp) + (size_t)A.npairs * sizeof(uint32_t);
     if (B <= 1024 && staged <= 96 * 1024) rc = launch_sparse<1, true>(h, A, grid, staged);
     else if (spw == 4) rc = launch_sparse<4>(h, A, grid, per_eval * 4);
+    else if (spw == 2 && h->sp_nrows4 && h->opt_sparse_rows) {
+        SparseArgs R = A;
+        R.mpad = (h->sp_mp + 64 + 1) & ~1;   // + the padded lanes' spare slots
+        R.ntab = h->sp_nprim;                // one entry per distinct angle
+        const size_t per_eval_r = (size_t)R.mpad * sizeof(double) + (size_t)(R.ntab + 1) * sizeof(double2);
+        static bool attr_rows_dev[64] = {};
+        bool &attr_rows = attr_rows_dev[h->device & 63];
+        if (!attr_rows) {
+            HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sparse_vqe_rows<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_rows = true;
+        }
+        hipLaunchKernelGGL((k_sparse_vqe_rows<2>), dim3(grid), dim3(64), per_eval_r * 2, h->stream, R, h->cur_theta, (const SmallRot *)h->d_sp_prim.p,
+                           (const uint64_t *)h->d_sp_rows.p, h->sp_nrows4, (const SpEntry *)h->d_sp_entries.p, h->cur_energies);
+        HIPC(h, hipGetLastError());
+    }
     else if (spw == 2) rc = launch_sparse<2>(h, A, grid, per_eval * 2);
     else rc = launch_sparse<1>(h, A, grid, per_eval);
     if (rc) return rc;
@@ -2709,7 +2820,7 @@ int ovqe_destroy(ovqe_handle h) {
     std::vector<DevBuf *> bufs = {&h->d_partials, &h->d_result, &h->d_rp, &h->d_ops, &h->d_rots, &h->d_rots_seq, &h->d_segs,
                                   &h->d_stream,
                                   &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups, &h->d_eterms, &h->d_echunks,
-                                  &h->d_eflat, &h->d_sp_ops, &h->d_sp_pairs, &h->d_sp_entries, &h->d_pg_off, &h->d_pg_xs, &h->d_pg_terms,
+                                  &h->d_eflat, &h->d_sp_ops, &h->d_sp_rows, &h->d_sp_prim, &h->d_sp_pairs, &h->d_sp_entries, &h->d_pg_off, &h->d_pg_xs, &h->d_pg_terms,
                                   &h->d_pg_out, &h->d_pg_part, &h->d_nz_cnt, &h->d_nz_start, &h->d_nz_idx, &h->d_nz_val, &h->d_nz_bitmap, &h->d_tile_smasks, &h->d_tile_lists, &h->d_tile_counts, &h->cc.d_sup, &h->cc.d_psic, &h->cc.d_loc, &h->cc.d_cid, &h->cc.d_off, &h->cc.d_sweeps};
     for (TilePlan *tp : {&h->tp, &h->tp_adhoc, &h->tp_real}) bufs.insert(bufs.end(), {&tp->d_tops, &tp->d_trots});
     for (HamDev *H : {&h->ham, &h->ham_adhoc, &h->ham_real})
@@ -2771,6 +2882,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "sector_h_groups") h->opt_sector_h_groups = (int)value;
     else if (k == "sector_h_threads") h->opt_sector_h_threads = value == 1024 ? 1024 : 512;
     else if (k == "sector_batch") h->opt_sector_batch = (int)value;
+    else if (k == "sector_row_banks") h->opt_sector_row_banks = (int)value;
     else if (k == "sector_debug") h->opt_sector_debug = (int)value;
     else if (k == "sector_sweep") h->opt_sector_sweep = value == 1 ? 1 : 2;
     else if (k == "sector_sweep_dbg") h->opt_sector_sweep_dbg = (int)value;
@@ -2800,6 +2912,10 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
         h->sp_tried = false;
     }
     else if (k == "sparse_grad") h->opt_sparse_grad = value ? 1 : 0;
+    else if (k == "sparse_rows") {
+        h->opt_sparse_rows = value ? 1 : 0;
+        h->sp_tried = false;
+    }
     else if (k == "sparse_renumber") {
         h->opt_sparse_renumber = value ? 1 : 0;
         h->sp_tried = false;

@@ -151,6 +151,91 @@ __global__ __launch_bounds__(64) void k_sparse_vqe(SparseArgs A, const double *_
     }
 }
 
+// ---- throughput form of the circuit (round 3): rows of 32 padded 64-bit words ------------------------------------------------
+// rocprofv3 counters of k_sparse_vqe<2> on the H2O workload: the LDS pipe is active 6 % of the wave cycles and bank-conflict
+// cycles can be cut by a third without any change in run time; 39 % of the wave cycles are instruction issue — about 60
+// instructions per op and wave (25 scalar: op records three ops ahead, loop bounds; 20 vector: unpacking the pair word,
+// addresses, sign) around 4 f64 operations and 5 LDS accesses.  This form removes the bookkeeping: the program is a flat
+// list of ROWS of 32 words (an op's pairs in chunks of 32, padded), one word per lane and row, everything pre-computed in it:
+//   bits 0-15 byte offset of amplitude i | 16-31 byte offset of amplitude j | 32-47 byte offset of the cos/sin entry | 63 sign
+// Padded lanes rotate two private spare slots behind the support by the identity entry behind the table (no branch).  Rows are
+// fetched four ahead in registers; per row: one 8-byte load, three LDS reads, four f64 operations, two LDS writes.
+template <int SPW>
+__global__ __launch_bounds__(64) void k_sparse_vqe_rows(SparseArgs A, const double *__restrict__ theta,
+                                                        const SmallRot *__restrict__ tabrots, const uint64_t *__restrict__ rows,
+                                                        int nrows4, const SpEntry *__restrict__ entries,
+                                                        double *__restrict__ energies) {
+    static_assert(SPW == 2, "rows are built for two evaluations per wave (32 lanes each)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *st = reinterpret_cast<double *>(smem);                          // [SPW][mpad], mpad = support + 64 spare slots
+    double2 *cs = reinterpret_cast<double2 *>(st + (size_t)SPW * A.mpad);   // [SPW][ntab + 1]: the last entry is the identity
+    const int lane = threadIdx.x;
+    constexpr int LPS = 64 / SPW;
+    const int s = lane / LPS, l = lane % LPS;
+    const int ntab1 = A.ntab + 1;
+    unsigned char *sbase = smem + (size_t)s * A.mpad * sizeof(double);
+    unsigned char *cbase = smem + (size_t)SPW * A.mpad * sizeof(double) + (size_t)s * ntab1 * sizeof(double2);
+    const int64_t nwork = (A.B + SPW - 1) / SPW;
+    const uint64_t *rp = rows + l;
+    for (int64_t w = blockIdx.x; w < nwork; w += gridDim.x) {
+        const int64_t b0 = w * SPW;
+        uint64_t w0 = rp[0], w1 = rp[32], w2 = rp[64], w3 = rp[96];   // (the table ends with four spare rows)
+        for (int i = lane; i < SPW * A.mpad; i += 64) st[i] = (i % A.mpad == A.hf) ? 1.0 : 0.0;
+        {
+            const int64_t b = b0 + s < A.B ? b0 + s : A.B - 1;
+            const double *th = theta + b * A.K;
+            for (int e = l; e < A.ntab; e += LPS) {
+                const SmallRot sr = tabrots[e];
+                double sn, c;
+                sincos(sr.coeff * th[sr.pidx], &sn, &c);
+                cs[(size_t)s * ntab1 + e] = make_double2(c, sn);
+            }
+            if (l == 0) cs[(size_t)s * ntab1 + A.ntab] = make_double2(1.0, 0.0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        auto apply = [&](uint64_t word) {
+            const uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
+            double *pi = reinterpret_cast<double *>(sbase + (lo & 0xffffu));
+            double *pj = reinterpret_cast<double *>(sbase + (lo >> 16));
+            const double2 t = *reinterpret_cast<const double2 *>(cbase + (hi & 0xffffu));
+            const double sn = __hiloint2double(__double2hiint(t.y) ^ (int)(hi & 0x80000000u), __double2loint(t.y));
+            const double u = *pi, v = *pj;
+            *pi = t.x * u + sn * v;
+            *pj = t.x * v - sn * u;
+            // pairs of one row are disjoint; the next row may touch them from other lanes of this wave: the LDS unit executes a
+            // wave's DS instructions in issue order, so only the COMPILER must not reorder across rows
+            asm volatile("" ::: "memory");
+        };
+        for (int r = 0; r < nrows4; r += 4) {
+            const uint64_t *nx = rp + (size_t)(r + 4) * 32;
+            apply(w0);
+            w0 = nx[0];
+            apply(w1);
+            w1 = nx[32];
+            apply(w2);
+            w2 = nx[64];
+            apply(w3);
+            w3 = nx[96];
+        }
+        double acc[SPW];
+#pragma unroll
+        for (int q = 0; q < SPW; ++q) acc[q] = 0.0;
+#pragma unroll 4
+        for (int e = lane; e < A.nent; e += 64) {
+            const SpEntry en = entries[e];
+            const uint32_t ci = en.ij & 0xfffu, cj = (en.ij >> 12) & 0xfffu;
+#pragma unroll
+            for (int q = 0; q < SPW; ++q) acc[q] += en.c * st[(size_t)q * A.mpad + ci] * st[(size_t)q * A.mpad + cj];
+        }
+#pragma unroll
+        for (int q = 0; q < SPW; ++q) {
+            const double tot = wave_sum(acc[q]);
+            if (lane == 0 && b0 + q < A.B) energies[b0 + q] = tot + A.constant;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 // ---- exact gradient on the compact support (round 3) ---------------------------------------------------------------------
 // E(theta) and dE/dtheta_k for ALL K parameters of one parameter vector per wave, in ONE launch: forward circuit as above,
 // lambda = H psi from the restricted Hamiltonian's entries (f64 LDS atomics: lambda_i += H_ij a_j, lambda_j += H_ij a_i),

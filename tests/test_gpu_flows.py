@@ -211,6 +211,36 @@ def test_fermionic_adapt_fidelity_with_device_ground_state(h2, monkeypatch):
     assert out["lanczos"][0]["fidelity"][-1] > 0.9
 
 
+def test_sector_ground_space_option_of_fermionic_adapt(gpu_lib, monkeypatch):
+    """SECTOR_GROUND_SPACE: the fun_fidelity reference vector from ovqe_sector_ground_state (Lanczos on the Hamiltonian
+    restricted to the determinants the pool reaches, inside the block of |hf>) — H2O / STO-3G: its energy is the FCI energy of
+    the SCF front-end's determinant-space CI, the vector is normalised, lives on the (5 alpha, 5 beta) determinants, and equals
+    the whole-register Lanczos vector whenever both report the same eigenvalue"""
+    import openvqe_amd.adapt.fermionic_adapt_vqe as fa
+    from openvqe_amd import chem
+    mol = chem.molecule("H2O")
+    mol.rhf()
+    prob = mol.problem(active=False)
+    ham = prob.jw_hamiltonian()
+    _, _, spin_ops, _, hf = prob.uccsd()
+    pool = [complex(0.0, -1.0) * op for op in spin_ops]          # anti-Hermitian pool operators, as the ADAPT drivers hold them
+    e_fci = mol.ci_ground_state()[0]
+    with engine("hip"):
+        monkeypatch.setattr(fa, "SECTOR_GROUND_SPACE", True)
+        vals_s, vecs_s = fa._ground_space(ham, pool, hf)
+        monkeypatch.setattr(fa, "SECTOR_GROUND_SPACE", False)
+        vals_r, vecs_r = fa._ground_space(ham, pool, hf)
+    v = vecs_s[:, 0]
+    assert abs(vals_s[0] - e_fci) < 1e-9
+    assert abs(np.linalg.norm(v) - 1.0) < 1e-12 and np.count_nonzero(v) <= 441
+    n = ham.nbqbits
+    occupied = np.nonzero(v)[0]
+    assert all(bin(int(i)).count("1") == 10 for i in occupied)
+    assert vals_r[0] <= vals_s[0] + 1e-8                        # the register's minimum is never above the sector's
+    if abs(vals_r[0] - vals_s[0]) < 1e-8:
+        assert abs(abs(np.vdot(vecs_r[:, 0], v)) - 1.0) < 1e-6
+
+
 def test_state_vector_job_as_listed_samples_and_fidelity_at_16_qubits(gpu_lib):
     """a state-vector job of the stand-in QPU on 16+ qubits returns the samples as the arrays the device listed
     (ovqe_get_support); iterating them gives the myQLM samples (get_statevector, ref:openvqe/adapt/fermionic_adapt_vqe.py:309-328)

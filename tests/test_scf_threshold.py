@@ -92,3 +92,49 @@ def test_scf_stopped_at_pyscf_thresholds_leaves_rotated_orbitals():
     assert 1e-9 < off < 1e-4 and abs(tight.e_hf - loose.e_hf) < 1e-9
     # symmetry-conserving: only the sigma_g / sigma_g and sigma_u / sigma_u blocks mix
     assert abs(rot[0, 1]) < 1e-12 and abs(rot[0, 3]) < 1e-12 and abs(rot[2, 1]) < 1e-12
+
+
+def test_h4_offsets_are_not_closed_by_the_two_allowed_rotations():
+    """The same question for the QUCCSD pins (K5, H4/STO-3G; VERDICT r2 "What's weak" 1): linear H4 has exactly two
+    occupied<->virtual rotations a symmetry-conserving SCF can leave unconverged (sigma_g 0<->2, sigma_u 1<->3).  Stored numbers
+    that depend on the orbitals to FIRST order: E(theta_MP2), E(0.01), the two stored optima evaluated at their stored
+    parameters, and the MP2 energy (the RHF energy itself agrees to 1e-14: second order).  RESULT — stated, not tolerated away:
+    two angles of the size PySCF's thresholds leave (< 1e-6) remove the MP2 offset (3.1e-9 -> < 1e-10) but NOT the others at the
+    same time: after the least-squares fit the four energies still differ by 0.5 - 1.5e-9 from the stored ones (before: 2.6e-9,
+    3e-10, 1.7e-10, 1.7e-10).  So for H4 the SCF threshold explains the SIZE of the offsets (all < 5e-9, the energy DIFFERENCES
+    of the same trace agree to 1e-12) but the two-parameter model does not close at the 5e-10 level; what is left is of the
+    order of the notebook's printed precision of theta_optimized (1e-8 in a parameter -> 1e-10 in E) and of myQLM's own MP2
+    guess, which this tree cannot see."""
+    from openvqe_amd.ucc_family.get_energy_qucc import EnergyUCC
+    from tests.oracle_backend import OracleStatevector
+    from tests.test_reference_quccsd import engine
+    r = json.load(open(os.path.join(GOLD, "k5_k7_notebook_runs.json")))["h4_quccsd"]
+    stored = np.array([r["energies_1"][0], r["energies_2"][0], r["minimum_energy_result1_guess"],
+                       r["minimum_energy_result2_guess"], r["info"]["MP2"]])
+
+    def observables(k02, k13):
+        mol = chem.molecule("H4")
+        mol.rhf()
+        if k02 or k13:
+            mol.rotate_orbitals({(0, 2): k02, (1, 3): k13})
+        p = mol.problem(active=False)
+        ham = p.jw_hamiltonian()
+        size, cluster_ops, _, theta_mp2, hf = p.uccsd()
+        q = EnergyUCC()
+        e = lambda th: q.action_quccsd(np.array(th), ham, cluster_ops, hf, [])   # noqa: E731
+        return np.array([e(theta_mp2), e(np.full(size, 0.01)), e(r["theta_optimized_result1"]),
+                         e(r["theta_optimized_result2"]), mol.mp2_energy()]), mol.e_hf
+
+    with engine(OracleStatevector):
+        o0, e_hf = observables(0.0, 0.0)
+        assert abs(e_hf - r["info"]["HF"]) < 1e-12
+        d0 = o0 - stored
+        assert np.abs(d0).max() < 5e-9 and abs(d0[4]) > 2e-9          # the offsets at stationary orbitals
+        h = 1e-5
+        J = np.stack([(observables(h, 0.0)[0] - observables(-h, 0.0)[0]) / (2 * h),
+                      (observables(0.0, h)[0] - observables(0.0, -h)[0]) / (2 * h)], axis=1)
+        kappa = np.linalg.lstsq(J, -d0, rcond=None)[0]
+        assert np.abs(kappa).max() < 1e-6                              # the size an SCF stopped at PySCF's thresholds leaves
+        d1 = observables(*kappa)[0] - stored
+    assert abs(d1[4]) < 1e-10                                          # the MP2 energy is explained ...
+    assert 3e-10 < np.abs(d1[:4]).max() < 2e-9                         # ... the four QUCCSD energies are not, at 5e-10
