@@ -243,7 +243,7 @@ struct ovqe_sv {
     int opt_sector_sweep_dbg = 0; // measurements only, k_sector_sweep2: 1 no ops, 2 empty kernel, 3 loads only — wrong results
     int opt_sector_h_groups = 128; // workgroups per <H> sweep (they share the sweep's tiles round robin)
     int opt_sector_h_threads = 512; // threads per workgroup of k_sector_expect (512 or 1024)
-    int opt_sector_row_banks = 1; // materialised <H>: the elements of every row ordered against LDS bank conflicts (k_sec_row_banks)
+    int opt_sector_row_banks = 0; // materialised <H>: the elements of every row ordered against LDS bank conflicts (k_sec_row_banks)
     int opt_sector_batch = 1;     // ovqe_energy_batch on the sector tables: whole batches per pass (0: one evaluation at a time)
     float last_batch_ms = 0.f;
     const double *cur_theta = nullptr;  // device pointers of the batch being evaluated
