@@ -187,7 +187,8 @@ struct ovqe_sv {
     int sp_m = 0, sp_nops = 0, sp_nent = 0;
     int sp_nrows4 = 0;            // rows of the throughput kernel (multiple of four; 0: not built)
     int sp_nprim = 0;             // distinct angles of the program = entries of that kernel's cos/sin table
-    DevBuf d_sp_rows, d_sp_prim;
+    DevBuf d_sp_rows, d_sp_rows64, d_sp_prim;
+    int sp_nrows8 = 0;            // rows of 64 of the latency kernel (multiple of eight; 0: not built)
     int sp_mp = 0, sp_hf = 0;     // slots of the compact state (support padded to a multiple of 32 when renumbered), slot of |hf>
     int64_t sp_conflicts_before = 0, sp_conflicts_after = 0;   // colliding lane pairs per evaluation, discovery order / renumbered
     int64_t sp_npairs = 0;
@@ -208,6 +209,7 @@ struct ovqe_sv {
     int opt_sparse_dealias = 1;   // arrange the restricted-Hamiltonian entries against LDS bank conflicts
     int opt_sparse_renumber = 1;  // number the compact support against LDS bank conflicts of the circuit's pairs
     int opt_sparse_rows = 1;      // support-compacted evaluation, large batches: flat rows of padded 64-bit pair words (k_sparse_vqe_rows)
+    int opt_sparse_wg = 1;        // small batches (<= 1024): one evaluation per 1024-thread workgroup (k_sparse_vqe_wg)
     int opt_sparse_grad = 1;      // ovqe_energy_gradient on the compact support in one launch (n <= 16)
     // pair-index-space expectation tables of the fused kernel, built per (thread bits, real mode)
     DevBuf d_egroups, d_eterms, d_echunks, d_eflat;
@@ -2557,9 +2559,42 @@ int build_sparse_program(ovqe_handle h) {
         h->sp_nrows4 = nrows4;
         h->sp_nprim = nprim;
     }
+    // ... and rows of 64 for the latency kernel (one evaluation per workgroup, the circuit on its first wave; byte offsets
+    // slot * 8, spare slots mp .. mp + 127)
+    std::vector<uint64_t> rows64;
+    h->sp_nrows8 = 0;
+    if (h->opt_sparse_rows && (size_t)(mp + 128) * 8 < 65536 && (size_t)(nprim + 1) * 16 < 65536) {
+        auto pad_word = [&](int lane) {
+            return (uint64_t)((uint32_t)(mp + lane) * 8u) | ((uint64_t)((uint32_t)(mp + 64 + lane) * 8u) << 16) |
+                   ((uint64_t)((uint32_t)nprim * 16u) << 32);
+        };
+        for (const SpOp &so : ops)
+            for (int c0 = 0; c0 < so.npairs; c0 += 64)
+                for (int lane = 0; lane < 64; ++lane) {
+                    if (c0 + lane >= so.npairs) {
+                        // padded lanes rotate their (zero) spare slots by the row's FIRST cos/sin entry: rows of one entry stay
+                        // uniform for the gradient kernel's wave sums
+                        const uint32_t pw0 = pairs[(size_t)so.first + c0];
+                        const uint32_t ent0 = (uint32_t)prim_of[(uint32_t)so.tab0 + (pw0 >> 25)];
+                        rows64.push_back((pad_word(lane) & 0xffffffffull) | ((uint64_t)(ent0 * 16u) << 32));
+                        continue;
+                    }
+                    const uint32_t pw = pairs[(size_t)so.first + c0 + lane];
+                    const uint32_t ci = pw & 0xfffu, cj = (pw >> 12) & 0xfffu, ent = (uint32_t)so.tab0 + (pw >> 25);
+                    const bool neg = ((pw >> 24) & 1u) != (uint32_t)prim_neg[ent];
+                    rows64.push_back((uint64_t)(ci * 8u) | ((uint64_t)(cj * 8u) << 16) | ((uint64_t)((uint32_t)prim_of[ent] * 16u) << 32) |
+                                     (neg ? (1ull << 63) : 0ull));
+                }
+        const int nrows = (int)(rows64.size() / 64);
+        const int nrows8 = (nrows + 7) & ~7;
+        for (int r = nrows; r < nrows8 + 8; ++r)
+            for (int lane = 0; lane < 64; ++lane) rows64.push_back(pad_word(lane));
+        h->sp_nrows8 = nrows8;
+    }
     int rc = upload(h, h->d_sp_ops, ops.data(), ops.size() * sizeof(SpOp));
     if (!rc && h->sp_nrows4) rc = upload(h, h->d_sp_rows, rows.data(), rows.size() * sizeof(uint64_t));
-    if (!rc && h->sp_nrows4) rc = upload(h, h->d_sp_prim, prim.data(), prim.size() * sizeof(SmallRot));
+    if (!rc && (h->sp_nrows4 || h->sp_nrows8)) rc = upload(h, h->d_sp_prim, prim.data(), prim.size() * sizeof(SmallRot));
+    if (!rc && h->sp_nrows8) rc = upload(h, h->d_sp_rows64, rows64.data(), rows64.size() * sizeof(uint64_t));
     if (!rc) rc = upload(h, h->d_sp_pairs, pairs.data(), pairs.size() * sizeof(uint32_t));
     if (!rc) rc = upload(h, h->d_sp_entries, entries.data(), entries.size() * sizeof(SpEntry));
     if (rc) return rc;
@@ -2632,7 +2667,25 @@ int run_sparse(ovqe_handle h, int64_t B, const double *theta, double *energies, 
     if (!zero_copy) HIPC(h, hipEventRecord(h->ev0, h->stream));
     // latency path: op table + pair words staged in LDS (one wave per evaluation, occupancy does not matter)
     const size_t staged = per_eval + (size_t)A.nops * sizeof(SpOp) + (size_t)A.npairs * sizeof(uint32_t);
-    if (B <= 1024 && staged <= 96 * 1024) rc = launch_sparse<1, true>(h, A, grid, staged);
+    if (B <= 256 && h->sp_nrows8 && h->opt_sparse_rows && h->opt_sparse_wg) {
+        // latency path: one evaluation per 1024-thread workgroup, at most one workgroup per CU (k_sparse_vqe_wg; measured: H2O
+        // B = 1 / 141 32 / 37 us against 60 / 61 us with one wave per evaluation, B = 1024 129 against 115 us)
+        SparseArgs R = A;
+        R.mpad = (h->sp_mp + 128 + 1) & ~1;
+        R.ntab = h->sp_nprim;
+        const size_t smem = (size_t)R.mpad * sizeof(double) + (size_t)(R.ntab + 1) * sizeof(double2);
+        static bool attr_wg_dev[64] = {};
+        bool &attr_wg = attr_wg_dev[h->device & 63];
+        if (!attr_wg) {
+            HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sparse_vqe_wg<1024, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_wg = true;
+        }
+        hipLaunchKernelGGL((k_sparse_vqe_wg<1024, 10>), dim3((unsigned)std::min<int64_t>(B, 1024)), dim3(1024), smem, h->stream, R, h->cur_theta,
+                           (const SmallRot *)h->d_sp_prim.p, (const uint64_t *)h->d_sp_rows64.p, h->sp_nrows8, (const SpEntry *)h->d_sp_entries.p,
+                           h->cur_energies);
+        HIPC(h, hipGetLastError());
+    }
+    else if (B <= 1024 && staged <= 96 * 1024) rc = launch_sparse<1, true>(h, A, grid, staged);
     else if (spw == 4) rc = launch_sparse<4>(h, A, grid, per_eval * 4);
     else if (spw == 2 && h->sp_nrows4 && h->opt_sparse_rows) {
         SparseArgs R = A;
@@ -2717,7 +2770,29 @@ int run_sparse_gradient(ovqe_handle h, const double *theta, double *energy, doub
         d_e = (double *)h->d_energies.p;
         d_g = d_e + 1;
     }
-    if (stage)
+    if (h->sp_nrows8 && h->opt_sparse_rows && h->opt_sparse_wg) {
+        SparseArgs R = A;
+        R.mpad = (h->sp_mp + 128 + 1) & ~1;
+        R.ntab = h->sp_nprim;
+        const size_t smem = 2 * (size_t)R.mpad * sizeof(double) + (size_t)(R.ntab + 1) * sizeof(double2) + (size_t)((R.ntab + 2) & ~1) * sizeof(double) +
+                            (size_t)((R.K + 1) & ~1) * sizeof(double);
+        static bool attr_gwg_dev[64] = {};
+        bool &attr_gwg = attr_gwg_dev[h->device & 63];
+        if (!attr_gwg) {
+            HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sparse_grad_wg<1024, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_gwg = true;
+        }
+        if (smem <= 150 * 1024) {
+            hipLaunchKernelGGL((k_sparse_grad_wg<1024, 10>), dim3(1), dim3(1024), smem, h->stream, R, d_theta, (const SmallRot *)h->d_sp_prim.p,
+                               (const uint64_t *)h->d_sp_rows64.p, h->sp_nrows8, (const SpEntry *)h->d_sp_entries.p, d_e, d_g);
+        } else if (stage) {
+            hipLaunchKernelGGL((k_sparse_grad<true>), dim3(1), dim3(64), staged, h->stream, A, d_theta, (const SmallRot *)h->d_rots.p,
+                               (const SpOp *)h->d_sp_ops.p, (const uint32_t *)h->d_sp_pairs.p, (const SpEntry *)h->d_sp_entries.p, d_e, d_g);
+        } else {
+            hipLaunchKernelGGL((k_sparse_grad<false>), dim3(1), dim3(64), base, h->stream, A, d_theta, (const SmallRot *)h->d_rots.p,
+                               (const SpOp *)h->d_sp_ops.p, (const uint32_t *)h->d_sp_pairs.p, (const SpEntry *)h->d_sp_entries.p, d_e, d_g);
+        }
+    } else if (stage)
         hipLaunchKernelGGL((k_sparse_grad<true>), dim3(1), dim3(64), staged, h->stream, A, d_theta, (const SmallRot *)h->d_rots.p,
                            (const SpOp *)h->d_sp_ops.p, (const uint32_t *)h->d_sp_pairs.p, (const SpEntry *)h->d_sp_entries.p, d_e, d_g);
     else
@@ -2820,7 +2895,7 @@ int ovqe_destroy(ovqe_handle h) {
     std::vector<DevBuf *> bufs = {&h->d_partials, &h->d_result, &h->d_rp, &h->d_ops, &h->d_rots, &h->d_rots_seq, &h->d_segs,
                                   &h->d_stream,
                                   &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups, &h->d_eterms, &h->d_echunks,
-                                  &h->d_eflat, &h->d_sp_ops, &h->d_sp_rows, &h->d_sp_prim, &h->d_sp_pairs, &h->d_sp_entries, &h->d_pg_off, &h->d_pg_xs, &h->d_pg_terms,
+                                  &h->d_eflat, &h->d_sp_ops, &h->d_sp_rows, &h->d_sp_rows64, &h->d_sp_prim, &h->d_sp_pairs, &h->d_sp_entries, &h->d_pg_off, &h->d_pg_xs, &h->d_pg_terms,
                                   &h->d_pg_out, &h->d_pg_part, &h->d_nz_cnt, &h->d_nz_start, &h->d_nz_idx, &h->d_nz_val, &h->d_nz_bitmap, &h->d_tile_smasks, &h->d_tile_lists, &h->d_tile_counts, &h->cc.d_sup, &h->cc.d_psic, &h->cc.d_loc, &h->cc.d_cid, &h->cc.d_off, &h->cc.d_sweeps};
     for (TilePlan *tp : {&h->tp, &h->tp_adhoc, &h->tp_real}) bufs.insert(bufs.end(), {&tp->d_tops, &tp->d_trots});
     for (HamDev *H : {&h->ham, &h->ham_adhoc, &h->ham_real})
@@ -2912,6 +2987,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
         h->sp_tried = false;
     }
     else if (k == "sparse_grad") h->opt_sparse_grad = value ? 1 : 0;
+    else if (k == "sparse_wg") h->opt_sparse_wg = value ? 1 : 0;
     else if (k == "sparse_rows") {
         h->opt_sparse_rows = value ? 1 : 0;
         h->sp_tried = false;

@@ -56,6 +56,24 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// wave-wide sum by DPP row operations (no LDS crossbar: __shfl_xor on doubles costs two ds_bpermute per step); the total
+// is valid in lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double sec_dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sec_wave_sum63(double v) {
+    v = sec_dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = sec_dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = sec_dpp_add<0x141, 0xf>(v);   // row_half_mirror
+    v = sec_dpp_add<0x140, 0xf>(v);   // row_mirror
+    v = sec_dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = sec_dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // block-wide deterministic sum of a complex value; result valid in thread 0
 template <int NT>
 __device__ __forceinline__ double2 block_sum(double2 v, double2 *lds /* NT/64 entries */) {

@@ -1073,24 +1073,6 @@ __global__ __launch_bounds__(256) void k_sec_dot(const double *__restrict__ a, c
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
-// wave-wide sum by DPP row operations (no LDS crossbar: __shfl_xor on doubles costs two ds_bpermute per step); the total
-// is valid in lane 63
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double sec_dpp_add(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
-    return v + __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double sec_wave_sum63(double v) {
-    v = sec_dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
-    v = sec_dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
-    v = sec_dpp_add<0x141, 0xf>(v);   // row_half_mirror
-    v = sec_dpp_add<0x140, 0xf>(v);   // row_mirror
-    v = sec_dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-    v = sec_dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
 // One sweep of the circuit BACKWARDS on psi and lambda together (both in this sweep's order): for every op, last to
 // first, w[entry] += sum over its pairs of sigma (lambda_i psi_j - lambda_j psi_i) on the states after the op (dE/dtheta =
 // 2 coeff w), then both states are rotated back.  Output in the PREVIOUS sweep's order (scatter through src; the first

@@ -236,6 +236,78 @@ __global__ __launch_bounds__(64) void k_sparse_vqe_rows(SparseArgs A, const doub
     }
 }
 
+// ---- latency form (round 3): ONE evaluation per workgroup of NT threads ---------------------------------------------------------
+// What scipy's one-evaluation-per-call optimisers see.  rocprofv3: the single-wave kernel above takes 45 us per H2O evaluation
+// — 26 us of it its wave walking the 9443 entries of the restricted Hamiltonian four loads at a time, the rest 140 ops of ~60
+// instructions plus staging.  Here the workgroup's NT threads prepare everything in parallel (state, ONE sincos per thread) and
+// pull the Hamiltonian's entries into REGISTERS while wave 0 runs the circuit — rows of 64 padded words straight from memory,
+// eight rows ahead — then all waves contract their entries against the state in LDS.
+template <int NT, int EPT>
+__global__ __launch_bounds__(NT) void k_sparse_vqe_wg(SparseArgs A, const double *__restrict__ theta,
+                                                      const SmallRot *__restrict__ tabrots, const uint64_t *__restrict__ rows,
+                                                      int nrows8, const SpEntry *__restrict__ entries,
+                                                      double *__restrict__ energies) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *st = reinterpret_cast<double *>(smem);                 // [mpad] = support + 128 spare slots
+    double2 *cs = reinterpret_cast<double2 *>(st + A.mpad);        // [ntab + 1]: the last entry is the identity
+    __shared__ double2 red[NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+        const double *th = theta + b * A.K;
+        // Hamiltonian entries of this thread: in flight from here on
+        SpEntry ent[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) ent[k] = entries[min(tid + k * NT, A.nent - 1)];
+        uint64_t w[8];
+        const uint64_t *rp = rows + lane;
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = rp[k * 64];          // (the table ends with eight spare rows)
+        }
+        for (int i = tid; i < A.mpad; i += NT) st[i] = i == A.hf ? 1.0 : 0.0;
+        for (int e = tid; e < A.ntab; e += NT) {
+            const SmallRot sr = tabrots[e];
+            double sn, c;
+            sincos(sr.coeff * th[sr.pidx], &sn, &c);
+            cs[e] = make_double2(c, sn);
+        }
+        if (tid == 0) cs[A.ntab] = make_double2(1.0, 0.0);
+        __syncthreads();
+        if (wave == 0) {
+            auto apply = [&](uint64_t word) {
+                const uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
+                double *pi = reinterpret_cast<double *>(smem + (lo & 0xffffu));
+                double *pj = reinterpret_cast<double *>(smem + (lo >> 16));
+                const double2 t = *reinterpret_cast<const double2 *>(reinterpret_cast<const unsigned char *>(cs) + (hi & 0xffffu));
+                const double sn = __hiloint2double(__double2hiint(t.y) ^ (int)(hi & 0x80000000u), __double2loint(t.y));
+                const double u = *pi, v = *pj;
+                *pi = t.x * u + sn * v;
+                *pj = t.x * v - sn * u;
+                asm volatile("" ::: "memory");   // a wave's DS instructions execute in issue order (see k_sparse_vqe)
+            };
+            for (int r = 0; r < nrows8; r += 8) {
+                const uint64_t *nx = rp + (size_t)(r + 8) * 64;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    apply(w[k]);
+                    w[k] = nx[k * 64];
+                }
+            }
+        }
+        __syncthreads();
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k)
+            if (tid + k * NT < A.nent) acc += ent[k].c * st[ent[k].ij & 0xfffu] * st[(ent[k].ij >> 12) & 0xfffu];
+        for (int e = tid + EPT * NT; e < A.nent; e += NT) {       // (restricted Hamiltonians beyond EPT x NT entries)
+            const SpEntry en = entries[e];
+            acc += en.c * st[en.ij & 0xfffu] * st[(en.ij >> 12) & 0xfffu];
+        }
+        const double2 tot = block_sum<NT>(make_double2(acc, 0.0), red);
+        if (tid == 0) energies[b] = tot.x + A.constant;
+    }
+}
+
 // ---- exact gradient on the compact support (round 3) ---------------------------------------------------------------------
 // E(theta) and dE/dtheta_k for ALL K parameters of one parameter vector per wave, in ONE launch: forward circuit as above,
 // lambda = H psi from the restricted Hamiltonian's entries (f64 LDS atomics: lambda_i += H_ij a_j, lambda_j += H_ij a_i),
@@ -345,6 +417,133 @@ __global__ __launch_bounds__(64) void k_sparse_grad(SparseArgs A, const double *
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (int k = lane; k < A.K; k += 64) grads[b * A.K + k] = gk[k];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// ... and with ONE parameter vector per workgroup (latency form, as k_sparse_vqe_wg): all threads prepare and hold the restricted
+// Hamiltonian's entries in registers, wave 0 runs the circuit forwards over rows of 64 padded words, all waves form
+// E = <psi|H|psi> and lambda = H psi (f64 LDS atomics), wave 0 walks the rows BACKWARDS on psi and lambda — per row
+// g = lambda_i psi_j - lambda_j psi_i summed over the wave by DPP row operations when the row has one cos/sin entry (the rows of a
+// JW excitation do, their padded lanes carry it too), by LDS atomics otherwise — and all threads fold w into dE/dtheta.
+template <int NT, int EPT>
+__global__ __launch_bounds__(NT) void k_sparse_grad_wg(SparseArgs A, const double *__restrict__ theta, const SmallRot *__restrict__ tabrots,
+                                                       const uint64_t *__restrict__ rows, int nrows8, const SpEntry *__restrict__ entries,
+                                                       double *__restrict__ energies, double *__restrict__ grads) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *psi = reinterpret_cast<double *>(smem);                 // [mpad]
+    double *lam = psi + A.mpad;                                     // [mpad]
+    double2 *cs = reinterpret_cast<double2 *>(lam + A.mpad);        // [ntab + 1]
+    double *w = reinterpret_cast<double *>(cs + A.ntab + 1);        // [ntab + 1]
+    double *gk = w + ((A.ntab + 2) & ~1);                           // [K]
+    __shared__ double2 red[NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t lam_off = (uint32_t)A.mpad * (uint32_t)sizeof(double);
+    for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+        const double *th = theta + b * A.K;
+        SpEntry ent[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) ent[k] = entries[min(tid + k * NT, A.nent - 1)];
+        uint64_t wd[8];
+        const uint64_t *rp = rows + lane;
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wd[k] = rp[k * 64];
+        }
+        for (int i = tid; i < A.mpad; i += NT) {
+            psi[i] = i == A.hf ? 1.0 : 0.0;
+            lam[i] = 0.0;
+        }
+        for (int e = tid; e < A.ntab; e += NT) {
+            const SmallRot sr = tabrots[e];
+            double sn, c;
+            sincos(sr.coeff * th[sr.pidx], &sn, &c);
+            cs[e] = make_double2(c, sn);
+            w[e] = 0.0;
+        }
+        if (tid == 0) {
+            cs[A.ntab] = make_double2(1.0, 0.0);
+            w[A.ntab] = 0.0;
+        }
+        for (int k = tid; k < A.K; k += NT) gk[k] = 0.0;
+        __syncthreads();
+        if (wave == 0) {   // forward
+            for (int r = 0; r < nrows8; r += 8) {
+                const uint64_t *nx = rp + (size_t)(r + 8) * 64;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t lo = (uint32_t)wd[k], hi = (uint32_t)(wd[k] >> 32);
+                    double *pi = reinterpret_cast<double *>(smem + (lo & 0xffffu));
+                    double *pj = reinterpret_cast<double *>(smem + (lo >> 16));
+                    const double2 t = *reinterpret_cast<const double2 *>(reinterpret_cast<const unsigned char *>(cs) + (hi & 0xffffu));
+                    const double sn = __hiloint2double(__double2hiint(t.y) ^ (int)(hi & 0x80000000u), __double2loint(t.y));
+                    const double u = *pi, v = *pj;
+                    *pi = t.x * u + sn * v;
+                    *pj = t.x * v - sn * u;
+                    asm volatile("" ::: "memory");
+                    wd[k] = nx[k * 64];
+                }
+            }
+            // the last eight rows, for the way back (the spare rows behind the table were fetched last)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wd[k] = rp[(size_t)(nrows8 - 1 - k) * 64];
+        }
+        __syncthreads();
+        double acc = 0.0;
+        auto entry = [&](const SpEntry &en) {
+            const uint32_t ci = en.ij & 0xfffu, cj = (en.ij >> 12) & 0xfffu;
+            const double ai = psi[ci], aj = psi[cj];
+            acc += en.c * ai * aj;
+            if (ci == cj) {
+                __hip_atomic_fetch_add(&lam[ci], en.c * ai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {   // c = 2 H_ij, the pair counted once
+                __hip_atomic_fetch_add(&lam[ci], 0.5 * en.c * aj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&lam[cj], 0.5 * en.c * ai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < EPT; ++k)
+            if (tid + k * NT < A.nent) entry(ent[k]);
+        for (int e = tid + EPT * NT; e < A.nent; e += NT) entry(entries[e]);
+        const double2 tot = block_sum<NT>(make_double2(acc, 0.0), red);   // (its barriers also complete lambda)
+        if (tid == 0) energies[b] = tot.x + A.constant;
+        if (wave == 0) {   // backward: rows nrows8 - 1 ... 0 (the rows of one op are independent of each other)
+            for (int r = nrows8 - 1; r >= 0; r -= 8) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t lo = (uint32_t)wd[k], hi = (uint32_t)(wd[k] >> 32);
+                    const uint32_t oi = lo & 0xffffu, oj = lo >> 16, oe = hi & 0xffffu;
+                    double *pi = reinterpret_cast<double *>(smem + oi), *pj = reinterpret_cast<double *>(smem + oj);
+                    double *li = reinterpret_cast<double *>(smem + lam_off + oi), *lj = reinterpret_cast<double *>(smem + lam_off + oj);
+                    const double2 t = *reinterpret_cast<const double2 *>(reinterpret_cast<const unsigned char *>(cs) + oe);
+                    const bool neg = (hi & 0x80000000u) != 0u;
+                    const double sn = neg ? -t.y : t.y;
+                    const double u1 = *pi, v1 = *pj, lu = *li, lv = *lj;
+                    const double g = lu * v1 - lv * u1, gs = neg ? -g : g;
+                    const uint32_t oe0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)oe);
+                    if (__all(oe == oe0)) {
+                        const double rowsum = sec_wave_sum63(gs);
+                        if (lane == 63) w[oe0 >> 4] += rowsum;
+                    } else {
+                        __hip_atomic_fetch_add(&w[oe >> 4], gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    *pi = t.x * u1 - sn * v1;
+                    *pj = t.x * v1 + sn * u1;
+                    *li = t.x * lu - sn * lv;
+                    *lj = t.x * lv + sn * lu;
+                    asm volatile("" ::: "memory");
+                    const int nr = r - 8 - k;
+                    wd[k] = rp[(size_t)max(nr, 0) * 64];
+                }
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < A.ntab; e += NT) {
+            const SmallRot sr = tabrots[e];
+            if (sr.pidx >= 0) __hip_atomic_fetch_add(&gk[sr.pidx], 2.0 * sr.coeff * w[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        for (int k = tid; k < A.K; k += NT) grads[b * A.K + k] = gk[k];
+        __syncthreads();
     }
 }
 
