@@ -426,6 +426,7 @@ __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ 
 // blockIdx.y = state of a batch (own in / out slices and angle tables).
 constexpr uint32_t SEC_CHUNK = 4096;            // pair words per chunk (k_sector_sweep2: NT x WPT), option "sector_chunk"
 constexpr uint32_t SEC_NO_ROUND = 0xfffu;
+constexpr uint32_t SEC_WIDE_MAX_PAIRS = 16u << 20;   // pairs of a sweep up to which the 64-bit tables are built (128 MB of words)
 __device__ __forceinline__ uint64_t sec_word64(uint32_t si, uint32_t sj, uint32_t sign, uint32_t csidx, uint32_t round) {
     return (uint64_t)si | ((uint64_t)sj << 16) | ((uint64_t)sign << 32) | ((uint64_t)csidx << 33) | ((uint64_t)round << 45);
 }
