@@ -243,7 +243,7 @@ struct ovqe_sv {
     int opt_sector_sweep = 2;     // circuit sweep kernel: 2 = scatter-on-write, pair words in registers (k_sector_sweep2); 1 = first form
     int opt_sector_chunk = 2048;  // k_sector_sweep2: pair words per chunk = threads x words per thread (1024, 2048, 4096)
     int opt_sector_sweep_dbg = 0; // measurements only, k_sector_sweep2: 1 no ops, 2 empty kernel, 3 loads only — wrong results
-    int opt_sector_h_groups = 128; // workgroups per <H> sweep (they share the sweep's tiles round robin)
+    int opt_sector_h_groups = 256; // workgroups per <H> sweep (they share the sweep's tiles round robin)
     int opt_sector_h_threads = 512; // threads per workgroup of k_sector_expect (512 or 1024)
     int opt_sector_row_banks = 0; // materialised <H>: the elements of every row ordered against LDS bank conflicts (k_sec_row_banks)
     int opt_sector_batch = 1;     // ovqe_energy_batch on the sector tables: whole batches per pass (0: one evaluation at a time)

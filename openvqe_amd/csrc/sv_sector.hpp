@@ -58,6 +58,7 @@ struct SecGroup {     // x-group of the Hamiltonian, global masks
 //   coded element (x-groups with >= 3 mixing bits): word = slot_j | sign << 13 | dictionary index << 14, value 2 H_ij =
 //     +- dict[index] (index == ndict: null, 0);
 //   explicit element (diagonal, single-excitation-like groups): word = slot_j, value H_ii or 2 H_ij (null: 0).
+constexpr int SEC_H_INFLIGHT = 4;   // 16-byte loads of coded words in flight per lane in the <H> kernels (8: slower, 4.0 against 4.4 TB/s)
 constexpr int SEC_HSLOT_BITS = 13;
 constexpr uint32_t SEC_HSLOT_MASK = (1u << SEC_HSLOT_BITS) - 1u;
 constexpr uint32_t SEC_HMAX_TILE = SEC_HSLOT_MASK - 1u;   // entries per <H> tile
@@ -808,13 +809,25 @@ __global__ __launch_bounds__(256) void k_sec_row_banks(const uint32_t *__restric
 // ---- materialised <H>: evaluation --------------------------------------------------------------------------------------
 // The sum over the elements of the lane's row: sum_e value_e a[slot_j]  (APPLY: also lambda[slot_j] += H_ij a_i for the
 // off-diagonal elements, f64 LDS atomics on scattered slots)
+struct SecSliceMeta {   // what a wave needs to know about a slice before it can fetch its elements
+    uint32_t cbase, clen, xbase, xlen, row;
+};
+__device__ __forceinline__ SecSliceMeta sec_slice_meta(const SecHSweep &sw, size_t sl, uint32_t e0, uint32_t p, uint32_t n) {
+    SecSliceMeta m;
+    m.cbase = sw.cbase[sl];
+    m.clen = sw.clen[sl];
+    m.xbase = sw.xbase[sl];
+    m.xlen = sw.xlen[sl];
+    m.row = p < n ? sw.order[e0 + p] : SEC_HSLOT_MASK;
+    return m;
+}
 template <bool APPLY>
-__device__ __forceinline__ double sec_row_sum(const SecHSweep &sw, size_t sl, uint32_t lane, uint32_t row, double ai,
+__device__ __forceinline__ double sec_row_sum(const SecHSweep &sw, const SecSliceMeta &mt, uint32_t lane, uint32_t row, double ai,
                                               const double *tile, const double *dict, double *lam) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     {
-        const uint32_t L = sw.clen[sl];   // a multiple of 4
-        const uint32_t *wp = sw.cwords + sw.cbase[sl] + 4u * lane;
+        const uint32_t L = mt.clen;   // a multiple of 4
+        const uint32_t *wp = sw.cwords + mt.cbase + 4u * lane;
         if (sw.ndict) {
             auto term = [&](uint32_t w) {
                 const uint32_t sj = w & SEC_HSLOT_MASK;
@@ -826,12 +839,12 @@ __device__ __forceinline__ double sec_row_sum(const SecHSweep &sw, size_t sl, ui
             };
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             uint32_t q = 0;
-            for (; q + 15u < L; q += 16u) {
-                u32x4 w[4];
+            for (; q + 4u * SEC_H_INFLIGHT - 1u < L; q += 4u * SEC_H_INFLIGHT) {   // SEC_H_INFLIGHT 16-byte loads in flight per lane
+                u32x4 w[SEC_H_INFLIGHT];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wp + 64u * (q + 4u * (uint32_t)u)));
+                for (int u = 0; u < SEC_H_INFLIGHT; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wp + 64u * (q + 4u * (uint32_t)u)));
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < SEC_H_INFLIGHT; ++u) {
                     a0 += term(w[u].x);
                     a1 += term(w[u].y);
                     a2 += term(w[u].z);
@@ -846,7 +859,7 @@ __device__ __forceinline__ double sec_row_sum(const SecHSweep &sw, size_t sl, ui
                 a3 += term(w.w);
             }
         } else {
-            const double *vp = sw.cvals + sw.cbase[sl] + 4u * lane;
+            const double *vp = sw.cvals + mt.cbase + 4u * lane;
             for (uint32_t q = 0; q < L; ++q) {
                 const uint32_t at = 256u * (q >> 2) + (q & 3u);
                 const uint32_t sj = wp[at] & SEC_HSLOT_MASK;
@@ -858,9 +871,9 @@ __device__ __forceinline__ double sec_row_sum(const SecHSweep &sw, size_t sl, ui
     }
     double diag = 0.0;   // APPLY: H_ii a_i enters lambda_i once, the off-diagonal parts with H_ij = value / 2
     {
-        const uint32_t L = sw.xlen[sl];
-        const uint32_t *wp = sw.xwords + sw.xbase[sl] + lane;
-        const double *vp = sw.xvals + sw.xbase[sl] + lane;
+        const uint32_t L = mt.xlen;
+        const uint32_t *wp = sw.xwords + mt.xbase + lane;
+        const double *vp = sw.xvals + mt.xbase + lane;
         for (uint32_t q = 0; q < L; ++q) {
             const uint32_t sj = wp[64u * q] & SEC_HSLOT_MASK;
             const double v = vp[64u * q];
@@ -898,11 +911,20 @@ __global__ __launch_bounds__(NT) void k_sector_expect(const double *__restrict__
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < n; k += NT) tile[k] = state[sw.src[e0 + k]];
         __syncthreads();
+        // A slice is only a few iterations of the element loop long (24 qubits: 71 elements per row and sweep), so a wave walking
+        // one slice after the other spends a good part of its time in the dependent trip base / length -> first elements: the
+        // metadata of the NEXT slice of this wave is fetched while the current one is summed (0.62 -> 0.56 ms with 256 workgroups
+        // per sweep).  Measured on top and dropped: the next slice's first elements fetched ahead as well (0.61 ms), two slices
+        // summed in one loop (0.59 ms), eight instead of four 16-byte loads in flight (0.66 ms).
+        SecSliceMeta mt = sec_slice_meta(sw, (size_t)t * SEC_HSLICES + wave, e0, 64u * wave + lane, n);
         for (uint32_t s = wave; 64u * s < n; s += NW) {
             const uint32_t p = 64u * s + lane;
-            const uint32_t row = p < n ? sw.order[e0 + p] : SEC_HSLOT_MASK;
+            const SecSliceMeta cur = mt;
+            const uint32_t sn = s + NW;
+            if (64u * sn < n) mt = sec_slice_meta(sw, (size_t)t * SEC_HSLICES + sn, e0, 64u * sn + lane, n);
+            const uint32_t row = cur.row;
             const double ai = p < n ? tile[row] : 0.0;
-            acc += ai * sec_row_sum<false>(sw, (size_t)t * SEC_HSLICES + s, lane, row, ai, tile, dict, nullptr);
+            acc += ai * sec_row_sum<false>(sw, cur, lane, row, ai, tile, dict, nullptr);
         }
     }
     __syncthreads();
@@ -941,16 +963,19 @@ __global__ __launch_bounds__(NT) void k_sector_expect_batch(const double *__rest
             for (int s = 0; s < NB; ++s) tile[(size_t)k * NB + s] = states[(size_t)s * stride + src];
         }
         __syncthreads();
+        SecSliceMeta mt = sec_slice_meta(sw, (size_t)t * SEC_HSLICES + wave, e0, 64u * wave + lane, n);
         for (uint32_t sl0 = wave; 64u * sl0 < n; sl0 += NW) {
             const uint32_t p = 64u * sl0 + lane;
-            const uint32_t row = p < n ? sw.order[e0 + p] : 0u;
-            const size_t sl = (size_t)t * SEC_HSLICES + sl0;
+            const SecSliceMeta cur = mt;
+            const uint32_t sn = sl0 + NW;
+            if (64u * sn < n) mt = sec_slice_meta(sw, (size_t)t * SEC_HSLICES + sn, e0, 64u * sn + lane, n);
+            const uint32_t row = p < n ? cur.row : 0u;
             double r[NB];
 #pragma unroll
             for (int s = 0; s < NB; ++s) r[s] = 0.0;
             {
-                const uint32_t L = sw.clen[sl];   // a multiple of 4
-                const uint32_t *wp = sw.cwords + sw.cbase[sl] + 4u * lane;
+                const uint32_t L = cur.clen;   // a multiple of 4
+                const uint32_t *wp = sw.cwords + cur.cbase + 4u * lane;
                 if (sw.ndict) {
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                     auto term = [&](uint32_t w) {
@@ -961,12 +986,12 @@ __global__ __launch_bounds__(NT) void k_sector_expect_batch(const double *__rest
                         for (int s = 0; s < NB; ++s) r[s] += v * a[s];
                     };
                     uint32_t q = 0;
-                    for (; q + 7u < L; q += 8u) {
-                        u32x4 w[2];
+                    for (; q + 4u * SEC_H_INFLIGHT - 1u < L; q += 4u * SEC_H_INFLIGHT) {
+                        u32x4 w[SEC_H_INFLIGHT];
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wp + 64u * (q + 4u * (uint32_t)u)));
+                        for (int u = 0; u < SEC_H_INFLIGHT; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wp + 64u * (q + 4u * (uint32_t)u)));
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
+                        for (int u = 0; u < SEC_H_INFLIGHT; ++u) {
                             term(w[u].x);
                             term(w[u].y);
                             term(w[u].z);
@@ -981,7 +1006,7 @@ __global__ __launch_bounds__(NT) void k_sector_expect_batch(const double *__rest
                         term(w.w);
                     }
                 } else {
-                    const double *vp = sw.cvals + sw.cbase[sl] + 4u * lane;
+                    const double *vp = sw.cvals + cur.cbase + 4u * lane;
                     for (uint32_t q = 0; q < L; ++q) {
                         const uint32_t at = 256u * (q >> 2) + (q & 3u);
                         const double *a = tile + (size_t)(wp[at] & SEC_HSLOT_MASK) * NB;
@@ -992,9 +1017,9 @@ __global__ __launch_bounds__(NT) void k_sector_expect_batch(const double *__rest
                 }
             }
             {
-                const uint32_t L = sw.xlen[sl];
-                const uint32_t *wp = sw.xwords + sw.xbase[sl] + lane;
-                const double *vp = sw.xvals + sw.xbase[sl] + lane;
+                const uint32_t L = cur.xlen;
+                const uint32_t *wp = sw.xwords + cur.xbase + lane;
+                const double *vp = sw.xvals + cur.xbase + lane;
                 for (uint32_t q = 0; q < L; ++q) {   // (a diagonal element reads the row's own amplitude: value * a_i)
                     const double *a = tile + (size_t)(wp[64u * q] & SEC_HSLOT_MASK) * NB;
                     const double v = vp[64u * q];
@@ -1053,11 +1078,15 @@ __global__ __launch_bounds__(NT) void k_sector_apply(const double *__restrict__ 
             lam[k] = 0.0;
         }
         __syncthreads();
+        SecSliceMeta mt = sec_slice_meta(sw, (size_t)t * SEC_HSLICES + wave, e0, 64u * wave + lane, n);
         for (uint32_t s = wave; 64u * s < n; s += NW) {
             const uint32_t p = 64u * s + lane;
-            const uint32_t row = p < n ? sw.order[e0 + p] : SEC_HSLOT_MASK;
+            const SecSliceMeta cur = mt;
+            const uint32_t sn = s + NW;
+            if (64u * sn < n) mt = sec_slice_meta(sw, (size_t)t * SEC_HSLICES + sn, e0, 64u * sn + lane, n);
+            const uint32_t row = cur.row;
             const double ai = p < n ? tile[row] : 0.0;
-            const double ci = sec_row_sum<true>(sw, (size_t)t * SEC_HSLICES + s, lane, row, ai, tile, dict, lam);
+            const double ci = sec_row_sum<true>(sw, cur, lane, row, ai, tile, dict, lam);
             if (p < n) __hip_atomic_fetch_add(&lam[row], ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
