@@ -889,11 +889,33 @@ __device__ __forceinline__ double sec_row_sum(const SecHSweep &sw, const SecSlic
     return APPLY ? 0.5 * offd + diag : offd + diag;
 }
 
+// tile <- state[src[e0 + k]], k < n, in batches of eight gathers per thread: a plain `load index -> load amplitude -> LDS store`
+// loop is compiled to two dependent trips to memory per iteration (15 iterations per tile at 512 threads), and a workgroup
+// loads half a dozen tiles per launch
+template <int NT, int NB>
+__device__ __forceinline__ void sec_load_tile(double *__restrict__ tile, const double *__restrict__ state, size_t stride,
+                                              const uint32_t *__restrict__ src, uint32_t e0, uint32_t n) {
+    constexpr int TB = 8;
+    for (uint32_t k0 = threadIdx.x; k0 < n; k0 += TB * NT) {
+        uint32_t ix[TB];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) ix[j] = src[e0 + min(k0 + (uint32_t)j * NT, n - 1u)];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            double v[TB];
+#pragma unroll
+            for (int j = 0; j < TB; ++j) v[j] = state[(size_t)q * stride + ix[j]];
+#pragma unroll
+            for (int j = 0; j < TB; ++j)
+                if (k0 + (uint32_t)j * NT < n) tile[(size_t)(k0 + (uint32_t)j * NT) * NB + q] = v[j];
+        }
+    }
+}
 // E = sum over the sweeps and tiles of sum_rows a_i (sum_e value_e a_j): blockIdx.y = sweep; the workgroups of a sweep
 // share its tiles round robin; one wave per slice of a tile
 template <int NT>
 __global__ __launch_bounds__(NT) void k_sector_expect(const double *__restrict__ state, const SecHSweep *__restrict__ sweeps,
-                                                      double2 *__restrict__ partials, uint32_t tile_cap) {
+                                                      double2 *__restrict__ partials, uint32_t tile_cap, int dbg = 0) {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
     double *tile = reinterpret_cast<double *>(sec_smem);
@@ -909,8 +931,9 @@ __global__ __launch_bounds__(NT) void k_sector_expect(const double *__restrict__
         const uint32_t e0 = sw.off[t], n = sw.off[t + 1] - e0;
         if (n == 0) continue;
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < n; k += NT) tile[k] = state[sw.src[e0 + k]];
+        if (dbg != 2) sec_load_tile<NT, 1>(tile, state, 0, sw.src, e0, n);   // dbg: measurements only (1: tile loads only, 2: no tile loads, 3: metadata only)
         __syncthreads();
+        if (dbg == 1) continue;
         // A slice is only a few iterations of the element loop long (24 qubits: 71 elements per row and sweep), so a wave walking
         // one slice after the other spends a good part of its time in the dependent trip base / length -> first elements: the
         // metadata of the NEXT slice of this wave is fetched while the current one is summed (0.62 -> 0.56 ms with 256 workgroups
@@ -924,6 +947,10 @@ __global__ __launch_bounds__(NT) void k_sector_expect(const double *__restrict__
             if (64u * sn < n) mt = sec_slice_meta(sw, (size_t)t * SEC_HSLICES + sn, e0, 64u * sn + lane, n);
             const uint32_t row = cur.row;
             const double ai = p < n ? tile[row] : 0.0;
+            if (dbg == 3) {
+                acc += (double)(cur.clen + cur.xlen + cur.cbase + cur.xbase) * ai;
+                continue;
+            }
             acc += ai * sec_row_sum<false>(sw, cur, lane, row, ai, tile, dict, nullptr);
         }
     }
@@ -957,11 +984,7 @@ __global__ __launch_bounds__(NT) void k_sector_expect_batch(const double *__rest
         const uint32_t e0 = sw.off[t], n = sw.off[t + 1] - e0;
         if (n == 0) continue;
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < n; k += NT) {
-            const uint32_t src = sw.src[e0 + k];
-#pragma unroll
-            for (int s = 0; s < NB; ++s) tile[(size_t)k * NB + s] = states[(size_t)s * stride + src];
-        }
+        sec_load_tile<NT, NB>(tile, states, stride, sw.src, e0, n);
         __syncthreads();
         SecSliceMeta mt = sec_slice_meta(sw, (size_t)t * SEC_HSLICES + wave, e0, 64u * wave + lane, n);
         for (uint32_t sl0 = wave; 64u * sl0 < n; sl0 += NW) {
@@ -1073,10 +1096,8 @@ __global__ __launch_bounds__(NT) void k_sector_apply(const double *__restrict__ 
         const uint32_t e0 = sw.off[t], n = sw.off[t + 1] - e0;
         if (n == 0) continue;
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < n; k += NT) {
-            tile[k] = state[sw.src[e0 + k]];
-            lam[k] = 0.0;
-        }
+        sec_load_tile<NT, 1>(tile, state, 0, sw.src, e0, n);
+        for (uint32_t k = threadIdx.x; k < n; k += NT) lam[k] = 0.0;
         __syncthreads();
         SecSliceMeta mt = sec_slice_meta(sw, (size_t)t * SEC_HSLICES + wave, e0, 64u * wave + lane, n);
         for (uint32_t s = wave; 64u * s < n; s += NW) {

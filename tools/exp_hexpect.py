@@ -16,6 +16,13 @@ with Statevector(2 * m) as sv:
     e0 = sv.energy(theta); sv.energy(theta)
     sv.set_option("sector_profile", 1)
     hb = sv.program_info()["sector_h_stream_bytes"]
+    for dbg in (1, 2, 3):
+        sv.set_option("sector_h_dbg", dbg)
+        us = []
+        for _ in range(5):
+            sv.energy(theta); us.append(sv.program_info()["sector_expect_us"])
+        print(f"dbg {dbg} (1 tile loads only, 2 no tile loads, 3 tile loads + slice metadata only): {min(us[1:])} us", flush=True)
+    sv.set_option("sector_h_dbg", 0)
     for threads in (512, 1024):
         for groups in (64, 128, 256, 512):
             sv.set_option("sector_h_threads", threads); sv.set_option("sector_h_groups", groups)
