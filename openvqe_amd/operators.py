@@ -43,6 +43,14 @@ class Term:
     def copy(self):
         return Term(self.coeff, self.op, list(self.qbits))
 
+    @property
+    def _coeff(self):
+        """myQLM keeps a term's coefficient as a serialisable record, and one reference helper reads it directly
+        (``term._coeff.complex_p.re`` / ``.im``, ref:openvqe/common_files/qubit_pool.py:729-732): the same shape here"""
+        import types
+        c = complex(self.coeff)
+        return types.SimpleNamespace(complex_p=types.SimpleNamespace(re=c.real, im=c.imag))
+
     def _canonical(self):
         """(sorted qubits, ops) with identities dropped; key for merging."""
         pairs = sorted((q, c) for q, c in zip(self.qbits, self.op) if c != "I")

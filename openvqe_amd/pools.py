@@ -253,13 +253,18 @@ def generate_pool_from_cluster(pool_condition, cluster_ops, nbqbits):
 
 
 # ---------------------------------------------------------------------------------------------- qubit pools
-def qubit_pool(kind, nbqbits, rng=None):
+def qubit_pool(kind, nbqbits, rng=None, source_pool=None, molecule_symbol=None):
     """Single-Pauli-string pools of qubit-ADAPT (ref:openvqe/common_files/qubit_pool.py:278-465, 1184-1268):
     'YXXX' | 'XYXX' | 'XXYX' | 'XXXY' — "YX" on every pair (a, b) with a + b even, then the 4-letter string on every
     quadruple with an even number of odd indices, each as Hamiltonian(n, [Term(-1.0, string, qubits)]);
     'random' — position by position one of the four pools (the reference draws with an unseeded
     np.random.randint; pass ``rng`` for a reproducible draw).  50 operators at 8 qubits
-    (ref:tests/test_main_qubit_adapt.py:14)."""
+    (ref:tests/test_main_qubit_adapt.py:14).
+    The other kinds of the reference's dispatcher (ref:openvqe/common_files/qubit_pool.py:1249-1266): 'two' / 'four' — the
+    XXYX family times projectors (1 -+ Z..Z) on its qubits (sums of two / four strings, ref:...:470-697); 'minimal' — the 2n - 2
+    operators V of the qubit-ADAPT article (ref:...:906-958); 'pure_with_symmetry' — the eleven H4 strings of ref:...:961-1040
+    (``molecule_symbol="H4"``); 'eight' / 'without_Z_from_generator' — ``source_pool`` with every Z dropped from its strings
+    (ref:...:790-903; 'eight' also drops repeated operators)."""
     import itertools
 
     from .operators import Hamiltonian, Term
@@ -276,6 +281,16 @@ def qubit_pool(kind, nbqbits, rng=None):
 
     if kind in ("YXXX", "XYXX", "XXYX", "XXXY"):
         pool = family(kind)
+    elif kind in ("two", "four"):
+        pool = _projected_family(nbqbits, kind)
+    elif kind == "minimal":
+        pool = _minimal_family(nbqbits)
+    elif kind == "pure_with_symmetry":
+        pool = _pure_with_symmetry(nbqbits, molecule_symbol)
+    elif kind in ("eight", "without_Z_from_generator"):
+        if source_pool is None:
+            raise ValueError(f"qubit pool {kind!r} is derived from another pool: pass source_pool")
+        pool = _z_stripped(nbqbits, source_pool, unique=(kind == "eight"))
     elif kind == "random":
         import numpy as np
         rng = rng or np.random.default_rng()
@@ -284,3 +299,97 @@ def qubit_pool(kind, nbqbits, rng=None):
     else:
         raise KeyError(kind)
     return len(pool), pool
+
+
+def _projected_family(nbqbits, kind):
+    """'two' / 'four' pools, written as data: the base string -YX (pairs a + b even) or -XXYX (quadruples with an even number of
+    odd indices) times factors (c_I + c_Z Z..Z(qubits)).  'two': one factor on all qubits of the string; 'four': (-1 - ZZZZ) and
+    one ZZ factor on the two qubits the spin pattern picks — the same-spin quadruples contribute three operators (ZZ on (c,d),
+    (b,d), (a,d)).  Factors are multiplied out in the order (term x Z-part) first, then (term x constant), so the strings
+    come out in the order the reference's Hamiltonian products give them."""
+    import itertools
+
+    from .operators import Hamiltonian, Term
+
+    def expand(word, qubits, factors):
+        terms = [Term(-1.0, word, list(qubits))]
+        for c_i, c_z, zq in factors:
+            zterm = Term(c_z, "Z" * len(zq), list(zq))
+            terms = [t * zterm for t in terms] + [Term(t.coeff * c_i, t.op, list(t.qbits)) for t in terms]
+        return Hamiltonian(nbqbits, terms)
+
+    out = []
+    for a, b in itertools.combinations(range(nbqbits), 2):
+        if (a + b) % 2 == 0:
+            out.append(expand("YX", (a, b), [(1.0, -1.0, (a, b))] if kind == "two" else [(-1.0, 1.0, (a, b))]))
+    for q in itertools.combinations(range(nbqbits), 4):
+        a, b, c, d = q
+        if sum(k % 2 for k in q) % 2:
+            continue
+        if kind == "two":
+            out.append(expand("XXYX", q, [(1.0, 1.0, q)]))
+            continue
+        first = (-1.0, -1.0, q)
+        if a % 2 == b % 2 == c % 2 == d % 2:
+            picks = [(c, d), (b, d), (a, d)]
+        elif a % 2 == b % 2:
+            picks = [(c, d)]
+        elif a % 2 == c % 2:
+            picks = [(b, d)]
+        else:
+            picks = [(a, d)]
+        for pair in picks:
+            out.append(expand("XXYX", q, [first, (-1.0, 1.0, pair)]))
+    return out
+
+
+def _minimal_family(nbqbits):
+    """V_i = -Y_{k-i} Z_{k-i+1} .. Z_k (i = 0 .. n - 1, k = n - 1) and, for 0 < i < n - 1, the same string without its first Z"""
+    from .operators import Hamiltonian, Term
+    k = nbqbits - 1
+    out = []
+    for i in range(nbqbits):
+        for skip in ((0,) if i in (0, nbqbits - 1) else (0, 1)):
+            zs = list(range(k - i + 1 + skip, k + 1))
+            out.append(Hamiltonian(nbqbits, [Term(-1, "Y" + "Z" * len(zs), [k - i] + zs)]))
+    return out
+
+
+#: the symmetry-adapted H4 pool of Shkolnikov et al. (arXiv:2109.05340) as the reference lists it (sign, string over qubits 0..7)
+_PURE_H4 = ((-1.0, "YIXIYIYI"), (-1.0, "ZYXIYIZY"), (-1.0, "YIZYXIZY"), (-1.0, "ZZYXYYII"), (1.0, "XXIZIIXY"), (-1.0, "YIZYZXYI"),
+            (-1.0, "XIYZYZYI"), (1.0, "XZIIYZII"), (1.0, "ZXXZZXYI"), (1.0, "XXIIIIXY"), (-1.0, "IYYZXIZY"))
+
+
+def _pure_with_symmetry(nbqbits, molecule_symbol):
+    from .operators import Hamiltonian, Term
+    if molecule_symbol != "H4":
+        return []            # the reference supports H4 only and returns an empty pool otherwise
+    if nbqbits != 8:
+        raise ValueError("the H4 pool lives on 8 qubits")
+    return [Hamiltonian(8, [Term(float(c), word, list(range(8)))]) for c, word in _PURE_H4]
+
+
+def _z_stripped(nbqbits, source_pool, unique):
+    """every operator of ``source_pool`` with the Z letters dropped from its strings and the sign of every coefficient
+    flipped (imaginary coefficients contribute their imaginary part: the pools the reference feeds in are i x Hermitian);
+    ``unique``: an operator equal to an earlier one, or to its negative, is left out (compared as {string: coefficient})"""
+    from .operators import Hamiltonian, Term
+    out, seen = [], []
+    for op in source_pool:
+        if not op.terms:
+            continue
+        terms = []
+        for t in op.terms:
+            c = complex(t.coeff)
+            value = c.imag if c.real == 0 else c.real
+            kept = [(q, letter) for q, letter in zip(t.qbits, t.op) if letter != "Z"]
+            terms.append(Term(-1 * value, "".join(letter for _, letter in kept), [q for q, _ in kept]))
+        new = Hamiltonian(nbqbits, terms)
+        if unique:
+            key = {(t.op, tuple(t.qbits)): complex(t.coeff) for t in new.terms}
+            neg = {k: -v for k, v in key.items()}
+            if any(k == key or k == neg for k in seen):
+                continue
+            seen.append(key)
+        out.append(new)
+    return out

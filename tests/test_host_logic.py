@@ -333,3 +333,34 @@ def test_qpu_cache_keys_follow_operator_contents():
     assert f2 != f1
     ham.constant_coeff = 0.25
     assert HipQPU._fingerprint(ham) != f2
+
+
+def test_remaining_qubit_pool_kinds_have_the_expected_shape():
+    """'two' / 'four' / 'minimal' / 'pure_with_symmetry' / 'eight' / 'without_Z_from_generator' of pools.qubit_pool (the dispatcher
+    kinds of ref:openvqe/common_files/qubit_pool.py:1249-1266; operator-by-operator equality with the reference's module is
+    checked in tests/test_reference_quccsd.py where the reference tree is present): sizes, Hermiticity of i x operator, and the
+    defining property of the projected families — every string of an operator is the base string times Z's on its own qubits"""
+    import numpy as np
+    from openvqe_amd import pools
+    n = 8
+    n2, two = pools.qubit_pool("two", n)
+    n4, four = pools.qubit_pool("four", n)
+    assert n2 == 50 == len(two) and all(len(op.terms) == 2 for op in two)
+    assert n4 == 54 and all(len(op.terms) in (2, 4) for op in four)
+    for op in two + four:
+        support = set(op.terms[-1].qbits)
+        assert all(set(t.qbits) == support for t in op.terms)
+        assert all(abs(complex(t.coeff).imag) < 1e-15 and abs(abs(complex(t.coeff).real) - 1.0) < 1e-15 for t in op.terms)
+        assert all(sum(c in "Y" for c in t.op) % 2 == 1 for t in op.terms)       # odd number of Y: i x operator is real antisymmetric
+    nm, minimal = pools.qubit_pool("minimal", n)
+    assert nm == 2 * n - 2 and all(len(op.terms) == 1 and op.terms[0].op[0] == "Y" for op in minimal)
+    assert pools.qubit_pool("pure_with_symmetry", 8, molecule_symbol="H4")[0] == 11
+    _, _, source = pools.singlet_sd(2, 4, "JW")
+    ne, eight = pools.qubit_pool("eight", n, source_pool=source)
+    nw, plain = pools.qubit_pool("without_Z_from_generator", n, source_pool=source)
+    assert ne <= nw == sum(1 for op in source if op.terms)
+    assert all("Z" not in t.op for op in plain for t in op.terms)
+    with pytest.raises(ValueError):
+        pools.qubit_pool("eight", n)
+    with pytest.raises(KeyError):
+        pools.qubit_pool("no such pool", n)

@@ -278,6 +278,27 @@ def test_pools_equal_the_reference_generators_on_the_stand_ins():
             n2, p2 = pools.generate_pool_from_cluster(cond, f2, 8)
             assert n1 == n2, cond
             same(p1, p2)
+        # the remaining kinds of the qubit-pool dispatcher (ref:openvqe/common_files/qubit_pool.py:1249-1266)
+        for n in (4, 6, 8):
+            for kind in ("two", "four", "minimal"):
+                n1, p1 = qp.QubitPool().generate_pool_without_cluster(kind, nbqbits=n)
+                n2, p2 = pools.qubit_pool(kind, n)
+                assert n1 == n2, (kind, n)
+                same(p1, p2)
+        n1, p1 = qp.QubitPool().generate_pool_without_cluster("pure_with_symmetry", nbqbits=8, molecule_symbol="H4")
+        n2, p2 = pools.qubit_pool("pure_with_symmetry", 8, molecule_symbol="H4")
+        assert n1 == n2 == 11
+        same(p1, p2)
+        assert pools.qubit_pool("pure_with_symmetry", 8, molecule_symbol="LiH") == (0, [])
+        _, _, source = gen.singlet_sd(2, 4, "JW")
+        n1, p1 = qp.QubitPool().generate_pool_without_cluster("without_Z_from_generator", nbqbits=8, qubit_pool=source)
+        n2, p2 = pools.qubit_pool("without_Z_from_generator", 8, source_pool=source)
+        assert n1 == n2
+        same(p1, p2)
+        n1, p1 = qp.QubitPool().generate_pool_without_cluster("eight", nbqbits=8, qubit_pool=source)
+        n2, p2 = pools.qubit_pool("eight", 8, source_pool=source)
+        assert n1 == n2
+        same(p1, p2)
 
 
 # ------------------------------------------------------------------------------------------------ K6b: derived qubit pool
