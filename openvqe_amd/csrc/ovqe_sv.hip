@@ -89,6 +89,7 @@ struct SectorSeg {      // one sweep of the circuit
     DevBuf d_srcpad;              // gather indices of the sweep, tile-padded (k_sec_pad_src): first form of the sweep kernel
     DevBuf d_dstpad;              // scatter indices into the next sweep's tile-padded order (k_sector_sweep2)
     DevBuf d_wide, d_rounds;      // 64-bit pair words, rounds per (tile, chunk) (k_sec_widen)
+    DevBuf d_bdst;                // scatter indices into the PREVIOUS sweep's tile-padded order (k_sector_adjoint2)
     uint32_t maxchunks = 0;
 };
 struct SectorHSweep {   // one sweep of the materialised <H>
@@ -245,6 +246,7 @@ struct ovqe_sv {
     int opt_sector_sweep_dbg = 0; // measurements only, k_sector_sweep2: 1 no ops, 2 empty kernel, 3 loads only — wrong results
     int opt_sector_h_groups = 256; // workgroups per <H> sweep (they share the sweep's tiles round robin)
     int opt_sector_h_dbg = 0;     // measurements only, k_sector_expect: 1 tile loads only, 2 no tile loads, 3 metadata only — wrong results
+    int opt_sector_adjoint = 2;   // backward sweeps of the gradient: 2 = on the 64-bit tables (k_sector_adjoint2) where they exist and fit; 1 = first form
     int opt_sector_h_threads = 512; // threads per workgroup of k_sector_expect (512 or 1024)
     int opt_sector_row_banks = 0; // materialised <H>: the elements of every row ordered against LDS bank conflicts (k_sec_row_banks)
     int opt_sector_batch = 1;     // ovqe_energy_batch on the sector tables: whole batches per pass (0: one evaluation at a time)
@@ -2957,6 +2959,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     } else if (k == "sector_threads") h->opt_sector_threads = (value == 0 || value == 64 || value == 512 || value == 1024) ? (int)value : 256;
     else if (k == "sector_h_groups") h->opt_sector_h_groups = (int)value;
     else if (k == "sector_h_dbg") h->opt_sector_h_dbg = (int)value;
+    else if (k == "sector_adjoint") h->opt_sector_adjoint = value == 1 ? 1 : 2;
     else if (k == "sector_h_threads") h->opt_sector_h_threads = value == 1024 ? 1024 : 512;
     else if (k == "sector_batch") h->opt_sector_batch = (int)value;
     else if (k == "sector_row_banks") h->opt_sector_row_banks = (int)value;

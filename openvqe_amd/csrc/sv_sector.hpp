@@ -1270,6 +1270,151 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint(const double *__restrict_
         }
     }
 }
+// Second form of the backward sweep, on the tables of k_sector_sweep2 (64-bit words in registers, rounds numbered at build
+// time, walked from the last chunk / round to the first): a word is applied exactly once, so its gradient term
+// sigma (lambda_i psi_j - lambda_j psi_i) stays in a register until its chunk is done and the chunk's terms are then summed
+// by table entry inside every wave (DPP sums over the lanes that share an entry, usually all 64) into the wave's own row
+// of partial sums — the first form pays a select chain over eight patterns per pair and a wave sum per op and pattern in
+// every wave.  psi / lambda come in this sweep's tile-padded order (in_compact: contiguous, the last sweep — what the forward
+// pass and lambda = H psi leave) and go out into the PREVIOUS sweep's tile-padded order (bdst; null: first sweep, no output).
+template <int NT, int WPT>
+__global__ __launch_bounds__(NT) void k_sector_adjoint2(const double *__restrict__ psi_in, const double *__restrict__ lam_in,
+                                                        double *__restrict__ psi_out, double *__restrict__ lam_out, int in_compact,
+                                                        const uint32_t *__restrict__ bdst, const uint32_t *__restrict__ off,
+                                                        const uint32_t *__restrict__ poff, int nops, const uint64_t *__restrict__ wide,
+                                                        const uint16_t *__restrict__ rounds, uint32_t maxchunks,
+                                                        const RotParam *__restrict__ rp, int rot0, int nrot, uint32_t tile_cap,
+                                                        double *__restrict__ wpart, int wstride) {
+    constexpr uint32_t CH = (uint32_t)NT * WPT;
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
+    const uint32_t capp = (tile_cap + 2u) & ~1u;
+    double *tp = reinterpret_cast<double *>(sec_smem);
+    double *tl = tp + capp;
+    double2 *cs = reinterpret_cast<double2 *>(tl + capp);
+    double *wacc = reinterpret_cast<double *>(cs + nrot);   // [NW][nrot]
+    uint32_t *dst = reinterpret_cast<uint32_t *>(wacc + (size_t)NW * nrot);
+    uint32_t *nround = dst + tile_cap;   // [maxchunks]
+    const uint32_t t = blockIdx.x;
+    const uint32_t e0 = off[t];
+    const uint32_t n = off[t + 1] - e0;
+    if (n == 0) return;
+    const uint32_t pbase = poff[(size_t)t * (nops + 1)], ptot = poff[(size_t)t * (nops + 1) + nops] - pbase;
+    const uint32_t nchunks = (ptot + CH - 1u) / CH;
+    const size_t tbase = (size_t)t * tile_cap, ibase = in_compact ? (size_t)e0 : tbase;
+    const uint64_t *wp = wide + pbase;
+    const uint32_t lane = threadIdx.x & 63u;
+    double *mine = wacc + (size_t)(threadIdx.x >> 6) * nrot;
+    uint64_t wa[WPT], wb[WPT];
+    // ---- one trip to memory: the last chunk's words, both tiles, the scatter indices, cos/sin, rounds per chunk
+    const uint32_t lastc = nchunks ? nchunks - 1u : 0u;
+#pragma unroll
+    for (int r = 0; r < WPT; ++r) wa[r] = wp[min(lastc * CH + threadIdx.x + (uint32_t)r * NT, ptot ? ptot - 1u : 0u)];
+    constexpr int TB = 4;
+    for (uint32_t k0 = threadIdx.x; k0 < n; k0 += TB * NT) {
+        uint32_t d[TB];
+        double u[TB], v[TB];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const uint32_t k = min(k0 + (uint32_t)j * NT, n - 1u);
+            d[j] = bdst ? bdst[tbase + k] : 0u;
+            u[j] = psi_in[ibase + k];
+            v[j] = lam_in[ibase + k];
+        }
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const uint32_t k = k0 + (uint32_t)j * NT;
+            if (k < n) {
+                tp[k] = u[j];
+                tl[k] = v[j];
+                dst[k] = d[j];
+            }
+        }
+    }
+    for (int r0 = threadIdx.x; r0 < nrot; r0 += NT) {
+        const RotParam ra = rp[rot0 + r0];
+        cs[r0] = make_double2(ra.c, ra.s);
+    }
+    for (int r0 = threadIdx.x; r0 < NW * nrot; r0 += NT) wacc[r0] = 0.0;
+    if (threadIdx.x < maxchunks) nround[threadIdx.x] = rounds[(size_t)t * maxchunks + threadIdx.x];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (uint32_t c = nchunks; c-- > 0u;) {
+        // the chunk before this one: in flight while this chunk is applied
+        const uint32_t pbeg = c ? (c - 1u) * CH : 0u;
+#pragma unroll
+        for (int r = 0; r < WPT; ++r) wb[r] = wp[min(pbeg + threadIdx.x + (uint32_t)r * NT, ptot - 1u)];
+        uint32_t qs[WPT], qr[WPT], qe[WPT];
+        double qc[WPT], qn[WPT], g[WPT];
+#pragma unroll
+        for (int r = 0; r < WPT; ++r) {
+            qe[r] = (uint32_t)(wa[r] >> 33) & 0xfffu;
+            const double2 cr = cs[qe[r]];
+            const bool live = c * CH + threadIdx.x + (uint32_t)r * NT < ptot;
+            const bool orphan = ((uint32_t)(wa[r] >> 16) & 0xffffu) == 0xffffu;   // partner outside the support: amplitude zero, no term
+            qs[r] = (uint32_t)wa[r];
+            qr[r] = (live && !orphan) ? ((uint32_t)(wa[r] >> 45) & 0xfffu) : SEC_NO_ROUND;
+            qc[r] = cr.x;
+            qn[r] = ((uint32_t)(wa[r] >> 32) & 1u) ? -cr.y : cr.y;
+            g[r] = 0.0;
+        }
+        const uint32_t R = nround[c];
+        for (uint32_t q = R; q-- > 0u;) {
+#pragma unroll
+            for (int r = 0; r < WPT; ++r) {
+                if (qr[r] == q) {
+                    const uint32_t si = qs[r] & 0xffffu, sj = qs[r] >> 16;
+                    const double u1 = tp[si], v1 = tp[sj], lu = tl[si], lv = tl[sj];
+                    const double gg = lu * v1 - lv * u1;
+                    g[r] = ((uint32_t)(wa[r] >> 32) & 1u) ? -gg : gg;
+                    tp[si] = qc[r] * u1 - qn[r] * v1;
+                    tp[sj] = qc[r] * v1 + qn[r] * u1;
+                    tl[si] = qc[r] * lu - qn[r] * lv;
+                    tl[sj] = qc[r] * lv + qn[r] * lu;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        // the chunk's gradient terms, summed by table entry inside the wave (its lanes hold consecutive words: mostly one entry)
+#pragma unroll
+        for (int r = 0; r < WPT; ++r) {
+            uint64_t todo = __ballot(qr[r] != SEC_NO_ROUND);
+            while (todo) {
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)qe[r], __ffsll((long long)todo) - 1);
+                const bool m = qr[r] != SEC_NO_ROUND && qe[r] == e;
+                const double tsum = sec_wave_sum63(m ? g[r] : 0.0);
+                if (lane == 63u) mine[e] += tsum;
+                todo &= ~__ballot(m);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < WPT; ++r) wa[r] = wb[r];
+    }
+    __syncthreads();
+    double *wout = wpart + (size_t)t * wstride + rot0;   // [tile][table entry], zeroed by the host
+    for (int r = threadIdx.x; r < nrot; r += NT) {
+        double tsum = 0.0;
+        for (int w = 0; w < NW; ++w) tsum += wacc[(size_t)w * nrot + r];
+        wout[r] = tsum;
+    }
+    if (bdst) {
+        for (uint32_t k = threadIdx.x; k < n; k += NT) {
+            const uint32_t d = dst[k];
+            psi_out[d] = tp[k];
+            lam_out[d] = tl[k];
+        }
+    }
+}
+// bdst of k_sector_adjoint2: padpos[p] = where position p of a sweep's order sits in its tile-padded form ...
+__global__ __launch_bounds__(256) void k_sec_padpos(const uint32_t *__restrict__ off, uint32_t cap, uint32_t *__restrict__ padpos) {
+    const uint32_t t = blockIdx.x, e0 = off[t], n = off[t + 1] - e0;
+    for (uint32_t k = threadIdx.x; k < n; k += 256u) padpos[e0 + k] = t * cap + k;
+}
+// ... and, tile-padded for this sweep, where its entries sit in the PREVIOUS sweep's tile-padded form
+__global__ __launch_bounds__(256) void k_sec_bdst(const uint32_t *__restrict__ src, const uint32_t *__restrict__ off, uint32_t cap,
+                                                  const uint32_t *__restrict__ padpos_prev, uint32_t *__restrict__ bdst) {
+    const uint32_t t = blockIdx.x, e0 = off[t], n = off[t + 1] - e0;
+    for (uint32_t k = threadIdx.x; k < cap; k += 256u) bdst[(size_t)t * cap + k] = k < n ? padpos_prev[src[e0 + k]] : 0xffffffffu;
+}
 // w[r] = sum over the tiles of wpart[tile][r] (fixed order), r over the whole angle table: 64 entries per workgroup, the
 // tiles dealt to its four waves, the four partial sums added in wave order
 __global__ __launch_bounds__(256) void k_sec_reduce_w(const double *__restrict__ wpart, uint32_t ntiles, int nrot,
