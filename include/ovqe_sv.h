@@ -75,6 +75,7 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * "sparse_renumber" (1, default: the compact support is numbered so that the pairs of an op fall into distinct LDS banks),
  * "sector_sweep" (2, default: circuit sweeps of the sector path scatter into the next sweep's order and keep 64-bit pair
  * words in registers; 1: first form), "sector_chunk" (pair words per chunk of those sweeps: 1024, 2048 default, 4096),
+ * "sector_adjoint" (2, default: the backward sweeps of ovqe_energy_gradient on the sector tables use those 64-bit tables too; 1: first form),
  * "sector_batch" (1, default: ovqe_energy_batch runs whole batches per pass of the sector tables),
  * "small_max_qubits", "small_batch_max_qubits", "unroll", "real_mode" (1: allow the real-amplitude
  * specialisation of the fused kernel when every rotation string has an odd number of Y),

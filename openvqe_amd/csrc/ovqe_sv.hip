@@ -247,8 +247,11 @@ struct ovqe_sv {
     int opt_sector_h_groups = 256; // workgroups per <H> sweep (they share the sweep's tiles round robin)
     int opt_sector_h_dbg = 0;     // measurements only, k_sector_expect: 1 tile loads only, 2 no tile loads, 3 metadata only — wrong results
     int opt_sector_adjoint = 2;   // backward sweeps of the gradient: 2 = on the 64-bit tables (k_sector_adjoint2) where they exist and fit; 1 = first form
+    int opt_sector_apply_threads = 0; // threads per workgroup of k_sector_apply (0 = automatic, 512, 1024)
     int opt_sector_h_threads = 512; // threads per workgroup of k_sector_expect (512 or 1024)
     int opt_sector_row_banks = 0; // materialised <H>: the elements of every row ordered against LDS bank conflicts (k_sec_row_banks)
+    int opt_sector_batch_nb = 2;      // states per tile of the batched <H> (2 or 3)
+    int opt_sector_batch_threads = 1024;   // its workgroup size (512, 1024)
     int opt_sector_batch = 1;     // ovqe_energy_batch on the sector tables: whole batches per pass (0: one evaluation at a time)
     float last_batch_ms = 0.f;
     const double *cur_theta = nullptr;  // device pointers of the batch being evaluated
@@ -2960,8 +2963,11 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "sector_h_groups") h->opt_sector_h_groups = (int)value;
     else if (k == "sector_h_dbg") h->opt_sector_h_dbg = (int)value;
     else if (k == "sector_adjoint") h->opt_sector_adjoint = value == 1 ? 1 : 2;
+    else if (k == "sector_apply_threads") h->opt_sector_apply_threads = value == 1024 ? 1024 : (value == 512 ? 512 : 0);
     else if (k == "sector_h_threads") h->opt_sector_h_threads = value == 1024 ? 1024 : 512;
     else if (k == "sector_batch") h->opt_sector_batch = (int)value;
+    else if (k == "sector_batch_nb") h->opt_sector_batch_nb = value == 3 ? 3 : 2;
+    else if (k == "sector_batch_threads") h->opt_sector_batch_threads = value == 512 ? 512 : 1024;
     else if (k == "sector_row_banks") h->opt_sector_row_banks = (int)value;
     else if (k == "sector_debug") h->opt_sector_debug = (int)value;
     else if (k == "sector_sweep") h->opt_sector_sweep = value == 1 ? 1 : 2;

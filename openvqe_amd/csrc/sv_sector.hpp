@@ -821,42 +821,70 @@ __device__ __forceinline__ SecSliceMeta sec_slice_meta(const SecHSweep &sw, size
     m.row = p < n ? sw.order[e0 + p] : SEC_HSLOT_MASK;
     return m;
 }
+// APPLY: the atomics of a block of elements are issued AFTER all of its reads, and unconditionally — padding elements (value
+// zero) add to a per-lane dummy slot behind the dictionary.  (A masked atomic between the reads of consecutive elements made
+// every element wait out an LDS round trip: 1.43 ms per pass at 24 qubits against 0.58 ms for the sum alone;
+// tools/micro/lds_atomic.hip: the atomics themselves cost 9-20 cycles per wave instruction.)
 template <bool APPLY>
 __device__ __forceinline__ double sec_row_sum(const SecHSweep &sw, const SecSliceMeta &mt, uint32_t lane, uint32_t row, double ai,
                                               const double *tile, const double *dict, double *lam) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    double *dummy = const_cast<double *>(dict) + sw.ndict + 2 + lane;   // APPLY only: 64 doubles behind the dictionary (sector_h_smem)
+    const double hai = 0.5 * ai;
     {
         const uint32_t L = mt.clen;   // a multiple of 4
         const uint32_t *wp = sw.cwords + mt.cbase + 4u * lane;
         if (sw.ndict) {
-            auto term = [&](uint32_t w) {
-                const uint32_t sj = w & SEC_HSLOT_MASK;
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            auto value = [&](uint32_t w) {
                 double v = dict[w >> 14];
                 if (w & (1u << SEC_HSLOT_BITS)) v = -v;
-                if (APPLY && (w >> 14) != (uint32_t)sw.ndict)
-                    __hip_atomic_fetch_add(&lam[sj], 0.5 * v * ai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                return v * tile[sj];
+                return v;
             };
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            auto scatter = [&](uint32_t w, double v) {
+                double *to = (w >> 14) != (uint32_t)sw.ndict ? lam + (w & SEC_HSLOT_MASK) : dummy;
+                __hip_atomic_fetch_add(to, v * hai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
             uint32_t q = 0;
             for (; q + 4u * SEC_H_INFLIGHT - 1u < L; q += 4u * SEC_H_INFLIGHT) {   // SEC_H_INFLIGHT 16-byte loads in flight per lane
                 u32x4 w[SEC_H_INFLIGHT];
 #pragma unroll
                 for (int u = 0; u < SEC_H_INFLIGHT; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wp + 64u * (q + 4u * (uint32_t)u)));
+                double v[SEC_H_INFLIGHT][4];
 #pragma unroll
                 for (int u = 0; u < SEC_H_INFLIGHT; ++u) {
-                    a0 += term(w[u].x);
-                    a1 += term(w[u].y);
-                    a2 += term(w[u].z);
-                    a3 += term(w[u].w);
+                    v[u][0] = value(w[u].x);
+                    v[u][1] = value(w[u].y);
+                    v[u][2] = value(w[u].z);
+                    v[u][3] = value(w[u].w);
+                    a0 += v[u][0] * tile[w[u].x & SEC_HSLOT_MASK];
+                    a1 += v[u][1] * tile[w[u].y & SEC_HSLOT_MASK];
+                    a2 += v[u][2] * tile[w[u].z & SEC_HSLOT_MASK];
+                    a3 += v[u][3] * tile[w[u].w & SEC_HSLOT_MASK];
+                }
+                if (APPLY) {
+#pragma unroll
+                    for (int u = 0; u < SEC_H_INFLIGHT; ++u) {
+                        scatter(w[u].x, v[u][0]);
+                        scatter(w[u].y, v[u][1]);
+                        scatter(w[u].z, v[u][2]);
+                        scatter(w[u].w, v[u][3]);
+                    }
                 }
             }
             for (; q < L; q += 4u) {
                 const u32x4 w = *reinterpret_cast<const u32x4 *>(wp + 64u * q);
-                a0 += term(w.x);
-                a1 += term(w.y);
-                a2 += term(w.z);
-                a3 += term(w.w);
+                const double v0 = value(w.x), v1 = value(w.y), v2 = value(w.z), v3 = value(w.w);
+                a0 += v0 * tile[w.x & SEC_HSLOT_MASK];
+                a1 += v1 * tile[w.y & SEC_HSLOT_MASK];
+                a2 += v2 * tile[w.z & SEC_HSLOT_MASK];
+                a3 += v3 * tile[w.w & SEC_HSLOT_MASK];
+                if (APPLY) {
+                    scatter(w.x, v0);
+                    scatter(w.y, v1);
+                    scatter(w.z, v2);
+                    scatter(w.w, v3);
+                }
             }
         } else {
             const double *vp = sw.cvals + mt.cbase + 4u * lane;
@@ -864,8 +892,8 @@ __device__ __forceinline__ double sec_row_sum(const SecHSweep &sw, const SecSlic
                 const uint32_t at = 256u * (q >> 2) + (q & 3u);
                 const uint32_t sj = wp[at] & SEC_HSLOT_MASK;
                 const double v = vp[at];
-                if (APPLY && v != 0.0) __hip_atomic_fetch_add(&lam[sj], 0.5 * v * ai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 a0 += v * tile[sj];
+                if (APPLY) __hip_atomic_fetch_add(v != 0.0 ? lam + sj : dummy, v * hai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }
@@ -877,12 +905,10 @@ __device__ __forceinline__ double sec_row_sum(const SecHSweep &sw, const SecSlic
         for (uint32_t q = 0; q < L; ++q) {
             const uint32_t sj = wp[64u * q] & SEC_HSLOT_MASK;
             const double v = vp[64u * q];
-            if (sj == row) {
-                diag += v * ai;
-            } else {
-                if (APPLY && v != 0.0) __hip_atomic_fetch_add(&lam[sj], 0.5 * v * ai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                a1 += v * tile[sj];
-            }
+            const bool on_diag = sj == row;
+            diag += on_diag ? v * ai : 0.0;
+            a1 += on_diag ? 0.0 : v * tile[sj];
+            if (APPLY) __hip_atomic_fetch_add((on_diag || v == 0.0) ? dummy : lam + sj, on_diag ? 0.0 : v * hai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     const double offd = (a0 + a1) + (a2 + a3);

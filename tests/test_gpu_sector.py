@@ -219,11 +219,14 @@ def test_sector_adjoint_gradient(SV, m, o, bits, coded):
         e3, g3 = sv.energy_gradient(th2)
         e3b = sv.energy(th2)
         info = sv.program_info()
+        sv.set_option("sector_adjoint", 1)        # the first form of the backward sweeps (the default takes the 64-bit tables)
+        e5, g5 = sv.energy_gradient(th2)
         sv.set_option("sector", 0)
         e4, g4 = sv.energy_gradient(th2)
     assert info["sector_support"] == comb(m, o) ** 2 and info["sector_h_elements"] > 0, info
     assert abs(e2 - e1) < 1e-12 * l1 and abs(e3 - e4) < 1e-12 * l1 and abs(e3 - e3b) < 1e-12 * l1
     assert np.abs(g2 - g1).max() < 1e-11 * l1 and np.abs(g3 - g4).max() < 1e-11 * l1
+    assert abs(e5 - e3) < 1e-13 * l1 and np.abs(g5 - g3).max() < 1e-12 * l1   # (lambda = H psi adds with atomics: to rounding)
     picks = rng.choice(K, 4, replace=False)
     h = 1e-5
     for k in picks:
