@@ -328,7 +328,9 @@ class HipQPU:
     A circuit made of Pauli evolutions of the SAME operator objects as the previous one (what an optimiser loop submits)
     differs from it only in its angles: it is compiled once with symbolic angles and later submissions only pass the new
     angle vector — so the compiled-program paths of the backend (table fusion, sector tables at 18+ qubits) serve the
-    unchanged reference code too.  Circuits with literal rotation gates are compiled per submission."""
+    unchanged reference code too.  Circuits of literal gates (the QUCCSD templates) are cached by their structure — gate
+    names, qubits, quarter-turn angles — with every other rotation gate as a parameter of its own, so the second submission
+    of a template only passes its angles (and the Clifford-frame / sector paths keep their tables)."""
 
     def __init__(self, device=0):
         self.device = device
@@ -376,9 +378,46 @@ class HipQPU:
             items.append((kind, PauliEvolution(ops, what.init, sym, what.arity), qubits))
         return tuple(key), angles, items
 
+    @staticmethod
+    def _gate_skeleton(circuit):
+        """-> (key, angles, symbolic circuit items) for a circuit of literal gates with concrete angles, else None.  The
+        reference's gate templates (ref:openvqe/common_files/circuit.py) are rebuilt per evaluation with the optimiser's
+        angles inside: the STRUCTURE (gate names, qubits, which rotation gates carry a quarter turn — the basis changes of
+        the templates, kept concrete so that they stay Clifford gates) repeats, every other rotation gate becomes a
+        parameter of its own."""
+        key, angles, items = [], [], []
+        for kind, what, qubits in circuit.items:
+            if kind != "gate" or isinstance(what.angle, AffineParam):
+                return None
+            if what.angle is None:
+                key.append((what.name, tuple(qubits)))
+                items.append((kind, what, qubits))
+                continue
+            a = float(what.angle)
+            quarter = a / (0.5 * math.pi)
+            if quarter == round(quarter):       # (bitwise k pi/2, as the templates write them)
+                key.append((what.name, tuple(qubits), a))
+                items.append((kind, what, qubits))
+            else:
+                key.append((what.name, tuple(qubits), None))
+                items.append((kind, Gate(what.name, what.arity, AffineParam(len(angles))), qubits))
+                angles.append(a)
+        return tuple(key), angles, items
+
     def _load(self, sv, circuit):
         """-> angle vector to evaluate the handle's program with"""
         n = circuit.nbqbits
+        gk = self._gate_skeleton(circuit)
+        if gk is not None and gk[1]:
+            key, angles, items = gk
+            cached = self._compiled.get(n)
+            if cached is not None and cached[0] == key and cached[2] == len(angles):
+                return np.asarray(angles, dtype=float)
+            hf, kind, payload = lower_circuit(Circuit(n, items))
+            if kind == "gates":
+                sv.set_gate_program(payload, len(angles), hf)
+                self._compiled[n] = (key, None, len(angles))
+                return np.asarray(angles, dtype=float)
         sk = self._skeleton(circuit)
         if sk is not None:
             key, angles, items = sk

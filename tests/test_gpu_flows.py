@@ -345,3 +345,46 @@ def test_stand_in_qpu_compiles_a_repeated_circuit_once(gpu_lib, monkeypatch):
         want_short = sv.energy(thetas[0][:5])
     _reset()
     assert np.abs(np.array(got) - np.array(want)).max() < 1e-10 and abs(got_short - want_short) < 1e-10
+
+
+def test_stand_in_qpu_caches_literal_gate_templates(gpu_lib, monkeypatch):
+    """route A with the reference's QUCCSD templates (ref:openvqe/ucc_family/get_energy_qucc.py:11-56 builds the RY/RZ/H/CNOT list
+    with the optimiser's angles inside and submits it per evaluation): compiled once per structure with every free rotation gate
+    as a parameter of its own; the energies are those of the traced gate program (tied parameters) of the mirrors"""
+    from openvqe_amd.backend import Statevector
+    from openvqe_amd.common_files.circuit import quccsd_gate_list
+    from openvqe_amd import qat_compat as qc
+    _reset()
+    m, o = 6, 2
+    n = 2 * m
+    ham, _, hf = fermion.synthetic_molecule(m, o, seed=77)
+    gates, K, hf2 = quccsd_gate_list(m, o, 1)
+    assert hf2 == hf
+    factory = {"X": lambda a: qc.X, "H": lambda a: qc.H, "CNOT": lambda a: qc.CNOT, "RX": qc.RX, "RY": qc.RY, "RZ": qc.RZ}
+    calls = []
+    orig = Statevector.set_gate_program
+    monkeypatch.setattr(Statevector, "set_gate_program", lambda self, g, k, h: (calls.append(k), orig(self, g, k, h))[1])
+
+    def reference_style_energy(theta):
+        prog = qc.Program()
+        q = prog.qalloc(n)
+        for j in range(n):
+            if (hf >> (n - 1 - j)) & 1:
+                prog.apply(qc.X, q[j])
+        for name, qubits, scale, const, p in gates:
+            angle = None if name in ("X", "H", "CNOT") else (scale * theta[p] + const if p >= 0 else const)
+            prog.apply(factory[name](angle), *[q[k] for k in qubits])
+        return qc.get_default_qpu().submit(prog.to_circ().to_job(job_type="OBS", observable=ham)).value
+
+    rng = np.random.default_rng(3)
+    thetas = [rng.uniform(-0.3, 0.3, K) for _ in range(4)]
+    got = [reference_style_energy(t) for t in thetas]
+    assert len(calls) == 1 and calls[0] >= K, calls          # (a template spends several rotation gates per parameter)
+    calls.clear()
+    with Statevector(n) as sv:
+        sv.set_hamiltonian(ham)
+        sv.set_gate_program(gates, K, hf)
+        want = [sv.energy(t) for t in thetas]
+    _reset()
+    l1 = float(np.abs(ham.packed()[2]).sum())
+    assert np.abs(np.array(got) - np.array(want)).max() < 1e-11 * max(1.0, l1)

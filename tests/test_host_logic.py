@@ -163,6 +163,46 @@ def test_qpu_submit_obs_and_sample(oracle_engine, h2):
     assert np.abs(psi - ref).max() < 1e-12
 
 
+def test_qpu_caches_literal_gate_circuits_by_structure(oracle_engine, h2, monkeypatch):
+    """Route A: a circuit of literal gates (what ref:openvqe/common_files/circuit.py's templates submit per evaluation) is compiled
+    once per STRUCTURE — gate names, qubits, quarter-turn angles — and later submissions pass their angles only"""
+    import math
+    from tests.oracle_backend import OracleStatevector
+    from openvqe_amd.qat_compat import CNOT, RX, RY, RZ, H as Hgate, Program, X, get_default_qpu
+    ham, _, _ = h2
+    compiled = []
+    real = OracleStatevector.set_gate_program
+    monkeypatch.setattr(OracleStatevector, "set_gate_program", lambda self, gates, k, hf: (compiled.append(k), real(self, gates, k, hf))[1])
+
+    def template(a, b, c):
+        prog = Program()
+        q = prog.qalloc(4)
+        prog.apply(X, q[0]); prog.apply(X, q[1])
+        prog.apply(Hgate, q[2]); prog.apply(RX(math.pi / 2), q[0]); prog.apply(CNOT, q[0], q[2])
+        prog.apply(RZ(a), q[2]); prog.apply(CNOT, q[0], q[2]); prog.apply(RX(-math.pi / 2), q[0]); prog.apply(Hgate, q[2])
+        prog.apply(RY(b), q[1]); prog.apply(CNOT, q[1], q[3]); prog.apply(RY(c), q[3]); prog.apply(CNOT, q[1], q[3])
+        gates = [("X", [0], None), ("X", [1], None), ("H", [2], None), ("RX", [0], math.pi / 2), ("CNOT", [0, 2], None), ("RZ", [2], a),
+                 ("CNOT", [0, 2], None), ("RX", [0], -math.pi / 2), ("H", [2], None), ("RY", [1], b), ("CNOT", [1, 3], None),
+                 ("RY", [3], c), ("CNOT", [1, 3], None)]
+        return prog.to_circ(), gates
+
+    qpu = get_default_qpu()
+    for k, angles in enumerate([(0.3, -0.2, 0.7), (0.31, 0.5, -0.1), (-1.2, 0.05, 0.9)]):
+        circ, gates = template(*angles)
+        psi = dense.gate_circuit_state(4, 0, gates)
+        want = float(np.real(np.vdot(psi, ham.get_matrix() @ psi)))
+        assert abs(qpu.submit(circ.to_job(job_type="OBS", observable=ham)).value - want) < 1e-12
+        got = np.zeros(16, complex)
+        for smp in qpu.submit(circ.to_job()):
+            got[smp.state.int] = smp.amplitude
+        assert np.abs(got - psi).max() < 1e-12
+    assert compiled == [3]                      # one compilation with three parameters for six submissions
+    circ, gates = template(0.3, 0.0, 0.7)       # an angle that IS a quarter turn changes the structure: compiled again, still right
+    psi = dense.gate_circuit_state(4, 0, gates)
+    assert abs(qpu.submit(circ.to_job(job_type="OBS", observable=ham)).value - float(np.real(np.vdot(psi, ham.get_matrix() @ psi)))) < 1e-12
+    assert compiled == [3, 2]
+
+
 # ------------------------------------------------------------------------------------ L1 mirrors
 def _pool_generator(n=4):
     return [Hamiltonian(n, [Term(1.0, s, [0, 1, 2, 3])], do_clean_up=False) for s in ("XXXY", "YXXX", "XYXX")]
