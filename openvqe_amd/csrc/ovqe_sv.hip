@@ -370,10 +370,12 @@ int build_groups(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z,
             g.jbase = (h->base ^ x[t]) & ~lmask;
             g.t0 = (int32_t)terms.size();
             g.t1 = g.t0;
+            g.tiny = 0.0;
             groups.push_back(g);
         }
         terms.push_back(ht);
         groups.back().t1 = (int32_t)terms.size();
+        groups.back().tiny += 64.0 * 2.220446049250313e-16 * (std::fabs(ht.cr) + std::fabs(ht.ci));
         if (xs_out) xs_out->push_back(x[t] & lmask);
     }
     if (perm_out) *perm_out = order;

@@ -33,7 +33,17 @@ struct HGroup {
     uint64_t x;      // local part of the x mask
     uint64_t jbase;  // high (global) bits of the partner's global index
     int32_t t0, t1;  // term range
+    double tiny;     // 64 eps sum_t |c_t|: a D_g(j) at or below it is a rounding residue of a sum that cancels (see group_coeff_snap)
 };
+// D_g(j) = sum_t +-c_t of an operator application.  The strings of a number-conserving operator cancel EXACTLY on the basis states
+// they must not connect, but their coefficients come out of the caller's algebra equal to an ulp, not bit for bit: the residue
+// (1e-17 c) would plant amplitudes outside the particle-number sector, which stay harmless in value (1e-17, 1e-34, ...) and
+// ruinous in cost — the support of an ADAPT state is what the screens and the exponentials walk (24 qubits, 30 operators:
+// 3.8 M "non-zero" amplitudes, 0.6 M of them above 1e-14).  A sum at or below 64 eps sum |c_t| is that residue: zero.
+__device__ __forceinline__ void group_coeff_snap(double &dr, double &di, double tiny) {
+    dr = fabs(dr) <= tiny ? 0.0 : dr;
+    di = fabs(di) <= tiny ? 0.0 : di;
+}
 
 __device__ __forceinline__ uint64_t insert_zero(uint64_t k, int p) {
     const uint64_t low = (1ull << p) - 1ull;
@@ -419,6 +429,7 @@ __global__ __launch_bounds__(256) void k_apply_sum(amp_t *__restrict__ out, cons
                 dr = fma(ht.cr, sg, dr);
                 di = fma(ht.ci, sg, di);
             }
+            group_coeff_snap(dr, di, gr.tiny);
             sx += dr * k.x - di * k.y;
             sy += dr * k.y + di * k.x;
         }
@@ -459,6 +470,7 @@ __global__ __launch_bounds__(256) void k_apply_sum_list(amp_t *__restrict__ out,
             dr = fma(ht.cr, sg, dr);
             di = fma(ht.ci, sg, di);
         }
+        group_coeff_snap(dr, di, gr.tiny);
         sx += dr * k.x - di * k.y;
         sy += dr * k.y + di * k.x;
     }
@@ -498,6 +510,7 @@ __global__ __launch_bounds__(256) void k_support_expand(uint64_t *__restrict__ i
             dr = fma(ht.cr, sg, dr);
             di = fma(ht.ci, sg, di);
         }
+        group_coeff_snap(dr, di, gr.tiny);
         if (dr == 0.0 && di == 0.0) continue;
         const uint64_t i = jl ^ gr.x;
         const uint32_t bit = 1u << (i & 31);
@@ -527,6 +540,7 @@ __global__ __launch_bounds__(256) void k_apply_terms(amp_t *__restrict__ out, co
                 dr = fma(ht.cr, sg, dr);
                 di = fma(ht.ci, sg, di);
             }
+            group_coeff_snap(dr, di, gr.tiny);
             sx += dr * k.x - di * k.y;
             sy += dr * k.y + di * k.x;
         }

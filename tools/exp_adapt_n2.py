@@ -11,6 +11,8 @@ prob = chem.cas_problem(mol, 2, 12)
 ham = prob.jw_hamiltonian()
 size, cluster_ops, spin_ops, theta_mp2, hf = prob.uccsd()
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+if "--sector-ground-space" in sys.argv:   # the fun_fidelity reference vector from ovqe_sector_ground_state (opt-in of the mirror)
+    fav.SECTOR_GROUND_SPACE = True
 t = time.perf_counter(); pool_size, _, pool = pools.singlet_sd(10, 12); print(f'pool {pool_size} operators, built in {time.perf_counter()-t:.1f}s', flush=True)
 t0 = time.perf_counter()
 buf = io.StringIO()
@@ -40,6 +42,7 @@ scr = [d for k, d in marks if k == "screen"]; en = [d for k, d in marks if k == 
 slow = sorted(en, reverse=True)
 print(f"energy evaluations: {sum(1 for d in en if d > 5e-3)} above 5 ms totalling {sum(d for d in en if d > 5e-3):.2f}s; largest {[round(1e3*d,1) for d in slow[:6]]} ms; "
       f"quartiles {[round(1e3*float(q),3) for q in np.percentile(en, [25, 50, 75, 95])]} ms")
+print("screen ms by macro-iteration:", [round(1e3 * d, 1) for d in scr])
 print(f"wall={wall:.1f}s screens={len(scr)} ({np.mean(scr)*1e3:.0f} ms each) energy evaluations={len(en)} (median {np.median(en)*1e3:.2f} ms, total {sum(en):.2f}s)")
 for name in ("_ground_space", "fun_fidelity", "prepare_adapt_state", "prepare_state_ansatz", "hf_energy"):
     d = [x for k, x in marks if k == name]
