@@ -267,7 +267,10 @@ int ovqe_last_batch_ms(ovqe_handle h, double *ms);
 
 /* amplitudes the last ovqe_pool_gradients call (which = 0) or ovqe_apply_exp_pauli_sum call (which = 1) walked instead of the
  * register ("screen_sparse"): the support of psi, resp. its closure under the operator's x-groups; -1 when the call walked the
- * register (dense state, sharded register, option off) */
+ * register (dense state, sharded register, option off).  which = 2: determinants of the symmetry sector whose materialised
+ * Hamiltonian produced sigma = H psi of the last ovqe_pool_gradients call (option "screen_sector", default 1: real Hamiltonian,
+ * real psi listing at least "screen_sector_min" = 1024 amplitudes; the tables are built once per Hamiltonian on the closure of
+ * psi's support under its x-groups), 0 when sigma came from the register / the tile cover */
 int ovqe_last_support(ovqe_handle h, int32_t which, int64_t *support);
 /* shape of the compiled program (diagnostics / tests), up to `count` entries of:
  *   [0] ops of the sequential program  [1] Pauli rotations  [2] literal X/H/CNOT ops  [3] streaming sweeps per

@@ -281,6 +281,13 @@ class Statevector:
         self._ck(self._L.ovqe_last_support(self._h, 0, ctypes.byref(out)))
         return out.value
 
+    def last_screen_sector(self):
+        """determinants of the symmetry sector whose materialised Hamiltonian gave sigma = H psi of the last ``pool_gradients``
+        call (0: sigma from the register / the tile cover)"""
+        out = ctypes.c_int64()
+        self._ck(self._L.ovqe_last_support(self._h, 2, ctypes.byref(out)))
+        return out.value
+
     def last_exp_support(self):
         """amplitudes the Taylor steps of the last ``apply_exp_pauli_sum`` call ran over (-1: the register)"""
         out = ctypes.c_int64()

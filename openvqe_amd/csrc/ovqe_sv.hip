@@ -200,6 +200,7 @@ struct ovqe_sv {
     DevBuf d_tile_smasks, d_tile_lists, d_tile_counts;   // non-empty tiles per sweep of H psi on a listed state (k_tile_lists)  // support list of the screened state (k_pool_grad_nz)
     int opt_screen_sparse = 16;   // the ADAPT screen walks the support of psi when it is at most 1/this of the register (0 = never)
     int64_t last_exp_support = -1;     // amplitudes the last ovqe_apply_exp_pauli_sum call's Taylor steps ran over (-1: the register)
+    int64_t last_screen_sector = 0;    // determinants of the symmetry sector whose materialised Hamiltonian gave the last screen's sigma (0: register / tile cover)
     int64_t last_screen_support = -1;  // support size seen by the last ovqe_pool_gradients call (-1: register walked)
     std::vector<int64_t> pg_off;
     std::vector<uint64_t> pg_xs;
@@ -227,6 +228,8 @@ struct ovqe_sv {
     int opt_compact_cpp = 1;      // host chunks (512 terms each) staged in LDS per pass of the compact-cover kernel
     int prog_version = 0;
     SectorEngine sec;             // of (current program, stored Hamiltonian)
+    SectorEngine scr;             // ADAPT screens: <H> tables on a symmetry sector, no circuit (build_screen_sector)
+    int scr_failed_version = -1;  // Hamiltonian version for which the screen engine was declined
     bool probe_independent = false;  // resolve_angles: one quasi-random angle per ROTATION (support probe, second attempt)
     int opt_sector = 1;           // allow the sector path (real-amplitude streaming energies on a sparse support)
     int opt_sector_bits = 0;      // index bits per tile (0 = automatic: n - 8, at most 16)
@@ -252,6 +255,8 @@ struct ovqe_sv {
     int opt_sector_row_banks = 0; // materialised <H>: the elements of every row ordered against LDS bank conflicts (k_sec_row_banks)
     int opt_sector_batch_nb = 2;      // states per tile of the batched <H> (2 or 3)
     int opt_sector_batch_threads = 1024;   // its workgroup size (512, 1024)
+    int opt_screen_sector = 1;        // ADAPT screens: sigma = H psi from the materialised Hamiltonian of psi's symmetry sector (real states)
+    int opt_screen_sector_min = 1024; // ... once psi lists at least this many amplitudes
     int opt_sector_batch = 1;     // ovqe_energy_batch on the sector tables: whole batches per pass (0: one evaluation at a time)
     float last_batch_ms = 0.f;
     const double *cur_theta = nullptr;  // device pointers of the batch being evaluated
@@ -2912,6 +2917,7 @@ int ovqe_destroy(ovqe_handle h) {
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     free_sector(h->sec);
+    free_sector(h->scr);
     if (h->h_rp) (void)hipHostFree(h->h_rp);
     if (h->h_result) (void)hipHostFree(h->h_result);
     if (h->h_io) (void)hipHostFree(h->h_io);
@@ -2968,6 +2974,8 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "sector_apply_threads") h->opt_sector_apply_threads = value == 1024 ? 1024 : (value == 512 ? 512 : 0);
     else if (k == "sector_h_threads") h->opt_sector_h_threads = value == 1024 ? 1024 : 512;
     else if (k == "sector_batch") h->opt_sector_batch = (int)value;
+    else if (k == "screen_sector") h->opt_screen_sector = (int)value;
+    else if (k == "screen_sector_min") h->opt_screen_sector_min = (int)value;
     else if (k == "sector_batch_nb") h->opt_sector_batch_nb = value == 3 ? 3 : 2;
     else if (k == "sector_batch_threads") h->opt_sector_batch_threads = value == 512 ? 512 : 1024;
     else if (k == "sector_row_banks") h->opt_sector_row_banks = (int)value;
@@ -3672,6 +3680,147 @@ static int list_support(ovqe_handle h, uint64_t *support, bool *listed, uint64_t
     return OVQE_OK;
 }
 
+// ---- sigma = H psi of the ADAPT screens from the materialised Hamiltonian of psi's symmetry sector ----------------------------
+// (ref:openvqe/adapt/fermionic_adapt_vqe.py:114 `sig = hamiltonian_sparse.dot(curr_state)`.)  An ADAPT state of a dozen operators
+// lists 10^5 amplitudes, spread over every tile of the register: the tile cover then costs its 61 sweeps of the whole register
+// (24 qubits: 24 ms) for a vector of 600 k numbers.  The sector — the closure of psi's support under the Hamiltonian's x-groups —
+// does not change while the ansatz grows, so the restricted Hamiltonian is materialised ONCE per Hamiltonian (the row-format tables
+// of the sector path, sector_host.inc build_sector_h, without a circuit) and sigma is one pass over it (k_sector_apply).  Real
+// Hamiltonians and real states only; anything else takes the register path.
+static int build_screen_sector(ovqe_handle h, uint64_t support) {
+    SectorEngine &E = h->scr;
+    free_sector(E);
+    E.ham_version = h->ham.version;
+    h->scr_failed_version = h->ham.version;   // until everything below succeeded
+    if (h->n_global != 0 || h->n_local > 32 || h->n_local < 12) return OVQE_OK;
+    for (const HTerm &t : h->ham.terms)
+        if (t.ci != 0.0) return OVQE_OK;       // an odd number of Y with a real coefficient (or a complex one): sigma is not real
+    for (const HGroup &g : h->ham.groups)
+        if (g.x > 0xffffffffull) return OVQE_OK;
+    // closure of the listed support under the x-groups (D_g(j) != 0, residues snapped): the symmetry sector psi lives in
+    const uint64_t cap = h->namps / (uint64_t)std::max(h->opt_sector_sparsity, 2);
+    if (support > cap) return OVQE_OK;
+    DevBuf list, bitmap, total_b;
+    auto done = [&](int code) {
+        free_buf(list);
+        free_buf(bitmap);
+        free_buf(total_b);
+        return code;
+    };
+    const size_t words = (size_t)std::max<uint64_t>(1, h->namps >> 5);
+    int rc = ensure(h, list, cap * sizeof(uint64_t));
+    if (!rc) rc = ensure(h, bitmap, words * sizeof(uint32_t) + 16);
+    if (!rc) rc = ensure(h, total_b, 256);
+    if (rc) return done(rc == OVQE_ERR_ALLOC ? ((void)hipGetLastError(), OVQE_OK) : rc);
+    HIPC(h, hipMemcpyAsync(list.p, h->d_nz_idx.p, support * sizeof(uint64_t), hipMemcpyDeviceToDevice, h->stream));
+    HIPC(h, hipMemsetAsync(bitmap.p, 0, words * sizeof(uint32_t), h->stream));
+    hipLaunchKernelGGL(k_support_mark, dim3((unsigned)((support + 255) / 256)), dim3(256), 0, h->stream, (const uint64_t *)list.p, support,
+                       (uint32_t *)bitmap.p);
+    unsigned long long total = support;
+    HIPC(h, hipMemcpyAsync(total_b.p, &total, sizeof(total), hipMemcpyHostToDevice, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    uint64_t first = 0, last = support;
+    for (int round = 0; round < 256 && last > first; ++round) {
+        hipLaunchKernelGGL(k_support_expand, dim3((unsigned)((last - first + 255) / 256)), dim3(256), 0, h->stream, (uint64_t *)list.p, first,
+                           last, cap, h->base, (const HGroup *)h->ham.d_groups.p, (int)h->ham.groups.size(),
+                           (const HTerm *)h->ham.d_terms.p, (uint32_t *)bitmap.p, (unsigned long long *)total_b.p);
+        HIPC(h, hipMemcpyAsync(&total, total_b.p, sizeof(total), hipMemcpyDeviceToHost, h->stream));
+        HIPC(h, hipStreamSynchronize(h->stream));
+        if (total > cap) return done(OVQE_OK);   // not a sparse sector
+        first = last;
+        last = total;
+    }
+    if (last > first || last > 0x7ffffff0ull) return done(OVQE_OK);
+    const uint32_t K = (uint32_t)last;
+    // ascending order (the sector path's canonical order), 32-bit indices
+    DevBuf sorted;
+    size_t tb = 0;
+    hipError_t e = hipcub::DeviceRadixSort::SortKeys(nullptr, tb, (const uint64_t *)list.p, (uint64_t *)nullptr, (int)K, 0, h->n_local, h->stream);
+    if (e != hipSuccess) return done(fail(h, OVQE_ERR_HIP, std::string("screen sector: sort (size query): ") + hipGetErrorString(e)));
+    DevBuf temp;
+    rc = ensure(h, sorted, (size_t)K * sizeof(uint64_t));
+    if (!rc) rc = ensure(h, temp, tb);
+    if (!rc) rc = ensure(h, E.d_sup, (size_t)K * sizeof(uint32_t));
+    if (rc) {
+        free_buf(sorted);
+        free_buf(temp);
+        return done(rc == OVQE_ERR_ALLOC ? ((void)hipGetLastError(), OVQE_OK) : rc);
+    }
+    tb = temp.cap;
+    e = hipcub::DeviceRadixSort::SortKeys(temp.p, tb, (const uint64_t *)list.p, (uint64_t *)sorted.p, (int)K, 0, h->n_local, h->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_scr_narrow, dim3((K + 255u) / 256u), dim3(256), 0, h->stream, (const uint64_t *)sorted.p, K, (uint32_t *)E.d_sup.p);
+        e = hipStreamSynchronize(h->stream);
+    }
+    free_buf(sorted);
+    free_buf(temp);
+    if (e != hipSuccess) return done(fail(h, OVQE_ERR_HIP, std::string("screen sector: sort: ") + hipGetErrorString(e)));
+    done(OVQE_OK);
+    E.K = K;
+    E.M = sector_tile_bits(h);
+    E.chunk = (uint32_t)h->opt_sector_chunk;
+    SectorScratch W;
+    rc = ensure(h, W.inv_circ, (size_t)K * sizeof(uint32_t));
+    if (rc) return rc == OVQE_ERR_ALLOC ? ((void)hipGetLastError(), OVQE_OK) : rc;
+    hipLaunchKernelGGL(k_scr_iota, dim3((K + 255u) / 256u), dim3(256), 0, h->stream, (uint32_t *)W.inv_circ.p, K);
+    size_t free_b = 0, total_mem = 0;
+    HIPC(h, hipMemGetInfo(&free_b, &total_mem));
+    const size_t budget = std::min<size_t>((size_t)std::max(h->opt_sector_max_gb, 0) << 30, free_b / 5 * 3);
+    E.budget = budget;
+    rc = build_sector_h(h, E, W, budget);
+    if (rc == OVQE_ERR_ALLOC) {
+        (void)hipGetLastError();
+        free_sector(E);
+        E.ham_version = h->ham.version;
+        return OVQE_OK;
+    }
+    if (rc) return rc;
+    if (!E.h_tables || E.hs.empty()) {
+        free_sector(E);
+        E.ham_version = h->ham.version;
+        return OVQE_OK;
+    }
+    rc = ensure(h, E.d_buf[0], (size_t)K * sizeof(double));
+    if (!rc) rc = ensure(h, E.d_buf[1], (size_t)K * sizeof(double));
+    if (!rc) rc = ensure(h, E.d_flag, 256);
+    if (rc) return rc;
+    E.valid = true;
+    h->scr_failed_version = -1;
+    return OVQE_OK;
+}
+// sig (register) = (H + constant) psi through the screen engine; *used = false: the caller computes it on the register
+static int screen_sector_sigma(ovqe_handle h, amp_t *sig, uint64_t support, bool *used) {
+    *used = false;
+    if (!h->opt_screen_sector || !h->opt_sector || h->n_global != 0 || support < (uint64_t)std::max(h->opt_screen_sector_min, 1)) return OVQE_OK;
+    SectorEngine &E = h->scr;
+    if (E.valid && E.ham_version != h->ham.version) free_sector(E);
+    if (!E.valid) {
+        if (h->scr_failed_version == h->ham.version) return OVQE_OK;
+        int rc = build_screen_sector(h, support);
+        if (rc) return rc;
+        if (!E.valid) return OVQE_OK;
+    }
+    const uint32_t K = E.K;
+    double *psic = (double *)E.d_buf[0].p, *sigc = (double *)E.d_buf[1].p;
+    HIPC(h, hipMemsetAsync(psic, 0, (size_t)K * sizeof(double), h->stream));
+    HIPC(h, hipMemsetAsync(E.d_flag.p, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_scr_compact, dim3((unsigned)((support + 255) / 256)), dim3(256), 0, h->stream, (const uint64_t *)h->d_nz_idx.p,
+                       (const double2 *)h->d_nz_val.p, support, (const uint32_t *)E.d_sup.p, K, psic, (int *)E.d_flag.p);
+    int flag = 0;
+    HIPC(h, hipMemcpyAsync(&flag, E.d_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    if (flag) return OVQE_OK;   // psi has left the sector the tables were built for, or is complex: register path (tables kept)
+    int rc = sector_matvec(h, E, psic, sigc);
+    if (rc) return rc;
+    HIPC(h, hipMemsetAsync(sig, 0, h->namps * sizeof(amp_t), h->stream));
+    hipLaunchKernelGGL(k_scr_scatter, dim3((K + 255u) / 256u), dim3(256), 0, h->stream, (double2 *)sig, (const uint32_t *)E.d_sup.p, K,
+                       (const double *)sigc, (const double *)psic, h->ham.constant);
+    HIPC(h, hipGetLastError());
+    h->last_screen_sector = (int64_t)K;
+    *used = true;
+    return OVQE_OK;
+}
+
 // ---- ADAPT --------------------------------------------------------------------------------------
 int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, const uint64_t *x, const uint64_t *z,
                         const double *coeff_re, const double *coeff_im, int mode, double *grads) {
@@ -3697,7 +3846,13 @@ int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, co
     if (rc) return rc;
     if (on_support) h->last_screen_support = (int64_t)support;
     // sigma = H psi (constant included)
-    rc = apply_hamiltonian(h, sig, h->state, h->ham.constant, on_support ? (const uint64_t *)h->d_nz_idx.p : nullptr, support);
+    bool sector_sigma = false;
+    h->last_screen_sector = 0;
+    if (on_support) {
+        rc = screen_sector_sigma(h, sig, support, &sector_sigma);
+        if (rc) return rc;
+    }
+    if (!sector_sigma) rc = apply_hamiltonian(h, sig, h->state, h->ham.constant, on_support ? (const uint64_t *)h->d_nz_idx.p : nullptr, support);
     if (rc) return rc;
     std::vector<double2> vals(n_ops);
     {
@@ -4294,8 +4449,8 @@ int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
 
 int ovqe_last_support(ovqe_handle h, int32_t which, int64_t *support) {
     OVQE_ENTER(h);
-    if (!h || !support || which < 0 || which > 1) return OVQE_ERR_INVALID;
-    *support = which == 0 ? h->last_screen_support : h->last_exp_support;
+    if (!h || !support || which < 0 || which > 2) return OVQE_ERR_INVALID;
+    *support = which == 0 ? h->last_screen_support : (which == 1 ? h->last_exp_support : h->last_screen_sector);
     return OVQE_OK;
 }
 

@@ -658,7 +658,6 @@ __global__ __launch_bounds__(256) void k_pool_grad_nz(const amp_t *__restrict__ 
         while (te < t1 && xs[te] == x) ++te;
         for (uint64_t e = e0 + threadIdx.x; e < e1; e += 256) {
             const uint64_t jl = idx[e];
-            const amp_t k = val[e], b = sig[jl ^ x];
             double cr = 0.0, ci = 0.0;
             for (int64_t u = t; u < te; ++u) {
                 const HTerm ht = terms[u];
@@ -666,6 +665,11 @@ __global__ __launch_bounds__(256) void k_pool_grad_nz(const amp_t *__restrict__ 
                 cr = fma(ht.cr, sg, cr);
                 ci = fma(ht.ci, sg, ci);
             }
+            // the coefficient first, sigma's amplitude only where it is not zero: an excitation operator connects about one
+            // determinant in sixteen, and the gather (a random 16 bytes of the register) is what this loop costs (24 qubits,
+            // 600 k listed amplitudes, 665 operators: 23.8 -> ms)
+            if (cr == 0.0 && ci == 0.0) continue;
+            const amp_t k = val[e], b = sig[jl ^ x];
             const double vx = b.x * k.x + b.y * k.y;
             const double vy = b.x * k.y - b.y * k.x;
             acc.x += cr * vx - ci * vy;

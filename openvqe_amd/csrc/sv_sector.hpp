@@ -1455,6 +1455,44 @@ __global__ __launch_bounds__(256) void k_sec_reduce_w(const double *__restrict__
     if (g == 0 && r < nrot) w[r] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+// ---- sigma = H psi of the ADAPT screens on the materialised Hamiltonian of a symmetry sector (sector_host.inc build_screen_sector)
+__global__ __launch_bounds__(256) void k_scr_narrow(const uint64_t *__restrict__ idx, uint32_t K, uint32_t *__restrict__ out) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k < K) out[k] = (uint32_t)idx[k];
+}
+__global__ __launch_bounds__(256) void k_scr_iota(uint32_t *__restrict__ out, uint32_t K) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k < K) out[k] = k;
+}
+// the listed amplitudes of psi into the sector's compact vector (zeroed by the caller); flag |= 1: an index outside the
+// sector, |= 2: an amplitude with an imaginary part — the caller then takes the register path
+__global__ __launch_bounds__(256) void k_scr_compact(const uint64_t *__restrict__ idx, const double2 *__restrict__ val, uint64_t count,
+                                                     const uint32_t *__restrict__ sup, uint32_t K, double *__restrict__ psic,
+                                                     int *__restrict__ flag) {
+    const uint64_t e = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (e >= count) return;
+    const uint32_t want = (uint32_t)idx[e];
+    uint32_t lo = 0, hi = K;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sup[mid] < want) lo = mid + 1u;
+        else hi = mid;
+    }
+    const double2 a = val[e];
+    if ((idx[e] >> 32) != 0 || lo >= K || sup[lo] != want) {
+        atomicOr(flag, 1);
+        return;
+    }
+    if (a.y != 0.0) atomicOr(flag, 2);
+    psic[lo] = a.x;
+}
+// sigma on the register (zeroed by the caller) from the compact product: sig[sup[k]] = sigma_c[k] + ident * psi_c[k]
+__global__ __launch_bounds__(256) void k_scr_scatter(double2 *__restrict__ sig, const uint32_t *__restrict__ sup, uint32_t K,
+                                                     const double *__restrict__ sigc, const double *__restrict__ psic, double ident) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k < K) sig[sup[k]] = make_double2(sigc[k] + ident * psic[k], 0.0);
+}
+
 // ---- Lanczos on the support (ovqe_sector_ground_state): vectors of K doubles in the circuit's final order --------------
 __device__ __forceinline__ double sec_unit_pm1(uint64_t seed, uint32_t k) {
     uint64_t z = seed + 0x9e3779b97f4a7c15ull * (uint64_t)(k + 1u);   // splitmix64

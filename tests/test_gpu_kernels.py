@@ -2,6 +2,8 @@
 
 Tolerances: amplitudes max-abs 1e-12, energies 1e-10 relative to |H|_1 scale (north_star: 1e-9 Ha).
 """
+from math import comb
+
 import numpy as np
 import pytest
 
@@ -258,8 +260,8 @@ def test_exact_exponentials_on_the_reachable_support(SV, m, o):
     assert reach[16][0] <= 16 and reach[16][-1] >= reach[16][0]
     assert np.array_equal(states[16], states[0])
     assert abs(np.linalg.norm(states[16]) - 1.0) < 1e-12
-    occupied = np.flatnonzero(np.abs(states[16]) > 1e-13)   # (rounding residues of cancelling coefficients aside)
-    assert all(bin(int(i)).count("1") == 2 * o for i in occupied)
+    occupied = np.flatnonzero(states[16])   # EVERY non-zero amplitude: cancelling coefficients leave no residues in other sectors
+    assert 1 < len(occupied) <= comb(m, o) ** 2 and all(bin(int(i)).count("1") == 2 * o for i in occupied)
     if n <= 12:
         mats = [dense.operator_matrix(pool[k], sparse=True, with_constant=False) for k in picks]
         psi0 = np.zeros(1 << n, complex)

@@ -399,3 +399,46 @@ def test_batched_evaluations_on_the_sector_tables_match_c_oracle(SV, m, o):
         assert e.shape == (B,) and np.abs(e - want[:B]).max() < 1e-10 * max(1.0, l1), B
     assert np.abs(got[141][:9] - serial).max() < 1e-12 * max(1.0, l1)
     assert np.abs(unbatched - serial).max() < 1e-13 * max(1.0, l1)
+
+
+@pytest.mark.parametrize("m,o,steps", [(8, 3, 12), (9, 4, 20)])
+def test_adapt_screen_sigma_from_the_materialised_sector_hamiltonian(SV, m, o, steps):
+    """ovqe_pool_gradients with sigma = H psi from the row-format tables of psi's symmetry sector (option "screen_sector": built once
+    per Hamiltonian on the closure of the support under its x-groups, no circuit) against the tile cover / register pass of the
+    same handle and, at 16 qubits, against the bit-mask oracle; the state is a chain of exact exponentials of spin-adapted
+    generators from the Hartree-Fock determinant (ref:openvqe/adapt/fermionic_adapt_vqe.py:77-122) and stays inside the sector"""
+    from openvqe_amd import fermion, pools
+    from openvqe_amd.backend import GRAD_FERMIONIC, GRAD_QUBIT
+    from openvqe_amd.operators import pack_terms
+    from oracle import masks
+    n = 2 * m
+    ham, _, hf = fermion.synthetic_molecule(m, o, seed=700 + m)
+    _, _, pool = pools.singlet_sd(2 * o, m)
+    rng = np.random.default_rng(70 * m + o)
+    picks = rng.choice(len(pool), size=steps, replace=False)
+    thetas = rng.uniform(-0.5, 0.5, steps)
+    l1 = float(np.abs(ham.packed()[2]).sum())
+    with SV(n) as sv:
+        sv.set_hamiltonian(ham)
+        sv.init_basis(hf)
+        for k, th in zip(picks, thetas):
+            sv.apply_exp_pauli_sum(pool[k], th)
+        psi = sv.get_state()
+        sv.set_option("screen_sector_min", 1)
+        g1 = np.array(sv.pool_gradients(pool, GRAD_FERMIONIC))
+        used, listed = sv.last_screen_sector(), sv.last_screen_support()
+        q1 = np.array(sv.pool_gradients(pool[::3], GRAD_QUBIT))
+        sv.set_option("screen_sector", 0)
+        g0 = np.array(sv.pool_gradients(pool, GRAD_FERMIONIC))
+        assert sv.last_screen_sector() == 0
+        q0 = np.array(sv.pool_gradients(pool[::3], GRAD_QUBIT))
+    nz = np.flatnonzero(psi)
+    assert listed == len(nz) and all(bin(int(i)).count("1") == 2 * o for i in nz)
+    assert used == comb(m, o) ** 2, (used, comb(m, o) ** 2)
+    scale = l1 * max(np.abs(pack_terms(n, op.terms)[2]).sum() for op in pool)
+    assert np.abs(g1).max() > 1e-3 and np.abs(g1 - g0).max() < 1e-12 * scale and np.abs(q1 - q0).max() < 1e-12 * scale
+    if n <= 16:
+        hx, hz, hc = ham.packed()
+        sigma = masks.apply_pauli_sum(psi, hx, hz, hc) + ham.constant_coeff * psi
+        want = np.array([2.0 * np.vdot(sigma, masks.apply_pauli_sum(psi, *pack_terms(n, op.terms))).real for op in pool])
+        assert np.abs(g1 - want).max() < 1e-11 * scale
