@@ -471,14 +471,15 @@ __global__ __launch_bounds__(NT) void k_sector_sweep2(const double *__restrict__
                                                       const uint32_t *__restrict__ off, const uint32_t *__restrict__ poff, int nops,
                                                       const uint64_t *__restrict__ wide, const uint16_t *__restrict__ rounds,
                                                       uint32_t maxchunks, const RotParam *__restrict__ rp, size_t rp_stride, int rot0,
-                                                      int nrot, uint32_t tile_cap, uint32_t hf_pos, int *__restrict__ flag, int dbg) {
+                                                      int nrot, uint32_t tile_cap, uint32_t hf_pos, int *__restrict__ flag, int dbg, int dst_lds) {
     constexpr uint32_t CH = (uint32_t)NT * WPT;   // = the chunk size the tables were built for (host checks)
     extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
     double *tile = reinterpret_cast<double *>(sec_smem);
     const uint32_t spare = tile_cap;     // one slot behind the tile (see the orphan words below); tile_cap < 0xffff
     double2 *cs = reinterpret_cast<double2 *>(tile + ((tile_cap + 2u) & ~1u));
     uint32_t *dst = reinterpret_cast<uint32_t *>(cs + nrot);
-    uint32_t *nround = dst + tile_cap;   // [maxchunks]
+    uint32_t *nround = dst + (dst_lds ? tile_cap : 0u);   // [maxchunks]; dst_lds = 0 (batches: three workgroups per CU instead of two): the
+                                                            // scatter indices are read from memory when the tile is written
     const uint32_t t = blockIdx.x, b = blockIdx.y;
     if (dbg == 4) return;
     const uint32_t e0 = off[t];
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(NT) void k_sector_sweep2(const double *__restrict__
     for (uint32_t k0 = threadIdx.x; k0 < n; k0 += TB * NT) {
         uint32_t d[TB];
 #pragma unroll
-        for (int j = 0; j < TB; ++j) d[j] = dstpad[tbase + min(k0 + (uint32_t)j * NT, n - 1u)];
+        for (int j = 0; j < TB; ++j) d[j] = dst_lds ? dstpad[tbase + min(k0 + (uint32_t)j * NT, n - 1u)] : 0u;
         if (in) {
             double v[TB];
 #pragma unroll
@@ -515,9 +516,11 @@ __global__ __launch_bounds__(NT) void k_sector_sweep2(const double *__restrict__
             for (int j = 0; j < TB; ++j)
                 if (k0 + (uint32_t)j * NT < n) tile[k0 + (uint32_t)j * NT] = (e0 + k0 + (uint32_t)j * NT == hf_pos) ? 1.0 : 0.0;
         }
+        if (dst_lds) {
 #pragma unroll
-        for (int j = 0; j < TB; ++j)
-            if (k0 + (uint32_t)j * NT < n) dst[k0 + (uint32_t)j * NT] = d[j];
+            for (int j = 0; j < TB; ++j)
+                if (k0 + (uint32_t)j * NT < n) dst[k0 + (uint32_t)j * NT] = d[j];
+        }
     }
     for (int r0 = threadIdx.x; r0 < nrot; r0 += 2 * NT) {
         const RotParam ra = rp[rot0 + r0], rb = rp[rot0 + min(r0 + NT, nrot - 1)];
@@ -574,7 +577,11 @@ __global__ __launch_bounds__(NT) void k_sector_sweep2(const double *__restrict__
         printf("tile %u n %u pairs %u chunks %u rounds %u: %.2f us in the chunk loop, clock %.0f MHz\n", t, n, ptot, nchunks, rtot,
                (double)(tr1 - tr0) / 100.0, (double)(tm1 - tm0) / (double)(tr1 - tr0) * 100.0);
     }
-    for (uint32_t k = threadIdx.x; k < n; k += NT) out[dst[k]] = tile[k];
+    if (dst_lds) {
+        for (uint32_t k = threadIdx.x; k < n; k += NT) out[dst[k]] = tile[k];
+    } else {
+        for (uint32_t k = threadIdx.x; k < n; k += NT) out[dstpad[tbase + k]] = tile[k];
+    }
     if (bad) atomicOr(flag, 1);
 }
 // scatter indices of a sweep: where every entry of its order sits in the NEXT sweep's tile-padded order
