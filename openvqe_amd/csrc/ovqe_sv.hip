@@ -3403,6 +3403,8 @@ int ovqe_set_hamiltonian(ovqe_handle h, int64_t T, const uint64_t *x, const uint
     if (!h || T < 0 || (T && (!x || !z || !coeff))) return OVQE_ERR_INVALID;
     int rc = install_hamdev(h, h->ham, T, x, z, coeff, constant);
     if (rc) return rc;
+    free_sector(h->scr);   // the screen engine's tables belong to the Hamiltonian that was replaced
+    h->scr_failed_version = -1;
     h->user_x.assign(x, x + T);
     h->user_z.assign(z, z + T);
     h->user_c.assign(coeff, coeff + T);
