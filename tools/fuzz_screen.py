@@ -60,3 +60,63 @@ for case in range(cases):
               f"dg={np.abs(out[16][0] - out[0][0]).max():.2e} dq={np.abs(out[16][1] - out[0][1]).max():.2e} "
               f"dstate={np.abs(out[16][4] - out[0][4]).max():.2e}", flush=True)
 print(f"{cases} cases, {bad} mismatches")
+
+# ---- sigma = H psi from the materialised Hamiltonian of psi's symmetry sector (option "screen_sector") against the register /
+# tile-cover pass: real states inside the (o alpha, o beta) sector of a molecule-shaped Hamiltonian, sometimes with a few
+# amplitudes in ANOTHER particle-number sector (the closure is then a union of sectors) or with an imaginary part (declined)
+from openvqe_amd import pools
+bad2 = 0
+for case in range(max(4, cases // 3)):
+    m = int(rng.choice([6, 7, 8, 9, 10]))
+    o = int(rng.integers(1, m // 2 + 1))
+    n = 2 * m
+    H, _, hf = fermion.synthetic_molecule(m, o, seed=int(rng.integers(1 << 30)))
+    sector = np.array([i for i in range(1 << n) if bin(i & 0xAAAAAAAA).count("1") == o and bin(i & 0x55555555).count("1") == o], np.int64) \
+        if n <= 16 else None
+    psi = np.zeros(1 << n, complex)
+    if sector is not None:
+        k = int(rng.choice([1, 5, len(sector) // 3 + 1, len(sector)]))
+        where = rng.choice(sector, size=min(k, len(sector)), replace=False)
+        psi[where] = rng.normal(size=len(where))
+    else:   # larger registers: a chain of exponentials from the reference determinant
+        where = None
+    kind = int(rng.integers(0, 4))   # 0, 1: inside the sector; 2: strays into another sector; 3: complex
+    _, _, singlets = pools.singlet_sd(2 * o, m)
+    pool = [singlets[int(k)] for k in rng.choice(len(singlets), size=min(len(singlets), 12), replace=False)]
+    for _ in range(4):
+        op, qs = random_string(rng, n)
+        pool.append(Hamiltonian(n, [Term(float(rng.normal()), op, qs)], do_clean_up=False))
+    out = {}
+    for on in (1, 0):
+        with Statevector(n) as sv:
+            sv.set_option("screen_sector", on)
+            sv.set_option("screen_sector_min", 1)
+            sv.set_hamiltonian(H)
+            if where is None:
+                sv.init_basis(hf)
+                if on:
+                    picks = rng.choice(len(singlets), size=6, replace=False)
+                    thetas = rng.uniform(-0.6, 0.6, 6)
+                for k, th in zip(picks, thetas):
+                    sv.apply_exp_pauli_sum(singlets[int(k)], float(th))
+                state = sv.get_state()
+            else:
+                state = psi.copy()
+            if kind == 2:
+                state[[1, (1 << n) - 2]] = 0.3, -0.2
+            if kind == 3:
+                state[np.flatnonzero(state)[0]] *= (0.6 + 0.8j)
+            state = state / np.linalg.norm(state)
+            sv.set_state(state)
+            g = np.array(sv.pool_gradients(pool, 0)); used = sv.last_screen_sector(); q = np.array(sv.pool_gradients(pool, 1))
+            out[on] = (g, q, used)
+    scale = max(1.0, np.abs(H.packed()[2]).sum()) * max(sum(abs(t.coeff) for t in op.terms) for op in pool)
+    ok = np.abs(out[1][0] - out[0][0]).max() < 1e-12 * scale and np.abs(out[1][1] - out[0][1]).max() < 1e-12 * scale and out[0][2] == 0
+    if kind == 3: ok = ok and out[1][2] == 0
+    if not ok:
+        bad2 += 1
+        print(f"SECTOR MISMATCH case {case}: n={n} o={o} kind={kind} used={out[1][2]} dg={np.abs(out[1][0] - out[0][0]).max():.2e} "
+              f"dq={np.abs(out[1][1] - out[0][1]).max():.2e} scale={scale:.2e}", flush=True)
+    else:
+        print(f"sector case {case}: n={n} o={o} kind={kind} sector engine on {out[1][2]} determinants", flush=True)
+print(f"sector cases: {bad2} mismatches")
