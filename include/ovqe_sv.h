@@ -254,7 +254,10 @@ int ovqe_ground_state(ovqe_handle h, double tol, int max_iter, uint64_t seed, do
  * routines cannot reach (N2/cc-pVDZ (10e,12o): 627 264 determinants, 538 M matrix elements).  Two-pass Lanczos on
  * vectors of |support| doubles, H v from the materialised matrix.  The normalised eigenvector is left in the handle's state
  * buffer (zeros outside the support: ovqe_get_state / ovqe_get_support).  OVQE_ERR_STATE when the program has no such tables
- * (not a real-amplitude program, support denser than 1/sector_sparsity, tables beyond sector_max_gb). */
+ * (not a real-amplitude program, support denser than 1/sector_sparsity, tables beyond sector_max_gb).
+ * WITHOUT a stored program the sector is that of the state in the buffer: the closure of its support under the Hamiltonian's
+ * x-groups — after ovqe_init_basis(hf) the (N_alpha, N_beta) sector of the reference determinant, with no UCCSD program to name it
+ * (the tables are those of the ADAPT screens, option "screen_sector", and are kept for them). */
 int ovqe_sector_ground_state(ovqe_handle h, double tol, int max_iter, uint64_t seed, double *energy, double *residual,
                              int *iterations);
 

@@ -148,21 +148,23 @@ def _ground_space(hamiltonian_sp, cluster_ops_sp=None, hf_init_sp=None):
     """dense eigh like the reference (fermionic_adapt_vqe.py:474) while it is feasible (its cost is O(8^n): 4 GiB and
     hours at the H2O size); above, the lowest eigenpair by Lanczos ON THE DEVICE (ovqe_ground_state: random start
     vector, i.e. the minimum over the whole register like eigh's column 0; or, with SECTOR_GROUND_SPACE, the sector's
-    ground state from the materialised Hamiltonian of the pool's support) — returned in eigh's (values, vectors) shape"""
+    ground state from the materialised Hamiltonian of the reference determinant's sector) — returned in eigh's (values, vectors) shape"""
     if hamiltonian_sp.nbqbits <= _DENSE_EIGH_MAX_QUBITS:
         return np.linalg.eigh(hamiltonian_sp.get_matrix())
     sv = _screen_backend(hamiltonian_sp.nbqbits)
     if getattr(sv, "_ham_token", None) is not hamiltonian_sp:
         sv.set_hamiltonian(hamiltonian_sp)
         sv._ham_token = hamiltonian_sp
-    if SECTOR_GROUND_SPACE and cluster_ops_sp is not None and hf_init_sp is not None:
+    if SECTOR_GROUND_SPACE and hf_init_sp is not None:
         from .._lib import BackendError
         try:
-            sv.set_ucc_program([complex(0.0, 1.0) * op for op in cluster_ops_sp], hf_init_sp)
+            # the sector of the reference determinant: the closure of |hf> under the Hamiltonian's x-groups (no program needed;
+            # ovqe_sector_ground_state without a stored program takes the sector of the state in the buffer)
+            sv.init_basis(hf_init_sp)
             energy, _, _ = sv.sector_ground_state(tol=1e-10)
             return np.array([energy]), sv.get_state().reshape(-1, 1)
         except BackendError:
-            pass   # no sector tables for this pool (support too dense, not a real-amplitude program): the register
+            pass   # no sector tables (complex Hamiltonian, sector denser than 1/sector_sparsity of the register): the register
     energy, _, _ = sv.ground_state(tol=1e-10)
     return np.array([energy]), sv.get_state().reshape(-1, 1)
 

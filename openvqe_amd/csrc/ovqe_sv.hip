@@ -4280,8 +4280,45 @@ extern "C" int ovqe_sector_ground_state(ovqe_handle h, double tol, int max_iter,
                                         int *iterations) {
     OVQE_ENTER(h);
     if (!h || !energy || max_iter < 1 || !(tol > 0.0)) return OVQE_ERR_INVALID;
-    if (!h->prog_set) return fail(h, OVQE_ERR_STATE, "no program set (ovqe_set_program / ovqe_set_gate_program)");
     if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
+    if (!h->prog_set) {
+        // no program: the sector of the state in the buffer — the closure of its support under the Hamiltonian's x-groups, e.g. of
+        // the Hartree-Fock determinant after ovqe_init_basis: the (N_alpha, N_beta) sector, no UCCSD program needed to name it
+        if (!h->opt_sector || h->n_global != 0) return fail(h, OVQE_ERR_STATE, "no program set, and the sector of the current state needs option sector on one device");
+        uint64_t support = 0;
+        bool listed = false;
+        int rc = list_support(h, &support, &listed, 0);
+        if (rc) return rc;
+        if (!listed) return fail(h, OVQE_ERR_STATE, "no program set, and the state in the buffer is empty or not sparse (ovqe_init_basis first)");
+        SectorEngine &S = h->scr;
+        if (S.valid && S.ham_version != h->ham.version) free_sector(S);
+        if (S.valid) {   // does the state live in the sector these tables were built for ?
+            HIPC(h, hipMemsetAsync(S.d_buf[0].p, 0, (size_t)S.K * sizeof(double), h->stream));
+            HIPC(h, hipMemsetAsync(S.d_flag.p, 0, sizeof(int), h->stream));
+            hipLaunchKernelGGL(k_scr_compact, dim3((unsigned)((support + 255) / 256)), dim3(256), 0, h->stream, (const uint64_t *)h->d_nz_idx.p,
+                               (const double2 *)h->d_nz_val.p, support, (const uint32_t *)S.d_sup.p, S.K, (double *)S.d_buf[0].p, (int *)S.d_flag.p);
+            int flag = 0;
+            HIPC(h, hipMemcpyAsync(&flag, S.d_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPC(h, hipStreamSynchronize(h->stream));
+            if (flag & 1) free_sector(S);
+        }
+        if (!S.valid) {
+            rc = build_screen_sector(h, support);
+            if (rc) return rc;
+        }
+        if (!S.valid) return fail(h, OVQE_ERR_STATE, "no sector tables for the current state (complex Hamiltonian, closure denser than 1/sector_sparsity, or tables beyond sector_max_gb)");
+        // the Lanczos block starts from the first listed determinant of the state
+        uint64_t first_index = 0;
+        HIPC(h, hipMemcpyAsync(&first_index, h->d_nz_idx.p, sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+        HIPC(h, hipStreamSynchronize(h->stream));
+        std::vector<uint32_t> sup(S.K);
+        HIPC(h, hipMemcpyAsync(sup.data(), S.d_sup.p, (size_t)S.K * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPC(h, hipStreamSynchronize(h->stream));
+        const auto it = std::lower_bound(sup.begin(), sup.end(), (uint32_t)first_index);
+        if (it == sup.end() || *it != (uint32_t)first_index) return fail(h, OVQE_ERR_STATE, "internal: state outside its own sector");
+        S.hf_final = (uint32_t)(it - sup.begin());
+        return run_sector_ground_state(h, S, tol, max_iter, seed, energy, residual, iterations);
+    }
     FrameHamGuard frame_guard(h);
     const bool real = h->opt_real_stream && h->prog_real_ok && h->n_global == 0 && tile_ok(h, true) && h->ham.groups.size() >= 3;
     if (!real || !h->opt_sector) return fail(h, OVQE_ERR_STATE, "the stored program has no sector tables (real-amplitude program on one device needed)");
@@ -4300,7 +4337,7 @@ extern "C" int ovqe_sector_ground_state(ovqe_handle h, double tol, int max_iter,
     }
     if (!E.valid || !E.h_tables)
         return fail(h, OVQE_ERR_STATE, "the stored program has no sector tables (support too dense, or the tables exceed sector_max_gb)");
-    return run_sector_ground_state(h, tol, max_iter, seed, energy, residual, iterations);
+    return run_sector_ground_state(h, h->sec, tol, max_iter, seed, energy, residual, iterations);
 }
 
 // ---- exact gradient by the adjoint method -------------------------------------------------------------------

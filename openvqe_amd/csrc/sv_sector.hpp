@@ -1572,7 +1572,7 @@ __global__ __launch_bounds__(256) void k_sec_lanczos_update(double *__restrict__
 __global__ __launch_bounds__(256) void k_sec_scatter_dense(const double *__restrict__ v, const uint32_t *__restrict__ cid,
                                                            const uint32_t *__restrict__ sup, uint32_t K, double2 *__restrict__ state) {
     const uint32_t e = blockIdx.x * 256u + threadIdx.x;
-    if (e < K) state[sup[cid[e]]] = make_double2(v[e], 0.0);
+    if (e < K) state[sup[cid ? cid[e] : e]] = make_double2(v[e], 0.0);   // cid == nullptr: v is in ascending-index order
 }
 // the compact state back in canonical (ascending index) order, e.g. for ovqe_get_state-like consumers and tests
 __global__ __launch_bounds__(256) void k_sec_scatter(const double *__restrict__ in, const uint32_t *__restrict__ cid, uint32_t K,

@@ -318,6 +318,17 @@ def test_sector_ground_state_is_the_fci_energy_of_the_sector(SV, m, o):
     assert info["sector_support"] == len(dets)
     assert abs(e - e_fci) < 1e-9 and res < 1e-6, (e, e_fci, res, its)
     assert e_all <= e + 1e-9 and e <= e_var + 1e-12            # global minimum <= sector minimum <= any ansatz energy
+    with SV(n) as sv:                                           # WITHOUT a program: the sector of the state in the buffer
+        sv.set_hamiltonian(ham)
+        sv.init_basis(hf)
+        e_free, res_free, _ = sv.sector_ground_state(tol=1e-12)
+        vec = sv.get_state()
+        sv.init_basis(int(dets[len(dets) // 2]))                # another determinant of the same sector: same tables, same number
+        e_again, _, _ = sv.sector_ground_state(tol=1e-12)
+    assert abs(e_free - e_fci) < 1e-9 and res_free < 1e-6 and abs(e_again - e_fci) < 1e-9
+    occupied = np.flatnonzero(vec)
+    assert abs(np.linalg.norm(vec) - 1.0) < 1e-12 and set(occupied.tolist()) <= set(dets.tolist())
+    assert abs(np.real(np.vdot(vec[dets.astype(np.int64)], block @ vec[dets.astype(np.int64)])) + ham.constant_coeff - e_fci) < 1e-9
 
 
 def test_problem_fci_energy_on_h2o(SV):
