@@ -464,15 +464,21 @@ class Problem:
     def fci_energy(self, tol=1e-10, device=0):
         """full-CI energy of this (active-space) problem in the Hartree-Fock determinant's (N_alpha, N_beta) sector — the
         ``info['FCI']`` the reference's drivers take from PySCF (ref:openvqe/common_files/molecule_factory.py:120-125) — for
-        active spaces beyond the determinant-space CI of ``Molecule.ci_ground_state``: Lanczos on the device, on the sector
-        tables of the problem's UCCSD program (``ovqe_sector_ground_state``; 14 qubits and more)"""
+        active spaces beyond the determinant-space CI of ``Molecule.ci_ground_state``: Lanczos on the device, on the
+        materialised Hamiltonian of the determinant's sector (``ovqe_sector_ground_state`` on the closure of |hf> under the
+        Hamiltonian; 12 qubits and more — when that is declined, on the sector tables of the problem's UCCSD program)"""
+        from ._lib import BackendError
         from .backend import Statevector
         ham = self.jw_hamiltonian()
         _, _, generators, _, hf = self.uccsd()
         with Statevector(ham.nbqbits, device=device) as sv:
             sv.set_hamiltonian(ham)
-            sv.set_ucc_program(generators, hf)
-            return sv.sector_ground_state(tol=tol)[0]
+            try:
+                sv.init_basis(hf)
+                return sv.sector_ground_state(tol=tol)[0]
+            except BackendError:
+                sv.set_ucc_program(generators, hf)
+                return sv.sector_ground_state(tol=tol)[0]
 
 
 def molecule(symbol):
