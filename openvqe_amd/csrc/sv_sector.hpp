@@ -953,7 +953,6 @@ __global__ __launch_bounds__(NT) void k_sector_expect(const double *__restrict__
     extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
     double *tile = reinterpret_cast<double *>(sec_smem);
     double *dict = tile + ((tile_cap + 1u) & ~1u);
-    __shared__ double2 red[NW];
     const SecHSweep sw = sweeps[blockIdx.y];
     const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     for (int k = threadIdx.x; k < sw.ndict; k += NT) dict[k] = sw.dict[k];
@@ -988,6 +987,7 @@ __global__ __launch_bounds__(NT) void k_sector_expect(const double *__restrict__
         }
     }
     __syncthreads();
+    double2 *red = reinterpret_cast<double2 *>(sec_smem);   // (the tile is done with: no static LDS next to the dynamic block)
     const double2 tsum = block_sum<NT>(make_double2(acc, 0.0), red);
     if (threadIdx.x == 0) partials[slot] = tsum;
 }
