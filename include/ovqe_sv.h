@@ -77,6 +77,7 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * words in registers; 1: first form), "sector_chunk" (pair words per chunk of those sweeps: 1024, 2048 default, 4096),
  * "sector_adjoint" (2, default: the backward sweeps of ovqe_energy_gradient on the sector tables use those 64-bit tables too; 1: first form),
  * "sector_batch" (1, default: ovqe_energy_batch runs whole batches per pass of the sector tables),
+ * "sector_eager_rots" (2048: programs of at most this many rotations build their sector tables at the first evaluation, longer ones at the second),
  * "small_max_qubits", "small_batch_max_qubits", "unroll", "real_mode" (1: allow the real-amplitude
  * specialisation of the fused kernel when every rotation string has an odd number of Y),
  * "table_fusion" (1: commuting same-x runs become single sparse pair rotations in the fused kernel),
