@@ -220,9 +220,12 @@ __global__ __launch_bounds__(64) void k_sparse_vqe_rows(SparseArgs A, const doub
         double acc[SPW];
 #pragma unroll
         for (int q = 0; q < SPW; ++q) acc[q] = 0.0;
-        // (measured and dropped: the next trip's entries in flight while this trip's are contracted — 0.69 ms per 65 536 against 0.67:
+        // (Measured and dropped: the next trip's entries in flight while this trip's are contracted — 0.69 ms per 65 536 against 0.67:
         // with nine waves per CU the kernel is bound by LDS instructions, ~5 per pair and 2 per entry and state at ~3 ns each per CU,
-        // tools/micro/lds_atomic.hip, not by this loop's latency)
+        // tools/micro/lds_atomic.hip, not by this loop's latency.  Also measured and dropped: the restricted Hamiltonian in row format
+        // (lane = row, a_i once per slice of 64 rows, ONE amplitude read per entry and state instead of two, entries ordered
+        // against bank conflicts): 0.673 ms against 0.675 — the entry loop's LDS reads are not what bounds the kernel either;
+        // per wave and pair of evaluations ~6600 VALU, 3700 SALU, 1400 LDS instructions at 2.25 waves per SIMD.)
 #pragma unroll 4
         for (int e = lane; e < A.nent; e += 64) {
             const SpEntry en = entries[e];
