@@ -197,6 +197,8 @@ struct ovqe_sv {
     DevBuf d_sp_ops, d_sp_pairs, d_sp_entries;
     // device copy of the ADAPT pool of the last ovqe_pool_gradients call (+ its host image for the change test)
     DevBuf d_pg_off, d_pg_xs, d_pg_terms, d_pg_out, d_pg_part;
+    DevBuf d_pg_runs, d_pg_tabs;   // pattern tables of the pool's same-x runs (PoolRun, k_pool_grad_nz)
+    bool pg_tables = false;
     DevBuf d_nz_cnt, d_nz_start, d_nz_idx, d_nz_val, d_nz_bitmap;
     DevBuf d_tile_smasks, d_tile_lists, d_tile_counts;   // non-empty tiles per sweep of H psi on a listed state (k_tile_lists)  // support list of the screened state (k_pool_grad_nz)
     int opt_screen_sparse = 16;   // the ADAPT screen walks the support of psi when it is at most 1/this of the register (0 = never)
@@ -259,6 +261,7 @@ struct ovqe_sv {
                                                  // per workgroup at 24 qubits: three 512-thread workgroups per CU; B = 64: 0.82 -> 0.70 ms per evaluation)
     int opt_sector_batch_nb = 2;      // states per tile of the batched <H> (2 or 3)
     int opt_sector_batch_threads = 1024;   // its workgroup size (512, 1024)
+    int opt_screen_tables = 1;        // ADAPT screens over the support list: pattern tables for the pool's same-x runs (PoolRun)
     int opt_screen_sector = 1;        // ADAPT screens: sigma = H psi from the materialised Hamiltonian of psi's symmetry sector (real states)
     int opt_screen_sector_min = 1024; // ... once psi lists at least this many amplitudes
     int opt_sector_eager_rots = 2048; // programs of at most this many rotations build their sector tables at the FIRST evaluation (else the second)
@@ -2916,7 +2919,7 @@ int ovqe_destroy(ovqe_handle h) {
     std::vector<DevBuf *> bufs = {&h->d_partials, &h->d_result, &h->d_rp, &h->d_ops, &h->d_rots, &h->d_rots_seq, &h->d_segs,
                                   &h->d_stream,
                                   &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups, &h->d_eterms, &h->d_echunks,
-                                  &h->d_eflat, &h->d_sp_ops, &h->d_sp_rows, &h->d_sp_rows64, &h->d_sp_prim, &h->d_sp_pairs, &h->d_sp_entries, &h->d_pg_off, &h->d_pg_xs, &h->d_pg_terms,
+                                  &h->d_eflat, &h->d_sp_ops, &h->d_sp_rows, &h->d_sp_rows64, &h->d_sp_prim, &h->d_sp_pairs, &h->d_sp_entries, &h->d_pg_off, &h->d_pg_xs, &h->d_pg_terms, &h->d_pg_runs, &h->d_pg_tabs,
                                   &h->d_pg_out, &h->d_pg_part, &h->d_nz_cnt, &h->d_nz_start, &h->d_nz_idx, &h->d_nz_val, &h->d_nz_bitmap, &h->d_tile_smasks, &h->d_tile_lists, &h->d_tile_counts, &h->cc.d_sup, &h->cc.d_psic, &h->cc.d_loc, &h->cc.d_cid, &h->cc.d_off, &h->cc.d_sweeps};
     for (TilePlan *tp : {&h->tp, &h->tp_adhoc, &h->tp_real}) bufs.insert(bufs.end(), {&tp->d_tops, &tp->d_trots});
     for (HamDev *H : {&h->ham, &h->ham_adhoc, &h->ham_real})
@@ -2984,6 +2987,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "sector_batch") h->opt_sector_batch = (int)value;
     else if (k == "sector_eager_rots") h->opt_sector_eager_rots = (int)value;
     else if (k == "screen_sector") h->opt_screen_sector = (int)value;
+    else if (k == "screen_tables") h->opt_screen_tables = (int)value;
     else if (k == "screen_sector_min") h->opt_screen_sector_min = (int)value;
     else if (k == "sector_batch_sweep_threads") h->opt_sector_batch_sweep_threads = value == 512 ? 512 : 1024;
     else if (k == "sector_batch_dst_lds") h->opt_sector_batch_dst_lds = (int)value;
@@ -3903,6 +3907,46 @@ int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, co
             h->pg_xs.swap(xs);
             h->pg_terms.swap(terms);
             h->pg_valid = true;
+            // pattern tables of the same-x runs (see PoolRun)
+            h->pg_tables = false;
+            if (h->opt_screen_tables) {
+                std::vector<PoolRun> runs((size_t)std::max<int64_t>(T, 1), PoolRun{0ull, 0u, -1, 0, 0});
+                std::vector<double2> tabs;
+                for (int64_t k = 0; k < n_ops; ++k)
+                    for (int64_t t = offsets[k]; t < offsets[k + 1];) {
+                        int64_t te = t + 1;
+                        while (te < offsets[k + 1] && h->pg_xs[te] == h->pg_xs[t]) ++te;
+                        const uint64_t z0 = h->pg_terms[t].z;
+                        uint64_t V = 0;
+                        for (int64_t u = t; u < te; ++u) V |= h->pg_terms[u].z ^ z0;
+                        const int nv = __builtin_popcountll(V);
+                        if (te - t >= 2 && nv <= 4) {
+                            PoolRun r{z0, 0u, nv, (int32_t)tabs.size(), 0};
+                            int pos[4] = {0, 0, 0, 0}, c = 0;
+                            for (uint64_t mk = V; mk; mk &= mk - 1ull) pos[c++] = __builtin_ctzll(mk);
+                            r.vpos = (uint32_t)pos[0] | ((uint32_t)pos[1] << 6) | ((uint32_t)pos[2] << 12) | ((uint32_t)pos[3] << 18);
+                            for (int pat = 0; pat < (1 << nv); ++pat) {
+                                uint64_t bits = 0;   // the pattern placed on V
+                                for (int b = 0; b < nv; ++b)
+                                    if ((pat >> b) & 1) bits |= 1ull << pos[b];
+                                double dr = 0.0, di = 0.0;
+                                for (int64_t u = t; u < te; ++u) {   // same terms, same order, fma: the device loop's doubles
+                                    const double sg = (__builtin_popcountll(bits & (h->pg_terms[u].z ^ z0)) & 1) ? -1.0 : 1.0;
+                                    dr = std::fma(h->pg_terms[u].cr, sg, dr);
+                                    di = std::fma(h->pg_terms[u].ci, sg, di);
+                                }
+                                tabs.push_back(make_double2(dr, di));
+                            }
+                            runs[t] = r;
+                        }
+                        t = te;
+                    }
+                rc = upload(h, h->d_pg_runs, runs.data(), runs.size() * sizeof(PoolRun));
+                if (tabs.empty()) tabs.push_back(make_double2(0.0, 0.0));
+                if (!rc) rc = upload(h, h->d_pg_tabs, tabs.data(), tabs.size() * sizeof(double2));
+                if (rc) return rc;
+                h->pg_tables = true;
+            }
         }
         // one workgroup per operator while the state re-streams from L2/MALL; above that 2^16 amplitudes per workgroup
         const int nchunks = on_support ? (int)std::min<uint64_t>(256, (support + 65535) >> 16)
@@ -3920,7 +3964,9 @@ int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, co
                 hipLaunchKernelGGL(k_pool_grad_nz, dim3((unsigned)nchunks, (unsigned)cnt), dim3(256), 0, h->stream,
                                    (const amp_t *)sig, (const uint64_t *)h->d_nz_idx.p, (const amp_t *)h->d_nz_val.p, support,
                                    h->base, (const int64_t *)h->d_pg_off.p, (const uint64_t *)h->d_pg_xs.p,
-                                   (const HTerm *)h->d_pg_terms.p, op0, part);
+                                   (const HTerm *)h->d_pg_terms.p, op0, part,
+                                   (h->pg_tables && h->opt_screen_tables) ? (const PoolRun *)h->d_pg_runs.p : (const PoolRun *)nullptr,
+                                   (const double2 *)h->d_pg_tabs.p);
             else
                 hipLaunchKernelGGL(k_pool_grad, dim3((unsigned)nchunks, (unsigned)cnt), dim3(256), 0, h->stream,
                                    (const amp_t *)sig, (const amp_t *)h->state, h->namps, h->base,

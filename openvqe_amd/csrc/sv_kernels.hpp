@@ -642,40 +642,64 @@ __global__ __launch_bounds__(256) void k_nz_fill(const amp_t *__restrict__ st, u
         }
 }
 
+// Pattern table of a same-x run of pool terms (k_pool_grad_nz): the z masks of the strings of one excitation differ on a few
+// bits V only (the Y positions among the excitation's orbitals), so D(j) = sum_t c_t (-1)^{|j & z_t|} = (-1)^{|j & z_0|} tab[j on V]:
+// 2^|V| <= 16 sums made once on the host (same terms, same order, fma: the same doubles the term loop produces) instead of a
+// loop over the run's terms per amplitude.  nv < 0: no table (more than four differing bits): the term loop.
+struct PoolRun {
+    uint64_t z0;
+    uint32_t vpos;   // four 6-bit bit numbers of V
+    int32_t nv;      // bits in V, or -1
+    int32_t toff;    // first entry of the run's table (double2 per pattern)
+    int32_t pad;
+};
 // block (chunk c, operator k): the slice [c, c+1) * count / gridDim.x of the support list; same value as k_pool_grad
 __global__ __launch_bounds__(256) void k_pool_grad_nz(const amp_t *__restrict__ sig, const uint64_t *__restrict__ idx,
                                                       const amp_t *__restrict__ val, uint64_t count, uint64_t base,
                                                       const int64_t *__restrict__ offsets, const uint64_t *__restrict__ xs,
-                                                      const HTerm *__restrict__ terms, int64_t op0, double2 *__restrict__ partials) {
+                                                      const HTerm *__restrict__ terms, int64_t op0, double2 *__restrict__ partials,
+                                                      const PoolRun *__restrict__ runs, const double2 *__restrict__ tabs) {
     __shared__ double2 red[4];
     const int64_t op = op0 + blockIdx.y;
     const uint64_t e0 = count * blockIdx.x / gridDim.x, e1 = count * (blockIdx.x + 1ull) / gridDim.x;
     double2 acc = make_double2(0.0, 0.0);
-    const int64_t t1 = offsets[op + 1];
-    for (int64_t t = offsets[op]; t < t1;) {
-        const uint64_t x = xs[t];
-        int64_t te = t + 1;
-        while (te < t1 && xs[te] == x) ++te;
-        for (uint64_t e = e0 + threadIdx.x; e < e1; e += 256) {
-            const uint64_t jl = idx[e];
+    const int64_t t0 = offsets[op], t1 = offsets[op + 1];
+    // a listed amplitude is read ONCE per operator and meets all of the operator's same-x runs (the list was re-read per run: 36 GB
+    // for 665 operators x 600 k amplitudes); per run the coefficient first, sigma's amplitude only where it is not zero: an
+    // excitation connects about one determinant in sixteen, and the gather is a random 16 bytes of the register
+    for (uint64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        const uint64_t jl = idx[e], gj = base | jl;
+        const amp_t k = val[e];
+        for (int64_t t = t0; t < t1;) {
+            const uint64_t x = xs[t];
+            int64_t te = t + 1;
+            while (te < t1 && xs[te] == x) ++te;
             double cr = 0.0, ci = 0.0;
-            for (int64_t u = t; u < te; ++u) {
-                const HTerm ht = terms[u];
-                const double sg = parity_sign64((base | jl) & ht.z);
-                cr = fma(ht.cr, sg, cr);
-                ci = fma(ht.ci, sg, ci);
+            const PoolRun run = runs ? runs[t] : PoolRun{0ull, 0u, -1, 0, 0};
+            if (run.nv >= 0) {
+                const uint32_t pat = (uint32_t)((gj >> (run.vpos & 63u)) & 1ull) | (uint32_t)(((gj >> ((run.vpos >> 6) & 63u)) & 1ull) << 1) |
+                                     (uint32_t)(((gj >> ((run.vpos >> 12) & 63u)) & 1ull) << 2) |
+                                     (uint32_t)(((gj >> ((run.vpos >> 18) & 63u)) & 1ull) << 3);
+                const double2 d = tabs[run.toff + (int)(pat & ((1u << run.nv) - 1u))];
+                const double sg = parity_sign64(gj & run.z0);
+                cr = d.x * sg;
+                ci = d.y * sg;
+            } else {
+                for (int64_t u = t; u < te; ++u) {
+                    const HTerm ht = terms[u];
+                    const double sg = parity_sign64(gj & ht.z);
+                    cr = fma(ht.cr, sg, cr);
+                    ci = fma(ht.ci, sg, ci);
+                }
             }
-            // the coefficient first, sigma's amplitude only where it is not zero: an excitation operator connects about one
-            // determinant in sixteen, and the gather (a random 16 bytes of the register) is what this loop costs (24 qubits,
-            // 600 k listed amplitudes, 665 operators: 23.8 -> ms)
+            t = te;
             if (cr == 0.0 && ci == 0.0) continue;
-            const amp_t k = val[e], b = sig[jl ^ x];
+            const amp_t b = sig[jl ^ x];
             const double vx = b.x * k.x + b.y * k.y;
             const double vy = b.x * k.y - b.y * k.x;
             acc.x += cr * vx - ci * vy;
             acc.y += cr * vy + ci * vx;
         }
-        t = te;
     }
     double2 t = block_sum<256>(acc, red);
     if (threadIdx.x == 0) partials[(size_t)(op - op0) * gridDim.x + blockIdx.x] = t;
