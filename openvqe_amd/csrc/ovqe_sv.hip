@@ -259,6 +259,7 @@ struct ovqe_sv {
     int opt_sector_batch_sweep_threads = 512;    // workgroup size of a batch's circuit sweeps (512, 1024)
     int opt_sector_batch_dst_lds = 0;            // their scatter indices staged in LDS (0: read when the tile is written — 44 instead of 64 KB
                                                  // per workgroup at 24 qubits: three 512-thread workgroups per CU; B = 64: 0.82 -> 0.70 ms per evaluation)
+    int opt_sector_batch_zfast = 1;              // batched <H>: state group = fastest grid index (the groups share a tile's elements through the caches)
     int opt_sector_batch_nb = 2;      // states per tile of the batched <H> (2 or 3)
     int opt_sector_batch_threads = 1024;   // its workgroup size (512, 1024)
     int opt_screen_tables = 1;        // ADAPT screens over the support list: pattern tables for the pool's same-x runs (PoolRun)
@@ -2991,6 +2992,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "screen_sector_min") h->opt_screen_sector_min = (int)value;
     else if (k == "sector_batch_sweep_threads") h->opt_sector_batch_sweep_threads = value == 512 ? 512 : 1024;
     else if (k == "sector_batch_dst_lds") h->opt_sector_batch_dst_lds = (int)value;
+    else if (k == "sector_batch_zfast") h->opt_sector_batch_zfast = (int)value;
     else if (k == "sector_batch_nb") h->opt_sector_batch_nb = value == 3 ? 3 : 2;
     else if (k == "sector_batch_threads") h->opt_sector_batch_threads = value == 512 ? 512 : 1024;
     else if (k == "sector_row_banks") h->opt_sector_row_banks = (int)value;

@@ -999,21 +999,25 @@ __global__ __launch_bounds__(NT) void k_sector_expect(const double *__restrict__
 template <int NT, int NB>
 __global__ __launch_bounds__(NT) void k_sector_expect_batch(const double *__restrict__ states, size_t stride,
                                                             const SecHSweep *__restrict__ sweeps, double *__restrict__ partials,
-                                                            uint32_t tile_cap) {
+                                                            uint32_t tile_cap, int zfast) {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
     double *tile = reinterpret_cast<double *>(sec_smem);
     double *dict = tile + (size_t)NB * ((tile_cap + 1u) & ~1u);
     __shared__ double2 red[NW];
-    const SecHSweep sw = sweeps[blockIdx.y];
-    states += (size_t)blockIdx.z * NB * stride;
+    // zfast: the state group is the FASTEST grid index — the workgroups that walk the same tile's elements for different states run
+    // side by side and share them through L2 / the Infinity Cache (cached loads) instead of streaming the table once per group
+    const uint32_t bx = zfast ? blockIdx.y : blockIdx.x, by = zfast ? blockIdx.z : blockIdx.y, bz = zfast ? blockIdx.x : blockIdx.z;
+    const uint32_t gx = zfast ? gridDim.y : gridDim.x, gy = zfast ? gridDim.z : gridDim.y;
+    const SecHSweep sw = sweeps[by];
+    states += (size_t)bz * NB * stride;
     for (int k = threadIdx.x; k < sw.ndict; k += NT) dict[k] = sw.dict[k];
     if (threadIdx.x == 0) dict[sw.ndict] = 0.0;   // the null element
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     double acc[NB];
 #pragma unroll
     for (int s = 0; s < NB; ++s) acc[s] = 0.0;
-    for (uint32_t t = blockIdx.x; t < (uint32_t)sw.ntiles; t += gridDim.x) {
+    for (uint32_t t = bx; t < (uint32_t)sw.ntiles; t += gx) {
         const uint32_t e0 = sw.off[t], n = sw.off[t + 1] - e0;
         if (n == 0) continue;
         __syncthreads();
@@ -1045,7 +1049,8 @@ __global__ __launch_bounds__(NT) void k_sector_expect_batch(const double *__rest
                     for (; q + 4u * SEC_H_INFLIGHT - 1u < L; q += 4u * SEC_H_INFLIGHT) {
                         u32x4 w[SEC_H_INFLIGHT];
 #pragma unroll
-                        for (int u = 0; u < SEC_H_INFLIGHT; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wp + 64u * (q + 4u * (uint32_t)u)));
+                        for (int u = 0; u < SEC_H_INFLIGHT; ++u) w[u] = zfast ? *reinterpret_cast<const u32x4 *>(wp + 64u * (q + 4u * (uint32_t)u))
+                                                           : __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wp + 64u * (q + 4u * (uint32_t)u)));
 #pragma unroll
                         for (int u = 0; u < SEC_H_INFLIGHT; ++u) {
                             term(w[u].x);
@@ -1089,7 +1094,7 @@ __global__ __launch_bounds__(NT) void k_sector_expect_batch(const double *__rest
             }
         }
     }
-    const size_t slot = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NB;
+    const size_t slot = (((size_t)bz * gy + by) * gx + bx) * NB;
 #pragma unroll
     for (int s = 0; s < NB; ++s) {
         __syncthreads();
