@@ -2990,7 +2990,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "screen_sector") h->opt_screen_sector = (int)value;
     else if (k == "screen_tables") h->opt_screen_tables = (int)value;
     else if (k == "screen_sector_min") h->opt_screen_sector_min = (int)value;
-    else if (k == "sector_batch_sweep_threads") h->opt_sector_batch_sweep_threads = value == 512 ? 512 : 1024;
+    else if (k == "sector_batch_sweep_threads") h->opt_sector_batch_sweep_threads = value == 512 ? 512 : (value == 256 ? 256 : 1024);
     else if (k == "sector_batch_dst_lds") h->opt_sector_batch_dst_lds = (int)value;
     else if (k == "sector_batch_zfast") h->opt_sector_batch_zfast = (int)value;
     else if (k == "sector_batch_nb") h->opt_sector_batch_nb = value == 3 ? 3 : 2;
