@@ -471,7 +471,7 @@ __global__ __launch_bounds__(NT) void k_sector_sweep2(const double *__restrict__
                                                       const uint32_t *__restrict__ off, const uint32_t *__restrict__ poff, int nops,
                                                       const uint64_t *__restrict__ wide, const uint16_t *__restrict__ rounds,
                                                       uint32_t maxchunks, const RotParam *__restrict__ rp, size_t rp_stride, int rot0,
-                                                      int nrot, uint32_t tile_cap, uint32_t hf_pos, int *__restrict__ flag, int dbg, int dst_lds) {
+                                                      int nrot, uint32_t tile_cap, uint32_t hf_pos, int *__restrict__ flag, int dbg, int dst_lds, int bfast) {
     constexpr uint32_t CH = (uint32_t)NT * WPT;   // = the chunk size the tables were built for (host checks)
     extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
     double *tile = reinterpret_cast<double *>(sec_smem);
@@ -480,7 +480,9 @@ __global__ __launch_bounds__(NT) void k_sector_sweep2(const double *__restrict__
     uint32_t *dst = reinterpret_cast<uint32_t *>(cs + nrot);
     uint32_t *nround = dst + (dst_lds ? tile_cap : 0u);   // [maxchunks]; dst_lds = 0 (batches: three workgroups per CU instead of two): the
                                                             // scatter indices are read from memory when the tile is written
-    const uint32_t t = blockIdx.x, b = blockIdx.y;
+    // bfast: the grid of a BATCH has the state as its fastest index: the workgroups that
+    // apply the same tile's pair words to different states run side by side and share the words through the caches
+    const uint32_t t = bfast ? blockIdx.y : blockIdx.x, b = bfast ? blockIdx.x : blockIdx.y;
     if (dbg == 4) return;
     const uint32_t e0 = off[t];
     const uint32_t n = off[t + 1] - e0;
