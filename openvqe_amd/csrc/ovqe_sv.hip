@@ -87,6 +87,7 @@ struct SectorSeg {      // one sweep of the circuit
     uint32_t hf_pos = 0;
     uint64_t npairs = 0;
     DevBuf d_tab0, d_poff, d_pairs;
+    uint32_t max_op_pairs = 0;    // most pair words of one op in one tile (k_sector_sweep<NT, true> needs them to fit a staging buffer)
     DevBuf d_srcpad;              // gather indices of the sweep, tile-padded (k_sec_pad_src): first form of the sweep kernel
     DevBuf d_dstpad;              // scatter indices into the next sweep's tile-padded order (k_sector_sweep2)
     DevBuf d_wide, d_rounds;      // 64-bit pair words, rounds per (tile, chunk) (k_sec_widen)
@@ -266,6 +267,7 @@ struct ovqe_sv {
     int opt_screen_sector = 1;        // ADAPT screens: sigma = H psi from the materialised Hamiltonian of psi's symmetry sector (real states)
     int opt_screen_sector_min = 1024; // ... once psi lists at least this many amplitudes
     int opt_sector_eager_rots = 2048; // programs of at most this many rotations build their sector tables at the FIRST evaluation (else the second)
+    int opt_sector_depth2 = 1;        // first form of the sweeps: two chunks of pair words ahead where every op of a tile fits a staging buffer
     int opt_sector_batch = 1;     // ovqe_energy_batch on the sector tables: whole batches per pass (0: one evaluation at a time)
     float last_batch_ms = 0.f;
     const double *cur_theta = nullptr;  // device pointers of the batch being evaluated
@@ -2986,6 +2988,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "sector_apply_threads") h->opt_sector_apply_threads = value == 1024 ? 1024 : (value == 512 ? 512 : 0);
     else if (k == "sector_h_threads") h->opt_sector_h_threads = value == 1024 ? 1024 : 512;
     else if (k == "sector_batch") h->opt_sector_batch = (int)value;
+    else if (k == "sector_depth2") h->opt_sector_depth2 = (int)value;
     else if (k == "sector_eager_rots") h->opt_sector_eager_rots = (int)value;
     else if (k == "screen_sector") h->opt_screen_sector = (int)value;
     else if (k == "screen_tables") h->opt_screen_tables = (int)value;

@@ -293,7 +293,11 @@ __device__ __forceinline__ void sec_rotate(double *tile, const double2 *tab, uin
     tile[si] = r.x * u + s * v;
     tile[sj] = r.x * v - s * u;
 }
-template <int NT>
+// D2: two chunks of pair words ahead in registers instead of one (sweeps whose tiles are dense: the reference's QUCCSD templates at
+// 24 qubits stream 3.5 G pair words per evaluation, two ops per chunk — a chunk's rotations take less time than a trip to HBM,
+// and with one chunk ahead the sweep ran at the bytes-in-flight limit, 2.4 TB/s); requires that no op of a tile exceeds a
+// buffer (host: SectorSeg::max_op_pairs).
+template <int NT, bool D2 = false>
 __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ in, double *__restrict__ out,
                                                      const uint32_t *__restrict__ src, const uint32_t *__restrict__ off,
                                                      const int32_t *__restrict__ tab0, int nops,
@@ -367,6 +371,57 @@ __global__ __launch_bounds__(NT) void k_sector_sweep(const double *__restrict__ 
     }
     if (ob > oa) stash(wbuf);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (D2) {
+        uint32_t r0[SEC_WORDS_PER_THREAD], r1[SEC_WORDS_PER_THREAD];
+        auto fetch2 = [&](uint32_t (&rr)[SEC_WORDS_PER_THREAD], int a, int b) {
+            const uint32_t base = lop[a].p0, cnt = lop[b].p0 - base;
+#pragma unroll
+            for (int r = 0; r < SEC_WORDS_PER_THREAD; ++r) {
+                const uint32_t idx = threadIdx.x + (uint32_t)r * NT;
+                rr[r] = idx < cnt ? pairs[base + idx] : 0u;
+            }
+        };
+        auto stash2 = [&](const uint32_t (&rr)[SEC_WORDS_PER_THREAD], uint32_t *buf) {
+#pragma unroll
+            for (int r = 0; r < SEC_WORDS_PER_THREAD; ++r) buf[threadIdx.x + (uint32_t)r * NT] = rr[r];
+        };
+        // chunk c = ops [q0, q1), c + 1 = [q1, q2), c + 2 = [q2, q3): r1 takes chunk 1, r0 chunk 2
+        int q0 = oa, q1 = ob, q2 = q1 < nops ? chunk_end(q1) : q1, q3 = q2 < nops ? chunk_end(q2) : q2;
+        if (q2 > q1) fetch2(r1, q1, q2);
+        if (q3 > q2) fetch2(r0, q2, q3);
+        auto iter = [&](uint32_t (&ra)[SEC_WORDS_PER_THREAD]) {   // ra holds chunk c + 1
+            const uint32_t *wb = wbuf + (size_t)cb * W;
+            const uint32_t base = lop[q0].p0;
+            uint32_t p0 = 0;
+            for (int o = q0; o < q1; ++o) {
+                const uint32_t p1 = lop[o + 1].p0 - base;
+                const double2 *tab = cs + lop[o].tab;
+                for (uint32_t k = p0 + threadIdx.x; k < p1; k += NT) sec_rotate<NT>(tile, tab, wb[k], bad, sb);
+                p0 = p1;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            int q4 = q3;
+            if (q2 > q1) {
+                stash2(ra, wbuf + (size_t)(cb ^ 1) * W);
+                q4 = q3 < nops ? chunk_end(q3) : q3;
+                if (q4 > q3) fetch2(ra, q3, q4);   // chunk c + 3, two chunks' rotations ahead of its use
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            cb ^= 1;
+            q0 = q1;
+            q1 = q2;
+            q2 = q3;
+            q3 = q4;
+            return q0 < q1;
+        };
+        if (q0 < q1) {
+            for (;;) {
+                if (!iter(r1)) break;
+                if (!iter(r0)) break;
+            }
+        }
+        oa = nops;   // (the one-chunk-ahead loop below is skipped)
+    }
     while (oa < nops) {
         if (ob == oa) {   // one op with more pairs in this tile than a buffer holds: straight from memory
             const uint32_t p0 = lop[oa].p0, p1 = lop[oa + 1].p0;
