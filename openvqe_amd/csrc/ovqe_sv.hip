@@ -268,6 +268,7 @@ struct ovqe_sv {
     int opt_screen_sector_min = 1024; // ... once psi lists at least this many amplitudes
     int opt_sector_eager_rots = 2048; // programs of at most this many rotations build their sector tables at the FIRST evaluation (else the second)
     int opt_sector_depth2 = 1;        // first form of the sweeps: two chunks of pair words ahead where every op of a tile fits a staging buffer
+    int opt_sector_many_tiles = 1;    // single evaluations with >= 768 tiles: the workgroup shape of the batches (512 threads, scatter indices from memory)
     int opt_sector_batch = 1;     // ovqe_energy_batch on the sector tables: whole batches per pass (0: one evaluation at a time)
     float last_batch_ms = 0.f;
     const double *cur_theta = nullptr;  // device pointers of the batch being evaluated
@@ -2988,6 +2989,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "sector_apply_threads") h->opt_sector_apply_threads = value == 1024 ? 1024 : (value == 512 ? 512 : 0);
     else if (k == "sector_h_threads") h->opt_sector_h_threads = value == 1024 ? 1024 : 512;
     else if (k == "sector_batch") h->opt_sector_batch = (int)value;
+    else if (k == "sector_many_tiles") h->opt_sector_many_tiles = (int)value;
     else if (k == "sector_depth2") h->opt_sector_depth2 = (int)value;
     else if (k == "sector_eager_rots") h->opt_sector_eager_rots = (int)value;
     else if (k == "screen_sector") h->opt_screen_sector = (int)value;
