@@ -99,6 +99,7 @@ struct SectorHSweep {   // one sweep of the materialised <H>
     uint64_t nnz = 0;
     int ndict = 0;          // magnitudes in the sweep's dictionary (0: the coded stream keeps explicit values)
     DevBuf d_cbase, d_clen, d_cwords, d_cvals, d_dict, d_xbase, d_xlen, d_xwords, d_xvals, d_order;   // row format (sv_sector.hpp)
+    DevBuf d_torder;              // tiles by population, largest first
 };
 struct SectorEngine {
     bool valid = false, disabled = false;
@@ -269,6 +270,7 @@ struct ovqe_sv {
     int opt_sector_eager_rots = 2048; // programs of at most this many rotations build their sector tables at the FIRST evaluation (else the second)
     int opt_sector_depth2 = 1;        // first form of the sweeps: two chunks of pair words ahead where every op of a tile fits a staging buffer
     int opt_sector_many_tiles = 1;    // single evaluations with >= 768 tiles: the workgroup shape of the batches (512 threads, scatter indices from memory)
+    int opt_sector_h_lpt = 1;         // <H> kernels take the tiles of a sweep largest first
     int opt_sector_batch = 1;     // ovqe_energy_batch on the sector tables: whole batches per pass (0: one evaluation at a time)
     float last_batch_ms = 0.f;
     const double *cur_theta = nullptr;  // device pointers of the batch being evaluated
@@ -2989,6 +2991,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "sector_apply_threads") h->opt_sector_apply_threads = value == 1024 ? 1024 : (value == 512 ? 512 : 0);
     else if (k == "sector_h_threads") h->opt_sector_h_threads = value == 1024 ? 1024 : 512;
     else if (k == "sector_batch") h->opt_sector_batch = (int)value;
+    else if (k == "sector_h_lpt") h->opt_sector_h_lpt = (int)value;
     else if (k == "sector_many_tiles") h->opt_sector_many_tiles = (int)value;
     else if (k == "sector_depth2") h->opt_sector_depth2 = (int)value;
     else if (k == "sector_eager_rots") h->opt_sector_eager_rots = (int)value;

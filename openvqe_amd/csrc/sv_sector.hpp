@@ -76,6 +76,7 @@ struct SecHSweep {    // one sweep of the materialised <H>: device pointers
     const uint32_t *xbase, *xlen, *xwords;
     const double *xvals;
     int32_t ndict, ntiles;
+    const uint32_t *torder;   // [ntiles] tiles by population, largest first: the order in which workgroups take them (nullptr: as numbered)
 };
 // which entry of an off-diagonal pair keeps its matrix element: a hash bit of the pair (lower index, x mask) — per pair, not
 // per entry, so that every row keeps about half of its elements
@@ -1016,7 +1017,8 @@ __global__ __launch_bounds__(NT) void k_sector_expect(const double *__restrict__
     if (threadIdx.x == 0) dict[sw.ndict] = 0.0;   // the null element
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     double acc = 0.0;
-    for (uint32_t t = blockIdx.x; t < (uint32_t)sw.ntiles; t += gridDim.x) {
+    for (uint32_t tt = blockIdx.x; tt < (uint32_t)sw.ntiles; tt += gridDim.x) {
+        const uint32_t t = sw.torder ? sw.torder[tt] : tt;
         const uint32_t e0 = sw.off[t], n = sw.off[t + 1] - e0;
         if (n == 0) continue;
         __syncthreads();
@@ -1074,7 +1076,8 @@ __global__ __launch_bounds__(NT) void k_sector_expect_batch(const double *__rest
     double acc[NB];
 #pragma unroll
     for (int s = 0; s < NB; ++s) acc[s] = 0.0;
-    for (uint32_t t = bx; t < (uint32_t)sw.ntiles; t += gx) {
+    for (uint32_t tt = bx; tt < (uint32_t)sw.ntiles; tt += gx) {
+        const uint32_t t = sw.torder ? sw.torder[tt] : tt;
         const uint32_t e0 = sw.off[t], n = sw.off[t + 1] - e0;
         if (n == 0) continue;
         __syncthreads();
@@ -1187,7 +1190,8 @@ __global__ __launch_bounds__(NT) void k_sector_apply(const double *__restrict__ 
     for (int k = threadIdx.x; k < sw.ndict; k += NT) dict[k] = sw.dict[k];
     if (threadIdx.x == 0) dict[sw.ndict] = 0.0;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    for (uint32_t t = blockIdx.x; t < (uint32_t)sw.ntiles; t += gridDim.x) {
+    for (uint32_t tt = blockIdx.x; tt < (uint32_t)sw.ntiles; tt += gridDim.x) {
+        const uint32_t t = sw.torder ? sw.torder[tt] : tt;
         const uint32_t e0 = sw.off[t], n = sw.off[t + 1] - e0;
         if (n == 0) continue;
         __syncthreads();
