@@ -92,6 +92,7 @@ struct SectorSeg {      // one sweep of the circuit
     DevBuf d_dstpad;              // scatter indices into the next sweep's tile-padded order (k_sector_sweep2)
     DevBuf d_wide, d_rounds;      // 64-bit pair words, rounds per (tile, chunk) (k_sec_widen)
     DevBuf d_bdst;                // scatter indices into the PREVIOUS sweep's tile-padded order (k_sector_adjoint2)
+    DevBuf d_torder;              // tiles by population, largest first (sweeps with many tiles per CU)
     uint32_t maxchunks = 0;
 };
 struct SectorHSweep {   // one sweep of the materialised <H>

@@ -527,7 +527,8 @@ __global__ __launch_bounds__(NT) void k_sector_sweep2(const double *__restrict__
                                                       const uint32_t *__restrict__ off, const uint32_t *__restrict__ poff, int nops,
                                                       const uint64_t *__restrict__ wide, const uint16_t *__restrict__ rounds,
                                                       uint32_t maxchunks, const RotParam *__restrict__ rp, size_t rp_stride, int rot0,
-                                                      int nrot, uint32_t tile_cap, uint32_t hf_pos, int *__restrict__ flag, int dbg, int dst_lds, int bfast) {
+                                                      int nrot, uint32_t tile_cap, uint32_t hf_pos, int *__restrict__ flag, int dbg, int dst_lds, int bfast,
+                                                      const uint32_t *__restrict__ torder) {
     constexpr uint32_t CH = (uint32_t)NT * WPT;   // = the chunk size the tables were built for (host checks)
     extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
     double *tile = reinterpret_cast<double *>(sec_smem);
@@ -538,7 +539,8 @@ __global__ __launch_bounds__(NT) void k_sector_sweep2(const double *__restrict__
                                                             // scatter indices are read from memory when the tile is written
     // bfast: the grid of a BATCH has the state as its fastest index: the workgroups that
     // apply the same tile's pair words to different states run side by side and share the words through the caches
-    const uint32_t t = bfast ? blockIdx.y : blockIdx.x, b = bfast ? blockIdx.x : blockIdx.y;
+    const uint32_t tq = bfast ? blockIdx.y : blockIdx.x, b = bfast ? blockIdx.x : blockIdx.y;
+    const uint32_t t = torder ? torder[tq] : tq;   // (many tiles per CU: largest first)
     if (dbg == 4) return;
     const uint32_t e0 = off[t];
     const uint32_t n = off[t + 1] - e0;
