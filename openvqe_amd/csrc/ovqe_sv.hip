@@ -3729,12 +3729,15 @@ static int build_screen_sector(ovqe_handle h, uint64_t support) {
     const uint64_t cap = h->namps / (uint64_t)std::max(h->opt_sector_sparsity, 2);
     if (support > cap) return OVQE_OK;
     DevBuf list, bitmap, total_b;
-    auto done = [&](int code) {
-        free_buf(list);
-        free_buf(bitmap);
-        free_buf(total_b);
-        return code;
-    };
+    struct Scratch {   // released on every way out (the HIPC macro returns from the middle)
+        DevBuf &a, &b, &c;
+        ~Scratch() {
+            free_buf(a);
+            free_buf(b);
+            free_buf(c);
+        }
+    } scratch{list, bitmap, total_b};
+    auto done = [&](int code) { return code; };
     const size_t words = (size_t)std::max<uint64_t>(1, h->namps >> 5);
     int rc = ensure(h, list, cap * sizeof(uint64_t));
     if (!rc) rc = ensure(h, bitmap, words * sizeof(uint32_t) + 16);
@@ -3783,7 +3786,7 @@ static int build_screen_sector(ovqe_handle h, uint64_t support) {
     free_buf(sorted);
     free_buf(temp);
     if (e != hipSuccess) return done(fail(h, OVQE_ERR_HIP, std::string("screen sector: sort: ") + hipGetErrorString(e)));
-    done(OVQE_OK);
+    free_buf(list);   // (the closure list: the largest of the three, not needed while the tables are built)
     E.K = K;
     E.M = sector_tile_bits(h);
     E.chunk = (uint32_t)h->opt_sector_chunk;
