@@ -78,6 +78,12 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * "sector_adjoint" (2, default: the backward sweeps of ovqe_energy_gradient on the sector tables use those 64-bit tables too; 1: first form),
  * "sector_batch" (1, default: ovqe_energy_batch runs whole batches per pass of the sector tables),
  * "sector_eager_rots" (2048: programs of at most this many rotations build their sector tables at the first evaluation, longer ones at the second),
+ * "sector_batch_threads" / "sector_batch_nb" / "sector_batch_sweep_threads" / "sector_batch_dst_lds" / "sector_batch_zfast" (workgroup shapes and
+ * grid order of batched sector evaluations; defaults 1024 / 2 / 512 / 0 / 1), "sector_apply_threads" (0 = automatic), "sector_h_lpt" (1: the <H>
+ * kernels and sweeps with many tiles take their tiles largest first), "sector_many_tiles" (1: single evaluations with >= 768 tiles use the
+ * batches' workgroup shape), "sector_depth2" (1: two chunks of pair words ahead in the first sweep form),
+ * "screen_sector" (1) / "screen_sector_min" (1024) / "screen_tables" (1): ADAPT screens — sigma = H psi from the materialised Hamiltonian of
+ * psi's symmetry sector, pattern tables for the pool's same-x runs (see ovqe_pool_gradients, ovqe_last_support),
  * "small_max_qubits", "small_batch_max_qubits", "unroll", "real_mode" (1: allow the real-amplitude
  * specialisation of the fused kernel when every rotation string has an odd number of Y),
  * "table_fusion" (1: commuting same-x runs become single sparse pair rotations in the fused kernel),
