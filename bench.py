@@ -570,6 +570,35 @@ def cpu_baseline_leg(ham, gens, hf, thetas, budget_s=12.0):
     return out, cores
 
 
+def launch_ranks(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py
+    <same arguments>` as a child process on a free local port, pass its stdout through line by line and print the JSON
+    line of rank 0 LAST (whatever a rank or RCCL wrote after it).  -> the child's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between the ranks on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    line_json = None
+    for ln in child.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line_json = ln.rstrip("\n")      # held back: printed after everything else
+            continue
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    rc = child.wait()
+    if line_json is not None:
+        print(line_json, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -588,6 +617,11 @@ def main():
     ap.add_argument("--sharded-terms", type=int, default=1000)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process has not touched the GPU and never will — it starts the N ranks
+        # as a fresh child (never exec), relays their output and leaves with their exit code
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -604,7 +638,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (plain `python bench.py --gpus N` "
+                 "does it by itself, or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)")
 
     import __graft_entry__ as entry
     if use_dist:

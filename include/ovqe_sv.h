@@ -15,7 +15,8 @@
  *   - a Pauli string is two uint64 masks (x,z): I=(0,0) X=(1,0) Z=(0,1) Y=(1,1);
  *     P = i^{popcount(x&z)} X^x Z^z.
  *   - every function returns 0 on success or a negative OVQE_ERR_*; ovqe_last_error() gives text.
- *     No C++ exception crosses the ABI.  A handle is not thread-safe; distinct handles are
+ *     No C++ exception crosses the ABI: every entry point is a function-try-block; std::bad_alloc -> OVQE_ERR_ALLOC,
+ *     any other exception -> OVQE_ERR_INVALID with its what() in ovqe_last_error.  A handle is not thread-safe; distinct handles are
  *     independent.  Calls are synchronous unless stated (results are on the host on return).
  *   - host arrays are borrowed for the duration of the call only.
  *   - sharded states (multi-GPU): a handle may own one shard of 2^n_local amplitudes of a
@@ -280,7 +281,9 @@ int ovqe_last_batch_ms(ovqe_handle h, double *ms);
  * register (dense state, sharded register, option off).  which = 2: determinants of the symmetry sector whose materialised
  * Hamiltonian produced sigma = H psi of the last ovqe_pool_gradients call (option "screen_sector", default 1: real Hamiltonian,
  * real psi listing at least "screen_sector_min" = 1024 amplitudes; the tables are built once per Hamiltonian on the closure of
- * psi's support under its x-groups), 0 when sigma came from the register / the tile cover */
+ * psi's support under its x-groups), 0 when sigma came from the register / the tile cover.  which = 3: matrix-vector rounds
+ * the last ovqe_sector_ground_state took to saturate the block of H connected to the reference determinant (the call
+ * returns OVQE_ERR_STATE instead of diagonalising a truncated block when the search does not saturate) */
 int ovqe_last_support(ovqe_handle h, int32_t which, int64_t *support);
 /* shape of the compiled program (diagnostics / tests), up to `count` entries of:
  *   [0] ops of the sequential program  [1] Pauli rotations  [2] literal X/H/CNOT ops  [3] streaming sweeps per

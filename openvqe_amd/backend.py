@@ -288,6 +288,13 @@ class Statevector:
         self._ck(self._L.ovqe_last_support(self._h, 2, ctypes.byref(out)))
         return out.value
 
+    def last_fci_rounds(self):
+        """matrix-vector rounds the last ``sector_ground_state`` call needed to saturate the block of H connected to the
+        reference determinant"""
+        out = ctypes.c_int64()
+        self._ck(self._L.ovqe_last_support(self._h, 3, ctypes.byref(out)))
+        return out.value
+
     def last_exp_support(self):
         """amplitudes the Taylor steps of the last ``apply_exp_pauli_sum`` call ran over (-1: the register)"""
         out = ctypes.c_int64()

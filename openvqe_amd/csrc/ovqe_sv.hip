@@ -111,6 +111,7 @@ struct SectorEngine {
     uint32_t K = 0, max_tile = 0, h_max_tile = 0;
     uint32_t hf_final = 0;        // position of |hf> in the final circuit order (= the order of the <H> tables' vectors)
     uint32_t last_fci_block = 0;  // determinants of the block ovqe_sector_ground_state diagonalised last
+    int last_fci_rounds = 0;      // matvec rounds its reachability search took to saturate
     int M = 0, Mh = 0;            // index bits per tile: circuit sweeps, <H> sweeps
     int sb = 13;                  // slot bits of the pair words
     uint64_t npairs = 0, nnz = 0;
@@ -284,6 +285,8 @@ struct ovqe_sv {
     int opt_index_streams = 1;    // precompute the pair-index streams of OP_TAB ops on the host
     int opt_table_fusion = 1;     // turn commuting same-x runs into single sparse pair rotations (OP_TAB)
     int opt_rot_variant = 0;      // tuning variant of the streaming pair sweep (0 = default kernel)
+    int64_t last_fci_rounds = 0;  // matvec rounds the last ovqe_sector_ground_state needed to saturate the block of |hf>
+    int fault_inject = 0;         // option "fault_inject" (tests of the ABI's exception barrier): 1 = the next term-list build throws std::bad_alloc
     int opt_persist_blocks = 2048;
     int opt_small_threads = 0;    // 0: automatic; 256/512/1024: workgroup size of the fused kernel
     int opt_real_mode = 1;        // allow the real-amplitude specialisation of the fused kernel
@@ -317,6 +320,29 @@ int fail(ovqe_handle h, int code, const std::string &msg) {
     if (h) h->err = msg; else g_create_error = msg;
     return code;
 }
+
+// The exception barrier of the C ABI (include/ovqe_sv.h: "No C++ exception crosses the ABI"): every extern "C" entry
+// point is a function-try-block that ends in OVQE_CATCH — a host std::bad_alloc in a table build, a std::length_error of
+// an absurd size, anything a library throws becomes a negative status + text on the handle instead of std::terminate in
+// the caller's process.
+int translate_exception(ovqe_handle h) noexcept {
+    int code = OVQE_ERR_INVALID;
+    try {
+        try {
+            throw;
+        } catch (const std::bad_alloc &) {
+            code = OVQE_ERR_ALLOC;
+            fail(h, code, "host allocation failed (std::bad_alloc)");
+        } catch (const std::exception &e) {
+            fail(h, code, std::string("C++ exception stopped at the ABI: ") + e.what());
+        } catch (...) {
+            fail(h, code, "unknown C++ exception stopped at the ABI");
+        }
+    } catch (...) {   // the message itself could not be stored
+    }
+    return code;
+}
+#define OVQE_CATCH(h) catch (...) { return translate_exception(h); }
 
 // every entry point runs on its handle's device, whatever the caller's current device is
 #define OVQE_ENTER(h)                        \
@@ -362,6 +388,10 @@ int build_groups(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z,
     const uint64_t lmask = local_mask(h);
     const int ntot = h->n_local + h->n_global;
     const uint64_t allmask = ntot >= 64 ? ~0ull : ((1ull << ntot) - 1ull);
+    if (h->fault_inject == 1) {   // what a failed host allocation of the vectors below does
+        h->fault_inject = 0;
+        throw std::bad_alloc();
+    }
     std::vector<int64_t> order(T);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return x[a] < x[b]; });
@@ -2909,13 +2939,15 @@ int ovqe_device_count(int *count) {
     return OVQE_OK;
 }
 
-int ovqe_create(int n_qubits, int device, ovqe_handle *out) { return create_common(n_qubits, 0, 0, device, out); }
+int ovqe_create(int n_qubits, int device, ovqe_handle *out) try {
+    return create_common(n_qubits, 0, 0, device, out);
+} OVQE_CATCH(nullptr)
 
-int ovqe_create_shard(int n_local, int n_global, uint64_t shard_index, int device, ovqe_handle *out) {
+int ovqe_create_shard(int n_local, int n_global, uint64_t shard_index, int device, ovqe_handle *out) try {
     return create_common(n_local, n_global, shard_index, device, out);
-}
+} OVQE_CATCH(nullptr)
 
-int ovqe_destroy(ovqe_handle h) {
+int ovqe_destroy(ovqe_handle h) try {
     OVQE_ENTER(h);
     if (!h) return OVQE_OK;
     (void)hipSetDevice(h->device);
@@ -2929,7 +2961,7 @@ int ovqe_destroy(ovqe_handle h) {
                                   &h->d_eflat, &h->d_sp_ops, &h->d_sp_rows, &h->d_sp_rows64, &h->d_sp_prim, &h->d_sp_pairs, &h->d_sp_entries, &h->d_pg_off, &h->d_pg_xs, &h->d_pg_terms, &h->d_pg_runs, &h->d_pg_tabs,
                                   &h->d_pg_out, &h->d_pg_part, &h->d_nz_cnt, &h->d_nz_start, &h->d_nz_idx, &h->d_nz_val, &h->d_nz_bitmap, &h->d_tile_smasks, &h->d_tile_lists, &h->d_tile_counts, &h->cc.d_sup, &h->cc.d_psic, &h->cc.d_loc, &h->cc.d_cid, &h->cc.d_off, &h->cc.d_sweeps};
     for (TilePlan *tp : {&h->tp, &h->tp_adhoc, &h->tp_real}) bufs.insert(bufs.end(), {&tp->d_tops, &tp->d_trots});
-    for (HamDev *H : {&h->ham, &h->ham_adhoc, &h->ham_real})
+    for (HamDev *H : {&h->ham, &h->ham_adhoc, &h->ham_real, &h->ham_conj})
         bufs.insert(bufs.end(), {&H->d_groups, &H->d_terms, &H->d_tchunks, &H->d_tgroups, &H->d_tterms, &H->d_tflats,
                                  &H->d_titems, &H->d_rest, &H->d_achunks, &H->d_agroups, &H->d_aterms});
     for (DevBuf *b : bufs)
@@ -2946,17 +2978,17 @@ int ovqe_destroy(ovqe_handle h) {
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     delete h;
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
-int ovqe_set_stream(ovqe_handle h, void *hip_stream) {
+int ovqe_set_stream(ovqe_handle h, void *hip_stream) try {
     OVQE_ENTER(h);
     if (!h) return OVQE_ERR_INVALID;
     HIPC(h, hipStreamSynchronize(h->stream));
     h->stream = (hipStream_t)hip_stream;
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
-int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
+int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     OVQE_ENTER(h);
     if (!h || !name) return OVQE_ERR_INVALID;
     const std::string k(name);
@@ -3020,6 +3052,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     else if (k == "lanczos_keep_gb") h->opt_lanczos_keep_gb = (int)value;
     else if (k == "screen_sparse") h->opt_screen_sparse = (int)std::max<int64_t>(0, value);
     else if (k == "rot_variant") h->opt_rot_variant = (int)value;
+    else if (k == "fault_inject") h->fault_inject = (int)value;
     else if (k == "real_stream") h->opt_real_stream = (int)value;
     else if (k == "apply_min_tiles") h->opt_apply_min_tiles = (int)value;
     else if (k == "clifford_frame") h->opt_clifford_frame = (int)value;  // applies to the next ovqe_set_gate_program
@@ -3068,16 +3101,16 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) {
     }
     else return fail(h, OVQE_ERR_INVALID, "unknown option " + k);
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
-int ovqe_state_ptr(ovqe_handle h, void **dev_ptr) {
+int ovqe_state_ptr(ovqe_handle h, void **dev_ptr) try {
     OVQE_ENTER(h);
     if (!h || !dev_ptr) return OVQE_ERR_INVALID;
     *dev_ptr = h->state;
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
-int ovqe_adopt_state(ovqe_handle h, void *dev_ptr) {
+int ovqe_adopt_state(ovqe_handle h, void *dev_ptr) try {
     OVQE_ENTER(h);
     if (!h || !dev_ptr) return OVQE_ERR_INVALID;
     HIPC(h, hipStreamSynchronize(h->stream));
@@ -3085,9 +3118,9 @@ int ovqe_adopt_state(ovqe_handle h, void *dev_ptr) {
     h->state = (amp_t *)dev_ptr;
     h->own_state = false;
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
-int ovqe_init_basis(ovqe_handle h, uint64_t index) {
+int ovqe_init_basis(ovqe_handle h, uint64_t index) try {
     OVQE_ENTER(h);
     if (!h) return OVQE_ERR_INVALID;
     const int ntot = h->n_local + h->n_global;
@@ -3096,25 +3129,25 @@ int ovqe_init_basis(ovqe_handle h, uint64_t index) {
     if (rc) return rc;
     HIPC(h, hipStreamSynchronize(h->stream));
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
-int ovqe_set_state(ovqe_handle h, const double *amps) {
+int ovqe_set_state(ovqe_handle h, const double *amps) try {
     OVQE_ENTER(h);
     if (!h || !amps) return OVQE_ERR_INVALID;
     HIPC(h, hipMemcpyAsync(h->state, amps, h->namps * sizeof(amp_t), hipMemcpyHostToDevice, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
-int ovqe_get_state(ovqe_handle h, double *amps) {
+int ovqe_get_state(ovqe_handle h, double *amps) try {
     OVQE_ENTER(h);
     if (!h || !amps) return OVQE_ERR_INVALID;
     HIPC(h, hipMemcpyAsync(amps, h->state, h->namps * sizeof(amp_t), hipMemcpyDeviceToHost, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
-int ovqe_get_amplitudes(ovqe_handle h, int64_t count, const uint64_t *idx, double *amps) {
+int ovqe_get_amplitudes(ovqe_handle h, int64_t count, const uint64_t *idx, double *amps) try {
     OVQE_ENTER(h);
     if (!h || count < 0 || (count && (!idx || !amps))) return OVQE_ERR_INVALID;
     if (count == 0) return OVQE_OK;
@@ -3136,9 +3169,9 @@ int ovqe_get_amplitudes(ovqe_handle h, int64_t count, const uint64_t *idx, doubl
     if (d_idx.p) (void)hipFree(d_idx.p);
     if (d_out.p) (void)hipFree(d_out.p);
     return rc;
-}
+} OVQE_CATCH(h)
 
-int ovqe_randomize(ovqe_handle h, uint64_t seed, double norm2_total, double *scale_out) {
+int ovqe_randomize(ovqe_handle h, uint64_t seed, double norm2_total, double *scale_out) try {
     OVQE_ENTER(h);
     if (!h) return OVQE_ERR_INVALID;
     const int nb = reduce_blocks(h->namps);
@@ -3159,9 +3192,9 @@ int ovqe_randomize(ovqe_handle h, uint64_t seed, double norm2_total, double *sca
     HIPC(h, hipStreamSynchronize(h->stream));
     if (scale_out) *scale_out = scale;
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
-int ovqe_norm2(ovqe_handle h, double *out) {
+int ovqe_norm2(ovqe_handle h, double *out) try {
     OVQE_ENTER(h);
     if (!h || !out) return OVQE_ERR_INVALID;
     const int nb = reduce_blocks(h->namps);
@@ -3176,10 +3209,10 @@ int ovqe_norm2(ovqe_handle h, double *out) {
     HIPC(h, hipStreamSynchronize(h->stream));
     *out = h->h_result[0].x;
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
 // ---- unit operations ----------------------------------------------------------------------------
-int ovqe_apply_pauli_rotations(ovqe_handle h, int64_t R, const uint64_t *x, const uint64_t *z, const double *phi) {
+int ovqe_apply_pauli_rotations(ovqe_handle h, int64_t R, const uint64_t *x, const uint64_t *z, const double *phi) try {
     OVQE_ENTER(h);
     if (!h || R < 0 || (R && (!x || !z || !phi))) return OVQE_ERR_INVALID;
     if (R == 0) return OVQE_OK;
@@ -3232,14 +3265,14 @@ int ovqe_apply_pauli_rotations(ovqe_handle h, int64_t R, const uint64_t *x, cons
     }
     HIPC(h, hipStreamSynchronize(h->stream));
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
-int ovqe_apply_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi) {
+int ovqe_apply_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi) try {
     OVQE_ENTER(h);
     return ovqe_apply_pauli_rotations(h, 1, &x, &z, &phi);
-}
+} OVQE_CATCH(h)
 
-int ovqe_apply_gate(ovqe_handle h, int opcode, int b0, int b1, double angle) {
+int ovqe_apply_gate(ovqe_handle h, int opcode, int b0, int b1, double angle) try {
     OVQE_ENTER(h);
     if (!h) return OVQE_ERR_INVALID;
     if (b0 < 0 || b0 >= h->n_local) return fail(h, OVQE_ERR_INVALID, "gate bit out of (local) range");
@@ -3260,10 +3293,10 @@ int ovqe_apply_gate(ovqe_handle h, int opcode, int b0, int b1, double angle) {
     if (rc) return rc;
     HIPC(h, hipStreamSynchronize(h->stream));
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
 int ovqe_bilinear(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64_t T, const uint64_t *x,
-                  const uint64_t *z, const double *coeff_re, const double *coeff_im, double *out_re_im) {
+                  const uint64_t *z, const double *coeff_re, const double *coeff_im, double *out_re_im) try {
     OVQE_ENTER(h);
     if (!h || T < 0 || !out_re_im || (T && (!x || !z || !coeff_re))) return OVQE_ERR_INVALID;
     bool real_coeffs = true;  // real coefficients: every term is Hermitian -> pair-trick kernels when bra == ket
@@ -3315,10 +3348,10 @@ int ovqe_bilinear(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64
     out_re_im[0] = res.x;
     out_re_im[1] = res.y;
     return rc;
-}
+} OVQE_CATCH(h)
 
 int ovqe_apply_pauli_sum(ovqe_handle h, const void *ket_dev, void *out_dev, int64_t T, const uint64_t *x, const uint64_t *z,
-                         const double *coeff_re, const double *coeff_im, int accumulate) {
+                         const double *coeff_re, const double *coeff_im, int accumulate) try {
     OVQE_ENTER(h);
     if (!h || !out_dev || T < 0 || (T && (!x || !z || !coeff_re))) return OVQE_ERR_INVALID;
     const amp_t *ket = ket_dev ? (const amp_t *)ket_dev : h->state;
@@ -3341,11 +3374,11 @@ int ovqe_apply_pauli_sum(ovqe_handle h, const void *ket_dev, void *out_dev, int6
     HIPC(h, hipGetLastError());
     HIPC(h, hipStreamSynchronize(h->stream));
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
 int ovqe_bilinear_batch(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64_t n_ops, const int64_t *offsets,
                         const uint64_t *x, const uint64_t *z, const double *coeff_re, const double *coeff_im,
-                        double *out_re_im) {
+                        double *out_re_im) try {
     OVQE_ENTER(h);
     if (!h || n_ops < 0 || !offsets || (n_ops && !out_re_im)) return OVQE_ERR_INVALID;
     if (n_ops == 0) return OVQE_OK;
@@ -3404,10 +3437,10 @@ int ovqe_bilinear_batch(ovqe_handle h, const void *bra_dev, const void *ket_dev,
     HIPC(h, hipMemcpyAsync(out_re_im, h->d_pg_out.p, n_ops * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
 int ovqe_expectation(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff,
-                     double constant, double *out) {
+                     double constant, double *out) try {
     OVQE_ENTER(h);
     if (!out) return OVQE_ERR_INVALID;
     double res[2] = {0.0, 0.0};
@@ -3415,11 +3448,11 @@ int ovqe_expectation(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t
     if (rc) return rc;
     *out = res[0] + constant;
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
 // ---- compiled evaluation ------------------------------------------------------------------------
 int ovqe_set_hamiltonian(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff,
-                         double constant) {
+                         double constant) try {
     OVQE_ENTER(h);
     if (!h || T < 0 || (T && (!x || !z || !coeff))) return OVQE_ERR_INVALID;
     int rc = install_hamdev(h, h->ham, T, x, z, coeff, constant);
@@ -3433,7 +3466,7 @@ int ovqe_set_hamiltonian(ovqe_handle h, int64_t T, const uint64_t *x, const uint
     h->exp_lbits = -1;
     h->sp_tried = false;
     return install_conjugated_hamiltonian(h);
-}
+} OVQE_CATCH(h)
 
 // energy-type entry points evaluate <phi|C^+ H C|phi> when the program's Clifford frame is open
 struct FrameHamGuard {
@@ -3448,7 +3481,7 @@ struct FrameHamGuard {
 };
 
 int ovqe_set_program(ovqe_handle h, int64_t R, const uint64_t *x, const uint64_t *z, const double *coeff,
-                     const double *phi0, const int32_t *pidx, int32_t K, uint64_t hf_index) {
+                     const double *phi0, const int32_t *pidx, int32_t K, uint64_t hf_index) try {
     OVQE_ENTER(h);
     if (!h || R < 0 || K < 0 || (R && (!x || !z || !coeff || !pidx))) return OVQE_ERR_INVALID;
     const int ntot = h->n_local + h->n_global;
@@ -3468,11 +3501,11 @@ int ovqe_set_program(ovqe_handle h, int64_t R, const uint64_t *x, const uint64_t
     h->frame_open = false;
     for (int64_t r = 0; r < R; ++r) push_rotation(h, x[r], z[r], coeff[r], phi0 ? phi0[r] : 0.0, pidx[r]);
     return finish_program(h);
-}
+} OVQE_CATCH(h)
 
 int ovqe_set_gate_program(ovqe_handle h, int64_t G, const int32_t *opcode, const int32_t *b0, const int32_t *b1,
                           const double *ascale, const double *aconst, const int32_t *pidx, int32_t K,
-                          uint64_t hf_index) {
+                          uint64_t hf_index) try {
     OVQE_ENTER(h);
     if (!h || G < 0 || K < 0 || (G && (!opcode || !b0 || !b1 || !ascale || !aconst || !pidx))) return OVQE_ERR_INVALID;
     if (h->n_global) return fail(h, OVQE_ERR_INVALID, "gate programs are single-device");
@@ -3494,22 +3527,28 @@ int ovqe_set_gate_program(ovqe_handle h, int64_t G, const int32_t *opcode, const
         if (done) return OVQE_OK;
     }
     return compile_gate_program_literal(h, G, opcode, b0, b1, ascale, aconst, pidx);
-}
+} OVQE_CATCH(h)
 
-int ovqe_prepare_state(ovqe_handle h, const double *theta, int32_t K) {
-    OVQE_ENTER(h);
-    if (!h) return OVQE_ERR_INVALID;
-    int rc = check_theta(h, theta, K);
-    if (rc) return rc;
-    rc = run_program_streaming(h, theta);
-    if (rc || !h->frame_open) return rc;
-    for (size_t g = 0; g + 3 < h->tail_gates.size() && !rc; g += 4) {   // the Clifford part of an open frame, literally
+// the Clifford part of an open frame, literally, on the state in the buffer: |psi> = C |phi>
+static int apply_tail_gates(ovqe_handle h) {
+    int rc = OVQE_OK;
+    for (size_t g = 0; g + 3 < h->tail_gates.size() && !rc; g += 4) {
         const int op = h->tail_gates[g], t = h->tail_gates[g + 1], c = h->tail_gates[g + 2];
         const double a = h->tail_gates[g + 3] > 0 ? M_PI_2 : -M_PI_2;
         rc = ovqe_apply_gate(h, op, t, c, a);
     }
     return rc;
 }
+
+int ovqe_prepare_state(ovqe_handle h, const double *theta, int32_t K) try {
+    OVQE_ENTER(h);
+    if (!h) return OVQE_ERR_INVALID;
+    int rc = check_theta(h, theta, K);
+    if (rc) return rc;
+    rc = run_program_streaming(h, theta);
+    if (rc || !h->frame_open) return rc;
+    return apply_tail_gates(h);
+} OVQE_CATCH(h)
 
 // batched sector evaluations need the tables of the second sweep kernel (64-bit pair words) and the materialised <H>
 static bool sector_batch_ready(ovqe_handle h) {
@@ -3520,7 +3559,7 @@ static bool sector_batch_ready(ovqe_handle h) {
            sector_h_smem(E, SEC_BATCH_NB) <= 156 * 1024;
 }
 
-int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, double *energies) {
+int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, double *energies) try {
     OVQE_ENTER(h);
     if (!h || B < 0 || (B && !energies)) return OVQE_ERR_INVALID;
     FrameHamGuard frame_guard(h);
@@ -3644,9 +3683,9 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
     HIPC(h, hipStreamSynchronize(h->stream));
     HIPC(h, hipEventElapsedTime(&h->last_batch_ms, h->ev0, h->ev1));
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
-int ovqe_energy_batch_device(ovqe_handle h, int64_t B, const void *theta_dev, int32_t K, void *energies_dev) {
+int ovqe_energy_batch_device(ovqe_handle h, int64_t B, const void *theta_dev, int32_t K, void *energies_dev) try {
     OVQE_ENTER(h);
     if (!h || B < 0 || (B && (!theta_dev || !energies_dev))) return OVQE_ERR_INVALID;
     FrameHamGuard frame_guard(h);
@@ -3666,12 +3705,12 @@ int ovqe_energy_batch_device(ovqe_handle h, int64_t B, const void *theta_dev, in
     if (h->n_global == 0 && h->n_local <= 16 && h->opt_force_path != 2)
         return run_small(h, B, (const double *)theta_dev, (double *)energies_dev, true);
     return fail(h, OVQE_ERR_INVALID, "device-resident batches are served by the fused kernels (n <= 16) only");
-}
+} OVQE_CATCH(h)
 
-int ovqe_energy(ovqe_handle h, const double *theta, int32_t K, double *energy) {
+int ovqe_energy(ovqe_handle h, const double *theta, int32_t K, double *energy) try {
     OVQE_ENTER(h);
     return ovqe_energy_batch(h, 1, theta, K, energy);
-}
+} OVQE_CATCH(h)
 
 // Ascending list of the non-zero amplitudes of the state (d_nz_idx, d_nz_val) when they are at most 1/"screen_sparse" of the
 // register; capacity: room for this many indices (0 = the support itself).
@@ -3854,7 +3893,7 @@ static int screen_sector_sigma(ovqe_handle h, amp_t *sig, uint64_t support, bool
 
 // ---- ADAPT --------------------------------------------------------------------------------------
 int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, const uint64_t *x, const uint64_t *z,
-                        const double *coeff_re, const double *coeff_im, int mode, double *grads) {
+                        const double *coeff_re, const double *coeff_im, int mode, double *grads) try {
     OVQE_ENTER(h);
     if (!h || n_ops < 0 || !offsets || (n_ops && !grads)) return OVQE_ERR_INVALID;
     if (mode != OVQE_GRAD_FERMIONIC && mode != OVQE_GRAD_QUBIT) return fail(h, OVQE_ERR_INVALID, "unknown gradient mode");
@@ -3999,10 +4038,10 @@ int ovqe_pool_gradients(ovqe_handle h, int64_t n_ops, const int64_t *offsets, co
     for (int64_t k = 0; k < n_ops; ++k)
         grads[k] = mode == OVQE_GRAD_FERMIONIC ? 2.0 * vals[k].x : 2.0 * std::hypot(vals[k].x, vals[k].y);
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
 int ovqe_apply_exp_pauli_sum(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff_re,
-                             const double *coeff_im, double theta) {
+                             const double *coeff_im, double theta) try {
     OVQE_ENTER(h);
     if (!h || T < 0 || (T && (!x || !z || !coeff_re))) return OVQE_ERR_INVALID;
     if (T == 0 || theta == 0.0) return OVQE_OK;
@@ -4097,10 +4136,10 @@ int ovqe_apply_exp_pauli_sum(ovqe_handle h, int64_t T, const uint64_t *x, const 
     if (dg.p) (void)hipFree(dg.p);
     if (dt.p) (void)hipFree(dt.p);
     return rc;
-}
+} OVQE_CATCH(h)
 
 // ---- the state as a list of its non-zero amplitudes ---------------------------------------------------------------
-int ovqe_get_support(ovqe_handle h, int64_t capacity, uint64_t *indices, double *amps, int64_t *count) {
+int ovqe_get_support(ovqe_handle h, int64_t capacity, uint64_t *indices, double *amps, int64_t *count) try {
     OVQE_ENTER(h);
     if (!h || !count || capacity < 0 || (capacity && (!indices || !amps))) return OVQE_ERR_INVALID;
     *count = -1;
@@ -4118,7 +4157,7 @@ int ovqe_get_support(ovqe_handle h, int64_t capacity, uint64_t *indices, double 
     HIPC(h, hipMemcpyAsync(amps, h->d_nz_val.p, support * sizeof(amp_t), hipMemcpyDeviceToHost, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
 // ---- ground state of the stored Hamiltonian: Lanczos on the device -------------------------------------------
 namespace {
@@ -4207,7 +4246,7 @@ struct Lanczos {
 }  // namespace
 
 extern "C" int ovqe_ground_state(ovqe_handle h, double tol, int max_iter, uint64_t seed, double *energy,
-                                 double *residual, int *iterations) {
+                                 double *residual, int *iterations) try {
     OVQE_ENTER(h);
     if (!h || !energy || max_iter < 1 || !(tol > 0.0)) return OVQE_ERR_INVALID;
     if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
@@ -4339,11 +4378,11 @@ extern "C" int ovqe_ground_state(ovqe_handle h, double tol, int max_iter, uint64
     if (iterations) *iterations = m;
     (void)est;
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
 // ---- lowest eigenpair inside the support of the stored program (sector tables) ------------------------------------
 extern "C" int ovqe_sector_ground_state(ovqe_handle h, double tol, int max_iter, uint64_t seed, double *energy, double *residual,
-                                        int *iterations) {
+                                        int *iterations) try {
     OVQE_ENTER(h);
     if (!h || !energy || max_iter < 1 || !(tol > 0.0)) return OVQE_ERR_INVALID;
     if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
@@ -4403,11 +4442,15 @@ extern "C" int ovqe_sector_ground_state(ovqe_handle h, double tol, int max_iter,
     }
     if (!E.valid || !E.h_tables)
         return fail(h, OVQE_ERR_STATE, "the stored program has no sector tables (support too dense, or the tables exceed sector_max_gb)");
-    return run_sector_ground_state(h, h->sec, tol, max_iter, seed, energy, residual, iterations);
-}
+    int rc = run_sector_ground_state(h, h->sec, tol, max_iter, seed, energy, residual, iterations);
+    // Lanczos diagonalised C^+ H C on the rotation-only program's support: the vector in the buffer is C^+ |psi0>; the header
+    // promises the eigenvector of the caller's H there (fidelities are taken against it), so the Clifford part goes on top
+    if (!rc && h->frame_open) rc = apply_tail_gates(h);
+    return rc;
+} OVQE_CATCH(h)
 
 // ---- exact gradient by the adjoint method -------------------------------------------------------------------
-extern "C" int ovqe_energy_gradient(ovqe_handle h, const double *theta, int32_t K, double *energy, double *grad) {
+extern "C" int ovqe_energy_gradient(ovqe_handle h, const double *theta, int32_t K, double *energy, double *grad) try {
     OVQE_ENTER(h);
     if (!h || !energy || !grad) return OVQE_ERR_INVALID;
     int rc = check_theta(h, theta, K);
@@ -4504,10 +4547,10 @@ extern "C" int ovqe_energy_gradient(ovqe_handle h, const double *theta, int32_t 
     }
     *energy = e.x + h->ham.constant;
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
 // ---- measurement support ------------------------------------------------------------------------
-int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, int warmup, int reps, double *avg_ms) {
+int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, int warmup, int reps, double *avg_ms) try {
     OVQE_ENTER(h);
     if (!h || !avg_ms || reps <= 0 || warmup < 0) return OVQE_ERR_INVALID;
     if (x & ~local_mask(h)) return fail(h, OVQE_ERR_INVALID, "x mask touches global (rank) bits");
@@ -4530,9 +4573,9 @@ int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, 
     HIPC(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *avg_ms = (double)ms / reps;
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
-int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
+int ovqe_program_info(ovqe_handle h, int64_t *info, int count) try {
     OVQE_ENTER(h);
     if (!h || !info || count < 0) return OVQE_ERR_INVALID;
     if (!h->prog_set) return fail(h, OVQE_ERR_STATE, "no program set");
@@ -4555,20 +4598,20 @@ int ovqe_program_info(ovqe_handle h, int64_t *info, int count) {
                             h->sp_valid ? h->sp_conflicts_before : 0, h->sp_valid ? h->sp_conflicts_after : 0};
     for (int i = 16; i < count && i < 28; ++i) info[i] = sv[i - 16];
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
-int ovqe_last_support(ovqe_handle h, int32_t which, int64_t *support) {
+int ovqe_last_support(ovqe_handle h, int32_t which, int64_t *support) try {
     OVQE_ENTER(h);
-    if (!h || !support || which < 0 || which > 2) return OVQE_ERR_INVALID;
-    *support = which == 0 ? h->last_screen_support : (which == 1 ? h->last_exp_support : h->last_screen_sector);
+    if (!h || !support || which < 0 || which > 3) return OVQE_ERR_INVALID;
+    *support = which == 0 ? h->last_screen_support : (which == 1 ? h->last_exp_support : (which == 2 ? h->last_screen_sector : h->last_fci_rounds));
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
-int ovqe_last_batch_ms(ovqe_handle h, double *ms) {
+int ovqe_last_batch_ms(ovqe_handle h, double *ms) try {
     OVQE_ENTER(h);
     if (!h || !ms) return OVQE_ERR_INVALID;
     *ms = h->last_batch_ms;
     return OVQE_OK;
-}
+} OVQE_CATCH(h)
 
 }  // extern "C"

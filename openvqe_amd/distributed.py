@@ -16,9 +16,12 @@ Per Pauli rotation exp(-i phi P), P = (x, z):
     rotations touching the same qubits pays for one exchange only.
 
 Expectation values: Hamiltonian terms are grouped by the global part of their x mask; the x_g = 0 group
-is a local partial sum; for each of the <= 2^g - 1 other groups the partner's shard is received
-(read-only, double-buffered: the transfer for group k + 1 runs under the contraction of group k) and
-``ovqe_bilinear`` contracts own-shard bra with partner-shard ket; one scalar all-reduce at the end.
+is a local partial sum; the <= 2^g - 1 other groups read their partner's shard in CHUNKS (2^26 amplitudes =
+1 GiB by default): chunk c of ALL partners is received as one batch — every xGMI link of the group list
+busy at once — double-buffered against the contraction of chunk c - 1 (2 x 7 x 1 GiB instead of two
+whole shards), and ``ovqe_bilinear`` on an m-bit sub-register contracts the matching chunk of the own
+shard (bra) with the received chunk (ket), the index bits above the chunk folded into the coefficients
+on the host; one scalar all-reduce at the end.
 The ADAPT gradient screen shards the same way (``apply_hamiltonian`` builds the sigma shard group by
 group, ``pool_gradients`` contracts the pool per partner shard in one batched launch each, one
 all-reduce of the pool-sized result).  Half-shard exchanges travel in pipelined pieces.  No other
@@ -59,6 +62,7 @@ class HipShardEngine:
         # on that very stream, or a contraction could read a partner shard before it has arrived
         self.stream = torch.cuda.current_stream(self.device)
         self.sv.set_stream(self.stream.cuda_stream)
+        self._subs = {}
 
     def check_stream(self):
         if torch.cuda.current_stream(self.device).cuda_stream != self.stream.cuda_stream:
@@ -93,6 +97,26 @@ class HipShardEngine:
         return self.sv.bilinear_batch(offsets, xs, zs, coeffs, bra_ptr=bra.data_ptr(),
                                       ket_ptr=None if ket is None else ket.data_ptr())
 
+    # -- the same three contractions on CHUNKS: 2^m consecutive amplitudes of a shard-sized buffer against a received chunk
+    # of the partner's shard; masks live on the m low bits (the host layer folds everything above them into the coefficients)
+    def _sub(self, m):
+        if m not in self._subs:
+            from .backend import Statevector
+            sub = Statevector(m, device=self.device.index)
+            sub.adopt_state(self.tensor.data_ptr())      # never used as a state: drops the handle's own 2^m-amplitude allocation
+            sub.set_stream(self.stream.cuda_stream)
+            self._subs[m] = sub
+        return self._subs[m]
+
+    def sub_bilinear(self, m, bra, bra_off, ket, xs, zs, coeffs):
+        return self._sub(m).bilinear(xs, zs, coeffs, bra_ptr=bra.data_ptr() + 16 * bra_off, ket_ptr=ket.data_ptr())
+
+    def sub_apply_sum(self, m, out, out_off, ket, xs, zs, coeffs):
+        self._sub(m).apply_pauli_sum(xs, zs, coeffs, out.data_ptr() + 16 * out_off, ket.data_ptr(), True)
+
+    def sub_bilinear_batch(self, m, offsets, xs, zs, coeffs, bra, bra_off, ket):
+        return self._sub(m).bilinear_batch(offsets, xs, zs, coeffs, bra_ptr=bra.data_ptr() + 16 * bra_off, ket_ptr=ket.data_ptr())
+
 
 class ShardedStatevector:
     """n-qubit state over ``dist.get_world_size()`` ranks (a power of two)."""
@@ -113,9 +137,10 @@ class ShardedStatevector:
             engine_factory = lambda nl, ng, r: HipShardEngine(nl, ng, r, dev)  # noqa: E731
         self.engine = engine_factory(self.n_local, self.g, self.rank)
         self._dist = dist.is_initialized()
-        self.stats = {"swaps": 0, "bytes_sent": 0, "full_shard_reads": 0, "pieces": 0, "swap_s": 0.0, "shard_read_s": 0.0}
+        self.stats = {"swaps": 0, "bytes_sent": 0, "full_shard_reads": 0, "chunk_reads": 0, "partners_per_read": 0, "pieces": 0,
+                      "swap_s": 0.0, "shard_read_s": 0.0, "local_launches": 0, "local_rotations": 0}
         self._tmp = None
-        self._shard_bufs = None
+        self._chunk_bufs = None
         self._sigma = None
 
     # -- helpers ----------------------------------------------------------------------------
@@ -298,48 +323,121 @@ class ShardedStatevector:
             groups.setdefault(xp >> self.n_local, []).append((xp, zp, complex(c), t))
         return [(xg, groups[xg]) for xg in sorted(groups)]
 
-    def _partner_shards(self, partners):
-        """generator over ``partners`` (rank differences != 0) yielding the partner's psi shard; the receive of shard
-        k + 1 is posted before shard k is handed out, into the second of two shard-sized buffers (double buffering: the
-        xGMI transfer of the next group overlaps the local contraction of the current one)"""
+    #: log2 of the amplitudes per chunk of a partner-shard read (26: 1 GiB); OVQE_SHARD_CHUNK_BITS overrides it (tests)
+    CHUNK_BITS = 26
+
+    def _chunk_bits(self):
+        import os
+        m = int(os.environ.get("OVQE_SHARD_CHUNK_BITS", self.CHUNK_BITS))
+        return max(1, min(self.n_local, m))
+
+    def _post_multi(self, items):
+        """post every (send tensor, receive tensor, partner rank, tag) of ``items`` as ONE batch -> object with ``wait()``.
+        RCCL runs the pairs of a batch concurrently — one xGMI link per partner — and takes the device tensors as they are;
+        gloo (tests; CPU engines) talks to raw host pointers, so device tensors travel through host copies there."""
+        staged = items[0][0].is_cuda and dist.get_backend(self.group) == "gloo"
+        if items[0][0].is_cuda and not staged and hasattr(self.engine, "check_stream"):
+            self.engine.check_stream()
+        ops, keep = [], []
+        for snd, rcv, partner, tag in items:
+            s_buf = snd.cpu() if staged else snd
+            r_buf = torch.empty(rcv.shape, dtype=rcv.dtype, device="cpu") if staged else rcv
+            keep.append((s_buf, r_buf, rcv))
+            pair = [dist.P2POp(dist.isend, s_buf, partner, self.group, tag=tag), dist.P2POp(dist.irecv, r_buf, partner, self.group, tag=tag)]
+            if self.rank > partner:   # lower rank sends first in a pair (gloo needs an order)
+                pair.reverse()
+            ops += pair
+        works = dist.batch_isend_irecv(ops)
+
+        class _Pending:
+            def wait(_self):
+                for w in works:
+                    w.wait()
+                if staged:
+                    for _, r_buf, rcv in keep:
+                        rcv.copy_(r_buf)
+                keep.clear()
+
+        return _Pending()
+
+    def _partner_chunks(self, partners):
+        """generator over the chunks of the partners' psi shards: yields (c, [chunk c of the shard of rank ^ d for d in
+        ``partners``]).  Chunk c + 1 of ALL partners is posted as one batch before chunk c is handed out (double buffering:
+        2 x len(partners) x 2^m amplitudes instead of two whole shards), so every link of the group list carries traffic at
+        once while the previous chunk is contracted ("several partners concurrently in chunks")."""
         if not partners:
             return
-        size = 1 << self.n_local
-        if getattr(self, "_shard_bufs", None) is None or self._shard_bufs[0].numel() < size:
-            self._shard_bufs = [self.engine.new_buffer(size), self.engine.new_buffer(size)]
+        m = self._chunk_bits()
+        csize = 1 << m
+        nchunks = 1 << (self.n_local - m)
+        np_ = len(partners)
+        if self._chunk_bufs is None or self._chunk_bufs[0].numel() < np_ * csize:
+            self._chunk_bufs = None
+            self._chunk_bufs = [self.engine.new_buffer(np_ * csize), self.engine.new_buffer(np_ * csize)]
         self.engine.sync()
 
-        def post(k):
-            partner = self.rank ^ partners[k]
-            return self._post_pair(self.engine.tensor, self._shard_bufs[k & 1][:size], partner)
+        def post(c):
+            own = self.engine.tensor[c * csize:(c + 1) * csize]
+            # one tag per (chunk parity, partner difference): gloo matches by tag, and both ends of a pair agree on it
+            return self._post_multi([(own, self._chunk_bufs[c & 1][k * csize:(k + 1) * csize], self.rank ^ d, 2 * d + (c & 1))
+                                     for k, d in enumerate(partners)])
 
         pending = post(0)
-        for k in range(len(partners)):
+        for c in range(nchunks):
             t0 = time.perf_counter()
             pending.wait()
             if hasattr(self.engine, "stream"):
-                self.engine.stream.synchronize()      # the transfer itself, for the per-link rate of the bench line
+                self.engine.stream.synchronize()      # the transfers themselves, for the link rates of the bench line
             self.stats["shard_read_s"] += time.perf_counter() - t0
-            pending = post(k + 1) if k + 1 < len(partners) else None
-            self.stats["full_shard_reads"] += 1
-            self.stats["bytes_sent"] += size * 16
-            yield self._shard_bufs[k & 1][:size]
-            self.engine.sync()   # the buffer is re-used two groups later
+            pending = post(c + 1) if c + 1 < nchunks else None
+            self.stats["chunk_reads"] += np_
+            self.stats["bytes_sent"] += np_ * csize * 16
+            yield c, [self._chunk_bufs[c & 1][k * csize:(k + 1) * csize] for k in range(np_)]
+            self.engine.sync()   # the buffers of this parity are posted again two chunks later
+        self.stats["full_shard_reads"] += np_
+        self.stats["partners_per_read"] = max(self.stats["partners_per_read"], np_)
+
+    def _split_by_chunk(self, terms, xg):
+        """terms of one partner group (physical masks) -> {h: (x_low, z_low, coefficient, z_high, x_high&z_high parity, t)} with
+        h = the part of the local x mask ABOVE the chunk bits: the term pairs ket chunk c with bra chunk c ^ h"""
+        m = self._chunk_bits()
+        low = (1 << m) - 1
+        lmask = self._local_mask()
+        out = {}
+        for xp, zp, c, t in terms:
+            h = (xp & lmask) >> m
+            ny_high = bin((xp & zp) >> m).count("1") & 3
+            out.setdefault(h, []).append((xp & low, zp & low, c * (1j) ** ny_high, zp >> m, t))
+        return out
+
+    @staticmethod
+    def _ket_sign(z_high, ket_high):
+        return -1.0 if bin(z_high & ket_high).count("1") & 1 else 1.0
+
+    def _remote_plan(self, groups):
+        """[(xg, {h: terms})] for the partner groups + the list of rank differences, in a rank-independent order"""
+        remote = [(xg, self._split_by_chunk(terms, xg)) for xg, terms in groups if xg]
+        return remote, [xg for xg, _ in remote]
 
     def expectation(self, xs, zs, coeffs, constant=0.0):
         """Re sum_t c_t <psi|P_t|psi> + constant over the whole register (same value on every rank)"""
         groups = self._group_by_partner(xs, zs, coeffs)
         total = 0.0 + 0.0j
-        remote = [(xg, terms) for xg, terms in groups if xg]
         for xg, terms in groups:
             if xg == 0:
                 total += self.engine.bilinear(np.array([t[0] for t in terms], np.uint64),
                                               np.array([t[1] for t in terms], np.uint64),
                                               np.array([t[2] for t in terms], np.complex128), None)
-        for (xg, terms), ket in zip(remote, self._partner_shards([xg for xg, _ in remote])):
-            total += self.engine.bilinear(np.array([t[0] for t in terms], np.uint64),
-                                          np.array([t[1] for t in terms], np.uint64),
-                                          np.array([t[2] for t in terms], np.complex128), ket)
+        remote, partners = self._remote_plan(groups)
+        m = self._chunk_bits()
+        for c, chunks in self._partner_chunks(partners):
+            for (xg, by_h), ket in zip(remote, chunks):
+                ket_high = ((self.rank ^ xg) << (self.n_local - m)) | c     # the ket chunk's global index above the chunk bits
+                for h, terms in sorted(by_h.items()):
+                    cs = np.array([t[2] * self._ket_sign(t[3], ket_high) for t in terms], np.complex128)
+                    total += self.engine.sub_bilinear(m, self.engine.tensor, (c ^ h) << m, ket,
+                                                      np.array([t[0] for t in terms], np.uint64),
+                                                      np.array([t[1] for t in terms], np.uint64), cs)
         val = torch.tensor([total.real], dtype=torch.float64, device=self.engine.tensor.device)
         if self._dist:
             dist.all_reduce(val, group=self.group)
@@ -347,8 +445,8 @@ class ShardedStatevector:
 
     # -- ADAPT gradient screen on the sharded register ("ADAPT screen identical with sigma also sharded")
     def apply_hamiltonian(self, xs, zs, coeffs, constant=0.0):
-        """sigma = (H + constant) psi, sharded like psi: the x_g = 0 terms act inside the shard; for every other rank
-        difference the partner's psi shard is received once (double-buffered) and its terms are accumulated.
+        """sigma = (H + constant) psi, sharded like psi: the x_g = 0 terms act inside the shard; the other rank differences
+        are accumulated chunk by chunk from the partners' psi shards (all partners of a chunk in flight at once).
         -> this rank's sigma shard (device buffer owned by the caller until the next call)"""
         size = 1 << self.n_local
         if getattr(self, "_sigma", None) is None or self._sigma.numel() < size:
@@ -360,16 +458,21 @@ class ShardedStatevector:
         tz = np.array([t[1] for t in local] + [0], np.uint64)
         tc = np.array([t[2] for t in local] + [complex(constant)], np.complex128)
         self.engine.apply_sum(tx, tz, tc, sigma, None, accumulate=False)
-        remote = [(xg, terms) for xg, terms in groups if xg]
-        for (xg, terms), ket in zip(remote, self._partner_shards([xg for xg, _ in remote])):
-            self.engine.apply_sum(np.array([t[0] for t in terms], np.uint64), np.array([t[1] for t in terms], np.uint64),
-                                  np.array([t[2] for t in terms], np.complex128), sigma, ket, accumulate=True)
+        remote, partners = self._remote_plan(groups)
+        m = self._chunk_bits()
+        for c, chunks in self._partner_chunks(partners):
+            for (xg, by_h), ket in zip(remote, chunks):
+                ket_high = ((self.rank ^ xg) << (self.n_local - m)) | c
+                for h, terms in sorted(by_h.items()):
+                    cs = np.array([t[2] * self._ket_sign(t[3], ket_high) for t in terms], np.complex128)
+                    self.engine.sub_apply_sum(m, sigma, (c ^ h) << m, ket, np.array([t[0] for t in terms], np.uint64),
+                                              np.array([t[1] for t in terms], np.uint64), cs)
         return sigma
 
     def pool_gradients(self, ham, pool, mode="fermionic"):
         """ADAPT screen over ``pool`` = [(xs, zs, coeffs) per operator] with H = (ham_xs, ham_zs, ham_coeffs, constant):
         sigma = H psi once (sharded), then v_k = sum_j c_j <sigma|P_j|psi> with the pool terms grouped by partner shard
-        — one batched launch per rank difference —, one all-reduce of the n_ops complex values;
+        — one batched launch per (rank difference, chunk pair) —, one all-reduce of the n_ops complex values;
         g_k = 2 Re v_k (fermionic, ref:openvqe/adapt/fermionic_adapt_vqe.py:67-73) or 2 |v_k| (qubit,
         ref:openvqe/adapt/qubit_adapt_vqe.py:147-150).  Same values on every rank."""
         hx, hz, hc, const = ham
@@ -379,28 +482,32 @@ class ShardedStatevector:
         owner = [f[3] for f in flat]
         vals = np.zeros(len(pool), np.complex128)
 
-        def contract(terms, ket):
+        def csr(terms, coeff_of):
             # CSR over the operators that have terms in this group (operator order kept)
             by_op = {}
-            for xp, zp, c, t in terms:
-                by_op.setdefault(owner[t], []).append((xp, zp, c))
+            for t in terms:
+                by_op.setdefault(owner[t[-1]], []).append(t)
             ops = sorted(by_op)
             offsets = np.zeros(len(ops) + 1, np.int64)
             xs, zs, cs = [], [], []
             for i, k in enumerate(ops):
                 offsets[i + 1] = offsets[i] + len(by_op[k])
-                for xp, zp, c in by_op[k]:
-                    xs.append(xp); zs.append(zp); cs.append(c)
-            out = self.engine.bilinear_batch(offsets, np.array(xs, np.uint64), np.array(zs, np.uint64),
-                                             np.array(cs, np.complex128), sigma, ket)
-            vals[ops] += out
+                for t in by_op[k]:
+                    xs.append(t[0]); zs.append(t[1]); cs.append(coeff_of(t))
+            return ops, offsets, np.array(xs, np.uint64), np.array(zs, np.uint64), np.array(cs, np.complex128)
 
-        remote = [(xg, terms) for xg, terms in groups if xg]
         for xg, terms in groups:
             if xg == 0:
-                contract(terms, None)
-        for (xg, terms), ket in zip(remote, self._partner_shards([xg for xg, _ in remote])):
-            contract(terms, ket)
+                ops, offsets, txs, tzs, tcs = csr(terms, lambda t: t[2])
+                vals[ops] += self.engine.bilinear_batch(offsets, txs, tzs, tcs, sigma, None)
+        remote, partners = self._remote_plan(groups)
+        m = self._chunk_bits()
+        for c, chunks in self._partner_chunks(partners):
+            for (xg, by_h), ket in zip(remote, chunks):
+                ket_high = ((self.rank ^ xg) << (self.n_local - m)) | c
+                for h, terms in sorted(by_h.items()):
+                    ops, offsets, txs, tzs, tcs = csr(terms, lambda t: t[2] * self._ket_sign(t[3], ket_high))
+                    vals[ops] += self.engine.sub_bilinear_batch(m, offsets, txs, tzs, tcs, sigma, (c ^ h) << m, ket)
         buf = torch.from_numpy(np.stack([vals.real, vals.imag])).to(self.engine.tensor.device)
         if self._dist:
             dist.all_reduce(buf, group=self.group)

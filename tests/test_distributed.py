@@ -91,6 +91,37 @@ class OracleShardEngine:
             self.tensor = saved
 
 
+    # -- chunk-level contractions (partner shards arrive in chunks of 2^m amplitudes; masks on the m low bits only)
+    @staticmethod
+    def _low_form(m, x, z):
+        j = np.arange(1 << m, dtype=np.uint64)
+        par = j & np.uint64(z)
+        for s in (32, 16, 8, 4, 2, 1):
+            par ^= par >> np.uint64(s)
+        sign = 1.0 - 2.0 * (par & np.uint64(1)).astype(float)
+        return (j ^ np.uint64(x)).astype(np.int64), sign, (1j) ** (bin(x & z).count("1") % 4)
+
+    def sub_bilinear(self, m, bra, bra_off, ket, xs, zs, coeffs):
+        b, k = bra.numpy()[bra_off:bra_off + (1 << m)], ket.numpy()
+        total = 0j
+        for x, z, c in zip(xs, zs, coeffs):
+            assert int(x) >> m == 0 and int(z) >> m == 0
+            i, sign, ph = self._low_form(m, int(x), int(z))
+            total += complex(c) * ph * np.vdot(b[i], sign * k)        # <bra|P|ket> = sum_j conj(bra_{j^x}) i^ny (-1)^{|j&z|} ket_j
+        return total
+
+    def sub_apply_sum(self, m, out, out_off, ket, xs, zs, coeffs):
+        o, k = out.numpy()[out_off:out_off + (1 << m)], ket.numpy()
+        for x, z, c in zip(xs, zs, coeffs):
+            assert int(x) >> m == 0 and int(z) >> m == 0
+            i, sign, ph = self._low_form(m, int(x), int(z))
+            o[i] += complex(c) * ph * sign * k
+
+    def sub_bilinear_batch(self, m, offsets, xs, zs, coeffs, bra, bra_off, ket):
+        return np.array([self.sub_bilinear(m, bra, bra_off, ket, xs[a:b], zs[a:b], coeffs[a:b])
+                         for a, b in zip(offsets[:-1], offsets[1:])])
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -99,14 +130,16 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, seed, out, engine="oracle"):
+def _worker(rank, world, port, n, seed, out, engine="oracle", chunk_bits=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if chunk_bits is not None:
+        os.environ["OVQE_SHARD_CHUNK_BITS"] = str(chunk_bits)   # partner shards in chunks of 2^chunk_bits amplitudes
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from openvqe_amd.distributed import ShardedStatevector
         rng = np.random.default_rng(seed)
-        R, T = 40, 25
+        R, T = 40, (25 if world < 8 else 90)
         g = world.bit_length() - 1
 
         def xmask():  # X/Y on at most n_local - 1 qubits (chemistry strings carry <= 4), anywhere in the register
@@ -118,6 +151,11 @@ def _worker(rank, world, port, n, seed, out, engine="oracle"):
         xs[3] = 0                                   # a diagonal string
         xs[7] = xs[6]                                # a fusable pair
         xs[10] = 1 << (n - 1); zs[10] = 0            # X on the top (global) qubit alone
+        if g >= 2:
+            xs[14] = 0b11 << (n - 2)                 # x on TWO rank bits at once (two half-shard exchanges for one rotation)
+        if g >= 3:
+            xs[20] = 0b111 << (n - 3)                # ... and on all THREE rank bits of eight shards
+            xs[27] = (0b101 << (n - 3)) | 1
         phis = rng.uniform(-1, 1, R)
         hx = [xmask() if rng.random() < 0.8 else 0 for _ in range(T)]
         hz = [int(v) for v in rng.integers(0, 1 << n, T)]
@@ -135,18 +173,23 @@ def _worker(rank, world, port, n, seed, out, engine="oracle"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 6), (4, 7), (2, 3)])
-def test_sharded_state_matches_single_process_oracle(world, n):
+@pytest.mark.parametrize("world,n,chunk_bits", [(2, 6, 3), (4, 7, None), (2, 3, 1), (8, 8, 3), (8, 10, 4)])
+def test_sharded_state_matches_single_process_oracle(world, n, chunk_bits):
+    """world size 8 = three rank bits: rotations whose x sits on two and on three of them, <H> with all seven partner groups,
+    every partner's shard read in chunks (chunk_bits below the shard size: several chunks per read, bra chunk != ket chunk)"""
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 1234 + n, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 1234 + n, out, "oracle", chunk_bits)) for r in range(world)]
     for p in procs:
         p.start()
-    e, full, n2, stats, (xs, zs, phis, hx, hz, hc, hf) = out.get(timeout=120)
+    e, full, n2, stats, (xs, zs, phis, hx, hz, hc, hf) = out.get(timeout=300)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
+    if world == 8:
+        assert stats["partners_per_read"] == 7                      # all seven partner groups in one chunked read
+        assert stats["chunk_reads"] == 7 * (1 << (n - 3 - chunk_bits))
     psi = np.zeros(1 << n, complex)
     psi[hf] = 1
     for x, z, p in zip(xs, zs, phis):
@@ -158,7 +201,8 @@ def test_sharded_state_matches_single_process_oracle(world, n):
     # lazy un-swapping + Belady victims: far fewer exchanges than one per global-x rotation
     g = world.bit_length() - 1
     glob = sum(1 for x in xs if x >> (n - g))
-    assert stats["swaps"] <= glob
+    # (one rotation can need an exchange per rank bit its x touches: the multi-bit masks of the world-8 cases)
+    assert stats["swaps"] <= (glob if world < 8 else g * glob)
 
 
 def test_permute_mask():
@@ -166,9 +210,11 @@ def test_permute_mask():
     assert permute_mask(0b1011, [2, 0, 1, 3]) == 0b1101
 
 
-def _screen_worker(rank, world, port, n, seed, out, engine="oracle"):
+def _screen_worker(rank, world, port, n, seed, out, engine="oracle", chunk_bits=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if chunk_bits is not None:
+        os.environ["OVQE_SHARD_CHUNK_BITS"] = str(chunk_bits)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from openvqe_amd.distributed import ShardedStatevector
@@ -179,7 +225,7 @@ def _screen_worker(rank, world, port, n, seed, out, engine="oracle"):
             w = int(rng.integers(1, maxw + 1))
             return sum(1 << int(b) for b in rng.choice(n, w, replace=False))
 
-        R, T, NOPS = 12, 20, 9
+        R, T, NOPS = 12, (20 if world < 8 else 60), (9 if world < 8 else 24)
         xs = [xmask(max(1, n - g - 1)) for _ in range(R)]
         zs = [int(v) for v in rng.integers(0, 1 << n, R)]
         phis = rng.uniform(-1, 1, R)
@@ -206,20 +252,22 @@ def _screen_worker(rank, world, port, n, seed, out, engine="oracle"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 6), (4, 7)])
-def test_sharded_adapt_screen_matches_single_process_oracle(world, n):
+@pytest.mark.parametrize("world,n,chunk_bits", [(2, 6, 2), (4, 7, None), (8, 9, 4)])
+def test_sharded_adapt_screen_matches_single_process_oracle(world, n, chunk_bits):
     """sigma = H psi assembled per partner shard + pool gradients per partner shard against the
-    dense single-process formulas 2 Re <psi|H A|psi> / 2 |<psi|H P|psi>|"""
+    dense single-process formulas 2 Re <psi|H A|psi> / 2 |<psi|H P|psi>|; world size 8: all seven partner groups, chunked"""
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_screen_worker, args=(r, world, port, n, 99 + n, out)) for r in range(world)]
+    procs = [ctx.Process(target=_screen_worker, args=(r, world, port, n, 99 + n, out, "oracle", chunk_bits)) for r in range(world)]
     for p in procs:
         p.start()
-    gf, gq, stats, (xs, zs, phis, hx, hz, hc, pool, hf) = out.get(timeout=120)
+    gf, gq, stats, (xs, zs, phis, hx, hz, hc, pool, hf) = out.get(timeout=300)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
+    if world == 8:
+        assert stats["partners_per_read"] == 7
     psi = np.zeros(1 << n, complex)
     psi[hf] = 1
     for x, z, p in zip(xs, zs, phis):

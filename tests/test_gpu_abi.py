@@ -1,0 +1,46 @@
+"""The C ABI's exception barrier on the GPU box (include/ovqe_sv.h: "No C++ exception crosses the ABI"):
+a host-side C++ exception inside an entry point — a failed allocation, an absurd size — must come back as a negative status with
+text in ovqe_last_error, the interpreter stays alive and the handle stays usable."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import masks
+from tests.util import random_hamiltonian, random_state
+
+pytestmark = pytest.mark.gpu
+
+
+def test_host_allocation_failure_is_a_status_not_a_dead_process(gpu_lib):
+    from openvqe_amd._lib import BackendError
+    from openvqe_amd.backend import Statevector
+    n = 10
+    rng = np.random.default_rng(5)
+    ham = random_hamiltonian(rng, n, 12)
+    psi = random_state(rng, n)
+    hx, hz, hc = ham.packed()
+    want = masks.expectation(psi, hx, hz, hc.real, ham.constant_coeff)
+    with Statevector(n) as sv:
+        sv.set_state(psi)
+        assert abs(sv.expectation(ham) - want) < 1e-11
+        sv.set_option("fault_inject", 1)            # the next term-list build throws std::bad_alloc on the host
+        other = random_hamiltonian(rng, n, 9)       # (a new operator: the term list of `ham` is cached on the handle)
+        with pytest.raises(BackendError) as ei:
+            sv.expectation(other)
+        assert "-4" in str(ei.value) or "bad_alloc" in str(ei.value)
+        assert "bad_alloc" in gpu_lib.ovqe_last_error(sv._h).decode()
+        # ... raised once; the handle is intact
+        ox, oz, oc = other.packed()
+        assert abs(sv.expectation(other) - masks.expectation(psi, ox, oz, oc.real, other.constant_coeff)) < 1e-11
+        assert abs(sv.expectation(ham) - want) < 1e-11
+        # an absurd size reaches std::vector's own check (std::length_error) before anything is read: status + text
+        offsets = np.array([0, 1 << 62], np.int64)
+        one = np.zeros(1, np.uint64)
+        out = np.zeros(2, np.float64)
+        rc = gpu_lib.ovqe_bilinear_batch(sv._h, ctypes.c_void_p(None), ctypes.c_void_p(None), 1, offsets, one, one,
+                                         np.zeros(1), np.zeros(1), out)
+        assert rc < 0
+        text = gpu_lib.ovqe_last_error(sv._h).decode()
+        assert "exception" in text or "allocation" in text, text
+        assert abs(sv.expectation(ham) - want) < 1e-11

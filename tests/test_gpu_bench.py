@@ -38,28 +38,25 @@ def test_two_process_replica_bench_line(gpu_lib):
 
 
 def test_two_process_sharded_block_against_oracle(gpu_lib):
-    """configs[4] through the driver's own command at a size the oracle holds: `bench.py --gpus 2` (gloo, both ranks on
-    device 0) must add the `sharded` block — weak run at n = 16 (one global qubit), strong run at n = 15 — and both energies
+    """configs[4] through the plain command `python bench.py --gpus 2` at a size the oracle holds (gloo, both ranks on
+    device 0): the parent starts the two ranks itself, and the line must carry the `sharded` block — weak run at n = 16 (one global qubit), strong run at n = 15 — and both energies
     must equal the bit-mask oracle's on the host-recomputed synthetic state."""
     import numpy as np
 
     import bench
     from openvqe_amd import synth
     from oracle import masks
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, OVQE_BENCH_BACKEND="gloo", OVQE_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    # the PLAIN command, no launcher and no WORLD_SIZE: bench.py starts its own two ranks (a fresh child, never exec)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OVQE_BENCH_BACKEND="gloo", OVQE_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--batch", "1024", "--no-roofline", "--no-cpu", "--no-extra", "--sharded-qubits", "15", "--sharded-rotations", "24",
            "--sharded-terms", "80"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    sh = json.loads(lines[0])["sharded"]
+    out = json.loads(r.stdout.strip().splitlines()[-1])     # the JSON line is the LAST line
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"].endswith("x2")
+    sh = out["sharded"]
     assert sh["weak"]["n_qubits"] == 16 and sh["strong"]["n_qubits"] == 15
     for leg in (sh["weak"], sh["strong"]):
         n = leg["n_qubits"]

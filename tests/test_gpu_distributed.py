@@ -13,12 +13,14 @@ from tests.test_distributed import _free_port, _screen_worker, _worker
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world,n", [(2, 14), (4, 15), (2, 17)])
-def test_sharded_state_on_hip_shards(gpu_lib, world, n):
+@pytest.mark.parametrize("world,n,chunk_bits", [(2, 14, None), (4, 15, 10), (2, 17, 12), (8, 16, 10)])
+def test_sharded_state_on_hip_shards(gpu_lib, world, n, chunk_bits):
+    """(8, 16, 10): eight HIP shards of 13 local qubits on the one GPU — x on two and three rank bits, all seven partner
+    groups of <H> read in 8 chunks of 2^10 amplitudes each (the m-bit sub-register contractions of the product engine)"""
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 4321 + n, out, "hip")) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 4321 + n, out, "hip", chunk_bits)) for r in range(world)]
     for p in procs:
         p.start()
     e, full, n2, stats, (xs, zs, phis, hx, hz, hc, hf) = out.get(timeout=600)
@@ -33,15 +35,17 @@ def test_sharded_state_on_hip_shards(gpu_lib, world, n):
     assert abs(n2 - 1.0) < 1e-12
     assert abs(e - masks.expectation(psi, hx, hz, hc, 0.25)) < 1e-11
     g = world.bit_length() - 1
-    assert 1 <= stats["swaps"] <= sum(1 for x in xs if x >> (n - g)) and stats["full_shard_reads"] >= 1
+    assert 1 <= stats["swaps"] <= (1 if world < 8 else g) * sum(1 for x in xs if x >> (n - g)) and stats["full_shard_reads"] >= 1
+    if world == 8:
+        assert stats["partners_per_read"] == 7 and stats["chunk_reads"] == 7 * (1 << (n - 3 - chunk_bits))
 
 
-@pytest.mark.parametrize("world,n", [(2, 13), (4, 14)])
-def test_sharded_adapt_screen_on_hip_shards(gpu_lib, world, n):
+@pytest.mark.parametrize("world,n,chunk_bits", [(2, 13, 9), (4, 14, None), (8, 15, 9)])
+def test_sharded_adapt_screen_on_hip_shards(gpu_lib, world, n, chunk_bits):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_screen_worker, args=(r, world, port, n, 77 + n, out, "hip")) for r in range(world)]
+    procs = [ctx.Process(target=_screen_worker, args=(r, world, port, n, 77 + n, out, "hip", chunk_bits)) for r in range(world)]
     for p in procs:
         p.start()
     gf, gq, stats, (xs, zs, phis, hx, hz, hc, pool, hf) = out.get(timeout=600)

@@ -453,3 +453,36 @@ def test_adapt_screen_sigma_from_the_materialised_sector_hamiltonian(SV, m, o, s
         sigma = masks.apply_pauli_sum(psi, hx, hz, hc) + ham.constant_coeff * psi
         want = np.array([2.0 * np.vdot(sigma, masks.apply_pauli_sum(psi, *pack_terms(n, op.terms))).real for op in pool])
         assert np.abs(g1 - want).max() < 1e-11 * scale
+
+
+def test_sector_ground_state_on_a_hopping_chain_needs_more_than_64_rounds(SV):
+    """a SHORT-RANGE Hamiltonian: spinless nearest-neighbour hopping chain (Jordan-Wigner: (X_i X_{i+1} + Y_i Y_{i+1}) / 2 plus
+    on-site Z terms), 20 sites, 10 particles all on one end.  The determinant graph of the sector (C(20,10) = 184 756) has
+    diameter 10 * 10 = 100 hops from that determinant, so the search for the block of H connected to it takes ~100 matvec
+    rounds — a search cut at 64 rounds diagonalised a truncated block and reported an energy above the minimum.  Free fermions:
+    the exact ground energy is the sum of the 10 lowest single-particle levels."""
+    from math import comb
+    from openvqe_amd.operators import Hamiltonian, Term
+    n, p = 20, 10
+    rng = np.random.default_rng(2024)
+    t = rng.uniform(0.6, 1.4, n - 1)
+    eps = rng.uniform(-0.5, 0.5, n)
+    terms = []
+    for i in range(n - 1):
+        terms += [Term(0.5 * t[i], "XX", [i, i + 1]), Term(0.5 * t[i], "YY", [i, i + 1])]
+    terms += [Term(float(eps[i]), "Z", [i]) for i in range(n)]
+    ham = Hamiltonian(n, terms, 0.125)
+    # Z_i = 1 - 2 n_i; (XX + YY)/2 = hopping with amplitude +-t_i (the sign is a gauge choice on a chain)
+    h1 = np.diag(-2.0 * eps) + np.diag(t, 1) + np.diag(t, -1)
+    e_exact = 0.125 + eps.sum() + np.sort(np.linalg.eigvalsh(h1))[:p].sum()
+    with SV(n) as sv:
+        sv.set_hamiltonian(ham)
+        sv.init_basis(((1 << p) - 1) << (n - p))
+        e, res, its = sv.sector_ground_state(tol=1e-11, max_iter=3000)
+        rounds = sv.last_fci_rounds()
+        vec = sv.get_state()
+    assert rounds > 64, rounds
+    assert abs(e - e_exact) < 1e-8, (e, e_exact, res, its)
+    occ = np.flatnonzero(np.abs(vec) > 0)
+    assert len(occ) <= comb(n, p) and all(bin(int(i)).count("1") == p for i in occ[:: max(1, len(occ) // 500)])
+    assert abs(np.linalg.norm(vec) - 1.0) < 1e-10

@@ -1,6 +1,6 @@
 """H2O QUCCSD gate list in Clifford-frame form: dense LDS kernel vs support-compacted kernel"""
 import sys, os, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 import bench
 from openvqe_amd import chem

@@ -1,4 +1,5 @@
-cd /root/repo
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
 for b in 15 16 17 18; do
  for cap in 6500 14000; do
   echo "== bits $b cap $cap"

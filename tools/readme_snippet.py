@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, "/root/repo")
+import sys; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from openvqe_amd import chem, fermion
 from openvqe_amd.ucc_family.get_energy_ucc import EnergyUCC
 mol = chem.molecule("H2O"); mol.rhf()

@@ -1,3 +1,4 @@
+#!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r3_dbl -- python3 $R/tools/exp_sector.py 12 5 --sector-only --opt=sector_sweep_dbg=16 > $R/gpurun_out/r3_dbl.log 2>&1
