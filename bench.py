@@ -409,12 +409,14 @@ def sharded_leg(n, local_rank, world, rank, rotations=64, terms=1000, barrier=No
     fence()
     t_rot = time.perf_counter() - t0
     st = dict(sv.stats)
+    cnt = dict(sv.engine.counters)
     t0 = time.perf_counter()
     e = sv.expectation(hx, hz, hc, 0.0)
     fence()
     t_exp = time.perf_counter() - t0
     n2 = sv.norm2()
     st2 = dict(sv.stats)
+    cnt2 = dict(sv.engine.counters)
     groups = len(set(hx))
     swap_bytes = st["bytes_sent"]
     read_bytes = st2["bytes_sent"] - st["bytes_sent"]
@@ -428,12 +430,27 @@ def sharded_leg(n, local_rank, world, rank, rotations=64, terms=1000, barrier=No
         "swaps": st["swaps"], "exchange_pieces": st["pieces"], "exchanged_GiB_per_rank": swap_bytes / 2 ** 30,
         "xgmi_link_GBs_exchange": (swap_bytes / st["swap_s"] / 1e9) if st["swap_s"] > 0 else None,
         "xgmi_link_frac_of_153": (swap_bytes / st["swap_s"] / 1e9 / XGMI_LINK_GBS) if st["swap_s"] > 0 else None,
-        "local_sweep_GBs_aggregate": 32.0 * 2 ** n * rotations / t_local / 1e9,
-        "rotations_GBs_aggregate_incl_exchange": 32.0 * 2 ** n * rotations / t_rot / 1e9,
-        "expectation_s": t_exp, "full_shard_reads": st2["full_shard_reads"],
+        # what the kernels did (this rank): the engine fuses same-x runs and takes several runs per LDS-tiled sweep, so the
+        # launches that stream the shard are FEWER than the rotations — the bandwidth is bytes actually moved / time
+        "local_sweeps_executed": cnt["rotation_passes"], "local_bytes_moved_per_rank": cnt["rotation_bytes"],
+        "local_sweep_GBs_per_gpu": cnt["rotation_bytes"] / t_local / 1e9,
+        "local_sweep_frac_of_hbm_peak": cnt["rotation_bytes"] / t_local / 1e9 / HBM_PEAK_GBS,
+        # the same work priced at one full sweep per rotation / x-group over the whole register (a RATE OF WORK, not a bandwidth:
+        # it exceeds the HBM peak whenever runs are fused)
+        "rotations_per_s_equivalent_GBs_aggregate": 32.0 * 2 ** n * rotations / t_local / 1e9,
+        "rotations_equivalent_GBs_aggregate_incl_exchange": 32.0 * 2 ** n * rotations / t_rot / 1e9,
+        "expectation_s": t_exp, "full_shard_reads": st2["full_shard_reads"], "chunk_reads": st2["chunk_reads"],
+        "partners_read_concurrently": st2["partners_per_read"],
         "shard_read_GiB_per_rank": read_bytes / 2 ** 30,
-        "xgmi_link_GBs_shard_reads": (read_bytes / st2["shard_read_s"] / 1e9) if st2["shard_read_s"] > 0 else None,
-        "expectation_GBs_aggregate": 16.0 * 2 ** n * groups / t_exp / 1e9,
+        "shard_read_wait_s": st2["shard_read_s"],
+        "xgmi_GBs_shard_reads_all_links": (read_bytes / st2["shard_read_s"] / 1e9) if st2["shard_read_s"] > 0 else None,
+        "xgmi_link_GBs_shard_reads": (read_bytes / st2["shard_read_s"] / 1e9 / max(1, st2["partners_per_read"]))
+                                     if st2["shard_read_s"] > 0 else None,
+        "expectation_passes_executed": cnt2["contraction_passes"] - cnt["contraction_passes"],
+        "expectation_contraction_calls": cnt2["contraction_calls"] - cnt["contraction_calls"],
+        "expectation_bytes_moved_per_rank": cnt2["contraction_bytes"] - cnt["contraction_bytes"],
+        "expectation_GBs_per_gpu": (cnt2["contraction_bytes"] - cnt["contraction_bytes"]) / t_exp / 1e9,
+        "expectation_x_groups_equivalent_GBs_aggregate": 16.0 * 2 ** n * groups / t_exp / 1e9,
         "energy": e, "norm2": n2,
     }
     del sv

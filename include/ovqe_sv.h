@@ -283,7 +283,10 @@ int ovqe_last_batch_ms(ovqe_handle h, double *ms);
  * real psi listing at least "screen_sector_min" = 1024 amplitudes; the tables are built once per Hamiltonian on the closure of
  * psi's support under its x-groups), 0 when sigma came from the register / the tile cover.  which = 3: matrix-vector rounds
  * the last ovqe_sector_ground_state took to saturate the block of H connected to the reference determinant (the call
- * returns OVQE_ERR_STATE instead of diagonalising a truncated block when the search does not saturate) */
+ * returns OVQE_ERR_STATE instead of diagonalising a truncated block when the search does not saturate).  which = 4 / 5:
+ * passes over the state (kernel launches that stream the shard) of the last ovqe_apply_pauli_rotations / ovqe_bilinear /
+ * ovqe_expectation call, and the bytes those passes move by construction (fused runs and tile covers make both smaller
+ * than one sweep per rotation / x-group: what bench.py's `sharded` block reports next to its formula rates) */
 int ovqe_last_support(ovqe_handle h, int32_t which, int64_t *support);
 /* shape of the compiled program (diagnostics / tests), up to `count` entries of:
  *   [0] ops of the sequential program  [1] Pauli rotations  [2] literal X/H/CNOT ops  [3] streaming sweeps per

@@ -295,6 +295,14 @@ class Statevector:
         self._ck(self._L.ovqe_last_support(self._h, 3, ctypes.byref(out)))
         return out.value
 
+    def last_passes(self):
+        """(passes over the state, bytes they move by construction) of the last ``apply_pauli_rotations`` / ``bilinear`` /
+        ``expectation`` call"""
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        self._ck(self._L.ovqe_last_support(self._h, 4, ctypes.byref(a)))
+        self._ck(self._L.ovqe_last_support(self._h, 5, ctypes.byref(b)))
+        return a.value, b.value
+
     def last_exp_support(self):
         """amplitudes the Taylor steps of the last ``apply_exp_pauli_sum`` call ran over (-1: the register)"""
         out = ctypes.c_int64()

@@ -285,6 +285,8 @@ struct ovqe_sv {
     int opt_index_streams = 1;    // precompute the pair-index streams of OP_TAB ops on the host
     int opt_table_fusion = 1;     // turn commuting same-x runs into single sparse pair rotations (OP_TAB)
     int opt_rot_variant = 0;      // tuning variant of the streaming pair sweep (0 = default kernel)
+    int64_t last_passes = 0;      // passes over the state buffer (kernel launches that stream it) of the last ovqe_apply_pauli_rotations /
+    int64_t last_pass_bytes = 0;  // ovqe_bilinear call and the bytes they move by construction (bench.py: the sharded block's real traffic)
     int64_t last_fci_rounds = 0;  // matvec rounds the last ovqe_sector_ground_state needed to saturate the block of |hf>
     int fault_inject = 0;         // option "fault_inject" (tests of the ABI's exception barrier): 1 = the next term-list build throws std::bad_alloc
     int opt_persist_blocks = 2048;
@@ -577,6 +579,8 @@ int run_bilinear(ovqe_handle h, const amp_t *bra, const amp_t *ket, const std::v
     if (rc) return rc;
     rc = ensure(h, h->d_result, 64 * sizeof(double2));
     if (rc) return rc;
+    h->last_passes = nchunks;
+    h->last_pass_bytes = (int64_t)(bytes_per_group * (double)G);
     for (int c = 0; c < nchunks; ++c) {
         const int g0 = c * per_launch, g1 = std::min(G, g0 + per_launch);
         if (hermitian_expectation) {
@@ -994,6 +998,8 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bo
     HIPC(h, hipStreamSynchronize(h->stream));
     *out = h->h_result[0];
     *used = true;
+    h->last_passes = ns + (H.n_rest ? 1 : 0);
+    h->last_pass_bytes = (int64_t)((real ? 8.0 : 16.0) * (double)h->namps * (double)(ns + H.n_rest));
     return OVQE_OK;
 }
 
@@ -3264,6 +3270,8 @@ int ovqe_apply_pauli_rotations(ovqe_handle h, int64_t R, const uint64_t *x, cons
         if (rc) return rc;
     }
     HIPC(h, hipStreamSynchronize(h->stream));
+    h->last_passes = (int64_t)tp.plan.size();               // every step reads and writes the shard once
+    h->last_pass_bytes = (int64_t)(32.0 * (double)h->namps * (double)tp.plan.size());
     return OVQE_OK;
 } OVQE_CATCH(h)
 
@@ -4602,8 +4610,9 @@ int ovqe_program_info(ovqe_handle h, int64_t *info, int count) try {
 
 int ovqe_last_support(ovqe_handle h, int32_t which, int64_t *support) try {
     OVQE_ENTER(h);
-    if (!h || !support || which < 0 || which > 3) return OVQE_ERR_INVALID;
-    *support = which == 0 ? h->last_screen_support : (which == 1 ? h->last_exp_support : (which == 2 ? h->last_screen_sector : h->last_fci_rounds));
+    if (!h || !support || which < 0 || which > 5) return OVQE_ERR_INVALID;
+    const int64_t v[6] = {h->last_screen_support, h->last_exp_support, h->last_screen_sector, h->last_fci_rounds, h->last_passes, h->last_pass_bytes};
+    *support = v[which];
     return OVQE_OK;
 } OVQE_CATCH(h)
 

@@ -63,6 +63,10 @@ class HipShardEngine:
         self.stream = torch.cuda.current_stream(self.device)
         self.sv.set_stream(self.stream.cuda_stream)
         self._subs = {}
+        # what the local kernels really did: passes over the shard (launches that stream it) and the bytes they move by
+        # construction — fused same-x runs and LDS-tiled multi-run sweeps make this smaller than one sweep per rotation
+        self.counters = {"rotations": 0, "rotation_passes": 0, "rotation_bytes": 0, "contraction_calls": 0, "contraction_passes": 0,
+                         "contraction_bytes": 0}
 
     def check_stream(self):
         if torch.cuda.current_stream(self.device).cuda_stream != self.stream.cuda_stream:
@@ -84,11 +88,20 @@ class HipShardEngine:
     def norm2(self):
         return self.sv.norm2()
 
+    def _count(self, what, sv, calls=1):
+        passes, nbytes = sv.last_passes()
+        self.counters[what + "_passes"] += passes
+        self.counters[what + "_bytes"] += nbytes
+        self.counters["rotations" if what == "rotation" else "contraction_calls"] += calls
+
     def rotations(self, xs, zs, phis):
         self.sv.apply_pauli_rotations(xs, zs, phis)
+        self._count("rotation", self.sv, len(xs))
 
     def bilinear(self, xs, zs, coeffs, ket=None):
-        return self.sv.bilinear(xs, zs, coeffs, ket_ptr=None if ket is None else ket.data_ptr())
+        out = self.sv.bilinear(xs, zs, coeffs, ket_ptr=None if ket is None else ket.data_ptr())
+        self._count("contraction", self.sv)
+        return out
 
     def apply_sum(self, xs, zs, coeffs, out, ket=None, accumulate=False):
         self.sv.apply_pauli_sum(xs, zs, coeffs, out.data_ptr(), None if ket is None else ket.data_ptr(), accumulate)
@@ -109,7 +122,9 @@ class HipShardEngine:
         return self._subs[m]
 
     def sub_bilinear(self, m, bra, bra_off, ket, xs, zs, coeffs):
-        return self._sub(m).bilinear(xs, zs, coeffs, bra_ptr=bra.data_ptr() + 16 * bra_off, ket_ptr=ket.data_ptr())
+        out = self._sub(m).bilinear(xs, zs, coeffs, bra_ptr=bra.data_ptr() + 16 * bra_off, ket_ptr=ket.data_ptr())
+        self._count("contraction", self._sub(m))
+        return out
 
     def sub_apply_sum(self, m, out, out_off, ket, xs, zs, coeffs):
         self._sub(m).apply_pauli_sum(xs, zs, coeffs, out.data_ptr() + 16 * out_off, ket.data_ptr(), True)
@@ -138,7 +153,7 @@ class ShardedStatevector:
         self.engine = engine_factory(self.n_local, self.g, self.rank)
         self._dist = dist.is_initialized()
         self.stats = {"swaps": 0, "bytes_sent": 0, "full_shard_reads": 0, "chunk_reads": 0, "partners_per_read": 0, "pieces": 0,
-                      "swap_s": 0.0, "shard_read_s": 0.0, "local_launches": 0, "local_rotations": 0}
+                      "swap_s": 0.0, "shard_read_s": 0.0}
         self._tmp = None
         self._chunk_bufs = None
         self._sigma = None
