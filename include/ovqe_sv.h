@@ -302,7 +302,10 @@ int ovqe_last_support(ovqe_handle h, int32_t which, int64_t *support);
  *   kernel of the most recent sector evaluation; bytes that kernel reads per evaluation
  *   [25] determinants of the block of H (restricted to the support) that the last ovqe_sector_ground_state diagonalised
  *   [26..27] support-compacted program: colliding lane pairs per evaluation (LDS bank conflicts of the circuit's pair
- *   rotations) with the support numbered in discovery order, and with the numbering in use (option "sparse_renumber") */
+ *   rotations) with the support numbered in discovery order, and with the numbering in use (option "sparse_renumber")
+ *   [28..29] sector path on a REGULAR support (the full coset of the program's Z2 symmetries, e.g. the spin-parity quarter of
+ *   the register that the reference's QUCCSD templates populate; option "sector_regular", default 1): slot bits of a circuit
+ *   tile — the sweeps then run from bit arithmetic, without pair words — and the number of free (dependent) index bits; 0 else */
 int ovqe_program_info(ovqe_handle h, int64_t *info, int count);
 
 #ifdef __cplusplus

@@ -340,14 +340,14 @@ class Statevector:
     def program_info(self):
         """shape of the compiled program: ops, rotations, literal gates, sweeps per evaluation, tiled sweeps,
         fused-kernel ops, support size (-1 = not analysed yet)"""
-        out = (ctypes.c_int64 * 28)()
-        self._ck(self._L.ovqe_program_info(self._h, out, 28))
+        out = (ctypes.c_int64 * 30)()
+        self._ck(self._L.ovqe_program_info(self._h, out, 30))
         keys = ("ops", "rotations", "literal_gates", "sweeps", "tiled_sweeps", "fused_ops", "support",
                 "h_tile_sweeps", "h_untiled_groups", "h_entries", "h_merged_terms", "h_pair_terms_per_tile",
                 "real_stream", "sp_ops", "sp_pairs", "sp_h_entries",
                 "sector_support", "sector_sweeps", "sector_pairs", "sector_h_sweeps", "sector_h_elements", "sector_bytes",
                 "sector_circuit_us", "sector_expect_us", "sector_h_stream_bytes", "sector_fci_block",
-                "sp_conflicts_discovery_order", "sp_conflicts")
+                "sp_conflicts_discovery_order", "sp_conflicts", "sector_regular_slot_bits", "sector_free_bits")
         return dict(zip(keys, [int(v) for v in out]))
 
     # -- ADAPT ----------------------------------------------------------------------------------

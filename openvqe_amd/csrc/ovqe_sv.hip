@@ -94,6 +94,9 @@ struct SectorSeg {      // one sweep of the circuit
     DevBuf d_bdst;                // scatter indices into the PREVIOUS sweep's tile-padded order (k_sector_adjoint2)
     DevBuf d_torder;              // tiles by population, largest first (sweeps with many tiles per CU)
     uint32_t maxchunks = 0;
+    DevBuf d_regops;              // regular supports (k_sector_sweep_reg): the sweep's SecRegOp list
+    int nregtab = 0;              // entries of its (c, s) table ...
+    uint32_t regtab0 = 0;         // ... from this entry of the engine's table on
 };
 struct SectorHSweep {   // one sweep of the materialised <H>
     SectorLayout L;
@@ -114,6 +117,11 @@ struct SectorEngine {
     int last_fci_rounds = 0;      // matvec rounds its reachability search took to saturate
     int M = 0, Mh = 0;            // index bits per tile: circuit sweeps, <H> sweeps
     int sb = 13;                  // slot bits of the pair words
+    bool regular = false;         // the support is a full coset of the program's Z2 symmetries and every sweep has its SecRegOp list
+    int reg_m = 0;                // slot bits of a tile then (tile bits minus the free bits)
+    uint32_t freemask = 0;        // the free (dependent) index bits of the coset
+    DevBuf d_regmap, d_regtab;    // table-entry map of all sweeps (angle-table entry | sign << 31, or none), the (c, s) table of the evaluation
+    uint32_t nregtab = 0;
     uint64_t npairs = 0, nnz = 0;
     size_t bytes = 0;
     size_t pad_elems = 0;         // doubles of a state buffer in tile-padded form (largest sweep; 0: no dst tables)
@@ -270,6 +278,8 @@ struct ovqe_sv {
     int opt_screen_sector = 1;        // ADAPT screens: sigma = H psi from the materialised Hamiltonian of psi's symmetry sector (real states)
     int opt_screen_sector_min = 1024; // ... once psi lists at least this many amplitudes
     int opt_sector_eager_rots = 2048; // programs of at most this many rotations build their sector tables at the FIRST evaluation (else the second)
+    int opt_sector_regular = 1;       // supports that are a full coset of the program's Z2 symmetries: sweeps from bit arithmetic, no pair words (k_sector_sweep_reg); 2: such engines build no pair tables at all (energies only)
+    int opt_sector_reg_threads = 256; // workgroup size of those sweeps
     int opt_sector_depth2 = 1;        // first form of the sweeps: two chunks of pair words ahead where every op of a tile fits a staging buffer
     int opt_sector_many_tiles = 1;    // single evaluations with >= 768 tiles: the workgroup shape of the batches (512 threads, scatter indices from memory)
     int opt_sector_h_lpt = 1;         // <H> kernels take the tiles of a sweep largest first
@@ -3033,6 +3043,13 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     else if (k == "sector_h_lpt") h->opt_sector_h_lpt = (int)value;
     else if (k == "sector_many_tiles") h->opt_sector_many_tiles = (int)value;
     else if (k == "sector_depth2") h->opt_sector_depth2 = (int)value;
+    else if (k == "sector_regular") {
+        h->opt_sector_regular = (int)value;
+        free_sector(h->sec);
+        h->sec.disabled = false;
+        h->sec.seen = 0;
+        h->sec.prog_version = -1;
+    } else if (k == "sector_reg_threads") h->opt_sector_reg_threads = value == 512 ? 512 : (value == 1024 ? 1024 : (value == 128 ? 128 : 256));
     else if (k == "sector_eager_rots") h->opt_sector_eager_rots = (int)value;
     else if (k == "screen_sector") h->opt_screen_sector = (int)value;
     else if (k == "screen_tables") h->opt_screen_tables = (int)value;
@@ -4599,12 +4616,14 @@ int ovqe_program_info(ovqe_handle h, int64_t *info, int count) try {
     for (const SmallOp &op : h->ops) v[2] += (op.kind == OP_X || op.kind == OP_H || op.kind == OP_CNOT);
     for (int i = 0; i < count && i < 16; ++i) info[i] = v[i];
     const SectorEngine &E = h->sec;
-    const int64_t sv[12] = {E.valid ? (int64_t)E.K : 0, E.valid ? (int64_t)E.segs.size() : 0, E.valid ? (int64_t)E.npairs : 0,
+    const int64_t sv[14] = {E.valid ? (int64_t)E.K : 0, E.valid ? (int64_t)E.segs.size() : 0, E.valid ? (int64_t)E.npairs : 0,
                            E.valid ? (int64_t)E.hs.size() : 0, E.valid ? (int64_t)E.nnz : 0, E.valid ? (int64_t)E.bytes : 0,
                            E.valid ? (int64_t)(1e3 * E.last_circuit_ms) : 0, E.valid ? (int64_t)(1e3 * E.last_expect_ms) : 0,
                            E.valid ? (int64_t)E.h_stream_bytes : 0, E.valid ? (int64_t)E.last_fci_block : 0,
-                            h->sp_valid ? h->sp_conflicts_before : 0, h->sp_valid ? h->sp_conflicts_after : 0};
-    for (int i = 16; i < count && i < 28; ++i) info[i] = sv[i - 16];
+                            h->sp_valid ? h->sp_conflicts_before : 0, h->sp_valid ? h->sp_conflicts_after : 0,
+                            (E.valid && E.regular && h->opt_sector_regular) ? (int64_t)E.reg_m : 0,
+                            (E.valid && E.regular) ? (int64_t)__builtin_popcount(E.freemask) : 0};
+    for (int i = 16; i < count && i < 30; ++i) info[i] = sv[i - 16];
     return OVQE_OK;
 } OVQE_CATCH(h)
 

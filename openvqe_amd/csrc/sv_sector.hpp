@@ -1649,4 +1649,157 @@ __global__ __launch_bounds__(256) void k_sec_scatter(const double *__restrict__ 
     if (e < K) out[cid[e]] = in[e];
 }
 
+
+// ---- circuit sweeps on a REGULAR support (round 4) ----------------------------------------------------------------------
+// When the support of a program is a full coset of its Z2 symmetries — every rotation string commutes with t independent
+// Z-type operators Z^{g_f} and the states fill the whole common eigenspace: 2^(n-t) amplitudes, e.g. the spin-parity quarter
+// of the register that the reference's QUCCSD templates populate (ref:openvqe/common_files/circuit.py:13-106 do not conserve
+// the particle number) — the pair lists describe a pattern that bit arithmetic gives for free.  g_f has its LOWEST bit f (the
+// "free" bit) to itself, so a member is fixed by its other bits, i_f = s_f ^ parity(i & G_f), G_f = g_f \ {f}; with the free
+// bits inside every sweep's tile bit set S, the sorted tile IS the m = |S| - t bit register of the kept inside bits:
+// slot = pext(i, S \ free), every tile full, partner slot = slot ^ xs.  A thread takes a GROUP — the 2^w slots that differ on
+// the op's w kept mixing bits — into registers, rotates its 2^(w-1) pairs and writes them back: two LDS accesses per amplitude
+// and op, no pair words (the reference's templates at 24 qubits: 14 GB per evaluation), no staging buffers.
+//   sign of a pair  = parity(slot & zin) ^ parity(tile & zt) ^ (bit 31 of its table entry)
+//   selector sigma_f (free bits INSIDE the op's x mask: which member of the pair matches which pattern depends on the value
+//   of the free bit, i.e. on a parity over kept bits outside x) = parity(slot & sel_in[f]) ^ parity(tile & sel_t[f]);
+//   table entry (c, s) of pair q under selector sigma: cs[tab + sigma * 2^(w-1) + q]; (1, 0) where no pattern is active.
+struct SecRegOp {         // 32 dwords, read with scalar loads (uniform per op); the host fills everything
+    uint32_t xs;          // kept mixing bits, slot space (w of them)
+    uint32_t zin, zt;     // sign masks: slot space (outside xs) / tile-number space
+    uint32_t sel_in[2], sel_t[2];
+    uint32_t tab;         // first entry of the op in the sweep's (c, s) table
+    uint32_t w_nsel;      // w | nsel << 16
+    uint32_t gpos[2];     // nibble k = slot position of bit k of the group number (the m - w positions outside xs; see below)
+    uint32_t pad[5];
+    uint32_t dep[8];      // 16-bit halves: swizzled slot offset of member e of a group, e = pattern over the mixing bits (ascending)
+    uint32_t pad2[8];
+};
+static_assert(sizeof(SecRegOp) == 128, "SecRegOp is read as 32 dwords");
+// LDS bank swizzle of a tile of doubles, linear over XOR (swz(a ^ b) = swz(a) ^ swz(b)): a group's members are base ^ spread(e).
+// Slot bit p lands on bank bit p mod 5 (8-byte slots: 32 per LDS cycle for reads, 16 for writes).  The host numbers the groups
+// so that bits 0..4 of the group number — the lanes of a read group — sit on positions of residues 0..4 mod 5 wherever the op's
+// mixing bits leave one free (bits 0..3, the 16 lanes of a write group, on residues 0..3): conflict-free whatever the x mask.
+__host__ __device__ __forceinline__ uint32_t sec_reg_swz(uint32_t v) { return v ^ ((v >> 5) & 31u) ^ ((v >> 10) & 31u); }
+
+__device__ __forceinline__ double sec_flip(double v, uint32_t signbit) {   // v with its sign bit xor-ed (signbit = 0 or 0x80000000)
+    return __hiloint2double(__double2hiint(v) ^ (int)signbit, __double2loint(v));
+}
+
+// Per-evaluation (c, s) table of all sweeps in global memory: entry e = (cos, +-sin) of its angle-table entry, or (1, 0).  The
+// sweeps read an op's entries with SCALAR loads when no selector is involved (they are wave-uniform), so the LDS carries
+// amplitudes only.
+__global__ __launch_bounds__(256) void k_sec_reg_angles(const uint32_t *__restrict__ emap, uint32_t n, const RotParam *__restrict__ rp,
+                                                        double2 *__restrict__ tab) {
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= n) return;
+    const uint32_t m = emap[e];
+    double2 r = make_double2(1.0, 0.0);
+    if (m != 0xffffffffu) {
+        const RotParam rr = rp[m & 0x7fffffffu];
+        r = make_double2(rr.c, (m >> 31) ? -rr.s : rr.s);
+    }
+    tab[e] = r;
+}
+
+template <int NT, int W, int MB, bool SEL>
+__device__ __forceinline__ void sec_reg_apply(double *__restrict__ tile, const double2 *__restrict__ tg, const SecRegOp &op, uint32_t nslots,
+                                              int mbits, uint32_t tnum) {
+    constexpr int NA = 1 << W, NP = NA / 2;
+    const uint32_t tz = __popc(tnum & op.zt) & 1u;
+    const uint32_t nsel = op.w_nsel >> 16;
+    const uint32_t ts0 = SEL ? (__popc(tnum & op.sel_t[0]) & 1u) : 0u, ts1 = (SEL && nsel > 1) ? (__popc(tnum & op.sel_t[1]) & 1u) : 0u;
+    uint32_t dep[NA];
+#pragma unroll
+    for (int e = 0; e < NA; ++e) dep[e] = (op.dep[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+    double2 T[NP];   // wave-uniform entries: scalar registers
+    if constexpr (!SEL) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) T[q] = tg[op.tab + q];
+    }
+    for (uint32_t g = threadIdx.x; g < (nslots >> W); g += NT) {
+        uint32_t b = 0;   // the group's base slot: bit k of g at its position, zeros at the mixing positions
+        if constexpr (MB > 0) {
+#pragma unroll
+            for (int k = 0; k < MB - W; ++k) b |= ((g >> k) & 1u) << ((op.gpos[k >> 3] >> (4 * (k & 7))) & 15u);
+        } else {
+            for (int k = 0; k < mbits - W; ++k) b |= ((g >> k) & 1u) << ((op.gpos[k >> 3] >> (4 * (k & 7))) & 15u);
+        }
+        const uint32_t neg = ((__popc(b & op.zin) & 1u) ^ tz) << 31;
+        const uint32_t sb = sec_reg_swz(b);
+        double a[NA];
+#pragma unroll
+        for (int e = 0; e < NA; ++e) a[e] = tile[sb ^ dep[e]];
+        if constexpr (SEL) {
+            uint32_t sel = (__popc(b & op.sel_in[0]) & 1u) ^ ts0;
+            if (nsel > 1) sel |= ((__popc(b & op.sel_in[1]) & 1u) ^ ts1) << 1;
+            const double2 *Tl = tg + op.tab + sel * NP;   // per-lane entries: vector loads (cached; in flight beside the LDS reads)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) T[q] = Tl[q];
+        }
+        // the group's sign on the second members: (u, sigma v) rotates by the plain (c, s)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const double u = a[q], v = sec_flip(a[NA - 1 - q], neg);
+            a[q] = T[q].x * u + T[q].y * v;
+            a[NA - 1 - q] = sec_flip(T[q].x * v - T[q].y * u, neg);
+        }
+#pragma unroll
+        for (int e = 0; e < NA; ++e) tile[sb ^ dep[e]] = a[e];
+    }
+}
+
+// one sweep: gather the tile from the previous sweep's order (srcpad: tile-padded gather indices; nullptr: |hf> at hf_pos),
+// apply the sweep's ops group by group, write the tile back contiguously (tile t = positions [t 2^m, (t + 1) 2^m) of this
+// sweep's order).  tg = the sweep's part of the (c, s) table (k_sec_reg_angles).
+template <int NT, int MB>
+__global__ __launch_bounds__(NT) void k_sector_sweep_reg(const double *__restrict__ in, double *__restrict__ out,
+                                                         const uint32_t *__restrict__ srcpad, const SecRegOp *__restrict__ ops, int nops,
+                                                         const double2 *__restrict__ tg, int ntab, int mbits, uint32_t hf_pos) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
+    const uint32_t nslots = 1u << mbits, t = blockIdx.x;
+    double *tile = reinterpret_cast<double *>(sec_smem);   // the LDS holds amplitudes only: four 4096-slot tiles per CU
+    const size_t e0 = (size_t)t * nslots;
+    if (srcpad) {
+        const uint32_t *sp = srcpad + e0;
+        for (uint32_t k0 = threadIdx.x; k0 < nslots; k0 += 4 * NT) {   // four gathers in flight per thread
+            uint32_t gi[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gi[r] = k0 + r * NT < nslots ? sp[k0 + r * NT] : 0u;
+            double v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = in[gi[r]];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (k0 + r * NT < nslots) tile[sec_reg_swz(k0 + r * NT)] = v[r];
+        }
+    } else {
+        for (uint32_t k = threadIdx.x; k < nslots; k += NT) tile[sec_reg_swz(k)] = (e0 + k == hf_pos) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    SecRegOp nxt = ops[0];
+    for (int o = 0; o < nops; ++o) {
+        const SecRegOp op = nxt;
+        nxt = ops[o + 1 < nops ? o + 1 : o];   // the next op's record is on its way while this one runs
+        const int w = (int)(op.w_nsel & 0xffffu);
+        if (op.w_nsel >> 16) {
+            switch (w) {
+            case 1: sec_reg_apply<NT, 1, MB, true>(tile, tg, op, nslots, mbits, t); break;
+            case 2: sec_reg_apply<NT, 2, MB, true>(tile, tg, op, nslots, mbits, t); break;
+            case 3: sec_reg_apply<NT, 3, MB, true>(tile, tg, op, nslots, mbits, t); break;
+            default: sec_reg_apply<NT, 4, MB, true>(tile, tg, op, nslots, mbits, t); break;
+            }
+        } else {
+            switch (w) {
+            case 1: sec_reg_apply<NT, 1, MB, false>(tile, tg, op, nslots, mbits, t); break;
+            case 2: sec_reg_apply<NT, 2, MB, false>(tile, tg, op, nslots, mbits, t); break;
+            case 3: sec_reg_apply<NT, 3, MB, false>(tile, tg, op, nslots, mbits, t); break;
+            default: sec_reg_apply<NT, 4, MB, false>(tile, tg, op, nslots, mbits, t); break;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    for (uint32_t k = threadIdx.x; k < nslots; k += NT) out[e0 + k] = tile[sec_reg_swz(k)];
+}
+
 }  // namespace ovqe

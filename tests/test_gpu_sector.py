@@ -269,9 +269,23 @@ def test_sector_on_the_reference_quccsd_templates(SV, m, o):
         got = [sv.energy(th) for th in thetas]
         info = sv.program_info()
         eg = [sv.energy_gradient(th) for th in thetas[1:]]
+        # the support is the full coset of the two spin parities: the sweeps run from bit arithmetic (k_sector_sweep_reg) —
+        # against the pair-word sweeps of the same tables, other workgroup sizes and other tile sizes
+        variants = {}
+        for name, opts in (("pair_words", {"sector_regular": 0}), ("threads_512", {"sector_regular": 1, "sector_reg_threads": 512}),
+                           ("threads_128", {"sector_reg_threads": 128}), ("bits_10", {"sector_reg_threads": 256, "sector_bits": 10}),
+                           ("bits_8", {"sector_bits": 8})):
+            for k, v in opts.items():
+                sv.set_option(k, v)
+            variants[name] = ([sv.energy(th) for th in thetas], sv.program_info())
+        sv.set_option("sector_bits", 0)
         sv.set_option("sector", 0)
         eg_dense = [sv.energy_gradient(th) for th in thetas[1:]]
     assert 0 < info["sector_support"] <= (1 << n) // 4 and info["sector_h_elements"] > 0, info
+    assert info["sector_support"] == (1 << n) // 4 and info["sector_free_bits"] == 2 and info["sector_regular_slot_bits"] > 0, info
+    assert variants["pair_words"][1]["sector_regular_slot_bits"] == 0 and variants["bits_8"][1]["sector_regular_slot_bits"] == 6
+    for name, (es, _) in variants.items():
+        assert np.abs(np.array(es) - np.array(got)).max() < 1e-13 * max(1.0, l1), name
     for e, ew in zip(got, want):
         assert abs(e - ew) < 1e-10 * max(1.0, l1)
     for (e, g), (ed, gd), ew in zip(eg, eg_dense, want[1:]):

@@ -16,7 +16,7 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"].split("(")[0][:50]
         a = acc[k][r["Counter_Name"]]
         a[0] += 1; a[1] += float(r["Counter_Value"])
-for k, d in sorted(acc.items(), key=lambda kv: -sum(v[1] for v in kv[1].values()))[:8]:
+for k, d in sorted(acc.items(), key=lambda kv: -sum(v[1] for v in kv[1].values()))[:40]:
     print(k, {c: (n, round(v / n, 1)) for c, (n, v) in d.items()})
 PY
 rm -rf $OUT/pmc
