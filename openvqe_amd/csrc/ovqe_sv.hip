@@ -94,7 +94,7 @@ struct SectorSeg {      // one sweep of the circuit
     DevBuf d_bdst;                // scatter indices into the PREVIOUS sweep's tile-padded order (k_sector_adjoint2)
     DevBuf d_torder;              // tiles by population, largest first (sweeps with many tiles per CU)
     uint32_t maxchunks = 0;
-    DevBuf d_regops;              // regular supports (k_sector_sweep_reg): the sweep's SecRegOp list
+    DevBuf d_regops, d_reggw;     // regular supports (k_sector_sweep_reg): the sweep's SecRegOp list, its group words
     int nregtab = 0;              // entries of its (c, s) table ...
     uint32_t regtab0 = 0;         // ... from this entry of the engine's table on
 };

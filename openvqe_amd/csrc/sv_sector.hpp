@@ -1664,16 +1664,22 @@ __global__ __launch_bounds__(256) void k_sec_scatter(const double *__restrict__ 
 //   selector sigma_f (free bits INSIDE the op's x mask: which member of the pair matches which pattern depends on the value
 //   of the free bit, i.e. on a parity over kept bits outside x) = parity(slot & sel_in[f]) ^ parity(tile & sel_t[f]);
 //   table entry (c, s) of pair q under selector sigma: cs[tab + sigma * 2^(w-1) + q]; (1, 0) where no pattern is active.
-struct SecRegOp {         // 32 dwords, read with scalar loads (uniform per op); the host fills everything
-    uint32_t xs;          // kept mixing bits, slot space (w of them)
-    uint32_t zin, zt;     // sign masks: slot space (outside xs) / tile-number space
-    uint32_t sel_in[2], sel_t[2];
-    uint32_t tab;         // first entry of the op in the sweep's (c, s) table
+struct SecRegOp {         // 32 dwords; the first 16 are what the sweep kernel reads (scalar loads, uniform per op), the host fills everything
     uint32_t w_nsel;      // w | nsel << 16
+    uint32_t zt;          // sign mask in tile-number space
+    uint32_t sel_t[2];    // selector masks in tile-number space
+    uint32_t dep[8];      // 16-bit halves: BYTE offset (swizzled) of member e of a group, e = pattern over the mixing bits (ascending)
+    uint32_t pad[4];
+    // host side (the group words carry their effect)
+    uint32_t xs;          // kept mixing bits, slot space (w of them)
+    uint32_t zin;         // sign mask, slot space (outside xs)
+    uint32_t sel_in[2];   // selector masks, slot space
+    uint32_t tab;         // first entry of the op in the sweep's (c, s) table (= 8 x its number)
     uint32_t gpos[2];     // nibble k = slot position of bit k of the group number (the m - w positions outside xs; see below)
-    uint32_t pad[5];
-    uint32_t dep[8];      // 16-bit halves: swizzled slot offset of member e of a group, e = pattern over the mixing bits (ascending)
-    uint32_t pad2[8];
+    uint32_t pad2[9];
+};
+struct SecRegHead {       // the kernel's view of a record
+    uint32_t w_nsel, zt, sel_t[2], dep[8];
 };
 static_assert(sizeof(SecRegOp) == 128, "SecRegOp is read as 32 dwords");
 // LDS bank swizzle of a tile of doubles, linear over XOR (swz(a ^ b) = swz(a) ^ swz(b)): a group's members are base ^ spread(e).
@@ -1702,63 +1708,66 @@ __global__ __launch_bounds__(256) void k_sec_reg_angles(const uint32_t *__restri
     tab[e] = r;
 }
 
-template <int NT, int W, int MB, bool SEL>
-__device__ __forceinline__ void sec_reg_apply(double *__restrict__ tile, const double2 *__restrict__ tg, const SecRegOp &op, uint32_t nslots,
-                                              int mbits, uint32_t tnum) {
+// group words (host-built, SEC_REG_GSTRIDE per op): bits 0..15 = BYTE address of the group's swizzled base slot, bit 16 = its
+// parity on zin, bits 17 / 18 = its parities on sel_in[0] / sel_in[1] — the whole per-group index arithmetic is one load.
+// (c, s) table: SEC_REG_TSTRIDE = 8 entries per op — 2^nsel variants of 2^(w-1) pairs, and w + nsel <= 4 — read with scalar loads.
+constexpr uint32_t SEC_REG_GSTRIDE = 2048;   // words per op: the groups of a one-bit op in a 4096-slot tile
+constexpr uint32_t SEC_REG_TSTRIDE = 8;
+template <int NT, int W, int NSEL>
+__device__ __forceinline__ void sec_reg_apply(double *__restrict__ tile, const double2 *__restrict__ T, const SecRegHead &op, uint32_t nslots,
+                                              uint32_t tnum, int dbg, const uint32_t *__restrict__ gwo, uint32_t wd0, uint32_t wd1) {
     constexpr int NA = 1 << W, NP = NA / 2;
+    static_assert((NP << NSEL) <= 8, "an op has at most 8 table entries");
     const uint32_t tz = __popc(tnum & op.zt) & 1u;
-    const uint32_t nsel = op.w_nsel >> 16;
-    const uint32_t ts0 = SEL ? (__popc(tnum & op.sel_t[0]) & 1u) : 0u, ts1 = (SEL && nsel > 1) ? (__popc(tnum & op.sel_t[1]) & 1u) : 0u;
-    uint32_t dep[NA];
+    const uint32_t ts0 = NSEL > 0 ? (__popc(tnum & op.sel_t[0]) & 1u) : 0u, ts1 = NSEL > 1 ? (__popc(tnum & op.sel_t[1]) & 1u) : 0u;
+    uint32_t dep[NA];   // byte offsets of the members (wave-uniform)
 #pragma unroll
     for (int e = 0; e < NA; ++e) dep[e] = (op.dep[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-    double2 T[NP];   // wave-uniform entries: scalar registers
-    if constexpr (!SEL) {
-#pragma unroll
-        for (int q = 0; q < NP; ++q) T[q] = tg[op.tab + q];
-    }
-    for (uint32_t g = threadIdx.x; g < (nslots >> W); g += NT) {
-        uint32_t b = 0;   // the group's base slot: bit k of g at its position, zeros at the mixing positions
-        if constexpr (MB > 0) {
-#pragma unroll
-            for (int k = 0; k < MB - W; ++k) b |= ((g >> k) & 1u) << ((op.gpos[k >> 3] >> (4 * (k & 7))) & 15u);
-        } else {
-            for (int k = 0; k < mbits - W; ++k) b |= ((g >> k) & 1u) << ((op.gpos[k >> 3] >> (4 * (k & 7))) & 15u);
-        }
-        const uint32_t neg = ((__popc(b & op.zin) & 1u) ^ tz) << 31;
-        const uint32_t sb = sec_reg_swz(b);
+    char *tb = reinterpret_cast<char *>(tile);
+    for (uint32_t g = threadIdx.x, it = 0; g < (nslots >> W); g += NT, ++it) {
+        const uint32_t wd = it == 0 ? wd0 : (it == 1 ? wd1 : gwo[g]);   // (the first two arrived under the previous op's barrier)
+        const uint32_t sb = wd & 0xffffu;
+        const uint32_t neg = (((wd >> 16) & 1u) ^ tz) << 31;
         double a[NA];
 #pragma unroll
-        for (int e = 0; e < NA; ++e) a[e] = tile[sb ^ dep[e]];
-        if constexpr (SEL) {
-            uint32_t sel = (__popc(b & op.sel_in[0]) & 1u) ^ ts0;
-            if (nsel > 1) sel |= ((__popc(b & op.sel_in[1]) & 1u) ^ ts1) << 1;
-            const double2 *Tl = tg + op.tab + sel * NP;   // per-lane entries: vector loads (cached; in flight beside the LDS reads)
+        for (int e = 0; e < NA; ++e) a[e] = *reinterpret_cast<const double *>(tb + (sb ^ dep[e]));
+        // this group's table entries: the op's 2^(w-1) pairs, of the variant its selector picks (a uniform address without selector)
+        uint32_t sel = 0;
+        if constexpr (NSEL > 0) sel = ((wd >> 17) & 1u) ^ ts0;
+        if constexpr (NSEL > 1) sel |= (((wd >> 18) & 1u) ^ ts1) << 1;
+        const double2 *Tl = T + sel * NP;
+        double2 r[NP];
 #pragma unroll
-            for (int q = 0; q < NP; ++q) T[q] = Tl[q];
-        }
+        for (int q = 0; q < NP; ++q) r[q] = Tl[q];
         // the group's sign on the second members: (u, sigma v) rotates by the plain (c, s)
+        if (dbg != 2)   // (measurement: 2 = no arithmetic, 3 = no stores)
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const double u = a[q], v = sec_flip(a[NA - 1 - q], neg);
-            a[q] = T[q].x * u + T[q].y * v;
-            a[NA - 1 - q] = sec_flip(T[q].x * v - T[q].y * u, neg);
+            a[q] = r[q].x * u + r[q].y * v;
+            a[NA - 1 - q] = sec_flip(r[q].x * v - r[q].y * u, neg);
         }
+        if (dbg != 3)
 #pragma unroll
-        for (int e = 0; e < NA; ++e) tile[sb ^ dep[e]] = a[e];
+        for (int e = 0; e < NA; ++e) *reinterpret_cast<double *>(tb + (sb ^ dep[e])) = a[e];
     }
 }
 
 // one sweep: gather the tile from the previous sweep's order (srcpad: tile-padded gather indices; nullptr: |hf> at hf_pos),
 // apply the sweep's ops group by group, write the tile back contiguously (tile t = positions [t 2^m, (t + 1) 2^m) of this
-// sweep's order).  tg = the sweep's part of the (c, s) table (k_sec_reg_angles).
-template <int NT, int MB>
+// sweep's order).  tg = the sweep's part of the (c, s) table (k_sec_reg_angles: 8 entries per op), staged in LDS behind the
+// tile — an op's entries are read next to its amplitudes, by every lane from the address its selector gives —; gw = the sweep's
+// group words.  What an op waits for is its LDS traffic only: the record of op o + 1 and this thread's first two group words of it
+// are requested while op o runs.
+template <int NT>
 __global__ __launch_bounds__(NT) void k_sector_sweep_reg(const double *__restrict__ in, double *__restrict__ out,
                                                          const uint32_t *__restrict__ srcpad, const SecRegOp *__restrict__ ops, int nops,
-                                                         const double2 *__restrict__ tg, int ntab, int mbits, uint32_t hf_pos) {
+                                                         const uint32_t *__restrict__ gw, const double2 *__restrict__ tg, int mbits,
+                                                         uint32_t hf_pos, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
     const uint32_t nslots = 1u << mbits, t = blockIdx.x;
-    double *tile = reinterpret_cast<double *>(sec_smem);   // the LDS holds amplitudes only: four 4096-slot tiles per CU
+    double *tile = reinterpret_cast<double *>(sec_smem);
+    double2 *cs = reinterpret_cast<double2 *>(tile + nslots);   // [nops][8]
     const size_t e0 = (size_t)t * nslots;
     if (srcpad) {
         const uint32_t *sp = srcpad + e0;
@@ -1776,28 +1785,33 @@ __global__ __launch_bounds__(NT) void k_sector_sweep_reg(const double *__restric
     } else {
         for (uint32_t k = threadIdx.x; k < nslots; k += NT) tile[sec_reg_swz(k)] = (e0 + k == hf_pos) ? 1.0 : 0.0;
     }
+    for (uint32_t e = threadIdx.x; e < (uint32_t)nops * SEC_REG_TSTRIDE; e += NT) cs[e] = tg[e];
     __syncthreads();
-    SecRegOp nxt = ops[0];
-    for (int o = 0; o < nops; ++o) {
-        const SecRegOp op = nxt;
-        nxt = ops[o + 1 < nops ? o + 1 : o];   // the next op's record is on its way while this one runs
-        const int w = (int)(op.w_nsel & 0xffffu);
-        if (op.w_nsel >> 16) {
-            switch (w) {
-            case 1: sec_reg_apply<NT, 1, MB, true>(tile, tg, op, nslots, mbits, t); break;
-            case 2: sec_reg_apply<NT, 2, MB, true>(tile, tg, op, nslots, mbits, t); break;
-            case 3: sec_reg_apply<NT, 3, MB, true>(tile, tg, op, nslots, mbits, t); break;
-            default: sec_reg_apply<NT, 4, MB, true>(tile, tg, op, nslots, mbits, t); break;
+    if (nops > 0) {
+        SecRegHead cur = *reinterpret_cast<const SecRegHead *>(ops);
+        uint32_t wd0 = gw[threadIdx.x], wd1 = gw[threadIdx.x + NT];
+        for (int o = 0; o < nops; ++o) {
+            const int on = o + 1 < nops ? o + 1 : o;
+            const SecRegHead nxt = *reinterpret_cast<const SecRegHead *>(ops + on);
+            const uint32_t nw0 = gw[(size_t)on * SEC_REG_GSTRIDE + threadIdx.x], nw1 = gw[(size_t)on * SEC_REG_GSTRIDE + threadIdx.x + NT];
+            const uint32_t *gwo = gw + (size_t)o * SEC_REG_GSTRIDE;
+            const double2 *T = cs + (size_t)o * SEC_REG_TSTRIDE;
+            switch (cur.w_nsel) {
+            case 4: sec_reg_apply<NT, 4, 0>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
+            case 3: sec_reg_apply<NT, 3, 0>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
+            case 3 | (1 << 16): sec_reg_apply<NT, 3, 1>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
+            case 2: sec_reg_apply<NT, 2, 0>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
+            case 2 | (1 << 16): sec_reg_apply<NT, 2, 1>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
+            case 2 | (2 << 16): sec_reg_apply<NT, 2, 2>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
+            case 1: sec_reg_apply<NT, 1, 0>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
+            case 1 | (1 << 16): sec_reg_apply<NT, 1, 1>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
+            default: sec_reg_apply<NT, 1, 2>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
             }
-        } else {
-            switch (w) {
-            case 1: sec_reg_apply<NT, 1, MB, false>(tile, tg, op, nslots, mbits, t); break;
-            case 2: sec_reg_apply<NT, 2, MB, false>(tile, tg, op, nslots, mbits, t); break;
-            case 3: sec_reg_apply<NT, 3, MB, false>(tile, tg, op, nslots, mbits, t); break;
-            default: sec_reg_apply<NT, 4, MB, false>(tile, tg, op, nslots, mbits, t); break;
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            cur = nxt;
+            wd0 = nw0;
+            wd1 = nw1;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     for (uint32_t k = threadIdx.x; k < nslots; k += NT) out[e0 + k] = tile[sec_reg_swz(k)];
 }

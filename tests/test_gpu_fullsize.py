@@ -171,9 +171,11 @@ def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
     """BASELINE configs[3] at its size AND on its molecule: N2 / cc-pVDZ, (10 electrons, 12 orbitals) active space = 24 qubits
     (integrals, RHF and frozen core from the in-repo front-end).  The literal QUCCSD gate list
     (ref:openvqe/common_files/circuit.py:13-106 templates on every 5th cluster operator in the reference's operator order:
-    343 parameters, ~13 k gates) against the plain-C oracle's gate-by-gate execution (orc_gate_energy: 256-MiB host
-    state) — energy on the molecule's JW Hamiltonian and sampled amplitudes, for the three forms the backend can run it in:
-    literal LDS-tiled sweeps, Clifford-frame form on real-amplitude streams, Clifford-frame form on the complex state."""
+    343 parameters, ~13 k gates) against the plain-C oracle's gate-by-gate execution (256-MiB host state) — energy on the
+    molecule's FULL 6464-term JW Hamiltonian and sampled amplitudes, for the three forms the backend can run it in: literal
+    LDS-tiled sweeps, Clifford-frame form on real-amplitude streams (the third evaluation comes from the sector tables on the
+    2^22 spin-parity support: asserted), Clifford-frame form on the complex state; three components of ovqe_energy_gradient
+    on the gate program against central differences of the oracle."""
     from openvqe_amd import chem
     from openvqe_amd.backend import GATE_OPCODES, Statevector
     from openvqe_amd.common_files.circuit import quccsd_gate_list
@@ -188,19 +190,37 @@ def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
     stride = 5
     gates, K, hf2 = quccsd_gate_list(12, 5, stride, excitations=[op.terms[0].qbits for op in cluster_ops])
     assert K == 343 and hf2 == hf and len(gates) > 10000
-    full = prob.jw_hamiltonian()
-    # every 3rd of the 6464 JW terms: the oracle evaluates term by term
-    ham = Hamiltonian(n, full.terms[::3], full.constant_coeff, do_clean_up=False)
+    ham = prob.jw_hamiltonian()                  # the FULL 6464-term Hamiltonian (the oracle sums it x-group by x-group)
     rng = np.random.default_rng(2424)
     theta = np.array(theta_mp2[::stride]) + rng.uniform(-0.05, 0.05, K)      # MP2 amplitudes + noise: no parameter is zero
-    hx, hz, hc = ham.packed()
-    hc = np.ascontiguousarray(hc.real)
+    hx, hz, hc = cref.sort_by_x(*[np.asarray(a) for a in (ham.packed()[0], ham.packed()[1], ham.packed()[2].real.copy())])
     opc = [GATE_OPCODES[g[0]] for g in gates]
     b0 = [n - 1 - g[1][0] for g in gates]
     b1 = [n - 1 - g[1][1] if len(g[1]) > 1 else 0 for g in gates]
-    e_ref, psi_ref = cref.gate_energy(n, hf, opc, b0, b1, [g[2] for g in gates], [g[3] for g in gates],
-                                      [g[4] for g in gates], theta, hx, hz, hc, ham.constant_coeff)
+    asc, aco, gpi = [g[2] for g in gates], [g[3] for g in gates], [g[4] for g in gates]
+    # oracle: the gates before the first gate of the last three parameters once (gate by gate, 256-MiB host state), then the
+    # tail — for the reference state and for the six shifted parameter vectors of three central differences
+    L = cref.lib()
+    none = np.zeros(0, np.uint64)
+    g_tail = min(g for g, p in enumerate(gpi) if p >= K - 3)
+    _, psi_prefix = cref.gate_energy(n, hf, opc[:g_tail], b0[:g_tail], b1[:g_tail], asc[:g_tail], aco[:g_tail], gpi[:g_tail], theta,
+                                     none, none, np.zeros(0), 0.0)
+
+    def oracle_tail(th):
+        psi = psi_prefix.copy()
+        for g in range(g_tail, len(gates)):
+            L.orc_apply_gate(psi, n, opc[g], b0[g], b1[g], aco[g] + (asc[g] * th[gpi[g]] if gpi[g] >= 0 else 0.0))
+        return L.orc_expectation_grouped(psi, n, len(hx), hx, hz, hc) + ham.constant_coeff, psi
+
+    e_ref, psi_ref = oracle_tail(theta)
     assert abs(np.vdot(psi_ref, psi_ref).real - 1.0) < 1e-10
+    fd_h = 1e-4
+    g_ref = {}
+    for k in (K - 3, K - 2, K - 1):
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += fd_h
+        tm[k] -= fd_h
+        g_ref[k] = (oracle_tail(tp)[0] - oracle_tail(tm)[0]) / (2 * fd_h)
     big = np.argsort(-np.abs(psi_ref))[:3000].astype(np.uint64)           # the amplitudes that carry the state
     idx = np.concatenate([big, rng.integers(0, 1 << n, 5000).astype(np.uint64)])
     want = psi_ref[idx.astype(np.int64)]
@@ -214,24 +234,38 @@ def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
             sv.set_gate_program(gates, K, hf)
             info = sv.program_info()
             e = sv.energy(theta)
-            e_again = sv.energy(theta)                                    # second call: compact cover where it applies
+            e_again = sv.energy(theta)                                    # second call: builds the sector tables / compact cover where they apply
+            e_third = sv.energy(theta)                                    # third call: an evaluation that comes FROM the tables
+            info_after = sv.program_info()
+            grad = sv.energy_gradient(theta) if label == "frame_real" else None
             sv.prepare_state(theta)
-            res[label] = (e, sv.get_amplitudes(idx), sv.norm2(), info, e_again)
+            res[label] = (e, sv.get_amplitudes(idx), sv.norm2(), info, e_again, e_third, info_after, grad)
     assert res["literal_tiled"][3]["literal_gates"] > 0 and res["literal_tiled"][3]["tiled_sweeps"] > 0
     assert res["literal_tiled"][3]["real_stream"] == 0
     assert res["frame_real"][3]["literal_gates"] == 0 and res["frame_real"][3]["real_stream"] == 1
     assert res["frame_complex"][3]["real_stream"] == 0
-    for label, (e, amps, n2, _, e_again) in res.items():
+    # the product's default path for configs[3]: sector tables on the 2^22 spin-parity support, sweeps from bit arithmetic
+    after = res["frame_real"][6]
+    assert after["sector_support"] == 1 << 22 and after["sector_h_elements"] > 0, after
+    assert after["sector_free_bits"] == 2 and after["sector_regular_slot_bits"] > 0, after
+    for label, (e, amps, n2, _, e_again, e_third, _, _) in res.items():
         assert abs(e - e_ref) < 1e-10 * max(1.0, l1), (label, e, e_ref)
         assert abs(e_again - e_ref) < 1e-10 * max(1.0, l1), (label, e_again, e_ref)
+        assert abs(e_third - e_ref) < 1e-10 * max(1.0, l1), (label, e_third, e_ref)
         assert np.abs(amps - want).max() < 1e-12, label
         assert abs(n2 - 1.0) < 1e-11, label
+    # ovqe_energy_gradient on the gate program (adjoint pass on the sector tables) against central differences of the oracle
+    e_g, g_gpu = res["frame_real"][7]
+    assert abs(e_g - e_ref) < 1e-10 * max(1.0, l1)
+    for k, want_g in g_ref.items():
+        assert abs(g_gpu[k] - want_g) < 2e-7 * max(1.0, l1), (k, g_gpu[k], want_g)
     # the whole list (1715 parameters, ~63 k gates): its Clifford part is ~49 k gates long and still has to be recognised as
     # closed (the rounding of that many quarter turns once sent it down the literal path); frame form == literal form
     gates, K, _ = quccsd_gate_list(12, 5, 1, excitations=[op.terms[0].qbits for op in cluster_ops])
     assert K == size == 1715
     theta = np.array(theta_mp2)
     idx = idx[:2000]
+    full = ham
     with Statevector(n) as sv:
         sv.set_hamiltonian(full)
         out = {}
