@@ -95,6 +95,8 @@ struct SectorSeg {      // one sweep of the circuit
     DevBuf d_torder;              // tiles by population, largest first (sweeps with many tiles per CU)
     uint32_t maxchunks = 0;
     DevBuf d_regops, d_reggw;     // regular supports (k_sector_sweep_reg): the sweep's SecRegOp list, its group words
+    uint32_t reg_kept = 0;        // its kept inside bits (index space; slot = pext(index, reg_kept))
+    DevBuf d_regsrc, d_reggslot, d_regoslot;   // gather in RUNS: source position / slot of gather step j; slot stored at position j (see k_sector_sweep_reg)
     int nregtab = 0;              // entries of its (c, s) table ...
     uint32_t regtab0 = 0;         // ... from this entry of the engine's table on
 };
@@ -280,6 +282,7 @@ struct ovqe_sv {
     int opt_sector_eager_rots = 2048; // programs of at most this many rotations build their sector tables at the FIRST evaluation (else the second)
     int opt_sector_regular = 1;       // supports that are a full coset of the program's Z2 symmetries: sweeps from bit arithmetic, no pair words (k_sector_sweep_reg); 2: such engines build no pair tables at all (energies only)
     int opt_sector_reg_threads = 256; // workgroup size of those sweeps
+    int opt_sector_reg_pairs = 1;     // two consecutive three-bit ops that share two bits run as one 16-slot block
     int opt_sector_depth2 = 1;        // first form of the sweeps: two chunks of pair words ahead where every op of a tile fits a staging buffer
     int opt_sector_many_tiles = 1;    // single evaluations with >= 768 tiles: the workgroup shape of the batches (512 threads, scatter indices from memory)
     int opt_sector_h_lpt = 1;         // <H> kernels take the tiles of a sweep largest first
@@ -3045,6 +3048,12 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     else if (k == "sector_depth2") h->opt_sector_depth2 = (int)value;
     else if (k == "sector_regular") {
         h->opt_sector_regular = (int)value;
+        free_sector(h->sec);
+        h->sec.disabled = false;
+        h->sec.seen = 0;
+        h->sec.prog_version = -1;
+    } else if (k == "sector_reg_pairs") {
+        h->opt_sector_reg_pairs = (int)value;
         free_sector(h->sec);
         h->sec.disabled = false;
         h->sec.seen = 0;

@@ -1680,6 +1680,8 @@ struct SecRegOp {         // 32 dwords; the first 16 are what the sweep kernel r
 };
 struct SecRegHead {       // the kernel's view of a record
     uint32_t w_nsel, zt, sel_t[2], dep[8];
+    uint32_t pad[4];      // a block of two ops (w_nsel bit 24): [0] = whether own B sits on A's sign / selector mask (bits 0, 1), own A on B's
+                          // (bits 2, 3); [1], [2] = zt, sel_t[0] of op B
 };
 static_assert(sizeof(SecRegOp) == 128, "SecRegOp is read as 32 dwords");
 // LDS bank swizzle of a tile of doubles, linear over XOR (swz(a ^ b) = swz(a) ^ swz(b)): a group's members are base ^ spread(e).
@@ -1753,6 +1755,61 @@ __device__ __forceinline__ void sec_reg_apply(double *__restrict__ tile, const d
     }
 }
 
+// A BLOCK of two consecutive ops A, B with three kept mixing bits each, two of them shared (the reference's doubles are listed with
+// three of their four indices running slowest): the 16 slots over (shared 0, shared 1, own A, own B) in registers, A on the two
+// halves own B = 0 / 1, then B on the two halves own A = 0 / 1 — one read and one write of the tile, one barrier, for two ops.
+// Group word: bit 16 / 17 = A's sign / selector parity of the base slot, 18 / 19 = B's.
+template <int NT, int NSEL>
+__device__ __forceinline__ void sec_reg_apply_pair(double *__restrict__ tile, const double2 *__restrict__ TA, const double2 *__restrict__ TB,
+                                                   const SecRegHead &op, uint32_t nslots, uint32_t tnum, int dbg,
+                                                   const uint32_t *__restrict__ gwo, uint32_t wd0, uint32_t wd1) {
+    const uint32_t fl = op.pad[0];
+    const uint32_t tzA = __popc(tnum & op.zt) & 1u, tzB = __popc(tnum & op.pad[1]) & 1u;
+    const uint32_t tsA = NSEL ? (__popc(tnum & op.sel_t[0]) & 1u) : 0u, tsB = NSEL ? (__popc(tnum & op.pad[2]) & 1u) : 0u;
+    uint32_t dep[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dep[e] = (op.dep[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+    char *tb = reinterpret_cast<char *>(tile);
+    for (uint32_t g = threadIdx.x, it = 0; g < (nslots >> 4); g += NT, ++it) {
+        const uint32_t wd = it == 0 ? wd0 : (it == 1 ? wd1 : gwo[g]);
+        const uint32_t sb = wd & 0xffffu;
+        double a[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] = *reinterpret_cast<const double *>(tb + (sb ^ dep[e]));
+        if (dbg != 2) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {   // op A on the half own B = v: members 8 v + (shared, own A)
+                const uint32_t neg = (((wd >> 16) & 1u) ^ tzA ^ ((uint32_t)v & fl)) << 31;
+                const uint32_t sel = NSEL ? (((wd >> 17) & 1u) ^ tsA ^ ((uint32_t)v & (fl >> 1))) & 1u : 0u;
+                const double2 *Tl = TA + sel * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double2 r = Tl[q];
+                    const double u = a[8 * v + q], w = sec_flip(a[8 * v + 7 - q], neg);
+                    a[8 * v + q] = r.x * u + r.y * w;
+                    a[8 * v + 7 - q] = sec_flip(r.x * w - r.y * u, neg);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {   // op B on the half own A = v: pairs (shared = q, own B = 0) <-> (shared = ~q, own B = 1)
+                const uint32_t neg = (((wd >> 18) & 1u) ^ tzB ^ ((uint32_t)v & (fl >> 2))) << 31;
+                const uint32_t sel = NSEL ? (((wd >> 19) & 1u) ^ tsB ^ ((uint32_t)v & (fl >> 3))) & 1u : 0u;
+                const double2 *Tl = TB + sel * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double2 r = Tl[q];
+                    const double u = a[4 * v + q], w = sec_flip(a[4 * v + 11 - q], neg);
+                    a[4 * v + q] = r.x * u + r.y * w;
+                    a[4 * v + 11 - q] = sec_flip(r.x * w - r.y * u, neg);
+                }
+            }
+        }
+        if (dbg != 3)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) *reinterpret_cast<double *>(tb + (sb ^ dep[e])) = a[e];
+    }
+}
+
 // one sweep: gather the tile from the previous sweep's order (srcpad: tile-padded gather indices; nullptr: |hf> at hf_pos),
 // apply the sweep's ops group by group, write the tile back contiguously (tile t = positions [t 2^m, (t + 1) 2^m) of this
 // sweep's order).  tg = the sweep's part of the (c, s) table (k_sec_reg_angles: 8 entries per op), staged in LDS behind the
@@ -1763,24 +1820,33 @@ template <int NT>
 __global__ __launch_bounds__(NT) void k_sector_sweep_reg(const double *__restrict__ in, double *__restrict__ out,
                                                          const uint32_t *__restrict__ srcpad, const SecRegOp *__restrict__ ops, int nops,
                                                          const uint32_t *__restrict__ gw, const double2 *__restrict__ tg, int mbits,
-                                                         uint32_t hf_pos, int dbg) {
+                                                         uint32_t hf_pos, int dbg, const uint16_t *__restrict__ gslot,
+                                                         const uint16_t *__restrict__ oslot) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
     const uint32_t nslots = 1u << mbits, t = blockIdx.x;
     double *tile = reinterpret_cast<double *>(sec_smem);
     double2 *cs = reinterpret_cast<double2 *>(tile + nslots);   // [nops][8]
     const size_t e0 = (size_t)t * nslots;
     if (srcpad) {
+        // gather step j takes slot gslot[j] from position srcpad[j] of the previous sweep's buffer (gslot == nullptr: slot j).  The
+        // host orders the steps — and the previous sweep its stores (oslot) — by the kept bits the two sweeps SHARE, lowest first:
+        // consecutive steps read consecutive positions in runs of 2^|shared| (10 or 11 of the 12 slot bits for the reference's
+        // QUCCSD list) instead of 8 bytes per 64-byte line
         const uint32_t *sp = srcpad + e0;
         for (uint32_t k0 = threadIdx.x; k0 < nslots; k0 += 4 * NT) {   // four gathers in flight per thread
-            uint32_t gi[4];
+            uint32_t gi[4], ks[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gi[r] = k0 + r * NT < nslots ? sp[k0 + r * NT] : 0u;
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t j = k0 + r * NT < nslots ? k0 + r * NT : 0u;
+                gi[r] = sp[j];
+                ks[r] = gslot ? (uint32_t)gslot[j] : j;
+            }
             double v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = in[gi[r]];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (k0 + r * NT < nslots) tile[sec_reg_swz(k0 + r * NT)] = v[r];
+                if (k0 + r * NT < nslots) tile[sec_reg_swz(ks[r])] = v[r];
         }
     } else {
         for (uint32_t k = threadIdx.x; k < nslots; k += NT) tile[sec_reg_swz(k)] = (e0 + k == hf_pos) ? 1.0 : 0.0;
@@ -1790,13 +1856,16 @@ __global__ __launch_bounds__(NT) void k_sector_sweep_reg(const double *__restric
     if (nops > 0) {
         SecRegHead cur = *reinterpret_cast<const SecRegHead *>(ops);
         uint32_t wd0 = gw[threadIdx.x], wd1 = gw[threadIdx.x + NT];
-        for (int o = 0; o < nops; ++o) {
-            const int on = o + 1 < nops ? o + 1 : o;
+        for (int o = 0; o < nops;) {
+            const int step = (cur.w_nsel >> 24) ? 2 : 1;   // a block of two ops
+            const int on = o + step < nops ? o + step : o;
             const SecRegHead nxt = *reinterpret_cast<const SecRegHead *>(ops + on);
             const uint32_t nw0 = gw[(size_t)on * SEC_REG_GSTRIDE + threadIdx.x], nw1 = gw[(size_t)on * SEC_REG_GSTRIDE + threadIdx.x + NT];
             const uint32_t *gwo = gw + (size_t)o * SEC_REG_GSTRIDE;
             const double2 *T = cs + (size_t)o * SEC_REG_TSTRIDE;
             switch (cur.w_nsel) {
+            case 3 | (1 << 24): sec_reg_apply_pair<NT, 0>(tile, T, T + SEC_REG_TSTRIDE, cur, nslots, t, dbg, gwo, wd0, wd1); break;
+            case 3 | (1 << 16) | (1 << 24): sec_reg_apply_pair<NT, 1>(tile, T, T + SEC_REG_TSTRIDE, cur, nslots, t, dbg, gwo, wd0, wd1); break;
             case 4: sec_reg_apply<NT, 4, 0>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
             case 3: sec_reg_apply<NT, 3, 0>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
             case 3 | (1 << 16): sec_reg_apply<NT, 3, 1>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
@@ -1811,9 +1880,26 @@ __global__ __launch_bounds__(NT) void k_sector_sweep_reg(const double *__restric
             cur = nxt;
             wd0 = nw0;
             wd1 = nw1;
+            o += step;
         }
     }
-    for (uint32_t k = threadIdx.x; k < nslots; k += NT) out[e0 + k] = tile[sec_reg_swz(k)];
+    if (oslot) {
+        for (uint32_t j = threadIdx.x; j < nslots; j += NT) out[e0 + j] = tile[sec_reg_swz(oslot[j])];
+    } else {
+        for (uint32_t k = threadIdx.x; k < nslots; k += NT) out[e0 + k] = tile[sec_reg_swz(k)];
+    }
+}
+
+// gather table of a sweep whose predecessor stored its tiles in permuted slot order: step j of tile t reads the element that the
+// canonical table (srcpad: position in the predecessor's canonical order, per slot) names for slot gslot[j], at the predecessor's
+// actual position of it (tile * cap + pos_prev[slot])
+__global__ __launch_bounds__(256) void k_sec_reg_src(const uint32_t *__restrict__ srcpad, const uint16_t *__restrict__ gslot,
+                                                     const uint16_t *__restrict__ pos_prev, uint32_t cap, uint32_t *__restrict__ rsrc) {
+    const size_t e0 = (size_t)blockIdx.x * cap;
+    for (uint32_t j = threadIdx.x; j < cap; j += 256u) {
+        const uint32_t p = srcpad[e0 + gslot[j]];
+        rsrc[e0 + j] = (p & ~(cap - 1u)) | (uint32_t)pos_prev[p & (cap - 1u)];
+    }
 }
 
 }  // namespace ovqe

@@ -272,7 +272,9 @@ def test_sector_on_the_reference_quccsd_templates(SV, m, o):
         # the support is the full coset of the two spin parities: the sweeps run from bit arithmetic (k_sector_sweep_reg) —
         # against the pair-word sweeps of the same tables, other workgroup sizes and other tile sizes
         variants = {}
-        for name, opts in (("pair_words", {"sector_regular": 0}), ("threads_512", {"sector_regular": 1, "sector_reg_threads": 512}),
+        for name, opts in (("pair_words", {"sector_regular": 0}), ("single_ops", {"sector_regular": 1, "sector_reg_pairs": 0}),
+                           ("canonical_orders", {"sector_regular": 3, "sector_reg_pairs": 1}),
+                           ("threads_512", {"sector_regular": 1, "sector_reg_threads": 512}),
                            ("threads_128", {"sector_reg_threads": 128}), ("bits_10", {"sector_reg_threads": 256, "sector_bits": 10}),
                            ("bits_8", {"sector_bits": 8})):
             for k, v in opts.items():
