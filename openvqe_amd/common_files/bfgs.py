@@ -1,0 +1,123 @@
+"""BFGS as the reference's drivers ask scipy for it (``scipy.optimize.minimize(method="BFGS", tol=...)``,
+ref:openvqe/ucc_family/get_energy_qucc.py:158-175, get_energy_ucc.py:158-175) — same line search (scipy's own
+Wolfe search), same convergence test (max |gradient| <= tol), same update formula — with the inverse-Hessian
+update written in its rank-two form.
+
+scipy (1.15) evaluates  H <- (I - rho s y^T) H (I - rho y s^T) + rho s s^T  with two dense n x n matrix
+products per iteration: 2 x 2 n^3 flops.  At the 1715 parameters of N2 / cc-pVDZ (10e,12o) that is 20 GFLOP of
+host BLAS per iteration — 12 of the 14 seconds of the QUCCSD ``get_energies`` run were spent there, four times
+what the device needs for the energies and gradients.  Expanded, the same expression is
+    H - rho (s (H y)^T + (H y) s^T) + (rho^2 y^T H y + rho) s s^T          (H symmetric),
+one matrix-vector product and two outer products: O(n^2).  The iterates agree with scipy's to rounding.
+
+Used by the mirrors for n >= ``RANK_TWO_FROM`` parameters when a Jacobian is supplied; below that scipy itself
+runs (the stored traces of the small molecules are reproduced call for call).
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.optimize import OptimizeResult
+
+RANK_TWO_FROM = 256
+
+
+def _line_search():
+    try:   # scipy's own: Wolfe search of MINPACK2 (dcsrch), falling back on the Python one — what its BFGS calls
+        from scipy.optimize._optimize import _LineSearchError, _line_search_wolfe12
+        return _line_search_wolfe12, _LineSearchError
+    except ImportError:   # the public search (strong Wolfe, Python)
+        from scipy.optimize import line_search
+
+        class _LineSearchError(RuntimeError):
+            pass
+
+        def search(f, fprime, xk, pk, gfk, old_fval, old_old_fval, **kwargs):
+            ret = line_search(f, fprime, xk, pk, gfk, old_fval, old_old_fval, c1=kwargs.get("c1", 1e-4), c2=kwargs.get("c2", 0.9))
+            if ret[0] is None:
+                raise _LineSearchError()
+            return ret
+
+        return search, _LineSearchError
+
+
+def minimize_bfgs(fun, x0, jac, tol=None, maxiter=None, disp=False, c1=1e-4, c2=0.9):
+    """-> OptimizeResult with the fields of scipy's BFGS (x, fun, jac, hess_inv, nit, nfev, njev, status, success, message)"""
+    search, LineSearchError = _line_search()
+    x0 = np.asarray(x0, dtype=float).flatten()
+    n = x0.size
+    gtol = 1e-5 if tol is None else tol
+    maxiter = n * 200 if maxiter is None else maxiter
+    count = {"f": 0, "g": 0}
+
+    def f(x):
+        count["f"] += 1
+        return float(fun(np.copy(x)))
+
+    def g(x):
+        count["g"] += 1
+        return np.asarray(jac(np.copy(x)), dtype=float)
+
+    old_fval = f(x0)
+    gfk = g(x0)
+    k = 0
+    Hk = np.eye(n)
+    old_old_fval = old_fval + np.linalg.norm(gfk) / 2
+    xk = x0
+    warnflag = 0
+    gnorm = np.abs(gfk).max() if n else 0.0
+    while gnorm > gtol and k < maxiter:
+        pk = -(Hk @ gfk)
+        try:
+            alpha_k, _, _, old_fval, old_old_fval, gfkp1 = search(f, g, xk, pk, gfk, old_fval, old_old_fval, amin=1e-100, amax=1e100,
+                                                                  c1=c1, c2=c2)
+        except LineSearchError:
+            warnflag = 2
+            break
+        sk = alpha_k * pk
+        xk = xk + sk
+        if gfkp1 is None:
+            gfkp1 = g(xk)
+        yk = gfkp1 - gfk
+        gfk = gfkp1
+        k += 1
+        gnorm = np.abs(gfk).max()
+        if gnorm <= gtol:
+            break
+        if not np.isfinite(old_fval):
+            warnflag = 2
+            break
+        rhok_inv = float(yk @ sk)
+        rhok = 1000.0 if rhok_inv == 0.0 else 1.0 / rhok_inv
+        Hy = Hk @ yk
+        yHy = float(yk @ Hy)
+        Hk -= rhok * (np.outer(sk, Hy) + np.outer(Hy, sk))
+        Hk += (rhok * rhok * yHy + rhok) * np.outer(sk, sk)
+    fval = old_fval
+    if warnflag == 2:
+        msg = "Desired error not necessarily achieved due to precision loss."
+    elif k >= maxiter:
+        warnflag = 1
+        msg = "Maximum number of iterations has been exceeded."
+    elif np.isnan(gnorm) or np.isnan(fval) or np.isnan(xk).any():
+        warnflag = 3
+        msg = "NaN result encountered."
+    else:
+        msg = "Optimization terminated successfully."
+    if disp:
+        print(("Warning: " if warnflag else "") + msg)
+        print("         Current function value: %f" % fval)
+        print("         Iterations: %d" % k)
+        print("         Function evaluations: %d" % count["f"])
+        print("         Gradient evaluations: %d" % count["g"])
+    return OptimizeResult(fun=fval, jac=gfk, hess_inv=Hk, nfev=count["f"], njev=count["g"], status=warnflag, success=(warnflag == 0),
+                          message=msg, x=xk, nit=k)
+
+
+def minimize(fun, x0, jac=None, method="BFGS", tol=None, options=None):
+    """``scipy.optimize.minimize`` for the mirrors' BFGS runs: the rank-two implementation above for >= RANK_TWO_FROM parameters
+    with a Jacobian, scipy otherwise"""
+    import scipy.optimize
+    options = dict(options or {})
+    if method == "BFGS" and callable(jac) and np.size(x0) >= RANK_TWO_FROM:
+        return minimize_bfgs(fun, x0, jac, tol=tol, maxiter=options.get("maxiter"), disp=options.get("disp", False))
+    return scipy.optimize.minimize(fun, x0=x0, jac=jac, method=method, tol=tol, options=options)

@@ -6,6 +6,7 @@ import numpy as np
 import scipy.optimize
 from numpy import binary_repr
 
+from ..common_files import bfgs
 from ..common_files.circuit import count, efficient_fermionic_ansatz
 from ..evaluator import GateEvaluator
 from ..qat_compat import AffineParam, Program, X, lower_circuit
@@ -82,17 +83,36 @@ class EnergyUCC:
         energies1, energies2 = [], []
         runs = []
         jac = None
+        fun_of = lambda sink: (lambda theta: self.action_quccsd(theta, hamiltonian_sp, cluster_ops, hf_init_sp, sink))  # noqa: E731
         if self.adjoint_gradient:
+            # one device pass gives E and all of dE/dtheta: the optimiser asks for both at every trial point of its line search,
+            # so the energy call keeps the gradient for the Jacobian call at the same theta (and appends to `energies` as ever)
             ev = self._evaluator(hamiltonian_sp, cluster_ops, hf_init_sp)
+            last = {}
+
+            def both(theta):
+                key = np.asarray(theta, dtype=float).tobytes()
+                if last.get("key") != key:
+                    e, g = ev.energy_gradient(np.asarray(theta, dtype=float))
+                    full = np.zeros(len(theta))
+                    full[: ev.n_params] = g
+                    last.update(key=key, e=float(e), g=full)
+                return last
+
+            def fun_of(sink):   # noqa: F811
+                def fun(theta):
+                    e = both(theta)["e"]
+                    sink.append(e)
+                    return e
+                return fun
 
             def jac(theta):
-                g = np.zeros(len(theta))
-                g[: ev.n_params] = ev.energy_gradient(np.asarray(theta, dtype=float))[1]
-                return g
+                return both(theta)["g"].copy()
         for x0, sink in ((theta_current1, energies1), (theta_current2, energies2)):
-            runs.append(scipy.optimize.minimize(
-                lambda theta, sink=sink: self.action_quccsd(theta, hamiltonian_sp, cluster_ops, hf_init_sp, sink),
-                x0=x0, jac=jac, method=method, tol=tolerance, options={"maxiter": 50000, "disp": True}))
+            # (bfgs.minimize IS scipy.optimize.minimize below 256 parameters or without a Jacobian; above, the same BFGS with its
+            # inverse-Hessian update in rank-two form)
+            runs.append(bfgs.minimize(fun_of(sink), x0=x0, jac=jac, method=method, tol=tolerance,
+                                      options={"maxiter": 50000, "disp": True}))
         opt_result1, opt_result2 = runs
         theta_optimized_result1 = [opt_result1.x[si] for si in range(len(theta_current1))]
         theta_optimized_result2 = [opt_result2.x[si] for si in range(len(theta_current2))]

@@ -4,6 +4,8 @@ reference's; the simulation runs in libovqe_sv instead of myQLM)."""
 import numpy as np
 import scipy.optimize
 
+from ..common_files import bfgs
+
 from ..common_files.circuit import count
 from ..evaluator import UCCEvaluator
 from ..qat_compat import Program, build_ucc_ansatz
@@ -69,8 +71,9 @@ class EnergyUCC:
                 pts[1:] += eps * np.eye(len(theta))
                 vals = ev.energy_batch(pts)
                 return (vals[1:] - vals[0]) / eps
-        return scipy.optimize.minimize(fun, x0=x0, jac=jac, method=method, tol=tolerance,
-                                       options={"maxiter": 50000, "disp": True})
+        # (bfgs.minimize IS scipy.optimize.minimize below 256 parameters or without a Jacobian; above, the same BFGS with its
+        # inverse-Hessian update in rank-two form: O(n^2) instead of scipy's two n x n matrix products per iteration)
+        return bfgs.minimize(fun, x0=x0, jac=jac, method=method, tol=tolerance, options={"maxiter": 50000, "disp": True})
 
     def get_energies(self, hamiltonian_sp, cluster_ops_sp, pool_generator, hf_init_sp, theta_current1,
                      theta_current2, fci):
