@@ -41,7 +41,19 @@ def _line_search():
 
 
 def minimize_bfgs(fun, x0, jac, tol=None, maxiter=None, disp=False, c1=1e-4, c2=0.9):
-    """-> OptimizeResult with the fields of scipy's BFGS (x, fun, jac, hess_inv, nit, nfev, njev, status, success, message)"""
+    """-> OptimizeResult with the fields of scipy's BFGS (x, fun, jac, hess_inv, nit, nfev, njev, status, success, message).
+    The O(n^2) host algebra of an iteration runs on ONE BLAS thread: a multi-threaded BLAS leaves its workers spinning after every
+    call, and the device calls that follow — a hundred kernel launches each — then take three times as long (measured on the
+    MI355X box, N2 QUCCSD gradient: 31 ms -> 89 ms with 10 ms of threaded numpy between the calls, tools/exp_mirror_eval_n2.py)."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        return _minimize_bfgs(fun, x0, jac, tol, maxiter, disp, c1, c2)
+    with threadpool_limits(limits=1, user_api="blas"):
+        return _minimize_bfgs(fun, x0, jac, tol, maxiter, disp, c1, c2)
+
+
+def _minimize_bfgs(fun, x0, jac, tol, maxiter, disp, c1, c2):
     search, LineSearchError = _line_search()
     x0 = np.asarray(x0, dtype=float).flatten()
     n = x0.size

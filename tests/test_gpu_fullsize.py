@@ -170,8 +170,8 @@ def test_32_qubit_state_on_one_gpu(gpu_lib):
 def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
     """BASELINE configs[3] at its size AND on its molecule: N2 / cc-pVDZ, (10 electrons, 12 orbitals) active space = 24 qubits
     (integrals, RHF and frozen core from the in-repo front-end).  The literal QUCCSD gate list
-    (ref:openvqe/common_files/circuit.py:13-106 templates on every 5th cluster operator in the reference's operator order:
-    343 parameters, ~13 k gates) against the plain-C oracle's gate-by-gate execution (256-MiB host state) — energy on the
+    (ref:openvqe/common_files/circuit.py:13-106 templates on every single and every 5th double of the cluster operators in
+    the reference's operator order: ~400 parameters, ~14 k gates) against the plain-C oracle's gate-by-gate execution (256-MiB host state) — energy on the
     molecule's FULL 6464-term JW Hamiltonian and sampled amplitudes, for the three forms the backend can run it in: literal
     LDS-tiled sweeps, Clifford-frame form on real-amplitude streams (the third evaluation comes from the sector tables on the
     coset of the program's Z2 symmetries, sweeps from bit arithmetic: asserted), Clifford-frame form on the complex state; three components of ovqe_energy_gradient
@@ -187,12 +187,15 @@ def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
     n = prob.nbqbits
     assert n == 24
     size, cluster_ops, _, theta_mp2, hf = prob.uccsd()
-    stride = 5
-    gates, K, hf2 = quccsd_gate_list(12, 5, stride, excitations=[op.terms[0].qbits for op in cluster_ops])
-    assert K == 343 and hf2 == hf and len(gates) > 10000
+    # every single excitation + every 5th double (the singles keep the thinned program's Z2 symmetries those of the full list: the
+    # two spin parities, so that its states fill the same 2^22 quarter of the register and take the same path as configs[3])
+    excitations = [op.terms[0].qbits for op in cluster_ops]
+    picked = [k for k, e in enumerate(excitations) if len(e) == 2 or k % 5 == 0]
+    gates, K, hf2 = quccsd_gate_list(12, 5, 1, excitations=[excitations[k] for k in picked])
+    assert K == len(picked) and 380 <= K <= 420 and hf2 == hf and len(gates) > 10000
     ham = prob.jw_hamiltonian()                  # the FULL 6464-term Hamiltonian (the oracle sums it x-group by x-group)
     rng = np.random.default_rng(2424)
-    theta = np.array(theta_mp2[::stride]) + rng.uniform(-0.05, 0.05, K)      # MP2 amplitudes + noise: no parameter is zero
+    theta = np.array([theta_mp2[k] for k in picked]) + rng.uniform(-0.05, 0.05, K)      # MP2 amplitudes + noise: no parameter is zero
     hx, hz, hc = cref.sort_by_x(*[np.asarray(a) for a in (ham.packed()[0], ham.packed()[1], ham.packed()[2].real.copy())])
     opc = [GATE_OPCODES[g[0]] for g in gates]
     b0 = [n - 1 - g[1][0] for g in gates]
@@ -246,8 +249,7 @@ def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
     assert res["frame_complex"][3]["real_stream"] == 0
     # the product's default path for configs[3]: sector tables on the 2^22 spin-parity support, sweeps from bit arithmetic
     after = res["frame_real"][6]
-    # (the full list fills the 2^22 spin-parity quarter; this thinned one keeps one more Z2 symmetry: 2^21)
-    assert after["sector_free_bits"] >= 2 and after["sector_support"] == 1 << (24 - after["sector_free_bits"]), after
+    assert after["sector_support"] == 1 << 22 and after["sector_free_bits"] == 2, after
     assert after["sector_h_elements"] > 0 and after["sector_regular_slot_bits"] > 0, after
     for label, (e, amps, n2, _, e_again, e_third, _, _) in res.items():
         assert abs(e - e_ref) < 1e-10 * max(1.0, l1), (label, e, e_ref)
