@@ -153,10 +153,18 @@ class ShardedStatevector:
         self.engine = engine_factory(self.n_local, self.g, self.rank)
         self._dist = dist.is_initialized()
         self.stats = {"swaps": 0, "bytes_sent": 0, "full_shard_reads": 0, "chunk_reads": 0, "partners_per_read": 0, "pieces": 0,
-                      "swap_s": 0.0, "shard_read_s": 0.0}
+                      "swap_s": 0.0, "shard_read_s": 0.0, "real_exchanges": 0, "real_chunk_reads": 0}
         self._tmp = None
         self._chunk_bufs = None
+        self._chunk_real = None
+        self._chunk_send = None
         self._sigma = None
+        # Real-amplitude transfers: a basis state evolved by rotations whose strings all carry an odd number of Y — every UCC / ADAPT
+        # generator (-i phi P is then a real antisymmetric matrix) — has real amplitudes; while that holds, half-shard exchanges and
+        # partner-shard reads move the real parts only: 8 instead of 16 bytes per amplitude over xGMI.  (The shard kernels keep their
+        # complex layout; the imaginary parts are exact zeros and are rebuilt as such on arrival.)
+        self.real = False
+        self.real_transfers = True
 
     # -- helpers ----------------------------------------------------------------------------
     def _phys(self, mask):
@@ -239,12 +247,24 @@ class ShardedStatevector:
         self.engine.sync()
         t_swap = time.perf_counter()
 
+        real = self.real and self.real_transfers      # (the same on every rank: the flag follows the rotation list)
+        if real:
+            rrecv = torch.view_as_real(recv).reshape(-1)[:half]        # the receive buffer's first half, as doubles
+            recv_pieces = [rrecv[starts[p]:starts[p] + sizes[p]] for p in range(P)]
+
         def pack(p):
             v = views[p]
+            if real:
+                return torch.view_as_real(v)[..., 0].contiguous().view(-1)
             return v.reshape(-1) if v.is_contiguous() else v.contiguous().view(-1)
 
         def unpack(p):
-            views[p].copy_(recv_pieces[p].view(views[p].shape))
+            if real:
+                dst = torch.view_as_real(views[p])
+                dst[..., 0].copy_(recv_pieces[p].view(views[p].shape))
+                dst[..., 1].zero_()
+            else:
+                views[p].copy_(recv_pieces[p].view(views[p].shape))
 
         self._exchange(partner, pack, recv_pieces, unpack)
         self.engine.sync()
@@ -253,7 +273,8 @@ class ShardedStatevector:
         la, lb = self.perm.index(gbit), self.perm.index(lbit)
         self.perm[la], self.perm[lb] = lbit, gbit
         self.stats["swaps"] += 1
-        self.stats["bytes_sent"] += half * 16
+        self.stats["bytes_sent"] += half * (8 if real else 16)
+        self.stats["real_exchanges"] += 1 if real else 0
         self.stats["pieces"] += P
 
     def _localise(self, x_logical_seq, r):
@@ -285,10 +306,12 @@ class ShardedStatevector:
     # -- state ------------------------------------------------------------------------------
     def init_basis(self, logical_index):
         self.engine.init_basis(self._phys(logical_index))
+        self.real = True
 
     def randomize(self, seed):
         """synthetic state defined on PHYSICAL indices (bench/scaling use; permutation reset)"""
         self.perm = list(range(self.n))
+        self.real = False
         self.engine.randomize(seed, 1.0)
         n2 = torch.tensor([self.engine.norm2()], dtype=torch.float64, device=self.engine.tensor.device)
         if self._dist:
@@ -307,6 +330,8 @@ class ShardedStatevector:
         """rotations in order, masks in LOGICAL index-bit space of the full register"""
         xs = [int(v) for v in xs]
         zs = [int(v) for v in zs]
+        if self.real and any(not (bin(x & z).count("1") & 1) for x, z in zip(xs, zs)):
+            self.real = False     # a string with an even number of Y (or a diagonal one) makes the amplitudes complex
         batch_x, batch_z, batch_p = [], [], []
 
         def flush():
@@ -391,8 +416,18 @@ class ShardedStatevector:
             self._chunk_bufs = [self.engine.new_buffer(np_ * csize), self.engine.new_buffer(np_ * csize)]
         self.engine.sync()
 
+        real = self.real and self.real_transfers
+        if real and (self._chunk_real is None or self._chunk_real[0].numel() < np_ * csize):
+            self._chunk_real = [torch.empty(np_ * csize, dtype=torch.float64, device=self.engine.tensor.device) for _ in range(2)]
+            self._chunk_send = [torch.empty(csize, dtype=torch.float64, device=self.engine.tensor.device) for _ in range(2)]
+
         def post(c):
             own = self.engine.tensor[c * csize:(c + 1) * csize]
+            if real:   # real parts only over the links; the complex chunks are rebuilt when the transfer has landed
+                send = self._chunk_send[c & 1]
+                send.copy_(torch.view_as_real(own)[:, 0])
+                return self._post_multi([(send, self._chunk_real[c & 1][k * csize:(k + 1) * csize], self.rank ^ d, 2 * d + (c & 1))
+                                         for k, d in enumerate(partners)])
             # one tag per (chunk parity, partner difference): gloo matches by tag, and both ends of a pair agree on it
             return self._post_multi([(own, self._chunk_bufs[c & 1][k * csize:(k + 1) * csize], self.rank ^ d, 2 * d + (c & 1))
                                      for k, d in enumerate(partners)])
@@ -404,9 +439,14 @@ class ShardedStatevector:
             if hasattr(self.engine, "stream"):
                 self.engine.stream.synchronize()      # the transfers themselves, for the link rates of the bench line
             self.stats["shard_read_s"] += time.perf_counter() - t0
+            if real:
+                dst = torch.view_as_real(self._chunk_bufs[c & 1][:np_ * csize])
+                dst[:, 0].copy_(self._chunk_real[c & 1][:np_ * csize])
+                dst[:, 1].zero_()
             pending = post(c + 1) if c + 1 < nchunks else None
             self.stats["chunk_reads"] += np_
-            self.stats["bytes_sent"] += np_ * csize * 16
+            self.stats["real_chunk_reads"] += np_ if real else 0
+            self.stats["bytes_sent"] += np_ * csize * (8 if real else 16)
             yield c, [self._chunk_bufs[c & 1][k * csize:(k + 1) * csize] for k in range(np_)]
             self.engine.sync()   # the buffers of this parity are posted again two chunks later
         self.stats["full_shard_reads"] += np_

@@ -279,3 +279,73 @@ def test_sharded_adapt_screen_matches_single_process_oracle(world, n, chunk_bits
     assert np.abs(gf - 2.0 * want.real).max() < 1e-11
     assert np.abs(gq - 2.0 * np.abs(want)).max() < 1e-11
     assert stats["full_shard_reads"] >= 2      # sigma and the pool contraction both needed partner shards
+
+
+def _real_worker(rank, world, port, n, seed, out, engine="oracle", chunk_bits=None):
+    """a UCC-like program: every rotation string has an odd number of Y, so the state stays real and the exchanges / partner reads
+    move real parts only"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if chunk_bits is not None:
+        os.environ["OVQE_SHARD_CHUNK_BITS"] = str(chunk_bits)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from openvqe_amd.distributed import ShardedStatevector
+        rng = np.random.default_rng(seed)
+        g = world.bit_length() - 1
+        R, T = 30, 40
+
+        def odd_y_string():
+            w = int(rng.integers(2, max(3, min(5, n - g))))
+            bits = [int(b) for b in rng.choice(n, w, replace=False)]
+            ny = 1 if w < 3 else int(rng.choice([1, 3]))
+            x = sum(1 << b for b in bits)
+            z = sum(1 << b for b in bits[:ny])                      # Y on `ny` of the X positions ...
+            for b in rng.choice(n, 2, replace=False):                # ... and a few Z elsewhere
+                if not (x >> int(b)) & 1:
+                    z |= 1 << int(b)
+            return x, z
+
+        xs, zs = zip(*[odd_y_string() for _ in range(R)])
+        phis = rng.uniform(-1, 1, R)
+        hx = [sum(1 << int(b) for b in rng.choice(n, int(rng.integers(1, 4)), replace=False)) if rng.random() < 0.85 else 0 for _ in range(T)]
+        hz = [int(v) for v in rng.integers(0, 1 << n, T)]
+        hc = rng.normal(size=T)
+        hf = int(rng.integers(0, 1 << n))
+        res = {}
+        for real_transfers in (True, False):
+            sv = (ShardedStatevector(n, device=0) if engine == "hip" else
+                  ShardedStatevector(n, engine_factory=lambda nl, ng, r: OracleShardEngine(nl, ng, r)))
+            sv.real_transfers = real_transfers
+            e = sv.energy(hx, hz, hc, 0.5, list(xs), list(zs), phis, hf)
+            res[real_transfers] = (e, sv.gather_state(), dict(sv.stats), sv.real)
+        if rank == 0:
+            out.put((res, (xs, zs, phis, hx, hz, hc, hf)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,chunk_bits", [(2, 7, 3), (4, 8, None), (8, 9, 3)])
+def test_real_amplitude_transfers_halve_the_exchanged_bytes(world, n, chunk_bits):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_real_worker, args=(r, world, port, n, 4242 + n, out, "oracle", chunk_bits)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res, (xs, zs, phis, hx, hz, hc, hf) = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    psi = np.zeros(1 << n, complex)
+    psi[hf] = 1
+    for x, z, p in zip(xs, zs, phis):
+        psi = masks.rotate(psi, int(x), int(z), p)
+    assert np.abs(psi.imag).max() < 1e-15                     # the premise: odd-Y strings keep a basis state real
+    want = masks.expectation(psi, hx, hz, hc, 0.5)
+    (e1, full1, st1, real1), (e0, full0, st0, _) = res[True], res[False]
+    assert real1 and np.abs(full1 - psi).max() < 1e-12 and np.abs(full0 - psi).max() < 1e-12
+    assert abs(e1 - want) < 1e-11 and abs(e0 - want) < 1e-11
+    assert st1["swaps"] == st0["swaps"] >= 1 and st1["real_exchanges"] == st1["swaps"] and st0["real_exchanges"] == 0
+    assert st1["real_chunk_reads"] == st1["chunk_reads"] > 0
+    assert st1["bytes_sent"] * 2 == st0["bytes_sent"]

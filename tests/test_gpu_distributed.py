@@ -63,3 +63,30 @@ def test_sharded_adapt_screen_on_hip_shards(gpu_lib, world, n, chunk_bits):
     assert np.abs(np.asarray(gf) - 2.0 * want.real).max() < 1e-11
     assert np.abs(np.asarray(gq) - 2.0 * np.abs(want)).max() < 1e-11
     assert stats["full_shard_reads"] >= 2
+
+
+@pytest.mark.parametrize("world,n,chunk_bits", [(4, 15, 10), (8, 16, 10)])
+def test_real_amplitude_transfers_on_hip_shards(gpu_lib, world, n, chunk_bits):
+    """odd-Y rotations from a basis state: the half-shard exchanges and the chunked partner reads carry real parts only (half the
+    bytes), the HIP shard kernels see complex shards with exact-zero imaginary parts — state and <H> against the oracle"""
+    from tests.test_distributed import _real_worker
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_real_worker, args=(r, world, port, n, 909 + n, out, "hip", chunk_bits)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res, (xs, zs, phis, hx, hz, hc, hf) = out.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    psi = np.zeros(1 << n, complex)
+    psi[hf] = 1
+    for x, z, p in zip(xs, zs, phis):
+        psi = masks.rotate(psi, int(x), int(z), p)
+    want = masks.expectation(psi, hx, hz, hc, 0.5)
+    (e1, full1, st1, real1), (e0, full0, st0, _) = res[True], res[False]
+    assert real1 and np.abs(np.asarray(full1) - psi).max() < 1e-12 and np.abs(np.asarray(full0) - psi).max() < 1e-12
+    assert abs(e1 - want) < 1e-11 and abs(e0 - want) < 1e-11
+    assert st1["real_exchanges"] == st1["swaps"] >= 1 and st1["real_chunk_reads"] == st1["chunk_reads"] > 0
+    assert st1["bytes_sent"] * 2 == st0["bytes_sent"]
