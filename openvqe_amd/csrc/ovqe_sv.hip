@@ -282,6 +282,7 @@ struct ovqe_sv {
     int opt_sector_eager_rots = 2048; // programs of at most this many rotations build their sector tables at the FIRST evaluation (else the second)
     int opt_sector_regular = 1;       // supports that are a full coset of the program's Z2 symmetries: sweeps from bit arithmetic, no pair words (k_sector_sweep_reg); 2: such engines build no pair tables at all (energies only)
     int opt_sector_reg_threads = 256; // workgroup size of those sweeps
+    int opt_sector_reg_adjoint = 1;   // ovqe_energy_gradient on a regular support: backward sweeps from bit arithmetic too (0: pair-word sweeps)
     int opt_sector_reg_pairs = 1;     // two consecutive three-bit ops that share two bits run as one 16-slot block
     int opt_sector_depth2 = 1;        // first form of the sweeps: two chunks of pair words ahead where every op of a tile fits a staging buffer
     int opt_sector_many_tiles = 1;    // single evaluations with >= 768 tiles: the workgroup shape of the batches (512 threads, scatter indices from memory)
@@ -3058,7 +3059,14 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
         h->sec.disabled = false;
         h->sec.seen = 0;
         h->sec.prog_version = -1;
-    } else if (k == "sector_reg_threads") h->opt_sector_reg_threads = value == 512 ? 512 : (value == 1024 ? 1024 : (value == 128 ? 128 : 256));
+    } else if (k == "sector_reg_adjoint") {
+        h->opt_sector_reg_adjoint = (int)value;   // (0 needs the pair words a large regular support does without: the tables are rebuilt)
+        free_sector(h->sec);
+        h->sec.disabled = false;
+        h->sec.seen = 0;
+        h->sec.prog_version = -1;
+    }
+    else if (k == "sector_reg_threads") h->opt_sector_reg_threads = value == 512 ? 512 : (value == 1024 ? 1024 : (value == 128 ? 128 : 256));
     else if (k == "sector_eager_rots") h->opt_sector_eager_rots = (int)value;
     else if (k == "screen_sector") h->opt_screen_sector = (int)value;
     else if (k == "screen_tables") h->opt_screen_tables = (int)value;

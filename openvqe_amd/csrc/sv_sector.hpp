@@ -1890,6 +1890,250 @@ __global__ __launch_bounds__(NT) void k_sector_sweep_reg(const double *__restric
     }
 }
 
+// ---- backward sweeps on a regular support (ovqe_energy_gradient): psi and lambda = H psi walk the program backwards together.
+// Per op, on the states AFTER it: w[entry] += sigma (lambda_A psi_B - lambda_B psi_A) over its pairs (dE/dphi of the entry's angle
+// is twice that), then both states are rotated back.  A lane's eight per-entry sums are reduced over the wave by a reduce-scatter
+// (three exchange-and-halve steps, then three butterfly steps: ten additions instead of forty-eight), the four waves' totals meet in
+// LDS and lanes 0..7 of wave 0 store the tile's partial sums of the op: wpart[tile][op][8].
+__device__ __forceinline__ double sec_reduce8(const double (&c)[8]) {   // -> the wave's total of entry 4 b0 + 2 b1 + b2 (b = lane bits)
+    const int lane = threadIdx.x & 63;
+    double t4[4], t2[2], t1;
+    {
+        const bool hi = lane & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t4[j] = (hi ? c[4 + j] : c[j]) + __shfl_xor(hi ? c[j] : c[4 + j], 1, 64);
+    }
+    {
+        const bool hi = lane & 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) t2[j] = (hi ? t4[2 + j] : t4[j]) + __shfl_xor(hi ? t4[j] : t4[2 + j], 2, 64);
+    }
+    {
+        const bool hi = lane & 4;
+        t1 = (hi ? t2[1] : t2[0]) + __shfl_xor(hi ? t2[0] : t2[1], 4, 64);
+    }
+    t1 += __shfl_xor(t1, 8, 64);
+    t1 += __shfl_xor(t1, 16, 64);
+    t1 += __shfl_xor(t1, 32, 64);
+    return t1;
+}
+__device__ __forceinline__ void sec_reg_wstore(double *__restrict__ wslot, const double (&acc)[8]) {   // this wave's row of 8 totals
+    const double tot = sec_reduce8(acc);
+    const int lane = threadIdx.x & 63;
+    if (lane < 8) wslot[((lane & 1) << 2) | (lane & 2) | ((lane & 4) >> 2)] = tot;
+}
+
+template <int NT, int W, int NSEL>
+__device__ __forceinline__ void sec_reg_unapply(double *__restrict__ psi, double *__restrict__ lam, const double2 *__restrict__ T,
+                                                const SecRegHead &op, uint32_t nslots, uint32_t tnum, const uint32_t *__restrict__ gwo,
+                                                uint32_t wd0, uint32_t wd1, double *__restrict__ wslot) {
+    constexpr int NA = 1 << W, NP = NA / 2;
+    const uint32_t tz = __popc(tnum & op.zt) & 1u;
+    const uint32_t ts0 = NSEL > 0 ? (__popc(tnum & op.sel_t[0]) & 1u) : 0u, ts1 = NSEL > 1 ? (__popc(tnum & op.sel_t[1]) & 1u) : 0u;
+    uint32_t dep[NA];
+#pragma unroll
+    for (int e = 0; e < NA; ++e) dep[e] = (op.dep[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+    char *pb = reinterpret_cast<char *>(psi), *lb = reinterpret_cast<char *>(lam);
+    double acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0;
+    for (uint32_t g = threadIdx.x, it = 0; g < (nslots >> W); g += NT, ++it) {
+        const uint32_t wd = it == 0 ? wd0 : (it == 1 ? wd1 : gwo[g]);
+        const uint32_t sb = wd & 0xffffu;
+        const uint32_t neg = (((wd >> 16) & 1u) ^ tz) << 31;
+        double a[NA], l[NA];
+#pragma unroll
+        for (int e = 0; e < NA; ++e) {
+            a[e] = *reinterpret_cast<const double *>(pb + (sb ^ dep[e]));
+            l[e] = *reinterpret_cast<const double *>(lb + (sb ^ dep[e]));
+        }
+        uint32_t sel = 0;
+        if constexpr (NSEL > 0) sel = ((wd >> 17) & 1u) ^ ts0;
+        if constexpr (NSEL > 1) sel |= (((wd >> 18) & 1u) ^ ts1) << 1;
+        const double2 *Tl = T + sel * NP;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const double2 r = Tl[q];
+            const double u = a[q], v = sec_flip(a[NA - 1 - q], neg), lu = l[q], lv = sec_flip(l[NA - 1 - q], neg);
+            const double cq = lu * v - lv * u;
+#pragma unroll
+            for (int vs = 0; vs < (1 << NSEL); ++vs) acc[vs * NP + q] += (NSEL == 0 || sel == (uint32_t)vs) ? cq : 0.0;
+            a[q] = r.x * u - r.y * v;
+            a[NA - 1 - q] = sec_flip(r.x * v + r.y * u, neg);
+            l[q] = r.x * lu - r.y * lv;
+            l[NA - 1 - q] = sec_flip(r.x * lv + r.y * lu, neg);
+        }
+#pragma unroll
+        for (int e = 0; e < NA; ++e) {
+            *reinterpret_cast<double *>(pb + (sb ^ dep[e])) = a[e];
+            *reinterpret_cast<double *>(lb + (sb ^ dep[e])) = l[e];
+        }
+    }
+    sec_reg_wstore(wslot, acc);
+}
+
+// a block of two ops backwards: B first, then A (see sec_reg_apply_pair); wslotA / wslotB = this wave's rows of the two ops
+template <int NT, int NSEL>
+__device__ __forceinline__ void sec_reg_unapply_pair(double *__restrict__ psi, double *__restrict__ lam, const double2 *__restrict__ TA,
+                                                     const double2 *__restrict__ TB, const SecRegHead &op, uint32_t nslots, uint32_t tnum,
+                                                     const uint32_t *__restrict__ gwo, uint32_t wd0, uint32_t wd1,
+                                                     double *__restrict__ wslotA, double *__restrict__ wslotB) {
+    const uint32_t fl = op.pad[0];
+    const uint32_t tzA = __popc(tnum & op.zt) & 1u, tzB = __popc(tnum & op.pad[1]) & 1u;
+    const uint32_t tsA = NSEL ? (__popc(tnum & op.sel_t[0]) & 1u) : 0u, tsB = NSEL ? (__popc(tnum & op.pad[2]) & 1u) : 0u;
+    uint32_t dep[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dep[e] = (op.dep[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+    char *pb = reinterpret_cast<char *>(psi), *lb = reinterpret_cast<char *>(lam);
+    double accA[8], accB[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) accA[e] = accB[e] = 0.0;
+    for (uint32_t g = threadIdx.x, it = 0; g < (nslots >> 4); g += NT, ++it) {
+        const uint32_t wd = it == 0 ? wd0 : (it == 1 ? wd1 : gwo[g]);
+        const uint32_t sb = wd & 0xffffu;
+        double a[16], l[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            a[e] = *reinterpret_cast<const double *>(pb + (sb ^ dep[e]));
+            l[e] = *reinterpret_cast<const double *>(lb + (sb ^ dep[e]));
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {   // op B on the half own A = v
+            const uint32_t neg = (((wd >> 18) & 1u) ^ tzB ^ ((uint32_t)v & (fl >> 2))) << 31;
+            const uint32_t sel = NSEL ? (((wd >> 19) & 1u) ^ tsB ^ ((uint32_t)v & (fl >> 3))) & 1u : 0u;
+            const double2 *Tl = TB + sel * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double2 r = Tl[q];
+                const int i = 4 * v + q, j = 4 * v + 11 - q;
+                const double u = a[i], w = sec_flip(a[j], neg), lu = l[i], lw = sec_flip(l[j], neg);
+                const double cq = lu * w - lw * u;
+                accB[q] += (NSEL == 0 || sel == 0u) ? cq : 0.0;
+                if (NSEL) accB[4 + q] += sel ? cq : 0.0;
+                a[i] = r.x * u - r.y * w;
+                a[j] = sec_flip(r.x * w + r.y * u, neg);
+                l[i] = r.x * lu - r.y * lw;
+                l[j] = sec_flip(r.x * lw + r.y * lu, neg);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {   // op A on the half own B = v
+            const uint32_t neg = (((wd >> 16) & 1u) ^ tzA ^ ((uint32_t)v & fl)) << 31;
+            const uint32_t sel = NSEL ? (((wd >> 17) & 1u) ^ tsA ^ ((uint32_t)v & (fl >> 1))) & 1u : 0u;
+            const double2 *Tl = TA + sel * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double2 r = Tl[q];
+                const int i = 8 * v + q, j = 8 * v + 7 - q;
+                const double u = a[i], w = sec_flip(a[j], neg), lu = l[i], lw = sec_flip(l[j], neg);
+                const double cq = lu * w - lw * u;
+                accA[q] += (NSEL == 0 || sel == 0u) ? cq : 0.0;
+                if (NSEL) accA[4 + q] += sel ? cq : 0.0;
+                a[i] = r.x * u - r.y * w;
+                a[j] = sec_flip(r.x * w + r.y * u, neg);
+                l[i] = r.x * lu - r.y * lw;
+                l[j] = sec_flip(r.x * lw + r.y * lu, neg);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            *reinterpret_cast<double *>(pb + (sb ^ dep[e])) = a[e];
+            *reinterpret_cast<double *>(lb + (sb ^ dep[e])) = l[e];
+        }
+    }
+    sec_reg_wstore(wslotA, accA);
+    sec_reg_wstore(wslotB, accB);
+}
+
+// one backward sweep: the tiles of psi and lambda arrive in this sweep's output order (oslot: slot stored at position j; nullptr:
+// slot j), the sweep's ops are undone last to first, the tiles leave for the positions this sweep's forward pass gathered them from
+// (srcpad / gslot of k_sector_sweep_reg; nullptr: the first sweep, nothing leaves).  wpart: [tile][nops][8] partial sums.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_sector_adjoint_reg(const double *__restrict__ psi_in, const double *__restrict__ lam_in,
+                                                           double *__restrict__ psi_out, double *__restrict__ lam_out,
+                                                           const uint32_t *__restrict__ srcpad, const uint16_t *__restrict__ gslot,
+                                                           const uint16_t *__restrict__ oslot, const SecRegOp *__restrict__ ops, int nops,
+                                                           const uint32_t *__restrict__ gw, const double2 *__restrict__ tg, int mbits,
+                                                           double *__restrict__ wpart) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
+    constexpr int NW = NT / 64;
+    const uint32_t nslots = 1u << mbits, t = blockIdx.x;
+    double *psi = reinterpret_cast<double *>(sec_smem), *lam = psi + nslots;
+    double2 *cs = reinterpret_cast<double2 *>(lam + nslots);                       // [nops][8]
+    double *wrow = reinterpret_cast<double *>(cs + (size_t)nops * SEC_REG_TSTRIDE);   // [2 parities][2 ops of a block][NW][8]
+    const size_t e0 = (size_t)t * nslots;
+    for (uint32_t j = threadIdx.x; j < nslots; j += NT) {
+        const uint32_t k = sec_reg_swz(oslot ? (uint32_t)oslot[j] : j);
+        psi[k] = psi_in[e0 + j];
+        lam[k] = lam_in[e0 + j];
+    }
+    for (uint32_t e = threadIdx.x; e < (uint32_t)nops * SEC_REG_TSTRIDE; e += NT) cs[e] = tg[e];
+    __syncthreads();
+    // blocks of two ops start at their first op: walk the list once forwards to find the starts, then backwards (wave-uniform)
+    const int wave = threadIdx.x >> 6;
+    double *wp = wpart + (size_t)t * nops * 8;
+    int o = nops - 1, parity = 0;
+    while (o >= 0) {
+        // the start of the block that ends at op o: op o - 1 carries the pair flag iff (o - 1, o) is a block
+        const bool pair = o > 0 && ((reinterpret_cast<const SecRegHead *>(ops + (o - 1))->w_nsel >> 24) & 1u);
+        const int ob = pair ? o - 1 : o;
+        const SecRegHead cur = *reinterpret_cast<const SecRegHead *>(ops + ob);
+        const uint32_t *gwo = gw + (size_t)ob * SEC_REG_GSTRIDE;
+        const uint32_t wd0 = gwo[threadIdx.x], wd1 = gwo[threadIdx.x + NT];
+        const double2 *T = cs + (size_t)ob * SEC_REG_TSTRIDE;
+        double *rowA = wrow + (size_t)((parity * 2 + 0) * NW + wave) * 8, *rowB = wrow + (size_t)((parity * 2 + 1) * NW + wave) * 8;
+        switch (cur.w_nsel) {
+        case 3 | (1 << 24): sec_reg_unapply_pair<NT, 0>(psi, lam, T, T + SEC_REG_TSTRIDE, cur, nslots, t, gwo, wd0, wd1, rowA, rowB); break;
+        case 3 | (1 << 16) | (1 << 24): sec_reg_unapply_pair<NT, 1>(psi, lam, T, T + SEC_REG_TSTRIDE, cur, nslots, t, gwo, wd0, wd1, rowA, rowB); break;
+        case 4: sec_reg_unapply<NT, 4, 0>(psi, lam, T, cur, nslots, t, gwo, wd0, wd1, rowA); break;
+        case 3: sec_reg_unapply<NT, 3, 0>(psi, lam, T, cur, nslots, t, gwo, wd0, wd1, rowA); break;
+        case 3 | (1 << 16): sec_reg_unapply<NT, 3, 1>(psi, lam, T, cur, nslots, t, gwo, wd0, wd1, rowA); break;
+        case 2: sec_reg_unapply<NT, 2, 0>(psi, lam, T, cur, nslots, t, gwo, wd0, wd1, rowA); break;
+        case 2 | (1 << 16): sec_reg_unapply<NT, 2, 1>(psi, lam, T, cur, nslots, t, gwo, wd0, wd1, rowA); break;
+        case 2 | (2 << 16): sec_reg_unapply<NT, 2, 2>(psi, lam, T, cur, nslots, t, gwo, wd0, wd1, rowA); break;
+        case 1: sec_reg_unapply<NT, 1, 0>(psi, lam, T, cur, nslots, t, gwo, wd0, wd1, rowA); break;
+        case 1 | (1 << 16): sec_reg_unapply<NT, 1, 1>(psi, lam, T, cur, nslots, t, gwo, wd0, wd1, rowA); break;
+        default: sec_reg_unapply<NT, 1, 2>(psi, lam, T, cur, nslots, t, gwo, wd0, wd1, rowA); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // the waves' rows of this block meet: wave 0 stores the tile's sums (the rows of the other parity take the next block)
+        if (threadIdx.x < 8u * (pair ? 2u : 1u)) {
+            const uint32_t which = threadIdx.x >> 3, e = threadIdx.x & 7u;
+            double sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += wrow[(size_t)((parity * 2 + which) * NW + w) * 8 + e];
+            wp[(size_t)(ob + which) * 8 + e] = sum;
+        }
+        parity ^= 1;
+        o = ob - 1;
+    }
+    if (srcpad) {
+        const uint32_t *sp = srcpad + e0;
+        for (uint32_t j = threadIdx.x; j < nslots; j += NT) {
+            const uint32_t k = sec_reg_swz(gslot ? (uint32_t)gslot[j] : j);
+            const uint32_t d = sp[j];
+            psi_out[d] = psi[k];
+            lam_out[d] = lam[k];
+        }
+    }
+}
+// w[angle-table entry] += sign * (sum over the tiles of wpart[.][e]) for the entries e of one sweep (one block per entry)
+__global__ __launch_bounds__(256) void k_sec_reg_wreduce(const double *__restrict__ wpart, uint32_t ntiles, uint32_t nent,
+                                                         const uint32_t *__restrict__ emap, double *__restrict__ w) {
+    __shared__ double part[4];
+    const uint32_t e = blockIdx.x, m = emap[e];
+    if (m == 0xffffffffu) return;
+    double s = 0.0;
+    for (uint32_t t = threadIdx.x; t < ntiles; t += 256u) s += wpart[(size_t)t * nent + e];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = part[0] + part[1] + part[2] + part[3];
+        atomicAdd(&w[m & 0x7fffffffu], (m >> 31) ? -tot : tot);
+    }
+}
+
 // gather table of a sweep whose predecessor stored its tiles in permuted slot order: step j of tile t reads the element that the
 // canonical table (srcpad: position in the predecessor's canonical order, per slot) names for slot gslot[j], at the predecessor's
 // actual position of it (tile * cap + pos_prev[slot])

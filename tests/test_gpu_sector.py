@@ -269,6 +269,9 @@ def test_sector_on_the_reference_quccsd_templates(SV, m, o):
         got = [sv.energy(th) for th in thetas]
         info = sv.program_info()
         eg = [sv.energy_gradient(th) for th in thetas[1:]]
+        sv.set_option("sector_reg_adjoint", 0)               # the backward sweeps on the pair words of the same tables
+        eg_words = [sv.energy_gradient(th) for th in thetas[1:]]
+        sv.set_option("sector_reg_adjoint", 1)
         # the support is the full coset of the two spin parities: the sweeps run from bit arithmetic (k_sector_sweep_reg) —
         # against the pair-word sweeps of the same tables, other workgroup sizes and other tile sizes
         variants = {}
@@ -290,6 +293,8 @@ def test_sector_on_the_reference_quccsd_templates(SV, m, o):
         assert np.abs(np.array(es) - np.array(got)).max() < 1e-13 * max(1.0, l1), name
     for e, ew in zip(got, want):
         assert abs(e - ew) < 1e-10 * max(1.0, l1)
+    for (e, g), (ew_, gw_) in zip(eg, eg_words):
+        assert abs(e - ew_) < 1e-13 * max(1.0, l1) and np.abs(g - gw_).max() < 1e-12 * max(1.0, l1)
     for (e, g), (ed, gd), ew in zip(eg, eg_dense, want[1:]):
         assert abs(e - ew) < 1e-10 * max(1.0, l1) and abs(ed - ew) < 1e-10 * max(1.0, l1)
         assert np.abs(g - gd).max() < 1e-11 * max(1.0, l1)
