@@ -15,14 +15,43 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 worst_e = worst_g = 0.0
-used = declined = 0
+used = declined = regular = 0
 for case in range(cases):
     m = int(rng.integers(7, 11))
     n = 2 * m
     o = int(rng.integers(2, max(3, m // 2 + 1)))
     ham, gens, hf = fermion.synthetic_molecule(m, o, seed=int(rng.integers(1 << 30)))
-    kind = str(rng.choice(["uccsd_subset", "uccsd_shuffled", "single_strings", "mixed"]))
-    if kind == "uccsd_subset":
+    kind = str(rng.choice(["uccsd_subset", "uccsd_shuffled", "single_strings", "mixed", "quccsd_templates", "quccsd_templates"]))
+    gate_program = None
+    if kind == "quccsd_templates":
+        # the reference's QUCCSD templates on a random list of (generalised) excitations: their states fill the spin-parity quarter of
+        # the register — a REGULAR support: sweeps and backward sweeps from bit arithmetic, selectors, blocks of two ops
+        from openvqe_amd.common_files.circuit import quccsd_gate_list
+        singles, doubles = fermion.uccsd_excitations(m, o)
+        exc = [[i, a] for i, a in singles] + [[i, j, a, b] for i, j, a, b in doubles]
+        for _ in range(int(rng.integers(0, 12))):      # generalised ones: any two (four) distinct qubits of matching spins
+            p, q = (int(v) for v in rng.choice(m, 2, replace=False))
+            sp = int(rng.integers(2))
+            if rng.random() < 0.4:
+                exc.append([2 * p + sp, 2 * q + sp])
+            else:
+                r, t2 = (int(v) for v in rng.choice(m, 2, replace=False))
+                sp2 = int(rng.integers(2))
+                quad = [2 * p + sp, 2 * r + sp2, 2 * q + sp, 2 * t2 + sp2]
+                if len(set(quad)) == 4:
+                    exc.append(quad)
+        order = rng.permutation(len(exc)) if rng.random() < 0.5 else np.arange(len(exc))
+        take = int(rng.integers(min(30, len(exc)), min(len(exc), 140) + 1))
+        if rng.random() < 0.5:
+            order = np.sort(order[:take])                 # a subset in list order: long runs that share indices (blocks of two ops)
+        else:
+            order = order[:take]
+        gates, Kq, hfq = quccsd_gate_list(m, o, 1, excitations=[exc[i] for i in order])
+        gate_program = (gates, Kq, hfq)
+        gens = [None] * Kq
+    if kind == "quccsd_templates":
+        pass
+    elif kind == "uccsd_subset":
         pick = sorted(rng.choice(len(gens), int(rng.integers(5, min(len(gens), 120) + 1)), replace=False))
         gens = [gens[i] for i in pick]
     elif kind == "uccsd_shuffled":
@@ -50,14 +79,20 @@ for case in range(cases):
     thetas = [rng.uniform(-0.5, 0.5, K) for _ in range(3)]
     opts = {"sector_bits": int(rng.choice([0, 8, 10, 12, 14])), "sector_threads": int(rng.choice([0, 64, 256, 512, 1024])),
             "sector_dict": int(rng.random() < 0.8), "sector_h_bits": int(rng.choice([0, 6, 9, 12])),
-            "sector_tile_cap": int(rng.choice([6500, 6500, 700, 150])), "sector_min_qubits": 8}
+            "sector_tile_cap": int(rng.choice([6500, 6500, 700, 150])), "sector_min_qubits": 8,
+            # regular supports (full cosets of the program's Z2 symmetries: the single-string kinds produce them): bit-arithmetic sweeps
+            "sector_reg_pairs": int(rng.random() < 0.7), "sector_reg_threads": int(rng.choice([128, 256, 512])),
+            "sector_reg_adjoint": int(rng.random() < 0.8), "sector_regular": int(rng.choice([1, 1, 1, 3, 0]))}
     scale = max(1.0, float(np.abs(ham.packed()[2]).sum()))
     with Statevector(n) as sv:
         sv.set_option("force_path", 2)
         for k, v in opts.items():
             sv.set_option(k, v)
         sv.set_hamiltonian(ham)
-        sv.set_ucc_program(gens, hf)
+        if gate_program:
+            sv.set_gate_program(*gate_program)
+        else:
+            sv.set_ucc_program(gens, hf)
         es = [sv.energy(t) for t in thetas]
         info = sv.program_info()
         eg = [sv.energy_gradient(t) for t in thetas[1:]]
@@ -70,7 +105,8 @@ for case in range(cases):
     worst_e, worst_g = max(worst_e, de), max(worst_g, dg)
     used += info["sector_support"] > 0
     declined += info["sector_support"] == 0
+    regular += info["sector_regular_slot_bits"] > 0
     flag = "" if de < 1e-11 and dg < 1e-10 else "   <-- MISMATCH"
     print(f"case {case}: n={n} o={o} {kind} K={K} opts={opts} support={info['sector_support']} sweeps={info['sector_sweeps']} "
-          f"h_sweeps={info['sector_h_sweeps']} dE={de:.1e} dG={dg:.1e}{flag}", flush=True)
-print(f"worst dE/|H|_1 = {worst_e:.2e}, worst dG/|H|_1 = {worst_g:.2e}; sector path used in {used} cases, declined in {declined}")
+          f"h_sweeps={info['sector_h_sweeps']} regular={info['sector_regular_slot_bits']}/{info['sector_free_bits']} dE={de:.1e} dG={dg:.1e}{flag}", flush=True)
+print(f"worst dE/|H|_1 = {worst_e:.2e}, worst dG/|H|_1 = {worst_g:.2e}; sector path used in {used} cases ({regular} of them on bit-arithmetic sweeps), declined in {declined}")
