@@ -89,12 +89,26 @@ def lib():
         # system one).  If torch is imported first, libovqe_sv binds to that already-loaded runtime; the other
         # order would load two runtimes (torch looks its copy up by the unversioned file name) and device pointers
         # could not be shared.  So when torch is installed it is imported before the library is opened.
+        # Importing torch costs ~1 s; what has to happen first is only that ITS copy of the HIP runtime is the one in the
+        # process: it is opened here by path (RTLD_GLOBAL), torch itself only if that fails.
         import sys
         if "torch" not in sys.modules:
+            loaded = False
             try:
-                import torch  # noqa: F401
-            except ImportError:
-                pass
+                import importlib.util
+                spec = importlib.util.find_spec("torch")
+                if spec and spec.submodule_search_locations:
+                    hip_rt = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+                    if os.path.exists(hip_rt):
+                        ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
+                        loaded = True
+            except (OSError, ImportError, ValueError):
+                loaded = False
+            if not loaded:
+                try:
+                    import torch  # noqa: F401
+                except ImportError:
+                    pass
         if not os.path.exists(LIB_PATH):
             raise BackendError(
                 f"{LIB_PATH} is not built — run `python -c 'import __graft_entry__ as g; g.build()'`. "

@@ -1759,7 +1759,7 @@ __device__ __forceinline__ void sec_reg_apply(double *__restrict__ tile, const d
 // three of their four indices running slowest): the 16 slots over (shared 0, shared 1, own A, own B) in registers, A on the two
 // halves own B = 0 / 1, then B on the two halves own A = 0 / 1 — one read and one write of the tile, one barrier, for two ops.
 // Group word: bit 16 / 17 = A's sign / selector parity of the base slot, 18 / 19 = B's.
-template <int NT, int NSEL>
+template <int NT, int NSEL, bool MOVE_A = true, bool MOVE_B = true>
 __device__ __forceinline__ void sec_reg_apply_pair(double *__restrict__ tile, const double2 *__restrict__ TA, const double2 *__restrict__ TB,
                                                    const SecRegHead &op, uint32_t nslots, uint32_t tnum, int dbg,
                                                    const uint32_t *__restrict__ gwo, uint32_t wd0, uint32_t wd1) {
@@ -1777,30 +1777,48 @@ __device__ __forceinline__ void sec_reg_apply_pair(double *__restrict__ tile, co
 #pragma unroll
         for (int e = 0; e < 16; ++e) a[e] = *reinterpret_cast<const double *>(tb + (sb ^ dep[e]));
         if (dbg != 2) {
+            // the second half of an op takes other table entries than the first only when the other op's own bit sits on this op's
+            // selector mask (MOVE_*: compile-time, so that the four LDS reads of the entries are not repeated where they are the same)
+            {
+                const uint32_t sel0 = NSEL ? (((wd >> 17) & 1u) ^ tsA) & 1u : 0u;
+                double2 r0[4], r1[4];
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {   // op A on the half own B = v: members 8 v + (shared, own A)
-                const uint32_t neg = (((wd >> 16) & 1u) ^ tzA ^ ((uint32_t)v & fl)) << 31;
-                const uint32_t sel = NSEL ? (((wd >> 17) & 1u) ^ tsA ^ ((uint32_t)v & (fl >> 1))) & 1u : 0u;
-                const double2 *Tl = TA + sel * 4;
+                for (int q = 0; q < 4; ++q) r0[q] = TA[sel0 * 4 + q];
+                if constexpr (NSEL && MOVE_A) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const double2 r = Tl[q];
-                    const double u = a[8 * v + q], w = sec_flip(a[8 * v + 7 - q], neg);
-                    a[8 * v + q] = r.x * u + r.y * w;
-                    a[8 * v + 7 - q] = sec_flip(r.x * w - r.y * u, neg);
+                    for (int q = 0; q < 4; ++q) r1[q] = TA[(sel0 ^ 1u) * 4 + q];
+                }
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {   // op A on the half own B = v: members 8 v + (shared, own A)
+                    const uint32_t neg = (((wd >> 16) & 1u) ^ tzA ^ ((uint32_t)v & fl)) << 31;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double2 r = (NSEL && MOVE_A && v) ? r1[q] : r0[q];
+                        const double u = a[8 * v + q], w = sec_flip(a[8 * v + 7 - q], neg);
+                        a[8 * v + q] = r.x * u + r.y * w;
+                        a[8 * v + 7 - q] = sec_flip(r.x * w - r.y * u, neg);
+                    }
                 }
             }
+            {
+                const uint32_t sel0 = NSEL ? (((wd >> 19) & 1u) ^ tsB) & 1u : 0u;
+                double2 r0[4], r1[4];
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {   // op B on the half own A = v: pairs (shared = q, own B = 0) <-> (shared = ~q, own B = 1)
-                const uint32_t neg = (((wd >> 18) & 1u) ^ tzB ^ ((uint32_t)v & (fl >> 2))) << 31;
-                const uint32_t sel = NSEL ? (((wd >> 19) & 1u) ^ tsB ^ ((uint32_t)v & (fl >> 3))) & 1u : 0u;
-                const double2 *Tl = TB + sel * 4;
+                for (int q = 0; q < 4; ++q) r0[q] = TB[sel0 * 4 + q];
+                if constexpr (NSEL && MOVE_B) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const double2 r = Tl[q];
-                    const double u = a[4 * v + q], w = sec_flip(a[4 * v + 11 - q], neg);
-                    a[4 * v + q] = r.x * u + r.y * w;
-                    a[4 * v + 11 - q] = sec_flip(r.x * w - r.y * u, neg);
+                    for (int q = 0; q < 4; ++q) r1[q] = TB[(sel0 ^ 1u) * 4 + q];
+                }
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {   // op B on the half own A = v: pairs (shared = q, own B = 0) <-> (shared = ~q, own B = 1)
+                    const uint32_t neg = (((wd >> 18) & 1u) ^ tzB ^ ((uint32_t)v & (fl >> 2))) << 31;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double2 r = (NSEL && MOVE_B && v) ? r1[q] : r0[q];
+                        const double u = a[4 * v + q], w = sec_flip(a[4 * v + 11 - q], neg);
+                        a[4 * v + q] = r.x * u + r.y * w;
+                        a[4 * v + 11 - q] = sec_flip(r.x * w - r.y * u, neg);
+                    }
                 }
             }
         }
@@ -1857,7 +1875,7 @@ __global__ __launch_bounds__(NT) void k_sector_sweep_reg(const double *__restric
         SecRegHead cur = *reinterpret_cast<const SecRegHead *>(ops);
         uint32_t wd0 = gw[threadIdx.x], wd1 = gw[threadIdx.x + NT];
         for (int o = 0; o < nops;) {
-            const int step = (cur.w_nsel >> 24) ? 2 : 1;   // a block of two ops
+            const int step = ((cur.w_nsel >> 24) & 1u) ? 2 : 1;   // a block of two ops
             const int on = o + step < nops ? o + step : o;
             const SecRegHead nxt = *reinterpret_cast<const SecRegHead *>(ops + on);
             const uint32_t nw0 = gw[(size_t)on * SEC_REG_GSTRIDE + threadIdx.x], nw1 = gw[(size_t)on * SEC_REG_GSTRIDE + threadIdx.x + NT];
@@ -1865,7 +1883,10 @@ __global__ __launch_bounds__(NT) void k_sector_sweep_reg(const double *__restric
             const double2 *T = cs + (size_t)o * SEC_REG_TSTRIDE;
             switch (cur.w_nsel) {
             case 3 | (1 << 24): sec_reg_apply_pair<NT, 0>(tile, T, T + SEC_REG_TSTRIDE, cur, nslots, t, dbg, gwo, wd0, wd1); break;
-            case 3 | (1 << 16) | (1 << 24): sec_reg_apply_pair<NT, 1>(tile, T, T + SEC_REG_TSTRIDE, cur, nslots, t, dbg, gwo, wd0, wd1); break;
+            case 3 | (1 << 16) | (1 << 24): sec_reg_apply_pair<NT, 1, false, false>(tile, T, T + SEC_REG_TSTRIDE, cur, nslots, t, dbg, gwo, wd0, wd1); break;
+            case 3 | (1 << 16) | (1 << 24) | (1 << 25): sec_reg_apply_pair<NT, 1, true, false>(tile, T, T + SEC_REG_TSTRIDE, cur, nslots, t, dbg, gwo, wd0, wd1); break;
+            case 3 | (1 << 16) | (1 << 24) | (1 << 26): sec_reg_apply_pair<NT, 1, false, true>(tile, T, T + SEC_REG_TSTRIDE, cur, nslots, t, dbg, gwo, wd0, wd1); break;
+            case 3 | (1 << 16) | (1 << 24) | (3 << 25): sec_reg_apply_pair<NT, 1, true, true>(tile, T, T + SEC_REG_TSTRIDE, cur, nslots, t, dbg, gwo, wd0, wd1); break;
             case 4: sec_reg_apply<NT, 4, 0>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
             case 3: sec_reg_apply<NT, 3, 0>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
             case 3 | (1 << 16): sec_reg_apply<NT, 3, 1>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
@@ -2082,7 +2103,7 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint_reg(const double *__restr
         const uint32_t wd0 = gwo[threadIdx.x], wd1 = gwo[threadIdx.x + NT];
         const double2 *T = cs + (size_t)ob * SEC_REG_TSTRIDE;
         double *rowA = wrow + (size_t)((parity * 2 + 0) * NW + wave) * 8, *rowB = wrow + (size_t)((parity * 2 + 1) * NW + wave) * 8;
-        switch (cur.w_nsel) {
+        switch (cur.w_nsel & ~(3u << 25)) {
         case 3 | (1 << 24): sec_reg_unapply_pair<NT, 0>(psi, lam, T, T + SEC_REG_TSTRIDE, cur, nslots, t, gwo, wd0, wd1, rowA, rowB); break;
         case 3 | (1 << 16) | (1 << 24): sec_reg_unapply_pair<NT, 1>(psi, lam, T, T + SEC_REG_TSTRIDE, cur, nslots, t, gwo, wd0, wd1, rowA, rowB); break;
         case 4: sec_reg_unapply<NT, 4, 0>(psi, lam, T, cur, nslots, t, gwo, wd0, wd1, rowA); break;
