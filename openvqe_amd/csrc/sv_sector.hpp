@@ -25,6 +25,7 @@
 // The same tables serve ovqe_energy_gradient (lambda = H psi + backward sweeps) and ovqe_sector_ground_state (Lanczos).
 #pragma once
 #include "sv_kernels.hpp"
+#include "sv_regular_host.hpp"
 
 namespace ovqe {
 
@@ -34,15 +35,6 @@ namespace ovqe {
 constexpr int SEC_MAX_PAT = 32;
 constexpr uint32_t SEC_TILE_LDS_CAP = 14000;      // amplitudes of a circuit tile that fit LDS next to the staging buffers
 constexpr uint32_t SEC_STAGE_WORDS = 4096;        // pair words per staging buffer
-struct SecBuildOp {   // one compact op = one OP_TAB op, or one rotation of an OP_PAIR run
-    uint64_t x;       // mixing mask
-    uint64_t zs;      // sign = parity(i & zs) ^ flip, i = the pair's member that matches the pattern
-    int32_t pat0, npat;
-    int32_t flip, tab0;  // rotation table entries tab0 + pattern
-};
-struct SecPat {
-    uint64_t pm, pv;  // i is the first member of an active pair when (i & pm) == pv
-};
 struct SecGroup {     // x-group of the Hamiltonian, global masks
     uint64_t x;
     int32_t t0, t1;
@@ -1664,32 +1656,6 @@ __global__ __launch_bounds__(256) void k_sec_scatter(const double *__restrict__ 
 //   selector sigma_f (free bits INSIDE the op's x mask: which member of the pair matches which pattern depends on the value
 //   of the free bit, i.e. on a parity over kept bits outside x) = parity(slot & sel_in[f]) ^ parity(tile & sel_t[f]);
 //   table entry (c, s) of pair q under selector sigma: cs[tab + sigma * 2^(w-1) + q]; (1, 0) where no pattern is active.
-struct SecRegOp {         // 32 dwords; the first 16 are what the sweep kernel reads (scalar loads, uniform per op), the host fills everything
-    uint32_t w_nsel;      // w | nsel << 16
-    uint32_t zt;          // sign mask in tile-number space
-    uint32_t sel_t[2];    // selector masks in tile-number space
-    uint32_t dep[8];      // 16-bit halves: BYTE offset (swizzled) of member e of a group, e = pattern over the mixing bits (ascending)
-    uint32_t pad[4];
-    // host side (the group words carry their effect)
-    uint32_t xs;          // kept mixing bits, slot space (w of them)
-    uint32_t zin;         // sign mask, slot space (outside xs)
-    uint32_t sel_in[2];   // selector masks, slot space
-    uint32_t tab;         // first entry of the op in the sweep's (c, s) table (= 8 x its number)
-    uint32_t gpos[2];     // nibble k = slot position of bit k of the group number (the m - w positions outside xs; see below)
-    uint32_t pad2[9];
-};
-struct SecRegHead {       // the kernel's view of a record
-    uint32_t w_nsel, zt, sel_t[2], dep[8];
-    uint32_t pad[4];      // a block of two ops (w_nsel bit 24): [0] = whether own B sits on A's sign / selector mask (bits 0, 1), own A on B's
-                          // (bits 2, 3); [1], [2] = zt, sel_t[0] of op B
-};
-static_assert(sizeof(SecRegOp) == 128, "SecRegOp is read as 32 dwords");
-// LDS bank swizzle of a tile of doubles, linear over XOR (swz(a ^ b) = swz(a) ^ swz(b)): a group's members are base ^ spread(e).
-// Slot bit p lands on bank bit p mod 5 (8-byte slots: 32 per LDS cycle for reads, 16 for writes).  The host numbers the groups
-// so that bits 0..4 of the group number — the lanes of a read group — sit on positions of residues 0..4 mod 5 wherever the op's
-// mixing bits leave one free (bits 0..3, the 16 lanes of a write group, on residues 0..3): conflict-free whatever the x mask.
-__host__ __device__ __forceinline__ uint32_t sec_reg_swz(uint32_t v) { return v ^ ((v >> 5) & 31u) ^ ((v >> 10) & 31u); }
-
 __device__ __forceinline__ double sec_flip(double v, uint32_t signbit) {   // v with its sign bit xor-ed (signbit = 0 or 0x80000000)
     return __hiloint2double(__double2hiint(v) ^ (int)signbit, __double2loint(v));
 }
@@ -1713,8 +1679,6 @@ __global__ __launch_bounds__(256) void k_sec_reg_angles(const uint32_t *__restri
 // group words (host-built, SEC_REG_GSTRIDE per op): bits 0..15 = BYTE address of the group's swizzled base slot, bit 16 = its
 // parity on zin, bits 17 / 18 = its parities on sel_in[0] / sel_in[1] — the whole per-group index arithmetic is one load.
 // (c, s) table: SEC_REG_TSTRIDE = 8 entries per op — 2^nsel variants of 2^(w-1) pairs, and w + nsel <= 4 — read with scalar loads.
-constexpr uint32_t SEC_REG_GSTRIDE = 2048;   // words per op: the groups of a one-bit op in a 4096-slot tile
-constexpr uint32_t SEC_REG_TSTRIDE = 8;
 template <int NT, int W, int NSEL>
 __device__ __forceinline__ void sec_reg_apply(double *__restrict__ tile, const double2 *__restrict__ T, const SecRegHead &op, uint32_t nslots,
                                               uint32_t tnum, int dbg, const uint32_t *__restrict__ gwo, uint32_t wd0, uint32_t wd1) {

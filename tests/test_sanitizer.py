@@ -66,3 +66,18 @@ def test_c_oracle_under_asan_ubsan(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "sanitizer-clean" in r.stdout
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_regular_support_tables_under_asan_ubsan(tmp_path):
+    """the host-side planner of the bit-arithmetic sweeps (openvqe_amd/csrc/sv_regular_host.hpp: Z2 symmetries of a program, per-sweep
+    dependent bits, SecRegOp records, group words, table-entry maps, blocks of two ops) compiled with g++ under ASan + UBSan:
+    tests/cpu/regular_tables_check.cpp replays random sweeps from the tables the way k_sector_sweep_reg does and compares every
+    amplitude with the pair-by-pair definition of the ops"""
+    src = os.path.join(ROOT, "tests", "cpu", "regular_tables_check.cpp")
+    exe = str(tmp_path / "regular_tables_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-o", exe, src])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    for seed in ("7", "2024"):
+        r = subprocess.run([exe, "400", seed], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert "regular tables ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
