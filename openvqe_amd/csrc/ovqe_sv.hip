@@ -3378,15 +3378,14 @@ int ovqe_bilinear(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64
     std::vector<HTerm> terms;
     int rc = build_groups(h, T, x, z, coeff_re, coeff_im, /*allow_global_x=*/ket_dev != nullptr, groups, terms);
     if (rc) return rc;
-    DevBuf dg, dt;
-    rc = upload(h, dg, groups.data(), groups.size() * sizeof(HGroup));
-    if (!rc) rc = upload(h, dt, terms.data(), terms.size() * sizeof(HTerm));
+    // (the handle's pool buffers carry the term list: a sharded <H> makes tens of thousands of these calls, one per partner chunk)
+    rc = upload(h, h->d_pg_xs, groups.data(), std::max<size_t>(groups.size(), 1) * sizeof(HGroup));
+    if (!rc) rc = upload(h, h->d_pg_terms, terms.data(), std::max<size_t>(terms.size(), 1) * sizeof(HTerm));
+    h->pg_valid = false;  // the pool buffers were borrowed
     double2 res = make_double2(0.0, 0.0);
     if (!rc)
         rc = run_bilinear(h, bra_dev ? (const amp_t *)bra_dev : h->state, ket_dev ? (const amp_t *)ket_dev : h->state,
-                          groups, (const HGroup *)dg.p, (const HTerm *)dt.p, &res, false);
-    if (dg.p) (void)hipFree(dg.p);
-    if (dt.p) (void)hipFree(dt.p);
+                          groups, (const HGroup *)h->d_pg_xs.p, (const HTerm *)h->d_pg_terms.p, &res, false);
     out_re_im[0] = res.x;
     out_re_im[1] = res.y;
     return rc;
