@@ -277,9 +277,25 @@ class ShardedStatevector:
         self.stats["real_exchanges"] += 1 if real else 0
         self.stats["pieces"] += P
 
-    def _localise(self, x_logical_seq, r):
-        """make every X/Y qubit of rotation r local; victims by farthest next X/Y use"""
+    @staticmethod
+    def _use_lists(x_logical_seq, n):
+        """per logical qubit: the (ascending) rotation numbers whose x mask touches it — next-use queries by bisection"""
+        uses = [[] for _ in range(n)]
+        for r, x in enumerate(x_logical_seq):
+            m, b = int(x), 0
+            while m:
+                if m & 1:
+                    uses[b].append(r)
+                m >>= 1
+                b += 1
+        return uses
+
+    def _localise(self, x_logical_seq, r, uses=None, swap=None):
+        """make every X/Y qubit of rotation r local; victims by farthest next X/Y use (Belady).  ``uses``: _use_lists of the
+        sequence (else scanned); ``swap``: what performs an exchange (default: the real one; the planner records instead)"""
+        import bisect
         lmask = self._local_mask()
+        swap = swap or self._swap
         while True:
             xp = self._phys(x_logical_seq[r])
             xg = xp & ~lmask
@@ -293,15 +309,21 @@ class ShardedStatevector:
                     continue
                 logical = self.perm.index(lbit)
                 nxt = len(x_logical_seq) + 1
-                for s in range(r + 1, len(x_logical_seq)):
-                    if (x_logical_seq[s] >> logical) & 1:
-                        nxt = s
-                        break
+                if uses is not None:
+                    u = uses[logical]
+                    k = bisect.bisect_right(u, r)
+                    if k < len(u):
+                        nxt = u[k]
+                else:
+                    for s in range(r + 1, len(x_logical_seq)):
+                        if (x_logical_seq[s] >> logical) & 1:
+                            nxt = s
+                            break
                 if nxt > best_next:
                     best, best_next = lbit, nxt
             if best is None:
                 raise ValueError("rotation touches more qubits than fit in one shard")
-            self._swap(gbit, best)
+            swap(gbit, best)
 
     # -- state ------------------------------------------------------------------------------
     def init_basis(self, logical_index):
@@ -340,10 +362,11 @@ class ShardedStatevector:
                                       np.array(batch_p, np.float64))
                 batch_x.clear(); batch_z.clear(); batch_p.clear()
 
+        uses = self._use_lists(xs, self.n) if len(xs) > 8 else None
         for r in range(len(xs)):
             if self._phys(xs[r]) & ~self._local_mask():
                 flush()  # the permutation is about to change: masks already queued used the old one
-                xp = self._localise(xs, r)
+                xp = self._localise(xs, r, uses)
             else:
                 xp = self._phys(xs[r])
             batch_x.append(xp)
@@ -477,13 +500,16 @@ class ShardedStatevector:
     def expectation(self, xs, zs, coeffs, constant=0.0):
         """Re sum_t c_t <psi|P_t|psi> + constant over the whole register (same value on every rank)"""
         groups = self._group_by_partner(xs, zs, coeffs)
+        remote, partners = self._remote_plan(groups)
+        return self._expectation_grouped(groups, remote, partners) + float(np.real(constant))
+
+    def _expectation_grouped(self, groups, remote, partners):
         total = 0.0 + 0.0j
         for xg, terms in groups:
             if xg == 0:
                 total += self.engine.bilinear(np.array([t[0] for t in terms], np.uint64),
                                               np.array([t[1] for t in terms], np.uint64),
                                               np.array([t[2] for t in terms], np.complex128), None)
-        remote, partners = self._remote_plan(groups)
         m = self._chunk_bits()
         for c, chunks in self._partner_chunks(partners):
             for (xg, by_h), ket in zip(remote, chunks):
@@ -496,7 +522,7 @@ class ShardedStatevector:
         val = torch.tensor([total.real], dtype=torch.float64, device=self.engine.tensor.device)
         if self._dist:
             dist.all_reduce(val, group=self.group)
-        return float(val.item()) + float(np.real(constant))
+        return float(val.item())
 
     # -- ADAPT gradient screen on the sharded register ("ADAPT screen identical with sigma also sharded")
     def apply_hamiltonian(self, xs, zs, coeffs, constant=0.0):
@@ -568,6 +594,75 @@ class ShardedStatevector:
             dist.all_reduce(buf, group=self.group)
         v = buf[0].cpu().numpy() + 1j * buf[1].cpu().numpy()
         return 2.0 * v.real if mode == "fermionic" else 2.0 * np.abs(v)
+
+    # -- compiled programs: the exchange plan of a rotation list is made ONCE (ref:openvqe/ucc_family/get_energy_ucc.py:42-45 runs the
+    # same list with new angles at every optimiser step) -----------------------------------------------------------------------
+    def compile_program(self, rot_xs, rot_zs, rot_coeffs, rot_pidx, hf_index, hamiltonian=None):
+        """plan of `|hf> -> prod_r exp(-i coeff_r theta[pidx_r] P_r)` on this partition, from the identity permutation: the
+        half-shard exchanges (Belady victims over the whole list, next uses by bisection: O(R n log R) instead of the O(R^2 n) scan)
+        and, between them, the local rotations with their masks already in PHYSICAL bit space; with ``hamiltonian`` =
+        (xs, zs, coeffs, constant) also its terms grouped by partner shard under the program's FINAL permutation.
+        -> an object for ``run_program`` / ``program_energy``; identical on every rank"""
+        xs = [int(v) for v in rot_xs]
+        zs = [int(v) for v in rot_zs]
+        saved = list(self.perm)
+        self.perm = list(range(self.n))
+        uses = self._use_lists(xs, self.n)
+        steps, batch = [], []
+
+        def record_swap(gbit, lbit):
+            la, lb = self.perm.index(gbit), self.perm.index(lbit)
+            self.perm[la], self.perm[lb] = lbit, gbit
+            steps.append(("swap", gbit, lbit))
+
+        def flush():
+            if batch:
+                idx = np.array([b[0] for b in batch], np.int64)
+                steps.append(("rot", np.array([b[1] for b in batch], np.uint64), np.array([b[2] for b in batch], np.uint64), idx))
+                batch.clear()
+
+        try:
+            for r in range(len(xs)):
+                if self._phys(xs[r]) & ~self._local_mask():
+                    flush()
+                    xp = self._localise(xs, r, uses, swap=record_swap)
+                else:
+                    xp = self._phys(xs[r])
+                batch.append((r, xp, self._phys(zs[r])))
+            flush()
+            final_perm = list(self.perm)
+            prog = {"steps": steps, "coeff": np.asarray(rot_coeffs, np.float64), "pidx": np.asarray(rot_pidx, np.int64),
+                    "hf": int(hf_index), "perm": final_perm, "real": all(bin(x & z).count("1") & 1 for x, z in zip(xs, zs)),
+                    "swaps": sum(1 for st in steps if st[0] == "swap"), "ham": None}
+            if hamiltonian is not None:
+                hx, hz, hc, const = hamiltonian
+                groups = self._group_by_partner(hx, hz, hc)        # under the final permutation (self.perm right now)
+                prog["ham"] = (groups, self._remote_plan(groups), float(np.real(const)))
+        finally:
+            self.perm = saved
+        return prog
+
+    def run_program(self, prog, theta):
+        """|hf> -> the program's state at ``theta`` (the plan's exchanges and local sweeps; no planning)"""
+        theta = np.asarray(theta, np.float64)
+        self.perm = list(range(self.n))
+        self.init_basis(prog["hf"])
+        self.real = prog["real"]      # (a list with one even-Y string anywhere travels complex from the start: the flag is per program)
+        phis = prog["coeff"] * np.where(prog["pidx"] >= 0, theta[np.clip(prog["pidx"], 0, max(len(theta) - 1, 0))] if len(theta) else 0.0, 1.0)
+        for st in prog["steps"]:
+            if st[0] == "swap":
+                self._swap(st[1], st[2])
+            else:
+                self.engine.rotations(st[1], st[2], phis[st[3]])
+        assert self.perm == prog["perm"]
+
+    def program_energy(self, prog, theta):
+        """E(theta) = <psi(theta)|H|psi(theta)> + constant with the Hamiltonian the program was compiled with"""
+        if prog["ham"] is None:
+            raise ValueError("compile_program was called without a Hamiltonian")
+        self.run_program(prog, theta)
+        groups, (remote, partners), const = prog["ham"]
+        return self._expectation_grouped(groups, remote, partners) + const
 
     def energy(self, ham_xs, ham_zs, ham_coeffs, constant, rot_xs, rot_zs, rot_phis, hf_index):
         """one whole evaluation: |hf> -> rotations -> <H>"""

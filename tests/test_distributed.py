@@ -349,3 +349,79 @@ def test_real_amplitude_transfers_halve_the_exchanged_bytes(world, n, chunk_bits
     assert st1["swaps"] == st0["swaps"] >= 1 and st1["real_exchanges"] == st1["swaps"] and st0["real_exchanges"] == 0
     assert st1["real_chunk_reads"] == st1["chunk_reads"] > 0
     assert st1["bytes_sent"] * 2 == st0["bytes_sent"]
+
+
+def _program_worker(rank, world, port, n, seed, out, engine="oracle", chunk_bits=None):
+    """a compiled program on the sharded register: planned once, evaluated at several parameter vectors"""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if chunk_bits is not None:
+        os.environ["OVQE_SHARD_CHUNK_BITS"] = str(chunk_bits)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from openvqe_amd.distributed import ShardedStatevector
+        rng = np.random.default_rng(seed)
+        g = world.bit_length() - 1
+        K, R, T = 7, 36, 30
+        xs, zs = [], []
+        for _ in range(R):
+            w = int(rng.integers(2, max(3, min(5, n - g))))
+            bits = [int(b) for b in rng.choice(n, w, replace=False)]
+            x = sum(1 << b for b in bits)
+            z = 1 << bits[0]
+            for b in rng.choice(n, 2, replace=False):
+                if not (x >> int(b)) & 1:
+                    z |= 1 << int(b)
+            xs.append(x); zs.append(z)
+        coeff = rng.uniform(0.5, 1.5, R)
+        pidx = rng.integers(0, K, R)
+        hx = [sum(1 << int(b) for b in rng.choice(n, int(rng.integers(1, 4)), replace=False)) if rng.random() < 0.85 else 0 for _ in range(T)]
+        hz = [int(v) for v in rng.integers(0, 1 << n, T)]
+        hc = rng.normal(size=T)
+        hf = int(rng.integers(0, 1 << n))
+        thetas = rng.uniform(-0.8, 0.8, (3, K))
+        sv = (ShardedStatevector(n, device=0) if engine == "hip" else
+              ShardedStatevector(n, engine_factory=lambda nl, ng, r: OracleShardEngine(nl, ng, r)))
+        prog = sv.compile_program(xs, zs, coeff, pidx, hf, hamiltonian=(hx, hz, hc, 0.75))
+        es = [sv.program_energy(prog, th) for th in thetas]
+        full = sv.gather_state()                                    # the state of the last evaluation, logical order
+        swaps_per_run = sv.stats["swaps"] // len(thetas)
+        # the same list through the uncompiled path: same exchanges, same energy
+        before = sv.stats["swaps"]
+        e_plain = sv.energy(hx, hz, hc, 0.75, xs, zs, coeff * thetas[2][pidx], hf)
+        plain_swaps = sv.stats["swaps"] - before
+        # planning a LONG list must stay cheap (the scan it replaces was quadratic in the list length)
+        long_x = [xs[int(k)] for k in rng.integers(0, R, 6000)]
+        t0 = time.perf_counter()
+        long_prog = sv.compile_program(long_x, [1] * 6000, np.ones(6000), np.zeros(6000, int), hf)
+        t_plan = time.perf_counter() - t0
+        if rank == 0:
+            out.put((es, full, e_plain, swaps_per_run, plain_swaps, prog["swaps"], t_plan, len(long_prog["steps"]),
+                     (xs, zs, coeff, pidx, hx, hz, hc, hf, thetas)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,chunk_bits", [(2, 7, 3), (4, 8, 2), (8, 9, 3)])
+def test_compiled_program_on_the_sharded_register(world, n, chunk_bits):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_program_worker, args=(r, world, port, n, 31 + n, out, "oracle", chunk_bits)) for r in range(world)]
+    for p in procs:
+        p.start()
+    es, full, e_plain, swaps_per_run, plain_swaps, planned, t_plan, nsteps, (xs, zs, coeff, pidx, hx, hz, hc, hf, thetas) = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for e, th in zip(es, thetas):
+        psi = np.zeros(1 << n, complex)
+        psi[hf] = 1
+        for x, z, c, k in zip(xs, zs, coeff, pidx):
+            psi = masks.rotate(psi, int(x), int(z), c * th[k])
+        assert abs(e - masks.expectation(psi, hx, hz, hc, 0.75)) < 1e-11
+    assert np.abs(full - psi).max() < 1e-12
+    assert abs(e_plain - es[2]) < 1e-12
+    assert swaps_per_run == plain_swaps == planned >= 1          # the plan IS what the uncompiled path does, made once
+    assert t_plan < 5.0 and nsteps > 0, t_plan

@@ -90,3 +90,27 @@ def test_real_amplitude_transfers_on_hip_shards(gpu_lib, world, n, chunk_bits):
     assert abs(e1 - want) < 1e-11 and abs(e0 - want) < 1e-11
     assert st1["real_exchanges"] == st1["swaps"] >= 1 and st1["real_chunk_reads"] == st1["chunk_reads"] > 0
     assert st1["bytes_sent"] * 2 == st0["bytes_sent"]
+
+
+def test_compiled_program_on_hip_shards(gpu_lib):
+    """the exchange plan of a rotation list made once, evaluated at three parameter vectors on eight HIP shards (one GPU, gloo)"""
+    from tests.test_distributed import _program_worker
+    world, n, chunk_bits = 8, 16, 10
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_program_worker, args=(r, world, port, n, 515, out, "hip", chunk_bits)) for r in range(world)]
+    for p in procs:
+        p.start()
+    es, full, e_plain, swaps_per_run, plain_swaps, planned, t_plan, nsteps, (xs, zs, coeff, pidx, hx, hz, hc, hf, thetas) = out.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for e, th in zip(es, thetas):
+        psi = np.zeros(1 << n, complex)
+        psi[hf] = 1
+        for x, z, c, k in zip(xs, zs, coeff, pidx):
+            psi = masks.rotate(psi, int(x), int(z), c * th[k])
+        assert abs(e - masks.expectation(psi, hx, hz, hc, 0.75)) < 1e-11
+    assert np.abs(np.asarray(full) - psi).max() < 1e-12 and abs(e_plain - es[2]) < 1e-12
+    assert swaps_per_run == plain_swaps == planned >= 1
