@@ -132,4 +132,9 @@ def minimize(fun, x0, jac=None, method="BFGS", tol=None, options=None):
     options = dict(options or {})
     if method == "BFGS" and callable(jac) and np.size(x0) >= RANK_TWO_FROM:
         return minimize_bfgs(fun, x0, jac, tol=tol, maxiter=options.get("maxiter"), disp=options.get("disp", False))
-    return scipy.optimize.minimize(fun, x0=x0, jac=jac, method=method, tol=tol, options=options)
+    try:   # scipy's own run, its host algebra on one BLAS thread too (see minimize_bfgs: spinning BLAS workers slow the device calls)
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        return scipy.optimize.minimize(fun, x0=x0, jac=jac, method=method, tol=tol, options=options)
+    with threadpool_limits(limits=1, user_api="blas"):
+        return scipy.optimize.minimize(fun, x0=x0, jac=jac, method=method, tol=tol, options=options)
