@@ -212,8 +212,10 @@ int ovqe_energy(ovqe_handle h, const double *theta, int32_t K, double *energy);
 /* B parameter vectors (row-major B x K) in one launch — one finite-difference gradient of
  * scipy.optimize.minimize(jac=None) (ref:openvqe/ucc_family/get_energy_ucc.py:158-175) is B = K+1 */
 int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, double *energies);
-/* same with theta (B x K doubles) and energies (B doubles) RESIDENT ON THE DEVICE: nothing crosses PCIe
- * (fused kernels, n <= 16; e.g. theta batches produced on the GPU, or uploaded once and re-used) */
+/* same with theta (B x K doubles) and energies (B doubles) RESIDENT ON THE DEVICE (e.g. theta batches produced on the GPU, or
+ * uploaded once and re-used): nothing crosses PCIe on the fused kernels (n <= 16) and on the batched sector evaluations (real-amplitude
+ * programs with sector tables: whole batches per pass of the tables); any other program is served through the host, one
+ * evaluation at a time (B x K doubles down, B energies up) */
 int ovqe_energy_batch_device(ovqe_handle h, int64_t B, const void *theta_dev, int32_t K, void *energies_dev);
 /* run the program and leave U(theta)|hf> in the handle's state buffer
  * (prepare_state_ansatz + get_statevector, ref:openvqe/adapt/fermionic_adapt_vqe.py:273-328) */

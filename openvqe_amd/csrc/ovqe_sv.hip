@@ -3745,7 +3745,26 @@ int ovqe_energy_batch_device(ovqe_handle h, int64_t B, const void *theta_dev, in
     }
     if (h->n_global == 0 && h->n_local <= 16 && h->opt_force_path != 2)
         return run_small(h, B, (const double *)theta_dev, (double *)energies_dev, true);
-    return fail(h, OVQE_ERR_INVALID, "device-resident batches are served by the fused kernels (n <= 16) only");
+    // larger registers: whole batches per pass of the sector tables, parameters and energies staying on the device
+    if (h->opt_sector_batch && h->opt_real_stream && h->prog_real_ok && h->n_global == 0 && tile_ok(h, true) && h->ham.groups.size() >= 3) {
+        rc = sector_prepare(h, true);
+        if (rc) return rc;
+        if (sector_batch_ready(h)) {
+            bool ok = false;
+            rc = run_sector_energy_batch(h, B, (const double *)theta_dev, true, (double *)energies_dev, &ok);
+            if (rc) return rc;
+            if (ok) return OVQE_OK;
+        }
+    }
+    // anything else: through the host (one evaluation at a time on whatever path the program takes; B x K doubles down, B up)
+    std::vector<double> th((size_t)B * K), en((size_t)B);
+    HIPC(h, hipMemcpyAsync(th.data(), theta_dev, th.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    rc = ovqe_energy_batch(h, B, th.data(), K, en.data());
+    if (rc) return rc;
+    HIPC(h, hipMemcpyAsync(energies_dev, en.data(), en.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPC(h, hipStreamSynchronize(h->stream));
+    return OVQE_OK;
 } OVQE_CATCH(h)
 
 int ovqe_energy(ovqe_handle h, const double *theta, int32_t K, double *energy) try {

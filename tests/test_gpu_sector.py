@@ -423,8 +423,25 @@ def test_batched_evaluations_on_the_sector_tables_match_c_oracle(SV, m, o):
         info = sv.program_info()
         got = {B: sv.energy_batch(thetas[:B]) for B in (1, 3, 8, 141)}
         serial = np.array([sv.energy(t) for t in thetas[:9]])
+        # parameters and energies resident on the device (ovqe_energy_batch_device beyond the fused kernels' 16 qubits): the same
+        # batched passes with nothing crossing PCIe; an odd batch (ragged last pair of states) and, with batches switched off, the
+        # route through the host
+        import torch
+        th_dev = torch.from_numpy(thetas).cuda()
+        en_dev = torch.zeros(141, dtype=torch.float64, device="cuda")
+        sv.energy_batch_device(141, th_dev.data_ptr(), en_dev.data_ptr())
+        torch.cuda.synchronize()
+        resident = en_dev.cpu().numpy()
+        en7 = torch.zeros(7, dtype=torch.float64, device="cuda")
+        sv.energy_batch_device(7, th_dev[10:17].contiguous().data_ptr(), en7.data_ptr())
+        resident7 = en7.cpu().numpy()
         sv.set_option("sector_batch", 0)
         unbatched = sv.energy_batch(thetas[:9])
+        en5 = torch.zeros(5, dtype=torch.float64, device="cuda")
+        sv.energy_batch_device(5, th_dev.data_ptr(), en5.data_ptr())
+        resident5 = en5.cpu().numpy()
+    assert np.abs(resident - got[141]).max() < 1e-13 * max(1.0, l1)
+    assert np.abs(resident7 - want[10:17]).max() < 1e-10 * max(1.0, l1) and np.abs(resident5 - serial[:5]).max() < 1e-13 * max(1.0, l1)
     assert info["sector_support"] == comb(m, o) ** 2
     assert np.abs(first - want[:8]).max() < 1e-10 * max(1.0, l1)
     for B, e in got.items():
