@@ -71,61 +71,67 @@ int ovqe_create_shard(int n_local, int n_global, uint64_t shard_index, int devic
 int ovqe_destroy(ovqe_handle h);
 /* run this handle's kernels on a caller-owned hipStream_t (NULL = default stream) */
 int ovqe_set_stream(ovqe_handle h, void *hip_stream);
-/* tuning knobs: "force_path" (0 auto, 1 fused small-register kernel, 2 streaming kernels, 3 support-compacted
- * kernel), "sparse" (1: allow the support-compacted kernel when the program has a small reachable support),
- * "sparse_renumber" (1, default: the compact support is numbered so that the pairs of an op fall into distinct LDS banks),
- * "sector_sweep" (2, default: circuit sweeps of the sector path scatter into the next sweep's order and keep 64-bit pair
- * words in registers; 1: first form), "sector_chunk" (pair words per chunk of those sweeps: 1024, 2048 default, 4096),
- * "sector_adjoint" (2, default: the backward sweeps of ovqe_energy_gradient on the sector tables use those 64-bit tables too; 1: first form),
- * "sector_batch" (1, default: ovqe_energy_batch runs whole batches per pass of the sector tables),
- * "sector_eager_rots" (2048: programs of at most this many rotations build their sector tables at the first evaluation, longer ones at the second),
- * "sector_batch_threads" / "sector_batch_nb" / "sector_batch_sweep_threads" / "sector_batch_dst_lds" / "sector_batch_zfast" (workgroup shapes and
- * grid order of batched sector evaluations; defaults 1024 / 2 / 512 / 0 / 1), "sector_apply_threads" (0 = automatic), "sector_h_lpt" (1: the <H>
- * kernels and sweeps with many tiles take their tiles largest first), "sector_many_tiles" (1: single evaluations with >= 768 tiles use the
- * batches' workgroup shape), "sector_depth2" (1: two chunks of pair words ahead in the first sweep form),
- * "screen_sector" (1) / "screen_sector_min" (1024) / "screen_tables" (1): ADAPT screens — sigma = H psi from the materialised Hamiltonian of
- * psi's symmetry sector, pattern tables for the pool's same-x runs (see ovqe_pool_gradients, ovqe_last_support),
- * "small_max_qubits", "small_batch_max_qubits", "unroll", "real_mode" (1: allow the real-amplitude
- * specialisation of the fused kernel when every rotation string has an odd number of Y),
- * "table_fusion" (1: commuting same-x runs become single sparse pair rotations in the fused kernel),
- * "tile_bits" (streaming path: 0 = one sweep per op; 10..12 = LDS tiles of 2^bits amplitudes that take runs of
- * consecutive ops per sweep; default -1 = automatic: 12 for n >= 25, else 11), "tile_low" (lowest index bits always inside a tile, default 4),
- * "real_stream" (1, default: a program
- * whose rotation strings all have an odd number of Y — every UCC / ADAPT generator, the QUCCSD templates in frame form —
- * keeps the amplitudes real; streaming energies (n >= 15) then store the state as 2^n doubles: half the HBM bytes per
- * sweep, one more mixing bit per LDS tile; ovqe_prepare_state always delivers the complex state),
- * "ham_tile_low" (lowest index bits forced into every tile of the Hamiltonian's cover, default 2; -1 = "tile_low"; fewer forced bits =
- * fewer sweeps per H psi / tiled <H>), "apply_min_tiles" (sigma = H psi uses the tile cover from this many tiles on, default 256; the gather
- * kernel below), "screen_sparse" (ovqe_pool_gradients: when at most 1/value of the amplitudes of psi are non-zero — an ADAPT state of a few
- * operators lives on a few determinants — the bilinear forms <sigma|A_i|psi> are summed over the list of those amplitudes (ascending
- * index, fixed order) instead of over the register; ovqe_apply_exp_pauli_sum: the Taylor steps run over the closure of that list
- * under the operator's x-groups while it stays within the same bound, bit-identical amplitudes; default 16, 0 = never), "lanczos_keep_gb" (ovqe_ground_state keeps its Lanczos vectors in HBM up to this many GB — and never more than 60 %
- * of the free memory — so that one pass of the recurrence gives the Ritz vector; default 160; 0, or vectors that do not fit: the
- * recurrence is run twice), "clifford_frame" (read by the NEXT ovqe_set_gate_program: 0 = execute the literal gate list; 1 (default) = when
- * the Clifford part of the list — X, H, CNOT, quarter-turn rotations — multiplies to the identity, run the
- * algebraically identical sequence of Pauli rotations with conjugated strings instead, and when it does NOT (an open
- * frame: interleaved CNOT ladders, stray gates) run that rotation sequence too: energies and gradients then use the stored
- * Hamiltonian conjugated by the net Clifford operator (<C phi|H|C phi> = <phi|C^+ H C|phi>, every term stays one Pauli
- * string) and ovqe_prepare_state applies the Clifford gates behind the rotations; 2 = frame form always, Clifford part
- * appended literally to the program; 3 = frame form only when the frame closes, literal list otherwise), "expect_sparse" (tiled <H>: a tile in which at most 1/value of the amplitudes are non-zero — the
- * particle-number / spin sector of a UCC-type state — is evaluated over the compacted list of its non-zero amplitudes
- * instead of over all pairs; skipped work is multiplication by exact zeros; default 4, 0 = never),
- * "compact" (1, default: compact cover — from the second evaluation of a (program, Hamiltonian) pair on, <H> of a
- * real-amplitude streaming energy runs over a compact copy of the state's support),
- * "sector" (1, default: sector path — from the second energy evaluation (or the first gradient call) on, a real-amplitude program whose states occupy at most
- * 1/4 of the register runs entirely on that support: circuit over compact tiles from precomputed pair lists, <H> from the
- * Hamiltonian materialised on the support; results equal the dense kernels' up to rounding; the tables live in device
- * memory next to the state), "sector_max_gb" (table budget, default 128, also capped at 60 % of the free device memory;
- * beyond it the circuit stays on the sector path and <H> goes through the compact cover), "sector_h" (0: never materialise
- * <H>), "sector_dict" (0: explicit doubles instead of dictionary-coded matrix elements), "sector_bits" / "sector_h_bits"
- * (index bits per circuit / <H> tile, 0 = automatic), "sector_threads" (0 automatic, 64, 256, 512, 1024),
- * "sector_min_qubits" (default 18), "sector_sparsity" (the support may fill at most 1/value of the register, default 4),
- * "sector_tile_cap" (amplitudes per circuit tile, default 6500 so that gradients fit; up to 14000 for energies only),
- * "sector_debug" (2: report on stderr why a program was left to the dense kernels or its tables dropped; 1: measurement only).
- * When an evaluation meets a non-zero amplitude whose partner is outside the probed support (generators whose strings share a
- * parameter can pass through determinants their final states do not hold) it is redone by the dense kernels and the tables are
- * rebuilt once from a probe with an independent angle per rotation (a superset of the support; still exact).
- * The state buffer holds unspecified data after an energy evaluation on this path. */
+/* Options.  None of them changes a result beyond rounding (tests/test_gpu_tile.py, test_gpu_kernels.py, test_gpu_sector.py compare the
+ * settings with one another and with the oracle); unknown names return OVQE_ERR_INVALID.  Three groups:
+ *
+ * (A) WHICH PATH RUNS — what a caller may reasonably set
+ *   "force_path"      0 automatic (default), 1 fused small-register kernel, 2 streaming kernels, 3 support-compacted kernel
+ *   "clifford_frame"  read by the NEXT ovqe_set_gate_program.  1 (default): a gate list whose Clifford part (X, H, CNOT, quarter-turn
+ *                     rotations) multiplies to the identity runs as the algebraically identical sequence of Pauli rotations with
+ *                     conjugated strings; when it does NOT close (interleaved CNOT ladders, stray gates) that rotation sequence runs
+ *                     too, energies / gradients then use the stored Hamiltonian conjugated by the net Clifford operator
+ *                     (<C phi|H|C phi> = <phi|C^+ H C|phi>, every term stays one Pauli string) and ovqe_prepare_state applies the
+ *                     Clifford gates behind the rotations.  0: execute the literal list; 2: frame form always, Clifford part appended
+ *                     literally; 3: frame form only when the frame closes
+ *   "real_mode" / "real_stream" (1)  a program whose rotation strings all have an odd number of Y (every UCC / ADAPT generator, the
+ *                     QUCCSD templates in frame form) keeps the amplitudes real: 8-byte amplitudes in the fused kernel / 2^n doubles in
+ *                     streaming energies (n >= 15): half the bytes per sweep; ovqe_prepare_state always delivers the complex state
+ *   "table_fusion" (1) commuting same-x runs become single sparse pair rotations in the fused kernel
+ *   "sparse" (1)      support-compacted kernel when the program's reachable support fits one workgroup's LDS
+ *   "compact" (1)     compact cover: from the second evaluation of a (program, Hamiltonian) pair, <H> of a real-amplitude streaming
+ *                     energy runs over a compact copy of the state's support
+ *   "sector" (1)      sector path: from the second energy evaluation (the first gradient call; the first evaluation for programs of at most
+ *                     "sector_eager_rots" = 2048 rotations) a real-amplitude program whose states occupy at most 1/"sector_sparsity" (4) of
+ *                     the register runs entirely on that support: circuit over compact tiles, <H> from the Hamiltonian materialised on
+ *                     the support; tables in device memory up to "sector_max_gb" (128; and 60 % of the free memory) — beyond it <H> goes
+ *                     through the compact cover; "sector_min_qubits" (18); "sector_h" 0: never materialise <H>.  When an evaluation meets
+ *                     a non-zero amplitude whose partner is outside the probed support it is redone by the dense kernels and the tables are
+ *                     rebuilt once from a probe with one angle per rotation.  The state buffer holds unspecified data after an energy
+ *                     evaluation on this path.
+ *   "sector_regular" (1)  supports that are the full coset of the program's Z2 symmetries (the spin-parity quarter that the reference's
+ *                     QUCCSD templates populate): circuit sweeps — and with "sector_reg_adjoint" (1) the backward sweeps of
+ *                     ovqe_energy_gradient — from bit arithmetic, no pair-word tables for supports of 2^20 amplitudes and more; 0: pair
+ *                     words; 3: without the slot orders that make the gathers between sweeps run in runs (measurement)
+ *   "sector_batch" (1) ovqe_energy_batch / _device run whole batches per pass of the sector tables
+ *   "screen_sparse" (16) / "screen_sector" (1) / "screen_sector_min" (1024) / "screen_tables" (1)  ADAPT screens: bilinear forms summed over
+ *                     the listed non-zero amplitudes of psi while they are at most 1/value of the register (0: never); sigma = H psi from the
+ *                     materialised Hamiltonian of psi's symmetry sector once psi lists that many amplitudes; pattern tables for the pool's
+ *                     same-x runs (see ovqe_pool_gradients, ovqe_last_support); ovqe_apply_exp_pauli_sum runs its Taylor steps over the
+ *                     closure of the support under the operator's x-groups within the same bound (bit-identical amplitudes)
+ *   "lanczos_keep_gb" (160) ovqe_ground_state keeps its Lanczos vectors in HBM up to this many GB (and 60 % of the free memory): one pass of
+ *                     the recurrence gives the Ritz vector; 0 or vectors that do not fit: the recurrence runs twice
+ *   "expect_sparse" (4) tiled <H>: a tile with at most 1/value non-zero amplitudes is evaluated over its compacted list (0: never)
+ *
+ * (B) GEOMETRY — defaults are the measured optimum on MI355X; for experiments
+ *   streaming path: "tile_bits" (-1 automatic: 12 for n >= 25, else 11; 0 = one sweep per op), "tile_low" (4), "ham_tile_low" (2; -1 =
+ *                     "tile_low"), "apply_min_tiles" (256), "expect_streams", "index_streams", "persist_blocks", "unroll", "compact_cpp"
+ *   fused / support-compacted kernels: "small_max_qubits", "small_batch_max_qubits", "small_threads", "sparse_rows" (1), "sparse_wg" (1),
+ *                     "sparse_grad" (1), "sparse_renumber" (1), "sparse_spw", "sparse_dealias"
+ *   sector path: "sector_bits" / "sector_h_bits" (index bits per circuit / <H> tile, 0 automatic), "sector_tile_cap" (6500 amplitudes per
+ *                     circuit tile so that gradients fit; up to 14000 for energies only), "sector_threads" (0 automatic, 64, 256, 512,
+ *                     1024), "sector_sweep" (2: second sweep form, 64-bit pair words in registers; 1: first form), "sector_chunk" (1024,
+ *                     2048, 4096), "sector_adjoint" (2 / 1), "sector_depth2", "sector_dict", "sector_many_tiles", "sector_h_lpt",
+ *                     "sector_h_threads", "sector_h_groups", "sector_apply_threads", "sector_row_banks", "sector_batch_threads" /
+ *                     "sector_batch_nb" / "sector_batch_sweep_threads" / "sector_batch_dst_lds" / "sector_batch_zfast" (1024 / 2 / 512 / 0 / 1),
+ *                     "sector_reg_threads" (256; 128, 512, 1024), "sector_reg_pairs" (1: blocks of two three-bit ops).  Combinations the
+ *                     second sweep form has no kernel for fall back to the first form / to one evaluation at a time.
+ *
+ * (C) MEASUREMENT AND TESTS — not for production use
+ *   "sector_profile" (HIP-event times of the two halves of a sector evaluation in ovqe_program_info), "sector_debug" (1: measurement;
+ *   2: say on stderr why a program was left to the dense kernels or its tables dropped; 4: wall time of the build's phases),
+ *   "sector_sweep_dbg" / "sector_h_dbg" (kernels truncated after a given phase: launch only, loads only, no arithmetic, no stores),
+ *   "rot_variant" (one launch geometry of the streaming pair sweep), "fault_inject" (1: the next term-list build throws std::bad_alloc:
+ *   the exception barrier's test) */
 int ovqe_set_option(ovqe_handle h, const char *name, int64_t value);
 /* device pointer to the 2^n_local amplitudes (for RCCL exchange by the host layer) */
 int ovqe_state_ptr(ovqe_handle h, void **dev_ptr);
