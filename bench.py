@@ -293,7 +293,9 @@ def gate_and_midsize_workloads(device):
             return e, g
 
         t0 = time.perf_counter()
-        res = minimize(fun, np.array(theta_mp2), jac=True, method="L-BFGS-B", options={"maxiter": 100, "gtol": 1e-6, "ftol": 1e-14})
+        from openvqe_amd.common_files.host_threads import one_blas_thread   # the optimiser's vectors on one BLAS thread (what the mirrors do)
+        with one_blas_thread():
+            res = minimize(fun, np.array(theta_mp2), jac=True, method="L-BFGS-B", options={"maxiter": 100, "gtol": 1e-6, "ftol": 1e-14})
         rown["uccsd_vqe_lbfgs_exact_gradient"] = {"energy": float(res.fun), "iterations": int(res.nit), "gradient_calls": len(calls),
                                                   "max_abs_gradient": float(np.abs(res.jac).max()),
                                                   "wall_s": time.perf_counter() - t0,
@@ -340,7 +342,8 @@ def gate_and_midsize_workloads(device):
                 "traffic_source": "profiles/r4_quccsd24 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
         calls = []
         t0 = time.perf_counter()
-        resq = minimize(fun, np.array(theta_mp2), jac=True, method="L-BFGS-B", options={"maxiter": 100, "gtol": 1e-6, "ftol": 1e-14})
+        with one_blas_thread():
+            resq = minimize(fun, np.array(theta_mp2), jac=True, method="L-BFGS-B", options={"maxiter": 100, "gtol": 1e-6, "ftol": 1e-14})
         rown["quccsd_vqe_lbfgs_exact_gradient"] = {"energy": float(resq.fun), "iterations": int(resq.nit), "gradient_calls": len(calls),
                                                    "max_abs_gradient": float(np.abs(resq.jac).max()),
                                                    "wall_s": time.perf_counter() - t0,

@@ -29,6 +29,7 @@ import numpy as np
 import scipy.optimize
 
 from ..common_files.circuit import count
+from ..common_files.host_threads import one_blas_thread
 from ..common_files.sorted_gradient import abs_sort_desc, corresponding_index, index_without_0, value_without_0
 
 
@@ -111,8 +112,9 @@ class AdaptEngine:
 
     def optimise(self, method: str, tol: float):
         gens = self.generators
-        self.last_fit = scipy.optimize.minimize(lambda t: self.energy(gens, t), x0=self.theta, method=method, tol=tol,
-                                                options={"maxiter": 100000, "disp": self.flavour.optimiser_display})
+        with one_blas_thread():   # (host_threads.py: spinning BLAS workers between device calls)
+            self.last_fit = scipy.optimize.minimize(lambda t: self.energy(gens, t), x0=self.theta, method=method, tol=tol,
+                                                    options={"maxiter": 100000, "disp": self.flavour.optimiser_display})
         self.theta = [float(v) for v in self.last_fit.x[: len(gens)]]
         self.circuit = self.rebuild(self.selected, self.theta)
         return self.last_fit

@@ -16,6 +16,7 @@ from numpy import binary_repr
 
 from ..backend import GRAD_FERMIONIC, Statevector
 from ..common_files.circuit import count
+from ..common_files.host_threads import on_one_blas_thread
 from ..common_files.sorted_gradient import abs_sort_desc, corresponding_index, index_without_0, value_without_0
 from ..evaluator import UCCEvaluator
 from .driver import AdaptEngine, Flavour, rank_gradients
@@ -194,6 +195,7 @@ def _banner(title, n_iter):
     print(rule)
 
 
+@on_one_blas_thread
 def fermionic_adapt_vqe(hamiltonian_sparse, cluster_ops_sparse, reference_ket, hamiltonian_sp, cluster_ops_sp,
                         hf_init_sp, n_max_grads, fci, optimizer, tolerance, type_conver, threshold_needed,
                         max_external_iterations=30):

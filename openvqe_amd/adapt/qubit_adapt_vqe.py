@@ -11,6 +11,7 @@ from numpy import binary_repr
 
 from ..backend import GRAD_QUBIT, Statevector
 from ..common_files.circuit import count
+from ..common_files.host_threads import on_one_blas_thread
 from ..evaluator import UCCEvaluator
 from .driver import AdaptEngine, Flavour, iterated_root_norm, rank_gradients
 from ..qat_compat import Program, X, build_ucc_ansatz, get_default_qpu
@@ -107,6 +108,7 @@ def _boxed(text, rule=_RULE, pad=True):
     print(rule)
 
 
+@on_one_blas_thread
 def qubit_adapt_vqe(hamiltonian_sp, hamiltonian_sp_sparse, reference_ket, nqubits, pool_mix, hf_init_sp, fci,
                     n_max_grads=2, adapt_conver="norm", adapt_thresh=1e-08, adapt_maxiter=45, tolerance_sim=1e-07,
                     method_sim="BFGS"):

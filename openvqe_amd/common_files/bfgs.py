@@ -18,6 +18,8 @@ from __future__ import annotations
 import numpy as np
 from scipy.optimize import OptimizeResult
 
+from .host_threads import one_blas_thread
+
 RANK_TWO_FROM = 256
 
 
@@ -45,11 +47,7 @@ def minimize_bfgs(fun, x0, jac, tol=None, maxiter=None, disp=False, c1=1e-4, c2=
     The O(n^2) host algebra of an iteration runs on ONE BLAS thread: a multi-threaded BLAS leaves its workers spinning after every
     call, and the device calls that follow — a hundred kernel launches each — then take three times as long (measured on the
     MI355X box, N2 QUCCSD gradient: 31 ms -> 89 ms with 10 ms of threaded numpy between the calls, tools/exp_mirror_eval_n2.py)."""
-    try:
-        from threadpoolctl import threadpool_limits
-    except ImportError:
-        return _minimize_bfgs(fun, x0, jac, tol, maxiter, disp, c1, c2)
-    with threadpool_limits(limits=1, user_api="blas"):
+    with one_blas_thread():
         return _minimize_bfgs(fun, x0, jac, tol, maxiter, disp, c1, c2)
 
 
@@ -132,9 +130,5 @@ def minimize(fun, x0, jac=None, method="BFGS", tol=None, options=None):
     options = dict(options or {})
     if method == "BFGS" and callable(jac) and np.size(x0) >= RANK_TWO_FROM:
         return minimize_bfgs(fun, x0, jac, tol=tol, maxiter=options.get("maxiter"), disp=options.get("disp", False))
-    try:   # scipy's own run, its host algebra on one BLAS thread too (see minimize_bfgs: spinning BLAS workers slow the device calls)
-        from threadpoolctl import threadpool_limits
-    except ImportError:
-        return scipy.optimize.minimize(fun, x0=x0, jac=jac, method=method, tol=tol, options=options)
-    with threadpool_limits(limits=1, user_api="blas"):
+    with one_blas_thread():   # scipy's own run, its host algebra on one BLAS thread too (host_threads.py)
         return scipy.optimize.minimize(fun, x0=x0, jac=jac, method=method, tol=tol, options=options)

@@ -3609,17 +3609,28 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
     if (!h->ham.set) return fail(h, OVQE_ERR_STATE, "no Hamiltonian set (ovqe_set_hamiltonian)");
     if (B == 0) return OVQE_OK;
     if (h->opt_force_path == 0 || h->opt_force_path == 3) {
-        if (!h->sp_tried) {
+        // one wave owns an evaluation on the compact support: unbeatable for batches, but a lone evaluation of a
+        // register beyond the LDS kernels is quicker on the whole chip (streaming + tiled sweeps) — and then the compact
+        // program is not even built (an ADAPT ansatz at 24 qubits with a few thousand determinants: 20-100 ms of host work
+        // per macro-iteration for tables no single evaluation would use)
+        const bool wanted = h->opt_force_path == 3 || h->n_local <= 14 || B >= 16;
+        if (wanted && !h->sp_tried) {
             rc = build_sparse_program(h);
             if (rc) return rc;
         }
-        // one wave owns an evaluation on the compact support: unbeatable for batches, but a lone evaluation of a
-        // register beyond the LDS kernels is quicker on the whole chip (streaming + tiled sweeps)
-        if (h->sp_valid && (h->opt_force_path == 3 || h->n_local <= 14 || B >= 16)) return run_sparse(h, B, theta, energies);
+        if (wanted && h->sp_valid) return run_sparse(h, B, theta, energies);
         if (h->opt_force_path == 3) return fail(h, OVQE_ERR_STATE, "program has no compact support (sparse path forced)");
     }
     if (use_small_path(h, B)) return run_small(h, B, theta, energies);
     HIPC(h, hipEventRecord(h->ev0, h->stream));
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {   // "sector_debug" bit 2 (value 4): stages of an evaluation that took more than 3 ms
+        if (!(h->opt_sector_debug & 4)) return;
+        const auto now = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(now - lap_t).count();
+        if (ms > 3.0) fprintf(stderr, "ovqe: evaluation, %s: %.2f ms\n", what, ms);
+        lap_t = now;
+    };
     int64_t b_first = 0;
     if (B >= 4 && h->opt_sector_batch && h->opt_real_stream && h->prog_real_ok && h->n_global == 0 && tile_ok(h, true) &&
         h->ham.groups.size() >= 3) {
@@ -3646,14 +3657,17 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
             R.version = h->ham.version;
         }
         if (real) {
+            lap("before the sector tables");
             rc = sector_prepare(h);
             if (rc) return rc;
+            lap("sector_prepare");
             SectorEngine &E = h->sec;
             if (E.valid && E.h_tables) {
                 double2 res;
                 bool ok = false;
                 rc = run_sector_energy(h, theta + b * (int64_t)K, &res, &ok);
                 if (rc) return rc;
+                lap("run_sector_energy");
                 if (ok) {
                     energies[b] = res.x + h->ham.constant;
                     continue;
@@ -3699,8 +3713,10 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
             }
             sector_orphaned(h);
         }
+        lap("before the dense run");
         rc = run_program_streaming(h, theta + b * (int64_t)K, real);
         if (rc) return rc;
+        lap("dense run");
         double2 res;
         bool tiled = false;
         if (use_cc) {
@@ -3718,6 +3734,7 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
             rc = run_bilinear(h, h->state, h->state, h->ham.groups, (const HGroup *)h->ham.d_groups.p,
                               (const HTerm *)h->ham.d_terms.p, &res, true);
         if (rc) return rc;
+        lap("dense <H>");
         energies[b] = res.x + h->ham.constant;
     }
     HIPC(h, hipEventRecord(h->ev1, h->stream));

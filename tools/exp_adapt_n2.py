@@ -14,6 +14,10 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 if "--sector-ground-space" in sys.argv:   # the fun_fidelity reference vector from ovqe_sector_ground_state (opt-in of the mirror)
     fav.SECTOR_GROUND_SPACE = True
 t = time.perf_counter(); pool_size, _, pool = pools.singlet_sd(10, 12); print(f'pool {pool_size} operators, built in {time.perf_counter()-t:.1f}s', flush=True)
+if "--nogc" in sys.argv:   # experiment: are the 70-ms evaluations full collections of the cyclic garbage collector?
+    import gc; gc.collect(); gc.disable()
+if "--freeze" in sys.argv:
+    import gc; gc.collect(); gc.freeze()
 t0 = time.perf_counter()
 buf = io.StringIO()
 marks = []
@@ -23,13 +27,29 @@ def timed_screen(*a, **k):
 fav.return_signed_gradients = timed_screen
 orig_action = fav.ucc_action
 def timed_action(*a, **k):
-    t = time.perf_counter(); r = orig_action(*a, **k); marks.append(("energy", time.perf_counter() - t)); return r
+    t = time.perf_counter(); r = orig_action(*a, **k); d = time.perf_counter() - t; marks.append(("energy", d))
+    if d > 5e-3 and "--slow" in sys.argv:
+        print(f"slow evaluation #{len(marks)}: {1e3 * d:.1f} ms", file=sys.stderr, flush=True)
+    return r
 fav.ucc_action = timed_action
 def _timed(name):
     orig = getattr(fav, name)
     def wrapper(*a, **k):
         t = time.perf_counter(); r = orig(*a, **k); marks.append((name, time.perf_counter() - t)); return r
     setattr(fav, name, wrapper)
+if "--slow" in sys.argv:   # which backend call the time of a slow evaluation went to
+    from openvqe_amd.backend import Statevector as _SV
+    def _wrap_sv(name):
+        orig = getattr(_SV, name)
+        def w(self, *a, **k):
+            t = time.perf_counter(); r = orig(self, *a, **k); d = time.perf_counter() - t
+            if d > 2e-3:
+                print(f"   Statevector.{name}: {1e3 * d:.1f} ms", file=sys.stderr, flush=True)
+            return r
+        setattr(_SV, name, w)
+    for name in ("set_hamiltonian", "set_ucc_program", "energy", "pool_gradients", "prepare_state", "get_support", "apply_exp_pauli_sum"):
+        if hasattr(_SV, name):
+            _wrap_sv(name)
 for name in ("_ground_space", "fun_fidelity", "prepare_adapt_state", "prepare_state_ansatz", "hf_energy"):
     _timed(name)
 try:
