@@ -10,7 +10,24 @@ of the mirrors therefore run their host algebra — vectors of at most a few tho
 from __future__ import annotations
 
 import functools
+import os
 from contextlib import contextmanager
+
+
+def usable_cpus():
+    """cores this process may keep busy: the affinity mask, capped by the cgroup-v2 CPU quota (`cpu.max`)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, int(quota) // int(period))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 @contextmanager
