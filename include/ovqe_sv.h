@@ -103,6 +103,8 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  *                     ovqe_energy_gradient — from bit arithmetic, no pair-word tables for supports of 2^20 amplitudes and more; 0: pair
  *                     words; 3: without the slot orders that make the gathers between sweeps run in runs (measurement)
  *   "sector_batch" (1) ovqe_energy_batch / _device run whole batches per pass of the sector tables
+ *   "sector_fused_reduce" (1)  the final reduction of a lone evaluation on the sector tables writes energy and orphan flag into mapped
+ *                     host memory; 0: reduction launch + two copies
  *   "screen_sparse" (16) / "screen_sector" (1) / "screen_sector_min" (1024) / "screen_tables" (1)  ADAPT screens: bilinear forms summed over
  *                     the listed non-zero amplitudes of psi while they are at most 1/value of the register (0: never); sigma = H psi from the
  *                     materialised Hamiltonian of psi's symmetry sector once psi lists that many amplitudes; pattern tables for the pool's
@@ -128,7 +130,8 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  *
  * (C) MEASUREMENT AND TESTS — not for production use
  *   "sector_profile" (HIP-event times of the two halves of a sector evaluation in ovqe_program_info), "sector_debug" (1: measurement;
- *   2: say on stderr why a program was left to the dense kernels or its tables dropped; 4: wall time of the build's phases),
+ *   2: say on stderr why a program was left to the dense kernels or its tables dropped; 4: wall time of the build's phases and of the
+ *   stages of every evaluation above 3 ms),
  *   "sector_sweep_dbg" / "sector_h_dbg" (kernels truncated after a given phase: launch only, loads only, no arithmetic, no stores),
  *   "rot_variant" (one launch geometry of the streaming pair sweep), "fault_inject" (1: the next term-list build throws std::bad_alloc:
  *   the exception barrier's test) */

@@ -158,6 +158,9 @@ struct ovqe_sv {
     RotParam *h_rp = nullptr;  // pinned
     size_t h_rp_cap = 0;
     double2 *h_result = nullptr;  // pinned, small
+    double *h_fin = nullptr, *d_fin = nullptr;   // mapped: energy + flag of a sector evaluation, written by k_sector_finish
+    bool fin_failed = false;
+    int opt_sector_fused_reduce = 1;
     // small batches (the one-evaluation-per-call loops of scipy's optimisers): parameters and energies travel through one
     // pinned, device-mapped buffer that the fused kernels read / write directly — launch + sync instead of two copies,
     // two event records and their completion round trips
@@ -1436,9 +1439,9 @@ inline RotParam resolve_rot(const SmallRot &sr, const double *theta) {
 
 // Angle table of one evaluation in h->d_rp: [0, S) the entries of the table-fused program (tile sweeps, sequential runs),
 // [S, S+R) the original rotations (commuting runs that keep their own sweep run in their sequential form).
-int resolve_angles(ovqe_handle h, const double *theta) {
+int resolve_angles(ovqe_handle h, const double *theta, bool fused_only = false) {   // fused_only: [0, S) is all the caller reads (sector path)
     int rc = OVQE_OK;
-    const size_t S = h->srots.size(), R = h->rots.size();
+    const size_t S = h->srots.size(), R = (fused_only && !h->probe_independent) ? 0 : h->rots.size();
     rc = ensure_rp(h, std::max<size_t>(S + R, 1));
     if (rc) return rc;
     static_assert(sizeof(RotSpec) == sizeof(SmallRot), "RotSpec mirrors SmallRot");
@@ -1460,7 +1463,7 @@ int resolve_angles(ovqe_handle h, const double *theta) {
             HIPC(h, hipMemcpyAsync(h->d_rp.p, h->h_rp, (S + R) * sizeof(RotParam), hipMemcpyHostToDevice, h->stream));
         return OVQE_OK;
     }
-    if (S + R >= 256 && (size_t)h->K <= ovqe_sv::IO_DOUBLES && mapped_io(h, 1)) {
+    if (S + h->rots.size() >= 256 && (size_t)h->K <= ovqe_sv::IO_DOUBLES && mapped_io(h, 1)) {
         // angles resolved on the device from the parameter vector (read through the pinned, mapped buffer): no host
         // trigonometry and no table upload on the evaluation path
         std::memcpy(h->h_io, theta, (size_t)h->K * sizeof(double));
@@ -2991,6 +2994,7 @@ int ovqe_destroy(ovqe_handle h) try {
     if (h->h_rp) (void)hipHostFree(h->h_rp);
     if (h->h_result) (void)hipHostFree(h->h_result);
     if (h->h_io) (void)hipHostFree(h->h_io);
+    if (h->h_fin) (void)hipHostFree(h->h_fin);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -3068,6 +3072,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     }
     else if (k == "sector_reg_threads") h->opt_sector_reg_threads = value == 512 ? 512 : (value == 1024 ? 1024 : (value == 128 ? 128 : 256));
     else if (k == "sector_eager_rots") h->opt_sector_eager_rots = (int)value;
+    else if (k == "sector_fused_reduce") h->opt_sector_fused_reduce = (int)value;
     else if (k == "screen_sector") h->opt_screen_sector = (int)value;
     else if (k == "screen_tables") h->opt_screen_tables = (int)value;
     else if (k == "screen_sector_min") h->opt_screen_sector_min = (int)value;

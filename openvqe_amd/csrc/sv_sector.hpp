@@ -1045,6 +1045,26 @@ __global__ __launch_bounds__(NT) void k_sector_expect(const double *__restrict__
     if (threadIdx.x == 0) partials[slot] = tsum;
 }
 
+// the partial sums of k_sector_expect -> energy and orphan flag, written straight into mapped host memory: a lone evaluation ends
+// with this launch instead of a reduction and two 16-byte copies behind it (an ADAPT-sized evaluation is a dozen dispatches of
+// ~7 us each).  Same summation order as k_reduce.  (Measured and dropped: the LAST workgroup of k_sector_expect doing this sum
+// behind an arrival counter — the device-scope release / acquire of 1800 workgroups, an L2 write-back each, cost 60-150 us.)
+__global__ __launch_bounds__(256) void k_sector_finish(const double2 *__restrict__ partials, int64_t count, const int *__restrict__ flag,
+                                                       double *__restrict__ host_out) {
+    __shared__ double2 red[4];
+    double2 acc = make_double2(0.0, 0.0);
+    for (int64_t i = threadIdx.x; i < count; i += 256) {
+        acc.x += partials[i].x;
+        acc.y += partials[i].y;
+    }
+    const double2 t = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) {
+        host_out[0] = t.x;
+        host_out[1] = t.y;
+        host_out[2] = (double)*flag;
+    }
+}
+
 // <H> of NB states per pass over the table (batched evaluations, ovqe_energy_batch on the sector tables): the tile holds the NB
 // states interleaved (tile[slot * NB + s]), so an element's word, its dictionary value and its row serve NB states and the
 // table — the bytes that bound the single-state kernel — streams once for all of them.  blockIdx.z = group of NB states

@@ -67,5 +67,7 @@ print(f"wall={wall:.1f}s screens={len(scr)} ({np.mean(scr)*1e3:.0f} ms each) ene
 for name in ("_ground_space", "fun_fidelity", "prepare_adapt_state", "prepare_state_ansatz", "hf_energy"):
     d = [x for k, x in marks if k == name]
     print(f"  {name}: {len(d)} calls, {sum(d):.2f}s")
+import re
+print("selected pool indices:", [int(m) for m in re.findall(r"sorted_index1:\s*\[(\d+)\]", buf.getvalue())])
 print({k: v for k, v in result.items() if not isinstance(v, (list, dict))})
 print("energies", trace.get("energies", trace)[:10] if isinstance(trace, dict) else trace)
