@@ -589,7 +589,7 @@ int run_bilinear(ovqe_handle h, const amp_t *bra, const amp_t *ket, const std::v
     }
     // chunk the group loop so that one launch streams at most ~64 GiB
     hermitian_expectation = hermitian_expectation && bra == ket;  // x is local whenever bra == ket (same shard)
-    const double bytes_per_group = (hermitian_expectation ? 16.0 : 32.0) * (double)h->namps;
+    const double bytes_per_group = 16.0 * (double)h->namps;   // (k_bilinear: + 16 B per amplitude and launch for the bra)
     int per_launch = (int)std::max(1.0, std::min((double)G, 6.4e10 / bytes_per_group));
     const int nchunks = (G + per_launch - 1) / per_launch;
     int rc = ensure(h, h->d_partials, (size_t)nchunks * nb * sizeof(double2));
@@ -597,7 +597,7 @@ int run_bilinear(ovqe_handle h, const amp_t *bra, const amp_t *ket, const std::v
     rc = ensure(h, h->d_result, 64 * sizeof(double2));
     if (rc) return rc;
     h->last_passes = nchunks;
-    h->last_pass_bytes = (int64_t)(bytes_per_group * (double)G);
+    h->last_pass_bytes = (int64_t)(bytes_per_group * (double)G + (hermitian_expectation ? 0.0 : 16.0 * (double)h->namps * nchunks));
     for (int c = 0; c < nchunks; ++c) {
         const int g0 = c * per_launch, g1 = std::min(G, g0 + per_launch);
         if (hermitian_expectation) {

@@ -322,11 +322,15 @@ __global__ __launch_bounds__(256) void k_bilinear(const amp_t *__restrict__ bra,
     __shared__ double2 red[4];
     double2 acc = make_double2(0.0, 0.0);
     const uint64_t stride = (uint64_t)gridDim.x * 256u;
-    for (int g = g0; g < g1; ++g) {
-        const HGroup gr = groups[g];
-        for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) {
+    // amplitudes outside, groups inside: bra_i is read once for all the groups of the launch and the ket reads of a wave stay inside
+    // the 64-amplitude neighbourhoods i ^ x_g — (16 + 16 G) instead of 32 G bytes per amplitude for G groups (the remote contraction of a
+    // partner chunk, distributed.py, runs tens of groups per launch)
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) {
+        const amp_t b = bra[i];
+        for (int g = g0; g < g1; ++g) {
+            const HGroup gr = groups[g];
             const uint64_t jl = i ^ gr.x;
-            const amp_t b = bra[i], k = ket[jl];
+            const amp_t k = ket[jl];
             const uint64_t gj = gr.jbase | jl;
             double dr = 0.0, di = 0.0;
             for (int t = gr.t0; t < gr.t1; ++t) {
