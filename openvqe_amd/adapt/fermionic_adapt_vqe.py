@@ -16,7 +16,7 @@ from numpy import binary_repr
 
 from ..backend import GRAD_FERMIONIC, Statevector
 from ..common_files.circuit import count
-from ..common_files.host_threads import on_one_blas_thread
+from ..common_files.host_threads import on_one_blas_thread, usable_blas_threads
 from ..common_files.sorted_gradient import abs_sort_desc, corresponding_index, index_without_0, value_without_0
 from ..evaluator import UCCEvaluator
 from .driver import AdaptEngine, Flavour, rank_gradients
@@ -151,7 +151,8 @@ def _ground_space(hamiltonian_sp, cluster_ops_sp=None, hf_init_sp=None):
     vector, i.e. the minimum over the whole register like eigh's column 0; or, with SECTOR_GROUND_SPACE, the sector's
     ground state from the materialised Hamiltonian of the reference determinant's sector) — returned in eigh's (values, vectors) shape"""
     if hamiltonian_sp.nbqbits <= _DENSE_EIGH_MAX_QUBITS:
-        return np.linalg.eigh(hamiltonian_sp.get_matrix())
+        with usable_blas_threads():
+            return np.linalg.eigh(hamiltonian_sp.get_matrix())
     sv = _screen_backend(hamiltonian_sp.nbqbits)
     if getattr(sv, "_ham_token", None) is not hamiltonian_sp:
         sv.set_hamiltonian(hamiltonian_sp)

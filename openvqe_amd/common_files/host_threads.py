@@ -41,6 +41,19 @@ def one_blas_thread():
         yield
 
 
+@contextmanager
+def usable_blas_threads():
+    """inside ``one_blas_thread``: a dense factorisation that is worth the cores (the reference's ``eigh`` of the whole Hamiltonian,
+    4096 x 4096 at 12 qubits) — as many BLAS threads as the CPU quota allows, not as many as the host shows"""
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        yield
+        return
+    with threadpool_limits(limits=usable_cpus(), user_api="blas"):
+        yield
+
+
 def on_one_blas_thread(fn):
     """decorator: the whole call under ``one_blas_thread`` (the ADAPT drivers: screens, fidelity and rebuilds between the optimiser runs
     use numpy as well)"""
