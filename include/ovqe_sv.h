@@ -133,7 +133,8 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  *   2: say on stderr why a program was left to the dense kernels or its tables dropped; 4: wall time of the build's phases and of the
  *   stages of every evaluation above 3 ms),
  *   "sector_sweep_dbg" / "sector_h_dbg" (kernels truncated after a given phase: launch only, loads only, no arithmetic, no stores),
- *   "rot_variant" (one launch geometry of the streaming pair sweep), "fault_inject" (1: the next term-list build throws std::bad_alloc:
+ *   "sparse_dbg" (the support-compacted throughput kernel without its sincos / circuit rows / Hamiltonian entries), "rot_variant" (one launch
+ *   geometry of the streaming pair sweep), "fault_inject" (1: the next term-list build throws std::bad_alloc:
  *   the exception barrier's test) */
 int ovqe_set_option(ovqe_handle h, const char *name, int64_t value);
 /* device pointer to the 2^n_local amplitudes (for RCCL exchange by the host layer) */

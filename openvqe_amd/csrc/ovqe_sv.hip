@@ -228,6 +228,7 @@ struct ovqe_sv {
     bool pg_valid = false;
     int opt_sparse = 1;           // allow the support-compacted path
     int opt_sparse_spw = 0;       // evaluations per wave (0 = automatic)
+    int opt_sparse_dbg = 0;       // measurement: k_sparse_vqe_rows without one of its phases (SparseArgs::dbg)
     int opt_sparse_dealias = 1;   // arrange the restricted-Hamiltonian entries against LDS bank conflicts
     int opt_sparse_renumber = 1;  // number the compact support against LDS bank conflicts of the circuit's pairs
     int opt_sparse_rows = 1;      // support-compacted evaluation, large batches: flat rows of padded 64-bit pair words (k_sparse_vqe_rows)
@@ -2739,6 +2740,7 @@ int run_sparse(ovqe_handle h, int64_t B, const double *theta, double *energies, 
     A.npairs = (int)h->sp_npairs;
     A.B = B;
     A.constant = h->ham.constant;
+    A.dbg = h->opt_sparse_dbg;
     const size_t per_eval = (size_t)A.mpad * sizeof(double) + (size_t)A.ntab * sizeof(double2);
     static_assert(sizeof(double2) == 16 && sizeof(SpOp) == 16, "LDS carve-up of k_sparse_vqe assumes 16-byte records");
     int spw = h->opt_sparse_spw;
@@ -3028,6 +3030,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
         h->opt_sparse = (int)value;
         h->sp_tried = false;
     } else if (k == "sparse_spw") h->opt_sparse_spw = (int)value;
+    else if (k == "sparse_dbg") h->opt_sparse_dbg = (int)value;
     else if (k == "index_streams") {
         h->opt_index_streams = (int)value;
         if (h->prog_set) return finish_program(h);

@@ -44,6 +44,7 @@ struct SparseArgs {
     int hf;       // compact slot of |hf>
     int64_t B;
     double constant;
+    int dbg = 0;  // measurements ("sparse_dbg"; k_sparse_vqe_rows only): 1 no sincos, 2 no circuit rows, 3 no Hamiltonian entries
 };
 
 // STAGE = true (small batches, the latency path of one-evaluation-per-call optimisers): the op table and the pair
@@ -187,7 +188,12 @@ __global__ __launch_bounds__(64) void k_sparse_vqe_rows(SparseArgs A, const doub
             for (int e = l; e < A.ntab; e += LPS) {
                 const SmallRot sr = tabrots[e];
                 double sn, c;
-                sincos(sr.coeff * th[sr.pidx], &sn, &c);
+                if (A.dbg == 1) {
+                    sn = sr.coeff * th[sr.pidx];
+                    c = 1.0;
+                } else {
+                    sincos(sr.coeff * th[sr.pidx], &sn, &c);
+                }
                 cs[(size_t)s * ntab1 + e] = make_double2(c, sn);
             }
             if (l == 0) cs[(size_t)s * ntab1 + A.ntab] = make_double2(1.0, 0.0);
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(64) void k_sparse_vqe_rows(SparseArgs A, const doub
             // wave's DS instructions in issue order, so only the COMPILER must not reorder across rows
             asm volatile("" ::: "memory");
         };
-        for (int r = 0; r < nrows4; r += 4) {
+        for (int r = 0; r < (A.dbg == 2 ? 0 : nrows4); r += 4) {
             const uint64_t *nx = rp + (size_t)(r + 4) * 32;
             apply(w0);
             w0 = nx[0];
@@ -226,8 +232,12 @@ __global__ __launch_bounds__(64) void k_sparse_vqe_rows(SparseArgs A, const doub
         // (lane = row, a_i once per slice of 64 rows, ONE amplitude read per entry and state instead of two, entries ordered
         // against bank conflicts): 0.673 ms against 0.675 — the entry loop's LDS reads are not what bounds the kernel either;
         // per wave and pair of evaluations ~6600 VALU, 3700 SALU, 1400 LDS instructions at 2.25 waves per SIMD.)
+        // (Round 4, measured and dropped: the two states copied side by side behind the circuit (slot -> double2) so that ONE 16-byte
+        // LDS read per amplitude serves both states and one address is computed instead of two — bit-identical energies, 0.885 ms
+        // against 0.755: random 16-byte reads conflict more than twice as often as random 8-byte reads.  tools/exp_value_phases.py:
+        // of the 0.79 ms per 65 536 evaluations through host buffers this loop is 0.40, the circuit rows 0.23, the sincos 0.03.)
 #pragma unroll 4
-        for (int e = lane; e < A.nent; e += 64) {
+        for (int e = lane; e < (A.dbg == 3 ? 0 : A.nent); e += 64) {
             const SpEntry en = entries[e];
             const uint32_t ci = en.ij & 0xfffu, cj = (en.ij >> 12) & 0xfffu;
 #pragma unroll
