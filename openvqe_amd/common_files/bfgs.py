@@ -8,7 +8,9 @@ products per iteration: 2 x 2 n^3 flops.  At the 1715 parameters of N2 / cc-pVDZ
 host BLAS per iteration — 12 of the 14 seconds of the QUCCSD ``get_energies`` run were spent there, four times
 what the device needs for the energies and gradients.  Expanded, the same expression is
     H - rho (s (H y)^T + (H y) s^T) + (rho^2 y^T H y + rho) s s^T          (H symmetric),
-one matrix-vector product and two outer products: O(n^2).  The iterates agree with scipy's to rounding.
+one matrix-vector product and a symmetric rank-two update: O(n^2) — and written so that the matrix is passed over twice per
+iteration (BLAS dsymv + dsyr2 on one triangle, in place; H y follows from H g_new and the search direction, the next direction
+from the same product): 1.3 ms per iteration at n = 1715 on one core.  The iterates agree with scipy's to rounding.
 
 Used by the mirrors for n >= ``RANK_TWO_FROM`` parameters when a Jacobian is supplied; below that scipy itself
 runs (the stored traces of the small molecules are reproduced call for call).
@@ -16,6 +18,7 @@ runs (the stored traces of the small molecules are reproduced call for call).
 from __future__ import annotations
 
 import numpy as np
+from scipy.linalg.blas import dsymv as _dsymv, dsyr2 as _dsyr2
 from scipy.optimize import OptimizeResult
 
 from .host_threads import one_blas_thread
@@ -70,13 +73,16 @@ def _minimize_bfgs(fun, x0, jac, tol, maxiter, disp, c1, c2):
     old_fval = f(x0)
     gfk = g(x0)
     k = 0
-    Hk = np.eye(n)
+    # The inverse Hessian lives in ONE triangle of a Fortran-ordered array and is touched twice per iteration: dsymv for H g and dsyr2
+    # for the update, in place (numpy's outer products and sums made about ten passes over the 1715 x 1715 matrix: 12 of the 40 ms of
+    # an N2 QUCCSD iteration).  H y needs no product of its own: y = g_new - g_old and H g_old = -p are known.
+    Hk = np.asfortranarray(np.eye(n))
     old_old_fval = old_fval + np.linalg.norm(gfk) / 2
     xk = x0
     warnflag = 0
     gnorm = np.abs(gfk).max() if n else 0.0
+    pk = -gfk.copy()   # H = 1
     while gnorm > gtol and k < maxiter:
-        pk = -(Hk @ gfk)
         try:
             alpha_k, _, _, old_fval, old_old_fval, gfkp1 = search(f, g, xk, pk, gfk, old_fval, old_old_fval, amin=1e-100, amax=1e100,
                                                                   c1=c1, c2=c2)
@@ -98,11 +104,18 @@ def _minimize_bfgs(fun, x0, jac, tol, maxiter, disp, c1, c2):
             break
         rhok_inv = float(yk @ sk)
         rhok = 1000.0 if rhok_inv == 0.0 else 1.0 / rhok_inv
-        Hy = Hk @ yk
+        Hg = _dsymv(1.0, Hk, gfk, lower=1)          # H_old g_new
+        Hy = Hg + pk                                # H_old (g_new - g_old),  H_old g_old = -p
         yHy = float(yk @ Hy)
-        Hk -= rhok * (np.outer(sk, Hy) + np.outer(Hy, sk))
-        Hk += (rhok * rhok * yHy + rhok) * np.outer(sk, sk)
+        cs = rhok * rhok * yHy + rhok
+        # H_new = H - rho (s Hy^T + Hy s^T) + cs s s^T = H + s w^T + w s^T,  w = -rho Hy + cs/2 s
+        wk = -rhok * Hy + (0.5 * cs) * sk
+        Hk = _dsyr2(1.0, sk, wk, a=Hk, lower=1, overwrite_a=1)
+        # next direction: -H_new g_new from H_old g_new (no second pass over the matrix)
+        sg, wg = float(sk @ gfk), float(wk @ gfk)
+        pk = -(Hg + sk * wg + wk * sg)
     fval = old_fval
+    Hk = np.tril(Hk) + np.tril(Hk, -1).T   # the full symmetric matrix of scipy's result
     if warnflag == 2:
         msg = "Desired error not necessarily achieved due to precision loss."
     elif k >= maxiter:
