@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <complex>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -229,6 +230,7 @@ struct ovqe_sv {
     int opt_sparse = 1;           // allow the support-compacted path
     int opt_sparse_spw = 0;       // evaluations per wave (0 = automatic)
     int opt_sparse_dbg = 0;       // measurement: k_sparse_vqe_rows without one of its phases (SparseArgs::dbg)
+    int opt_clifford_phase_host = 1;   // global phase of a closed Clifford frame from a sparse host simulation (0: the gates run on the device)
     int opt_sparse_dealias = 1;   // arrange the restricted-Hamiltonian entries against LDS bank conflicts
     int opt_sparse_renumber = 1;  // number the compact support against LDS bank conflicts of the circuit's pairs
     int opt_sparse_rows = 1;      // support-compacted evaluation, large batches: flat rows of padded 64-bit pair words (k_sparse_vqe_rows)
@@ -1870,6 +1872,61 @@ int install_conjugated_hamiltonian(ovqe_handle h) {
     return install_hamdev(h, h->ham_conj, (int64_t)T, cx.data(), cz.data(), cc.data(), h->user_const);
 }
 
+// <hf| C |hf> of the Clifford part C of a gate list (the gates `tail`: X, H, CNOT, quarter turns) by a SPARSE simulation on the host:
+// between the basis changes of one excitation template and their inverses the state is a superposition of a handful of basis states,
+// so the 49 272 Clifford gates of the N2 QUCCSD list cost a few milliseconds here against 0.4 s as a literal program on the 2^24
+// register (which was most of ovqe_set_gate_program's time).  false: more than `cap` basis states at some point — the caller runs
+// the gates on the device instead.
+static bool clifford_amplitude_on_host(uint64_t hf, const std::vector<int64_t> &tail, const int32_t *opcode, const int32_t *b0,
+                                       const int32_t *b1, const double *aconst, double2 *amp, size_t cap = 4096) {
+    using cd = std::complex<double>;
+    std::unordered_map<uint64_t, cd> cur, nxt;
+    cur.emplace(hf, cd(1.0, 0.0));
+    const double r = 0.70710678118654752440;
+    for (const int64_t g : tail) {
+        const uint64_t bt = 1ull << b0[g];
+        const int op = opcode[g];
+        if (op == OVQE_GATE_X || op == OVQE_GATE_CNOT) {   // permutations
+            nxt.clear();
+            const uint64_t flip = op == OVQE_GATE_X ? bt : (1ull << b1[g]);
+            for (const auto &kv : cur) nxt.emplace((op == OVQE_GATE_X || (kv.first & bt)) ? kv.first ^ flip : kv.first, kv.second);
+            cur.swap(nxt);
+            continue;
+        }
+        if (op == OVQE_GATE_RZ) {   // exp(-i phi Z), phi = aconst / 2 = +- pi/4: diagonal
+            const double sg = aconst[g] > 0 ? 1.0 : -1.0;
+            for (auto &kv : cur) kv.second *= (kv.first & bt) ? cd(r, sg * r) : cd(r, -sg * r);
+            continue;
+        }
+        // H, RX, RY: |b> -> u_bb |b> + u_{1-b,b} |1-b>
+        cd u[2][2];   // u[row][column]
+        if (op == OVQE_GATE_H) {
+            u[0][0] = r; u[0][1] = r; u[1][0] = r; u[1][1] = -r;
+        } else {
+            const double sg = aconst[g] > 0 ? 1.0 : -1.0;
+            if (op == OVQE_GATE_RX) {        // cos - i sin X
+                u[0][0] = r; u[1][1] = r; u[0][1] = cd(0.0, -sg * r); u[1][0] = cd(0.0, -sg * r);
+            } else {                         // RY: cos - i sin Y,  Y = [[0, -i], [i, 0]]
+                u[0][0] = r; u[1][1] = r; u[0][1] = -sg * r; u[1][0] = sg * r;
+            }
+        }
+        nxt.clear();
+        for (const auto &kv : cur) {
+            const int bit = (kv.first & bt) ? 1 : 0;
+            nxt[kv.first] += u[bit][bit] * kv.second;
+            nxt[kv.first ^ bt] += u[1 - bit][bit] * kv.second;
+        }
+        cur.clear();
+        for (const auto &kv : nxt)
+            if (std::abs(kv.second) > 1e-13) cur.emplace(kv.first, kv.second);   // what the inverse basis change cancels
+        if (cur.size() > cap) return false;
+    }
+    const auto it = cur.find(hf);
+    const cd a = it == cur.end() ? cd(0.0, 0.0) : it->second;
+    *amp = make_double2(a.real(), a.imag());
+    return true;
+}
+
 int compile_gate_program_frame(ovqe_handle h, int64_t G, const int32_t *opcode, const int32_t *b0, const int32_t *b1,
                                const double *ascale, const double *aconst, const int32_t *pidx, bool *done) {
     *done = false;
@@ -1965,20 +2022,26 @@ int compile_gate_program_frame(ovqe_handle h, int64_t G, const int32_t *opcode, 
         h->prog_set = false;
         h->ops.clear();
         h->rots.clear();
-        for (const int64_t g : tail) push_literal_gate(h, opcode[g], b0[g], b1[g], ascale[g], aconst[g], pidx[g]);
+        double2 amp = make_double2(0.0, 0.0);
+        const bool on_host = !tail.empty() && h->opt_clifford_phase_host && n <= 63 &&
+                             clifford_amplitude_on_host(h->hf, tail, opcode, b0, b1, aconst, &amp);
+        if (!tail.empty() && !on_host)
+            for (const int64_t g : tail) push_literal_gate(h, opcode[g], b0[g], b1[g], ascale[g], aconst[g], pidx[g]);
         if (!tail.empty()) {
-            // the Clifford part is installed as the handle's program only for this one execution: whatever happens
+            // (device form) the Clifford part is installed as the handle's program only for this one execution: whatever happens
             // below, the handle must not keep reporting it as a valid program (prog_set stays false until the final
             // program is installed by the last finish_program)
-            int rc = finish_program(h);
-            if (!rc) {
-                std::vector<double> zero((size_t)std::max(h->K, 1), 0.0);
-                rc = run_program_streaming(h, zero.data());
-            }
-            double2 amp = make_double2(0.0, 0.0);
-            if (!rc) {
-                const hipError_t e = hipMemcpy(&amp, h->state + h->hf, sizeof(double2), hipMemcpyDeviceToHost);
-                if (e != hipSuccess) rc = fail(h, OVQE_ERR_HIP, hipGetErrorString(e));
+            int rc = OVQE_OK;
+            if (!on_host) {
+                rc = finish_program(h);
+                if (!rc) {
+                    std::vector<double> zero((size_t)std::max(h->K, 1), 0.0);
+                    rc = run_program_streaming(h, zero.data());
+                }
+                if (!rc) {
+                    const hipError_t e = hipMemcpy(&amp, h->state + h->hf, sizeof(double2), hipMemcpyDeviceToHost);
+                    if (e != hipSuccess) rc = fail(h, OVQE_ERR_HIP, hipGetErrorString(e));
+                }
             }
             h->prog_set = false;
             if (rc) {
@@ -3031,6 +3094,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
         h->sp_tried = false;
     } else if (k == "sparse_spw") h->opt_sparse_spw = (int)value;
     else if (k == "sparse_dbg") h->opt_sparse_dbg = (int)value;
+    else if (k == "clifford_phase_host") h->opt_clifford_phase_host = (int)value;
     else if (k == "index_streams") {
         h->opt_index_streams = (int)value;
         if (h->prog_set) return finish_program(h);
