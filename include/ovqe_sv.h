@@ -87,6 +87,9 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  *                     QUCCSD templates in frame form) keeps the amplitudes real: 8-byte amplitudes in the fused kernel / 2^n doubles in
  *                     streaming energies (n >= 15): half the bytes per sweep; ovqe_prepare_state always delivers the complex state
  *   "table_fusion" (1) commuting same-x runs become single sparse pair rotations in the fused kernel
+ *   "clifford_phase_host" (1)  the global phase that the Clifford part of a closed gate list gives |hf> (ovqe_prepare_state reproduces the
+ *                     literal circuit's phase) from a sparse simulation on the host; 0 or more than 4096 basis states: the gates run on
+ *                     the device
  *   "sparse" (1)      support-compacted kernel when the program's reachable support fits one workgroup's LDS
  *   "compact" (1)     compact cover: from the second evaluation of a (program, Hamiltonian) pair, <H> of a real-amplitude streaming
  *                     energy runs over a compact copy of the state's support

@@ -130,6 +130,26 @@ def test_quccsd_templates_compile_to_pauli_rotations(SV, n, ns, nd):
     assert np.abs(res[0][2] - res[1][2]).max() < 1e-10 * scale
 
 
+@pytest.mark.parametrize("n,ns,nd", [(8, 4, 6), (14, 6, 12)])
+def test_clifford_phase_from_host_simulation_equals_device_run(SV, n, ns, nd):
+    """the global phase of a closed frame's Clifford part: sparse simulation on the host (default) against the gates run as a
+    literal program on the device (clifford_phase_host = 0) — the prepared states are equal INCLUDING the phase"""
+    rng = np.random.default_rng(777 + n)
+    gates, K = quccsd_like_gates(rng, n, ns, nd, disjoint_ladders=True)
+    theta = rng.uniform(-1, 1, K)
+    hf = int(rng.integers(0, 1 << n))
+    states = {}
+    with SV(n) as sv:
+        for host in (1, 0):
+            sv.set_option("clifford_phase_host", host)
+            sv.set_gate_program(gates, K, hf)
+            assert sv.program_info()["literal_gates"] == 0
+            sv.prepare_state(theta)
+            states[host] = sv.get_state()
+    assert np.abs(states[0] - states[1]).max() < 1e-12
+    assert abs(np.vdot(states[0], states[0]) - 1.0) < 1e-10
+
+
 @pytest.mark.parametrize("n,seed", [(3, 0), (5, 1), (6, 2), (9, 3), (13, 4)])
 def test_forced_clifford_frame_on_random_circuits(SV, n, seed):
     """the conjugation algebra (X, H, CNOT, RX/RY/RZ(+-pi/2) folded into the frame; every other rotation re-expressed
