@@ -658,11 +658,24 @@ __global__ __launch_bounds__(256) void k_sec_dst_pad(const uint32_t *__restrict_
 // k_sec_encode replaces them.
 // DENSE: the partner's slot comes from a dense LDS map local key -> slot (2 bytes x 2^M: M <= 16) instead of a binary
 // search in the tile's sorted keys (13 dependent LDS reads per pair: the construction was bound by them).
+// The x-groups of the sweep and their terms (those with an even number of Y: the others vanish on a real state) come as 16-byte
+// records, everything that does not depend on the entry precomputed (the x mask in tile-local bits), and are STAGED IN LDS when they
+// fit behind the slot map (`staged`): every thread walks all of them for each of its entries, and as scalar loads from memory each
+// record cost a full memory latency with four waves per SIMD to hide it — N2 UCCSD, 7 sweeps: 13.8 + 13.1 ms for the two passes.
+struct SecGroupL {
+    uint32_t x, lx;     // global x mask; pext(x, tile bit set)
+    uint32_t t0, t1;    // its terms in the sweep's list
+};
+struct SecTermL {
+    uint32_t z, pad;
+    double c;
+};
 template <bool FILL, int NT, bool DENSE>
 __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ sup, const uint32_t *__restrict__ keys,
                                                    const uint32_t *__restrict__ cid, const uint32_t *__restrict__ off, int M,
-                                                   uint32_t smask, const SecGroup *__restrict__ groups, int ngroups,
-                                                   const HTerm *__restrict__ terms, uint32_t *__restrict__ ccnt,
+                                                   uint32_t map_bytes, const SecGroupL *__restrict__ groups_g, int ngroups,
+                                                   const SecTermL *__restrict__ terms_g, int nterms, int staged,
+                                                   uint32_t *__restrict__ ccnt,
                                                    uint32_t *__restrict__ xcnt, const uint32_t *__restrict__ cbase,
                                                    const uint32_t *__restrict__ xbase, const uint32_t *__restrict__ clen,
                                                    const uint32_t *__restrict__ xlen, const uint16_t *__restrict__ rank,
@@ -674,6 +687,16 @@ __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ 
     const int n = (int)(off[t + 1] - e0);
     if (n == 0) return;
     const uint32_t lmask = (1u << M) - 1u;
+    const SecGroupL *groups = groups_g;
+    const SecTermL *terms = terms_g;
+    if (staged) {
+        uint4 *lg = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(sec_lk) + map_bytes);
+        uint4 *lt = lg + ngroups;
+        for (int k = threadIdx.x; k < ngroups; k += NT) lg[k] = reinterpret_cast<const uint4 *>(groups_g)[k];
+        for (int k = threadIdx.x; k < nterms; k += NT) lt[k] = reinterpret_cast<const uint4 *>(terms_g)[k];
+        groups = reinterpret_cast<const SecGroupL *>(lg);
+        terms = reinterpret_cast<const SecTermL *>(lt);
+    }
     if (DENSE) {
         for (uint32_t k = threadIdx.x; k < (1u << M) / 2u; k += NT) sec_lk[k] = 0xffffffffu;
         __syncthreads();
@@ -692,16 +715,16 @@ __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ 
             const uint64_t i = sup[cid[e0 + k]];
             const uint32_t li = keys[e0 + k] & lmask;
             for (int g = 0; g < ngroups; ++g) {
-                const SecGroup gr = groups[g];
+                const SecGroupL gr = groups[g];
                 int sj = k;
-                uint64_t hi = i;
+                uint32_t hi = (uint32_t)i;
                 if (gr.x) {
-                    const uint64_t pbit = 1ull << (63 - __clzll((long long)gr.x));
-                    const bool is_low = !(i & pbit);
-                    const uint64_t low = is_low ? i : i ^ gr.x;
-                    if (sec_low_owns(low, gr.x) != is_low) continue;   // the other member keeps this element
+                    const uint32_t pbit = 1u << (31 - __clz((int)gr.x));
+                    const bool is_low = !((uint32_t)i & pbit);
+                    const uint32_t low = is_low ? (uint32_t)i : (uint32_t)i ^ gr.x;
+                    if (sec_low_owns((uint64_t)low, (uint64_t)gr.x) != is_low) continue;   // the other member keeps this element
                     hi = low ^ gr.x;
-                    const uint32_t lj = li ^ sec_pext((uint32_t)gr.x, smask);
+                    const uint32_t lj = li ^ gr.lx;
                     if (DENSE) {
                         const uint32_t v = slot_of[lj];
                         sj = v == 0xffffu ? -1 : (int)v;
@@ -711,13 +734,12 @@ __global__ __launch_bounds__(NT) void k_sec_hbuild(const uint32_t *__restrict__ 
                     if (sj < 0) continue;
                 }
                 double d = 0.0;
-                for (int tt = gr.t0; tt < gr.t1; ++tt) {
-                    const HTerm ht = terms[tt];
-                    if (__popcll(gr.x & ht.z) & 1) continue;   // odd number of Y: <P> = 0 on a real state
-                    d += parity64(hi & ht.z) ? -ht.cr : ht.cr;
+                for (uint32_t tt = gr.t0; tt < gr.t1; ++tt) {
+                    const SecTermL ht = terms[tt];
+                    d += (__popc(hi & ht.z) & 1) ? -ht.c : ht.c;
                 }
                 if (d == 0.0) continue;
-                if (__popcll(gr.x) >= SEC_CODED_MIN_WEIGHT) {
+                if (__popc(gr.x) >= SEC_CODED_MIN_WEIGHT) {
                     if (FILL) {
                         cwords[cb + 256u * (cc >> 2) + (cc & 3u)] = (uint32_t)sj;
                         cvals[cb + 256u * (cc >> 2) + (cc & 3u)] = 2.0 * d;
