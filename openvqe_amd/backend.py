@@ -32,16 +32,15 @@ def compile_ucc_program(nbqbits, generators, n_params=None):
     (ref:openvqe/ucc_family/get_energy_ucc.py:42-45) into rotation arrays: rotation (k, j) is
     exp(-i theta_k c_kj P_kj), k outer / j in ``terms`` order (one Trotter step)."""
     K = len(generators) if n_params is None else min(len(generators), int(n_params))  # zip truncation
-    xs, zs, cs, ps = [], [], [], []
-    for k in range(K):
-        for term in generators[k].terms:
-            x, z = pack_string(nbqbits, term.op, term.qbits)
-            xs.append(x)
-            zs.append(z)
-            cs.append(_real_coeff(term.coeff, f"generator {k}"))
-            ps.append(k)
-    return (np.array(xs, np.uint64), np.array(zs, np.uint64), np.array(cs, np.float64),
-            np.array(ps, np.int32), K)
+    counts = [len(generators[k].terms) for k in range(K)]
+    terms = [term for k in range(K) for term in generators[k].terms]
+    xs, zs, cc = pack_terms(nbqbits, terms)
+    ps = np.repeat(np.arange(K, dtype=np.int32), counts)
+    bad = np.abs(cc.imag) > _REAL_TOL * np.maximum(1.0, np.abs(cc.real))
+    if bad.any():
+        j = int(np.argmax(bad))
+        _real_coeff(cc[j], f"generator {int(ps[j])}")   # raises with the reference's hint
+    return xs, zs, np.ascontiguousarray(cc.real), ps, K
 
 
 class Statevector:

@@ -1567,9 +1567,13 @@ int run_program_streaming(ovqe_handle h, const double *theta, bool real = false)
     int rc = OVQE_OK;
     if (real) {
         if (!h->tp_real_built) {
+            const auto t_plan = std::chrono::steady_clock::now();
             rc = build_tile_plan(h, h->sops, h->srots, h->sop_zc, h->tp_real, true);
             if (rc) return rc;
             h->tp_real_built = true;
+            if (h->opt_sector_debug & 4)
+                fprintf(stderr, "ovqe: tile plan of the real-amplitude program: %.2f ms\n",
+                        1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_plan).count());
         }
         hipLaunchKernelGGL(k_init_basis_real, dim3(reduce_blocks(h->namps)), dim3(256), 0, h->stream, (double *)h->state,
                            h->namps, h->hf);
