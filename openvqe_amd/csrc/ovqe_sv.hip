@@ -209,6 +209,7 @@ struct ovqe_sv {
     double *h_fin = nullptr, *d_fin = nullptr;   // mapped: energy + flag of a sector evaluation, written by k_sector_finish
     bool fin_failed = false;
     int opt_sector_fused_reduce = 1;
+    int opt_sector_pairs_form = 2;   // pair-table builder: 2 = k_sec_pairs2 (ops staged in LDS, no barrier per op), 1 = first form
     // small batches (the one-evaluation-per-call loops of scipy's optimisers): parameters and energies travel through one
     // pinned, device-mapped buffer that the fused kernels read / write directly — launch + sync instead of two copies,
     // two event records and their completion round trips
@@ -3219,6 +3220,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     else if (k == "sector_reg_threads") h->opt_sector_reg_threads = value == 512 ? 512 : (value == 1024 ? 1024 : (value == 128 ? 128 : 256));
     else if (k == "sector_eager_rots") h->opt_sector_eager_rots = (int)value;
     else if (k == "sector_fused_reduce") h->opt_sector_fused_reduce = (int)value;
+    else if (k == "sector_pairs_form") h->opt_sector_pairs_form = (int)value;
     else if (k == "screen_sector") h->opt_screen_sector = (int)value;
     else if (k == "screen_tables") h->opt_screen_tables = (int)value;
     else if (k == "screen_sector_min") h->opt_screen_sector_min = (int)value;
