@@ -128,7 +128,8 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  *                     2048, 4096), "sector_adjoint" (2 / 1), "sector_depth2", "sector_dict", "sector_many_tiles", "sector_h_lpt",
  *                     "sector_h_threads", "sector_h_groups", "sector_apply_threads", "sector_row_banks", "sector_batch_threads" /
  *                     "sector_batch_nb" / "sector_batch_sweep_threads" / "sector_batch_dst_lds" / "sector_batch_zfast" (1024 / 2 / 512 / 0 / 1),
- *                     "sector_reg_threads" (256; 128, 512, 1024), "sector_reg_pairs" (1: blocks of two three-bit ops).  Combinations the
+ *                     "sector_reg_threads" (256; 128, 512, 1024), "sector_reg_pairs" (1: blocks of two three-bit ops),
+ *                     "sector_pairs_form" (2: pair-table builder with the ops staged in LDS and no barrier per op; 1: first form).  Combinations the
  *                     second sweep form has no kernel for fall back to the first form / to one evaluation at a time.
  *
  * (C) MEASUREMENT AND TESTS — not for production use

@@ -61,6 +61,30 @@ def test_sector_uccsd_matches_c_oracle(SV, m, o, bits, threads):
         assert abs(e - ed) < 1e-12 * max(1.0, l1)
 
 
+@pytest.mark.parametrize("m,o,bits", [(8, 3, 0), (9, 4, 10), (10, 4, 0)])
+def test_pair_table_builder_forms_give_the_same_tables(SV, m, o, bits):
+    """k_sec_pairs2 (waves own contiguous entry ranges, ops staged in LDS) against the first form of the builder: the pairs of an op
+    come out in the same order, so energies are EQUAL and the pair counts too"""
+    ham, gens, hf = fermion.synthetic_molecule(m, o, seed=900 + m)
+    theta = np.random.default_rng(m).uniform(-0.3, 0.3, len(gens))
+    got = {}
+    for form in (1, 2):
+        with SV(2 * m) as sv:
+            sv.set_option("sector_min_qubits", 8)
+            sv.set_option("sector_pairs_form", form)
+            if bits:
+                sv.set_option("sector_bits", bits)
+            sv.set_hamiltonian(ham)
+            sv.set_ucc_program(gens, hf)
+            e = [sv.energy(theta) for _ in range(3)][-1]
+            eg, g = sv.energy_gradient(theta)
+            info = sv.program_info()
+            assert info["sector_support"] > 0
+            got[form] = (e, eg, g, info["sector_pairs"], info["sector_sweeps"])
+    assert got[1][0] == got[2][0] and got[1][3] == got[2][3] and got[1][4] == got[2][4]
+    assert abs(got[1][1] - got[2][1]) < 1e-13 and np.abs(got[1][2] - got[2][2]).max() < 1e-13
+
+
 @pytest.mark.parametrize("m,o", [(9, 4), (10, 5)])
 def test_sector_circuit_with_compact_cover_expectation(SV, m, o):
     """sector_h = 0 (what happens when the materialised <H> would not fit the table budget): the circuit runs on the sector
