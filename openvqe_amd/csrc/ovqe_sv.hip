@@ -2926,8 +2926,16 @@ int run_sparse(ovqe_handle h, int64_t B, const double *theta, double *energies, 
             HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sparse_vqe_rows<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_rows = true;
         }
-        hipLaunchKernelGGL((k_sparse_vqe_rows<2>), dim3(grid), dim3(64), per_eval_r * 2, h->stream, R, h->cur_theta, (const SmallRot *)h->d_sp_prim.p,
-                           (const uint64_t *)h->d_sp_rows.p, h->sp_nrows4, (const SpEntry *)h->d_sp_entries.p, h->cur_energies);
+#define OVQE_ROWS(DBG_)                                                                                                                       \
+    hipLaunchKernelGGL((k_sparse_vqe_rows<2, DBG_>), dim3(grid), dim3(64), per_eval_r * 2, h->stream, R, h->cur_theta, (const SmallRot *)h->d_sp_prim.p, \
+                       (const uint64_t *)h->d_sp_rows.p, h->sp_nrows4, (const SpEntry *)h->d_sp_entries.p, h->cur_energies)
+        switch (h->opt_sparse_dbg) {   // (measurement variants carry their own LDS attribute: set on the fly)
+        case 1: HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sparse_vqe_rows<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); OVQE_ROWS(1); break;
+        case 2: HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sparse_vqe_rows<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); OVQE_ROWS(2); break;
+        case 3: HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sparse_vqe_rows<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); OVQE_ROWS(3); break;
+        default: OVQE_ROWS(0);
+        }
+#undef OVQE_ROWS
         HIPC(h, hipGetLastError());
     }
     else if (spw == 2) rc = launch_sparse<2>(h, A, grid, per_eval * 2);

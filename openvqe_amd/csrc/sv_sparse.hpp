@@ -161,7 +161,8 @@ __global__ __launch_bounds__(64) void k_sparse_vqe(SparseArgs A, const double *_
 //   bits 0-15 byte offset of amplitude i | 16-31 byte offset of amplitude j | 32-47 byte offset of the cos/sin entry | 63 sign
 // Padded lanes rotate two private spare slots behind the support by the identity entry behind the table (no branch).  Rows are
 // fetched four ahead in registers; per row: one 8-byte load, three LDS reads, four f64 operations, two LDS writes.
-template <int SPW>
+template <int SPW, int DBG = 0>   // DBG: measurements ("sparse_dbg": 1 no sincos, 2 no circuit rows, 3 no Hamiltonian entries) — a
+// run-time test of A.dbg in the loop bounds cost the product kernel 12 % (0.714 -> 0.80 ms per 65 536 evaluations), hence compile time
 __global__ __launch_bounds__(64) void k_sparse_vqe_rows(SparseArgs A, const double *__restrict__ theta,
                                                         const SmallRot *__restrict__ tabrots, const uint64_t *__restrict__ rows,
                                                         int nrows4, const SpEntry *__restrict__ entries,
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(64) void k_sparse_vqe_rows(SparseArgs A, const doub
             for (int e = l; e < A.ntab; e += LPS) {
                 const SmallRot sr = tabrots[e];
                 double sn, c;
-                if (A.dbg == 1) {
+                if (DBG == 1) {
                     sn = sr.coeff * th[sr.pidx];
                     c = 1.0;
                 } else {
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(64) void k_sparse_vqe_rows(SparseArgs A, const doub
             // wave's DS instructions in issue order, so only the COMPILER must not reorder across rows
             asm volatile("" ::: "memory");
         };
-        for (int r = 0; r < (A.dbg == 2 ? 0 : nrows4); r += 4) {
+        for (int r = 0; r < (DBG == 2 ? 0 : nrows4); r += 4) {
             const uint64_t *nx = rp + (size_t)(r + 4) * 32;
             apply(w0);
             w0 = nx[0];
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(64) void k_sparse_vqe_rows(SparseArgs A, const doub
         // against 0.755: random 16-byte reads conflict more than twice as often as random 8-byte reads.  tools/exp_value_phases.py:
         // of the 0.79 ms per 65 536 evaluations through host buffers this loop is 0.40, the circuit rows 0.23, the sincos 0.03.)
 #pragma unroll 4
-        for (int e = lane; e < (A.dbg == 3 ? 0 : A.nent); e += 64) {
+        for (int e = lane; e < (DBG == 3 ? 0 : A.nent); e += 64) {
             const SpEntry en = entries[e];
             const uint32_t ci = en.ij & 0xfffu, cj = (en.ij >> 12) & 0xfffu;
 #pragma unroll

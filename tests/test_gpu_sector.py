@@ -65,6 +65,7 @@ def test_sector_uccsd_matches_c_oracle(SV, m, o, bits, threads):
 def test_pair_table_builder_forms_give_the_same_tables(SV, m, o, bits):
     """k_sec_pairs2 (waves own contiguous entry ranges, ops staged in LDS) against the first form of the builder: the pairs of an op
     come out in the same order, so energies are EQUAL and the pair counts too"""
+    from openvqe_amd import fermion
     ham, gens, hf = fermion.synthetic_molecule(m, o, seed=900 + m)
     theta = np.random.default_rng(m).uniform(-0.3, 0.3, len(gens))
     got = {}
