@@ -86,6 +86,23 @@ def test_pair_table_builder_forms_give_the_same_tables(SV, m, o, bits):
     assert abs(got[1][1] - got[2][1]) < 1e-13 and np.abs(got[1][2] - got[2][2]).max() < 1e-13
 
 
+def test_final_reduction_into_mapped_memory_equals_reduce_and_copies(SV):
+    """k_sector_finish (energy + orphan flag written into mapped host memory) sums like k_reduce: equal energies"""
+    from openvqe_amd import fermion
+    ham, gens, hf = fermion.synthetic_molecule(9, 4, seed=77)
+    thetas = np.random.default_rng(9).uniform(-0.3, 0.3, (3, len(gens)))
+    got = {}
+    for fused in (1, 0):
+        with SV(18) as sv:
+            sv.set_option("sector_fused_reduce", fused)
+            sv.set_hamiltonian(ham)
+            sv.set_ucc_program(gens, hf)
+            sv.energy(thetas[0])
+            got[fused] = [sv.energy(t) for t in thetas]
+            assert sv.program_info()["sector_support"] > 0
+    assert got[0] == got[1]
+
+
 @pytest.mark.parametrize("m,o", [(9, 4), (10, 5)])
 def test_sector_circuit_with_compact_cover_expectation(SV, m, o):
     """sector_h = 0 (what happens when the materialised <H> would not fit the table budget): the circuit runs on the sector
