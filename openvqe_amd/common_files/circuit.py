@@ -133,5 +133,10 @@ def count(gate, mylist):
     gate = str(gate)
     if gate == gate.lower():
         gate = gate.upper()
+    fast = getattr(mylist, "gate_count", None)   # qat_compat.OpList: one pass over the gate names (same answer: an instruction's
+    if fast is not None:                          # text carries exactly one gate='NAME')
+        n = fast(gate)
+        if n is not None:
+            return n
     needle = "gate='{}'".format(gate)
     return sum(1 for op in mylist if needle in str(op))

@@ -179,6 +179,23 @@ class Program:
 QRoutine = Program
 
 
+class OpList(list):
+    """the list ``Circuit.ops`` returns: a plain list of ``Op`` that also knows how many instructions carry each gate name, so
+    that ``common_files.circuit.count`` answers its four questions per ADAPT iteration from ONE pass instead of formatting
+    every instruction as text four times (76 000 instructions at the 30th iteration of the N2 run: 0.4 of its 3.1 s)"""
+
+    def gate_count(self, gate):
+        counts = getattr(self, "_gate_counts", None)
+        if counts is None or self._counted_len != len(self):
+            counts = {}
+            for op in self:
+                if type(op) is not Op:
+                    return None   # foreign elements: the caller formats them
+                counts[op.gate] = counts.get(op.gate, 0) + 1
+            self._gate_counts, self._counted_len = counts, len(self)
+        return counts.get(gate, 0)
+
+
 class Circuit:
     def __init__(self, nbqbits, items):
         self.nbqbits, self.items = nbqbits, items
@@ -186,7 +203,7 @@ class Circuit:
     @property
     def ops(self):
         """Gate list after synthesis of the Pauli evolutions (CNOT staircase), for ``count``."""
-        out = []
+        out = OpList()
         for kind, what, qubits in self.items:
             if kind == "gate":
                 out.append(Op(what.name, qubits, what.angle))
