@@ -3,7 +3,8 @@
 # program directly after --), then the records above 5 ms;  usage: tools/trace_slow_calls.sh <name> python3 tools/... args
 name=$1; shift
 cd /tmp && export TMPDIR=/tmp
-out=$GRAFT_REPO_ROOT/gpurun_out/$name
+R=${GRAFT_REPO_ROOT:-/root/repo}
+out=$R/gpurun_out/$name
 mkdir -p $out
 rocprofv3 --hip-trace --kernel-trace --output-format csv -d /tmp/trace_$name -o t -- "$@" > $out/run.log 2>&1
 python3 - /tmp/trace_$name >> $out/slow.txt <<'PY'
