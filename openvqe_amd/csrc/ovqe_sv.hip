@@ -21,6 +21,7 @@
 #include "sv_sparse.hpp"
 #include "sv_tile.hpp"
 #include "sv_sector.hpp"
+#include "sv_frame_host.hpp"
 #include <hipcub/hipcub.hpp>
 #include <unordered_map>
 #include <unordered_set>
@@ -28,6 +29,13 @@
 using namespace ovqe;
 
 namespace {
+
+using ovqe_frame::PauliRaw;
+using ovqe_frame::pauli_mul;
+using ovqe_frame::FrameEmit;
+using ovqe_frame::FrameTrack;
+using ovqe_frame::track_clifford_frame;
+using ovqe_frame::clifford_amplitude_on_host;
 
 thread_local std::string g_create_error;
 
@@ -1904,13 +1912,6 @@ int compile_gate_program_literal(ovqe_handle h, int64_t G, const int32_t *opcode
 // support-compacted paths.  C_total = e^{i alpha}: the phase is read from one execution of the Clifford part alone
 // on |hf>; anything but alpha = 0 (or a frame that does not close) keeps the literal program.
 // clifford_frame = 2 (tests): always use the frame form and append the Clifford part literally.
-struct PauliRaw {  // i^k X^x Z^z
-    uint64_t x, z;
-    int k;
-};
-inline PauliRaw pauli_mul(const PauliRaw &a, const PauliRaw &b) {
-    return PauliRaw{a.x ^ b.x, a.z ^ b.z, (a.k + b.k + 2 * __builtin_popcountll(a.z & b.x)) & 3};
-}
 
 int install_hamdev(ovqe_handle h, HamDev &H, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff, double constant) {
     H.set = false;
@@ -1951,114 +1952,17 @@ int install_conjugated_hamiltonian(ovqe_handle h) {
     return install_hamdev(h, h->ham_conj, (int64_t)T, cx.data(), cz.data(), cc.data(), h->user_const);
 }
 
-// <hf| C |hf> of the Clifford part C of a gate list (the gates `tail`: X, H, CNOT, quarter turns) by a SPARSE simulation on the host:
-// between the basis changes of one excitation template and their inverses the state is a superposition of a handful of basis states,
-// so the 49 272 Clifford gates of the N2 QUCCSD list cost a few milliseconds here against 0.4 s as a literal program on the 2^24
-// register (which was most of ovqe_set_gate_program's time).  false: more than `cap` basis states at some point — the caller runs
-// the gates on the device instead.
-static bool clifford_amplitude_on_host(uint64_t hf, const std::vector<int64_t> &tail, const int32_t *opcode, const int32_t *b0,
-                                       const int32_t *b1, const double *aconst, double2 *amp, size_t cap = 4096) {
-    using cd = std::complex<double>;
-    std::unordered_map<uint64_t, cd> cur, nxt;
-    cur.emplace(hf, cd(1.0, 0.0));
-    const double r = 0.70710678118654752440;
-    for (const int64_t g : tail) {
-        const uint64_t bt = 1ull << b0[g];
-        const int op = opcode[g];
-        if (op == OVQE_GATE_X || op == OVQE_GATE_CNOT) {   // permutations
-            nxt.clear();
-            const uint64_t flip = op == OVQE_GATE_X ? bt : (1ull << b1[g]);
-            for (const auto &kv : cur) nxt.emplace((op == OVQE_GATE_X || (kv.first & bt)) ? kv.first ^ flip : kv.first, kv.second);
-            cur.swap(nxt);
-            continue;
-        }
-        if (op == OVQE_GATE_RZ) {   // exp(-i phi Z), phi = aconst / 2 = +- pi/4: diagonal
-            const double sg = aconst[g] > 0 ? 1.0 : -1.0;
-            for (auto &kv : cur) kv.second *= (kv.first & bt) ? cd(r, sg * r) : cd(r, -sg * r);
-            continue;
-        }
-        // H, RX, RY: |b> -> u_bb |b> + u_{1-b,b} |1-b>
-        cd u[2][2];   // u[row][column]
-        if (op == OVQE_GATE_H) {
-            u[0][0] = r; u[0][1] = r; u[1][0] = r; u[1][1] = -r;
-        } else {
-            const double sg = aconst[g] > 0 ? 1.0 : -1.0;
-            if (op == OVQE_GATE_RX) {        // cos - i sin X
-                u[0][0] = r; u[1][1] = r; u[0][1] = cd(0.0, -sg * r); u[1][0] = cd(0.0, -sg * r);
-            } else {                         // RY: cos - i sin Y,  Y = [[0, -i], [i, 0]]
-                u[0][0] = r; u[1][1] = r; u[0][1] = -sg * r; u[1][0] = sg * r;
-            }
-        }
-        nxt.clear();
-        for (const auto &kv : cur) {
-            const int bit = (kv.first & bt) ? 1 : 0;
-            nxt[kv.first] += u[bit][bit] * kv.second;
-            nxt[kv.first ^ bt] += u[1 - bit][bit] * kv.second;
-        }
-        cur.clear();
-        for (const auto &kv : nxt)
-            if (std::abs(kv.second) > 1e-13) cur.emplace(kv.first, kv.second);   // what the inverse basis change cancels
-        if (cur.size() > cap) return false;
-    }
-    const auto it = cur.find(hf);
-    const cd a = it == cur.end() ? cd(0.0, 0.0) : it->second;
-    *amp = make_double2(a.real(), a.imag());
-    return true;
-}
-
 int compile_gate_program_frame(ovqe_handle h, int64_t G, const int32_t *opcode, const int32_t *b0, const int32_t *b1,
                                const double *ascale, const double *aconst, const int32_t *pidx, bool *done) {
     *done = false;
     const int n = h->n_local;
-    std::vector<PauliRaw> ix(n), iz(n);
-    for (int q = 0; q < n; ++q) {
-        ix[q] = PauliRaw{1ull << q, 0, 0};
-        iz[q] = PauliRaw{0, 1ull << q, 0};
-    }
-    struct Emit { uint64_t x, z; double coeff, phi0; int32_t pidx; };
-    std::vector<Emit> emitted;
-    std::vector<int64_t> tail;  // gates folded into the frame (the Clifford part, original order)
-    for (int64_t g = 0; g < G; ++g) {
-        const int t = b0[g];
-        switch (opcode[g]) {
-        case OVQE_GATE_H: std::swap(ix[t], iz[t]); tail.push_back(g); continue;
-        case OVQE_GATE_X: iz[t].k = (iz[t].k + 2) & 3; tail.push_back(g); continue;
-        case OVQE_GATE_CNOT:
-            ix[t] = pauli_mul(ix[t], ix[b1[g]]);          // X_c -> X_c X_t
-            iz[b1[g]] = pauli_mul(iz[t], iz[b1[g]]);      // Z_t -> Z_c Z_t
-            tail.push_back(g);
-            continue;
-        default: break;
-        }
-        const double phi0 = 0.5 * aconst[g], coeff = 0.5 * ascale[g];
-        if (pidx[g] < 0 && std::fabs(std::fabs(phi0) - M_PI_4) < 1e-15) {
-            // quarter turn exp(-i s pi/4 P): Q -> i s P Q for the generators anticommuting with P
-            const int s = phi0 > 0 ? 1 : 3;  // i^1 = i, i^3 = -i
-            const PauliRaw X = ix[t], Z = iz[t];
-            if (opcode[g] == OVQE_GATE_RZ) {
-                ix[t] = pauli_mul(PauliRaw{0, 0, s}, pauli_mul(Z, X));
-            } else if (opcode[g] == OVQE_GATE_RX) {
-                iz[t] = pauli_mul(PauliRaw{0, 0, s}, pauli_mul(X, Z));
-            } else {  // RY: X -> s Z, Z -> -s X
-                ix[t] = pauli_mul(PauliRaw{0, 0, s == 1 ? 0 : 2}, Z);
-                iz[t] = pauli_mul(PauliRaw{0, 0, s == 1 ? 2 : 0}, X);
-            }
-            tail.push_back(g);
-            continue;
-        }
-        PauliRaw P;
-        if (opcode[g] == OVQE_GATE_RX) P = ix[t];
-        else if (opcode[g] == OVQE_GATE_RZ) P = iz[t];
-        else P = pauli_mul(PauliRaw{0, 0, 1}, pauli_mul(ix[t], iz[t]));  // Y = i X Z
-        const int rel = (P.k - __builtin_popcountll(P.x & P.z)) & 3;    // Hermitian string = i^{|x&z|} X^x Z^z
-        if (rel & 1) return fail(h, OVQE_ERR_INVALID, "internal: non-Hermitian conjugated generator");
-        const double sg = rel ? -1.0 : 1.0;
-        emitted.push_back(Emit{P.x, P.z, sg * coeff, sg * phi0, pidx[g]});
-    }
-    bool closed = true;
-    for (int q = 0; q < n && closed; ++q)
-        closed = ix[q].x == (1ull << q) && ix[q].z == 0 && ix[q].k == 0 && iz[q].x == 0 && iz[q].z == (1ull << q) &&
-                 iz[q].k == 0;
+    FrameTrack F;
+    if (!track_clifford_frame(n, G, opcode, b0, b1, ascale, aconst, pidx, F))
+        return fail(h, OVQE_ERR_INVALID, "internal: non-Hermitian conjugated generator");
+    std::vector<PauliRaw> &ix = F.ix, &iz = F.iz;
+    std::vector<FrameEmit> &emitted = F.emitted;
+    std::vector<int64_t> &tail = F.tail;  // gates folded into the frame (the Clifford part, original order)
+    const bool closed = F.closed;
     const bool forced = h->opt_clifford_frame == 2;
     if (!closed && !forced) {
         // Open frame (e.g. interleaved CNOT ladders, which the reference's ladder code does not undo): the program is the
@@ -2069,7 +1973,7 @@ int compile_gate_program_frame(ovqe_handle h, int64_t G, const int32_t *opcode, 
         h->ops.clear();
         h->rots.clear();
         h->init_amp = make_double2(1.0, 0.0);
-        for (const Emit &e : emitted) push_rotation(h, e.x, e.z, e.coeff, e.phi0, e.pidx);
+        for (const FrameEmit &e : emitted) push_rotation(h, e.x, e.z, e.coeff, e.phi0, e.pidx);
         h->frame_img.assign((size_t)6 * n, 0);
         for (int q = 0; q < n; ++q) {
             h->frame_img[3 * q] = ix[q].x;
@@ -2102,8 +2006,10 @@ int compile_gate_program_frame(ovqe_handle h, int64_t G, const int32_t *opcode, 
         h->ops.clear();
         h->rots.clear();
         double2 amp = make_double2(0.0, 0.0);
+        std::complex<double> amp_host(0.0, 0.0);
         const bool on_host = !tail.empty() && h->opt_clifford_phase_host && n <= 63 &&
-                             clifford_amplitude_on_host(h->hf, tail, opcode, b0, b1, aconst, &amp);
+                             clifford_amplitude_on_host(h->hf, tail, opcode, b0, b1, aconst, &amp_host);
+        if (on_host) amp = make_double2(amp_host.real(), amp_host.imag());
         if (!tail.empty() && !on_host)
             for (const int64_t g : tail) push_literal_gate(h, opcode[g], b0[g], b1[g], ascale[g], aconst[g], pidx[g]);
         if (!tail.empty()) {
@@ -2140,7 +2046,7 @@ int compile_gate_program_frame(ovqe_handle h, int64_t G, const int32_t *opcode, 
     h->prog_set = false;
     h->ops.clear();
     h->rots.clear();
-    for (const Emit &e : emitted) push_rotation(h, e.x, e.z, e.coeff, e.phi0, e.pidx);
+    for (const FrameEmit &e : emitted) push_rotation(h, e.x, e.z, e.coeff, e.phi0, e.pidx);
     if (!drop_tail)
         for (const int64_t g : tail) push_literal_gate(h, opcode[g], b0[g], b1[g], ascale[g], aconst[g], pidx[g]);
     *done = true;

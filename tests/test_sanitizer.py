@@ -81,3 +81,18 @@ def test_regular_support_tables_under_asan_ubsan(tmp_path):
         r = subprocess.run([exe, "400", seed], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         assert "regular tables ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_clifford_frame_compiler_under_asan_ubsan(tmp_path):
+    """the host-side compiler of the Clifford-frame form (openvqe_amd/csrc/sv_frame_host.hpp: frame tracker of ovqe_set_gate_program,
+    sparse simulation of the Clifford part for its global phase) compiled with g++ under ASan + UBSan: tests/cpu/clifford_frame_check.cpp
+    compares the frame form of random gate lists — emitted Pauli rotations, then the Clifford part — with the literal lists on a dense
+    state, amplitude by amplitude, and the sparse <hf|C|hf> with the dense one (ref:openvqe/common_files/circuit.py:13-106 is such a list)"""
+    src = os.path.join(ROOT, "tests", "cpu", "clifford_frame_check.cpp")
+    exe = str(tmp_path / "clifford_frame_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-o", exe, src])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    for seed in ("11", "4242"):
+        r = subprocess.run([exe, "400", seed], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert "clifford frame ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
