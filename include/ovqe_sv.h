@@ -126,7 +126,7 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  *                     circuit tile so that gradients fit; up to 14000 for energies only), "sector_threads" (0 automatic, 64, 256, 512,
  *                     1024), "sector_sweep" (2: second sweep form, 64-bit pair words in registers; 1: first form), "sector_chunk" (1024,
  *                     2048, 4096), "sector_adjoint" (2 / 1), "sector_depth2", "sector_dict" (1: dictionary-coded matrix elements, dictionary from a sample of the stream
- *                     first; 2: from all values; 0: explicit values), "sector_many_tiles", "sector_h_lpt",
+ *                     first; 2: from all values; 3: from a sample too thin to be complete — the fall-back, tests; 0: explicit values), "sector_many_tiles", "sector_h_lpt",
  *                     "sector_h_threads", "sector_h_groups", "sector_apply_threads", "sector_row_banks", "sector_batch_threads" /
  *                     "sector_batch_nb" / "sector_batch_sweep_threads" / "sector_batch_dst_lds" / "sector_batch_zfast" (1024 / 2 / 512 / 0 / 1),
  *                     "sector_reg_threads" (256; 128, 512, 1024), "sector_reg_pairs" (1: blocks of two three-bit ops),

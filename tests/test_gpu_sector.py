@@ -86,6 +86,27 @@ def test_pair_table_builder_forms_give_the_same_tables(SV, m, o, bits):
     assert abs(got[1][1] - got[2][1]) < 1e-13 and np.abs(got[1][2] - got[2][2]).max() < 1e-13
 
 
+def test_dictionary_from_a_sample_falls_back_to_all_values(SV):
+    """the dictionary of the coded matrix elements is built from a sample of the stream first; k_sec_encode reports a magnitude the
+    sample missed and the dictionary is rebuilt from all values — forced here with a sample of every 4096th value (sector_dict = 3):
+    the tables, hence the energies, equal those of the full sort (sector_dict = 2)"""
+    from openvqe_amd import fermion
+    ham, gens, hf = fermion.synthetic_molecule(9, 4, seed=31)
+    thetas = np.random.default_rng(2).uniform(-0.3, 0.3, (2, len(gens)))
+    got = {}
+    for mode in (2, 3, 1):
+        with SV(18) as sv:
+            sv.set_option("sector_dict", mode)
+            sv.set_hamiltonian(ham)
+            sv.set_ucc_program(gens, hf)
+            sv.energy(thetas[0])
+            got[mode] = [sv.energy(t) for t in thetas] + [sv.energy_gradient(thetas[1])[0]]
+            info = sv.program_info()
+            assert info["sector_support"] > 0 and info["sector_h_sweeps"] > 0
+    assert got[2][:2] == got[3][:2] == got[1][:2]
+    assert abs(got[2][2] - got[3][2]) < 1e-13
+
+
 def test_final_reduction_into_mapped_memory_equals_reduce_and_copies(SV):
     """k_sector_finish (energy + orphan flag written into mapped host memory) sums like k_reduce: equal energies"""
     from openvqe_amd import fermion
