@@ -290,7 +290,8 @@ int ovqe_sector_ground_state(ovqe_handle h, double tol, int max_iter, uint64_t s
  * one Pauli-rotation sweep, bracketed by HIP events on the handle's stream */
 int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, int warmup, int reps,
                              double *avg_ms);
-/* device time in ms of the most recent ovqe_energy_batch launch (HIP events) */
+/* device time in ms of the most recent ovqe_energy_batch launch (HIP events); 0 for a call that is not timed: a lone evaluation
+ * beyond the fused kernels' register sizes, small batches through the mapped buffer */
 int ovqe_last_batch_ms(ovqe_handle h, double *ms);
 
 /* amplitudes the last ovqe_pool_gradients call (which = 0) or ovqe_apply_exp_pauli_sum call (which = 1) walked instead of the

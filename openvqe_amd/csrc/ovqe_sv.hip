@@ -3689,7 +3689,11 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
         if (h->opt_force_path == 3) return fail(h, OVQE_ERR_STATE, "program has no compact support (sparse path forced)");
     }
     if (use_small_path(h, B)) return run_small(h, B, theta, energies);
-    HIPC(h, hipEventRecord(h->ev0, h->stream));
+    // a lone evaluation is not timed with events (ovqe_last_batch_ms reads 0, as on the fused kernels' zero-copy path): every path below
+    // ends with the host reading its result behind a synchronisation, and two event records + a second synchronisation + the
+    // elapsed-time query are 6-8 us of the ~95 us of an ADAPT-sized evaluation
+    const bool timed = B > 1;
+    if (timed) HIPC(h, hipEventRecord(h->ev0, h->stream));
     auto lap_t = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {   // "sector_debug" bit 2 (value 4): stages of an evaluation that took more than 3 ms
         if (!(h->opt_sector_debug & 4)) return;
@@ -3803,6 +3807,10 @@ int ovqe_energy_batch(ovqe_handle h, int64_t B, const double *theta, int32_t K, 
         if (rc) return rc;
         lap("dense <H>");
         energies[b] = res.x + h->ham.constant;
+    }
+    if (!timed) {
+        h->last_batch_ms = 0.f;
+        return OVQE_OK;
     }
     HIPC(h, hipEventRecord(h->ev1, h->stream));
     HIPC(h, hipStreamSynchronize(h->stream));
