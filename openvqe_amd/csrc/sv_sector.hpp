@@ -1205,6 +1205,8 @@ __global__ __launch_bounds__(256) void k_sector_finish(const double2 *__restrict
         host_out[0] = t.x;
         host_out[1] = t.y;
         host_out[2] = (double)*flag;
+        __threadfence_system();
+        host_out[3] = 1.0;   // "result there": what a polling host watches (set to a sentinel before the launch)
     }
 }
 
