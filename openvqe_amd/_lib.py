@@ -118,6 +118,10 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the header and the library disagree
             fn.restype = res
             fn.argtypes = args
+        # the one-evaluation-per-call entry point once more with raw pointers: scipy's optimisers call it tens of thousands of times,
+        # and converting a numpy array through ndpointer + a fresh c_double per call is 2 us of a 24-us call
+        raw = ctypes.CFUNCTYPE(_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p)(("ovqe_energy", L))
+        L.ovqe_energy_raw = raw
         _lib = L
     return _lib
 

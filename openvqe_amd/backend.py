@@ -49,6 +49,7 @@ class Statevector:
     def __init__(self, n_qubits, device=0, n_global=0, shard_index=0):
         self._L = _lib.lib()
         self._h = ctypes.c_void_p()
+        self._energy_io = None
         self.nbqbits = int(n_qubits) + int(n_global)
         self.n_local = int(n_qubits)
         self.n_global = int(n_global)
@@ -230,11 +231,20 @@ class Statevector:
         self._K = int(n_params)
 
     def energy(self, theta):
-        theta = np.ascontiguousarray(theta, np.float64).reshape(-1)[: self._K]
-        if theta.shape[0] != self._K:
-            raise ValueError(f"expected {self._K} parameters")
-        out = ctypes.c_double()
-        self._ck(self._L.ovqe_energy(self._h, theta if self._K else np.zeros(1), self._K, ctypes.byref(out)))
+        K = self._K
+        io = self._energy_io
+        if io is None or io[0].shape[0] != max(K, 1):   # parameter buffer + result slot of this handle, their addresses taken once
+            buf = np.zeros(max(K, 1), np.float64)
+            out = ctypes.c_double()
+            io = self._energy_io = (buf, out, ctypes.c_void_p(buf.ctypes.data), ctypes.c_void_p(ctypes.addressof(out)))
+        buf, out, buf_p, out_p = io
+        theta = np.asarray(theta, np.float64).reshape(-1)
+        if theta.shape[0] < K:
+            raise ValueError(f"expected {K} parameters")
+        buf[:K] = theta[:K]
+        rc = self._L.ovqe_energy_raw(self._h, buf_p, K, out_p)
+        if rc:
+            self._ck(rc)
         return out.value
 
     def energy_batch(self, thetas):

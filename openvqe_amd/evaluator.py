@@ -34,12 +34,13 @@ class _Evaluator:
         self.nbqbits = hamiltonian.nbqbits
         self.device = device
         self.sv = shared_backend(self.nbqbits, device)
+        self._key = (self.nbqbits, self.device)
 
     def _load(self):
         raise NotImplementedError
 
     def _activate(self):
-        key = (self.nbqbits, self.device)
+        key = self._key
         if _Evaluator._owner.get(key) is not self:
             # the Hamiltonian of an ADAPT run is the same object for every ansatz: upload it once per backend (identity + the
             # content fingerprint of qat_compat.HipQPU — an observable edited in place is uploaded again); 9.5 ms per
@@ -54,8 +55,9 @@ class _Evaluator:
             _Evaluator._owner[key] = self
 
     def energy(self, theta):
-        self._activate()
-        return self.sv.energy(np.asarray(theta, dtype=np.float64))
+        if _Evaluator._owner.get(self._key) is not self:
+            self._activate()
+        return self.sv.energy(theta)
 
     def energy_batch(self, thetas):
         self._activate()

@@ -21,8 +21,17 @@ class EnergyUCC:
 
     def __init__(self):
         self._cache = {}
+        self._last = None
 
     def _evaluator(self, hamiltonian_sp, cluster_ops_sp, hf_init_sp, n_params):
+        last = self._last   # (the optimiser's loop asks for the same evaluator tens of thousands of times)
+        if last is not None and last[0] is hamiltonian_sp and last[1] is cluster_ops_sp and last[2] == hf_init_sp and last[3] == n_params:
+            return last[4]
+        ev = self._evaluator_lookup(hamiltonian_sp, cluster_ops_sp, hf_init_sp, n_params)
+        self._last = (hamiltonian_sp, cluster_ops_sp, hf_init_sp, n_params, ev)
+        return ev
+
+    def _evaluator_lookup(self, hamiltonian_sp, cluster_ops_sp, hf_init_sp, n_params):
         key = (id(hamiltonian_sp), id(cluster_ops_sp), int(hf_init_sp), int(n_params))
         ev = self._cache.get(key)
         if ev is None or ev.generators_ref is not cluster_ops_sp or ev.hamiltonian is not hamiltonian_sp:
@@ -36,7 +45,7 @@ class EnergyUCC:
         first min(len(ops), len(theta)) operators are applied.  Appends the value to ``energies``."""
         n_params = min(len(cluster_ops_sp), len(theta_current))
         ev = self._evaluator(hamiltonian_sp, cluster_ops_sp, hf_init_sp, n_params)
-        value = ev.energy(np.asarray(theta_current, dtype=float)[:n_params])
+        value = ev.energy(theta_current)   # (Statevector.energy takes the first n_params entries)
         energies.append(value)
         return value
 
