@@ -106,9 +106,10 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  *                     ovqe_energy_gradient — from bit arithmetic, no pair-word tables for supports of 2^20 amplitudes and more; 0: pair
  *                     words; 3: without the slot orders that make the gathers between sweeps run in runs (measurement)
  *   "sector_batch" (1) ovqe_energy_batch / _device run whole batches per pass of the sector tables
- *   "poll_result" (1)  a lone evaluation's host watches the mapped slot its last kernel writes instead of waiting for the stream's
- *                     completion signal (6 us per call; evaluations of the sector tables that took less than 2 ms the time before, the
- *                     support-compacted kernels always); nothing within 5 ms: the stream is synchronised after all
+ *   "poll_result" (1)  the host of a lone evaluation — or of a batch of at most 256 on the fused kernels (a finite-difference gradient) —
+ *                     watches the mapped slots its kernels write instead of waiting for the stream's completion signal (6 us per call;
+ *                     evaluations of the sector tables that took less than 2 ms the time before, the fused kernels always); nothing
+ *                     within 5 ms: the stream is synchronised after all
  *   "sector_fused_reduce" (1)  the final reduction of a lone evaluation on the sector tables writes energy and orphan flag into mapped
  *                     host memory; 0: reduction launch + two copies
  *   "screen_sparse" (16) / "screen_sector" (1) / "screen_sector_min" (1024) / "screen_tables" (1)  ADAPT screens: bilinear forms summed over

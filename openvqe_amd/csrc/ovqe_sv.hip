@@ -459,6 +459,16 @@ inline bool poll_mapped_slot(volatile uint64_t *slot) {
     return true;
 }
 
+// B result slots (a small batch through the mapped buffer): every slot written exactly once by its evaluation's kernel
+inline void poll_arm(double *slots, int64_t B) {
+    for (int64_t b = 0; b < B; ++b) std::memcpy(slots + b, &OVQE_POLL_SENTINEL, sizeof(uint64_t));
+}
+inline bool poll_mapped_slots(double *slots, int64_t B) {
+    for (int64_t b = 0; b < B; ++b)
+        if (!poll_mapped_slot(reinterpret_cast<volatile uint64_t *>(slots + b))) return false;
+    return true;
+}
+
 int ensure(ovqe_handle h, DevBuf &b, size_t bytes) {
     if (b.cap >= bytes && b.p) return OVQE_OK;
     release_block(b.p, b.cap);
@@ -2300,8 +2310,10 @@ int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies, b
     h->cur_theta = theta;
     h->cur_energies = energies;
     const bool zero_copy = !on_device && mapped_io(h, B);
+    const bool poll = zero_copy && B <= 256 && h->opt_poll_result;
     if (zero_copy) {
         if (h->K > 0) std::memcpy(h->h_io, theta, (size_t)B * h->K * sizeof(double));
+        if (poll) poll_arm(h->h_io + (size_t)B * h->K, B);
         h->cur_theta = h->d_io;
         h->cur_energies = h->d_io + (size_t)B * h->K;
     } else if (!on_device) {
@@ -2343,7 +2355,7 @@ int run_small(ovqe_handle h, int64_t B, const double *theta, double *energies, b
     }
     if (rc) return rc;
     if (zero_copy) {
-        HIPC(h, hipStreamSynchronize(h->stream));
+        if (!poll || !poll_mapped_slots(h->h_io + (size_t)B * h->K, B)) HIPC(h, hipStreamSynchronize(h->stream));
         std::memcpy(energies, h->h_io + (size_t)B * h->K, (size_t)B * sizeof(double));
         h->last_batch_ms = 0.f;  // not timed: no events on the latency path
         return OVQE_OK;
@@ -2781,10 +2793,10 @@ int run_sparse(ovqe_handle h, int64_t B, const double *theta, double *energies, 
     const double *d_theta = theta;
     double *d_energies = energies;
     const bool zero_copy = !on_device && mapped_io(h, B);
-    const bool poll = zero_copy && B == 1 && h->opt_poll_result;
+    const bool poll = zero_copy && B <= 256 && h->opt_poll_result;   // (lone evaluations and finite-difference batches: microseconds)
     if (zero_copy) {
         std::memcpy(h->h_io, theta, (size_t)B * h->K * sizeof(double));
-        if (poll) std::memcpy(h->h_io + (size_t)B * h->K, &OVQE_POLL_SENTINEL, sizeof(uint64_t));
+        if (poll) poll_arm(h->h_io + (size_t)B * h->K, B);
         d_theta = h->d_io;
         d_energies = h->d_io + (size_t)B * h->K;
     } else if (!on_device) {
@@ -2868,7 +2880,7 @@ int run_sparse(ovqe_handle h, int64_t B, const double *theta, double *energies, 
     else rc = launch_sparse<1>(h, A, grid, per_eval);
     if (rc) return rc;
     if (zero_copy) {
-        if (!poll || !poll_mapped_slot(reinterpret_cast<volatile uint64_t *>(h->h_io + (size_t)B * h->K))) HIPC(h, hipStreamSynchronize(h->stream));
+        if (!poll || !poll_mapped_slots(h->h_io + (size_t)B * h->K, B)) HIPC(h, hipStreamSynchronize(h->stream));
         std::memcpy(energies, h->h_io + (size_t)B * h->K, (size_t)B * sizeof(double));
         h->last_batch_ms = 0.f;
         return OVQE_OK;
