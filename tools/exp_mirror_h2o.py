@@ -1,3 +1,5 @@
+"""the H2O `get_energies` mirror three times over (scipy's own Jacobian / batched forward differences / exact Jacobian): wall time per
+run, to see the spread between repetitions"""
 import os, sys, time, io, contextlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
