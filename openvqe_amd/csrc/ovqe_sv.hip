@@ -178,6 +178,7 @@ struct SectorEngine {
     int sb = 13;                  // slot bits of the pair words
     bool regular = false;         // the support is a full coset of the program's Z2 symmetries and every sweep has its SecRegOp list
     int reg_m = 0;                // slot bits of a tile then (tile bits minus the free bits)
+    int reg_plan_threads = 0;     // workgroup size the barrier-free runs were planned for (0: none planned)
     uint32_t freemask = 0;        // the free (dependent) index bits of the coset
     DevBuf d_regmap, d_regtab;    // table-entry map of all sweeps (angle-table entry | sign << 31, or none), the (c, s) table of the evaluation
     uint32_t nregtab = 0;
@@ -349,6 +350,7 @@ struct ovqe_sv {
     int opt_sector_reg_threads = 256; // workgroup size of those sweeps
     int opt_sector_reg_adjoint = 1;   // ovqe_energy_gradient on a regular support: backward sweeps from bit arithmetic too (0: pair-word sweeps)
     int opt_sector_reg_pairs = 1;     // two consecutive three-bit ops that share two bits run as one 16-slot block
+    int opt_sector_reg_runs = 1;      // runs of consecutive ops whose waves stay inside their own slots: no barrier inside a run
     int opt_sector_depth2 = 1;        // first form of the sweeps: two chunks of pair words ahead where every op of a tile fits a staging buffer
     int opt_sector_many_tiles = 1;    // single evaluations with >= 768 tiles: the workgroup shape of the batches (512 threads, scatter indices from memory)
     int opt_sector_h_lpt = 1;         // <H> kernels take the tiles of a sweep largest first
@@ -3180,6 +3182,13 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     else if (k == "sector_debug") h->opt_sector_debug = (int)value;
     else if (k == "sector_sweep") h->opt_sector_sweep = value == 1 ? 1 : 2;
     else if (k == "sector_sweep_dbg") h->opt_sector_sweep_dbg = (int)value;
+    else if (k == "sector_reg_runs") {   // runs of ops without barriers (planned at build time: the tables are rebuilt)
+        h->opt_sector_reg_runs = (int)value;
+        free_sector(h->sec);
+        h->sec.disabled = false;
+        h->sec.seen = 0;
+        h->sec.prog_version = -1;
+    }
     else if (k == "sector_chunk") h->opt_sector_chunk = (value == 1024 || value == 4096) ? (int)value : 2048;
     else if (k == "sector_profile") h->opt_sector_profile = (int)value;
     else if (k == "sector_sparsity" || k == "sector_tile_cap") {

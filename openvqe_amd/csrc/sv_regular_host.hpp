@@ -117,9 +117,17 @@ inline uint32_t host_pext(uint64_t v, uint64_t mask) {
 // generators G); false: an op outside the kernel's shapes (more than 4 kept mixing bits, more than 2 dependent bits inside x).
 // pairs: two consecutive ops with three kept mixing bits each, two of them shared, and the same dependent bits in x become one
 // BLOCK — the 16 slots over (shared, own A, own B) in registers, both ops between one read and one write of them.
+//
+// RUNS WITHOUT BARRIERS (round 5; wave_bits > 0): the groups of an op are numbered so that bits lane_bits .. lane_bits + wave_bits - 1
+// of the group number — the WAVE that takes the group in a workgroup of 2^(lane_bits + wave_bits) threads — sit on slot positions
+// that a whole run of consecutive ops does not mix.  Every op of the run then keeps each wave inside its own 2^(m - wave_bits) slots:
+// what a wave reads was written by itself, the LDS pipeline keeps a wave's accesses in order, and the barrier between two ops of a
+// run is not needed at all — the waves drift apart and one wave's rotations run under another's LDS traffic.  A run ends where the
+// next op would leave fewer than wave_bits unmixed positions (or after run_cap units); the op (block: its first op) BEFORE which no
+// barrier is needed... is marked on its predecessor: w_nsel bit 27 of a unit's first op = "no barrier after this unit".
 inline bool build_reg_ops(const std::vector<SecBuildOp> &sops, const std::vector<SecPat> &spats, uint64_t S, uint64_t all, uint64_t hf,
                           const std::vector<int> &freebits, const std::vector<uint64_t> &G, int mbits, bool pairs, std::vector<SecRegOp> &out,
-                          std::vector<uint32_t> &emap, std::vector<uint32_t> &gwords) {
+                          std::vector<uint32_t> &emap, std::vector<uint32_t> &gwords, int lane_bits = 6, int wave_bits = 0, int run_cap = 64) {
     uint64_t freemask = 0;
     for (int f : freebits) freemask |= 1ull << f;
     const uint64_t kept_in = S & ~freemask, outside = all & ~S;
@@ -176,11 +184,12 @@ inline bool build_reg_ops(const std::vector<SecBuildOp> &sops, const std::vector
             ++i;
         }
     }
-    // numbering of the groups: bits 0..4 of the group number on slot positions of residues 0..4 mod 5 (sec_reg_swz), lowest first
-    auto group_order = [&](uint32_t mixing) {
+    // numbering of the groups: bits 0..4 of the group number on slot positions of residues 0..4 mod 5 (sec_reg_swz), lowest first;
+    // `wave` (a run without barriers): those positions, ascending, become bits lane_bits.. of the group number
+    auto group_order = [&](uint32_t mixing, uint32_t wave) {
         std::vector<int> free_pos, order;
         for (int p = 0; p < mbits; ++p)
-            if (!((mixing >> p) & 1u)) free_pos.push_back(p);
+            if (!(((mixing | wave) >> p) & 1u)) free_pos.push_back(p);
         std::vector<char> used(free_pos.size(), 0);
         for (int res = 0; res < 5; ++res)
             for (size_t k = 0; k < free_pos.size(); ++k)
@@ -192,8 +201,72 @@ inline bool build_reg_ops(const std::vector<SecBuildOp> &sops, const std::vector
         // (a residue without a free position: its lane bit takes the lowest position left — a two-way conflict at worst)
         for (size_t k = 0; k < free_pos.size(); ++k)
             if (!used[k]) order.push_back(free_pos[k]);
+        if (wave) {
+            std::vector<int> wp;
+            for (uint32_t m = wave; m; m &= m - 1u) wp.push_back(__builtin_ctz(m));
+            order.insert(order.begin() + lane_bits, wp.begin(), wp.end());
+        }
         return order;
     };
+    // residues 0..4 that the read lanes of an op would miss (each costs a two-way bank conflict on its accesses)
+    auto missing_residues = [&](uint32_t mixing, uint32_t wave) {
+        uint32_t have = 0;
+        for (int p = 0; p < mbits; ++p)
+            if (!(((mixing | wave) >> p) & 1u)) have |= 1u << (p % 5);
+        return 5 - __builtin_popcount(have & 31u);
+    };
+    // units (a block of two ops or one op), their mixing positions, and the runs that need no barrier inside
+    std::vector<uint32_t> wave_of(n, 0u);
+    if (wave_bits > 0) {
+        struct Unit {
+            size_t i;
+            uint32_t mixing;
+            int nbits;
+        };
+        std::vector<Unit> units;
+        bool feasible = true;
+        for (size_t i = 0; i < n; ++i) {
+            if (second[i]) continue;
+            Unit u{i, first[i] ? (out[i].xs | out[i + 1].xs) : out[i].xs, first[i] ? 4 : aux[i].w};
+            feasible = feasible && mbits - u.nbits >= lane_bits + wave_bits;
+            units.push_back(u);
+        }
+        const uint32_t allpos = (1u << mbits) - 1u;
+        auto close_run = [&](size_t u0, size_t u1, uint32_t avail) {
+            if (u1 <= u0) return;
+            uint32_t best = 0;
+            int best_score = 1 << 30;
+            for (uint32_t sub = 0; sub <= allpos; ++sub) {
+                if ((sub & ~avail) || __builtin_popcount(sub) != wave_bits) continue;
+                int score = 0;
+                for (size_t u = u0; u < u1; ++u) score += missing_residues(units[u].mixing, sub) - missing_residues(units[u].mixing, 0u);
+                if (score < best_score || (score == best_score && sub > best)) {
+                    best_score = score;
+                    best = sub;
+                }
+            }
+            for (size_t u = u0; u < u1; ++u) {
+                wave_of[units[u].i] = best;
+                if (first[units[u].i]) wave_of[units[u].i + 1] = best;
+                if (u + 1 < u1) out[units[u].i].w_nsel |= 1u << 27;   // the next unit of the run follows without a barrier
+            }
+        };
+        if (feasible) {
+            size_t u0 = 0;
+            uint32_t avail = allpos;
+            for (size_t u = 0; u < units.size(); ++u) {
+                const uint32_t na = avail & ~units[u].mixing;
+                if (u > u0 && (__builtin_popcount(na) < wave_bits || (int)(u - u0) >= run_cap)) {
+                    close_run(u0, u, avail);
+                    u0 = u;
+                    avail = allpos & ~units[u].mixing;
+                } else {
+                    avail = na;
+                }
+            }
+            close_run(u0, units.size(), avail);
+        }
+    }
     for (size_t i = 0; i < n; ++i) {
         const SecBuildOp &b = sops[i];
         const Aux &a = aux[i];
@@ -229,7 +302,7 @@ inline bool build_reg_ops(const std::vector<SecBuildOp> &sops, const std::vector
         }
         if (xp.empty())
             for (uint32_t m = r.xs; m; m &= m - 1u) xp.push_back(__builtin_ctz(m));
-        const std::vector<int> order = group_order(mixing);
+        const std::vector<int> order = group_order(mixing, wave_of[i]);
         for (size_t k = 0; k < order.size() && k < 16; ++k) r.gpos[k >> 3] |= (uint32_t)order[k] << (4 * (k & 7));
         // swizzled BYTE offsets of the members: pattern e spread over the positions of xp
         for (int e = 0; e < (1 << xp.size()); ++e) {

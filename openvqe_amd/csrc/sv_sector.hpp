@@ -1968,11 +1968,12 @@ __global__ __launch_bounds__(NT) void k_sector_sweep_reg(const double *__restric
                                                          const uint32_t *__restrict__ srcpad, const SecRegOp *__restrict__ ops, int nops,
                                                          const uint32_t *__restrict__ gw, const double2 *__restrict__ tg, int mbits,
                                                          uint32_t hf_pos, int dbg, const uint16_t *__restrict__ gslot,
-                                                         const uint16_t *__restrict__ oslot) {
+                                                         const uint16_t *__restrict__ oslot, int sync_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
     const uint32_t nslots = 1u << mbits, t = blockIdx.x;
     double *tile = reinterpret_cast<double *>(sec_smem);
     double2 *cs = reinterpret_cast<double2 *>(tile + nslots);   // [nops][8]
+    const uint32_t flagmask = sync_all ? 0u : (1u << 27);        // w_nsel bit 27: the next unit follows without a barrier (sv_regular_host.hpp)
     const size_t e0 = (size_t)t * nslots;
     if (srcpad) {
         // gather step j takes slot gslot[j] from position srcpad[j] of the previous sweep's buffer (gslot == nullptr: slot j).  The
@@ -2010,7 +2011,7 @@ __global__ __launch_bounds__(NT) void k_sector_sweep_reg(const double *__restric
             const uint32_t nw0 = gw[(size_t)on * SEC_REG_GSTRIDE + threadIdx.x], nw1 = gw[(size_t)on * SEC_REG_GSTRIDE + threadIdx.x + NT];
             const uint32_t *gwo = gw + (size_t)o * SEC_REG_GSTRIDE;
             const double2 *T = cs + (size_t)o * SEC_REG_TSTRIDE;
-            switch (cur.w_nsel) {
+            switch (cur.w_nsel & ~(1u << 27)) {
             case 3 | (1 << 24): sec_reg_apply_pair<NT, 0>(tile, T, T + SEC_REG_TSTRIDE, cur, nslots, t, dbg, gwo, wd0, wd1); break;
             case 3 | (1 << 16) | (1 << 24): sec_reg_apply_pair<NT, 1, false, false>(tile, T, T + SEC_REG_TSTRIDE, cur, nslots, t, dbg, gwo, wd0, wd1); break;
             case 3 | (1 << 16) | (1 << 24) | (1 << 25): sec_reg_apply_pair<NT, 1, true, false>(tile, T, T + SEC_REG_TSTRIDE, cur, nslots, t, dbg, gwo, wd0, wd1); break;
@@ -2026,7 +2027,8 @@ __global__ __launch_bounds__(NT) void k_sector_sweep_reg(const double *__restric
             case 1 | (1 << 16): sec_reg_apply<NT, 1, 1>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
             default: sec_reg_apply<NT, 1, 2>(tile, T, cur, nslots, t, dbg, gwo, wd0, wd1); break;
             }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // inside a run the waves own disjoint slot sets and the LDS pipeline keeps a wave's accesses in order: no barrier, no wait
+            if (!(cur.w_nsel & flagmask) && dbg != 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (measurement: 4 = no barriers, results wrong)
             cur = nxt;
             wd0 = nw0;
             wd1 = nw1;
@@ -2204,13 +2206,13 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint_reg(const double *__restr
                                                            const uint32_t *__restrict__ srcpad, const uint16_t *__restrict__ gslot,
                                                            const uint16_t *__restrict__ oslot, const SecRegOp *__restrict__ ops, int nops,
                                                            const uint32_t *__restrict__ gw, const double2 *__restrict__ tg, int mbits,
-                                                           double *__restrict__ wpart) {
+                                                           double *__restrict__ wpart, int runcap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
     constexpr int NW = NT / 64;
     const uint32_t nslots = 1u << mbits, t = blockIdx.x;
     double *psi = reinterpret_cast<double *>(sec_smem), *lam = psi + nslots;
     double2 *cs = reinterpret_cast<double2 *>(lam + nslots);                       // [nops][8]
-    double *wrow = reinterpret_cast<double *>(cs + (size_t)nops * SEC_REG_TSTRIDE);   // [2 parities][2 ops of a block][NW][8]
+    double *wrow = reinterpret_cast<double *>(cs + (size_t)nops * SEC_REG_TSTRIDE);   // [2 banks][runcap units][2 ops of a block][NW][8]
     const size_t e0 = (size_t)t * nslots;
     for (uint32_t j = threadIdx.x; j < nslots; j += NT) {
         const uint32_t k = sec_reg_swz(oslot ? (uint32_t)oslot[j] : j);
@@ -2219,10 +2221,12 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint_reg(const double *__restr
     }
     for (uint32_t e = threadIdx.x; e < (uint32_t)nops * SEC_REG_TSTRIDE; e += NT) cs[e] = tg[e];
     __syncthreads();
-    // blocks of two ops start at their first op: walk the list once forwards to find the starts, then backwards (wave-uniform)
+    // blocks of two ops start at their first op; the list is walked backwards (wave-uniform).  Units of a run (sv_regular_host.hpp:
+    // each wave stays inside its own slots) follow each other without a barrier; their rows of partial sums wait in LDS — one bank
+    // per run, at most `runcap` units — and are added up over the waves behind the barrier that ends the run.
     const int wave = threadIdx.x >> 6;
     double *wp = wpart + (size_t)t * nops * 8;
-    int o = nops - 1, parity = 0;
+    int o = nops - 1, bank = 0, slot = 0;
     while (o >= 0) {
         // the start of the block that ends at op o: op o - 1 carries the pair flag iff (o - 1, o) is a block
         const bool pair = o > 0 && ((reinterpret_cast<const SecRegHead *>(ops + (o - 1))->w_nsel >> 24) & 1u);
@@ -2231,8 +2235,9 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint_reg(const double *__restr
         const uint32_t *gwo = gw + (size_t)ob * SEC_REG_GSTRIDE;
         const uint32_t wd0 = gwo[threadIdx.x], wd1 = gwo[threadIdx.x + NT];
         const double2 *T = cs + (size_t)ob * SEC_REG_TSTRIDE;
-        double *rowA = wrow + (size_t)((parity * 2 + 0) * NW + wave) * 8, *rowB = wrow + (size_t)((parity * 2 + 1) * NW + wave) * 8;
-        switch (cur.w_nsel & ~(3u << 25)) {
+        double *rowA = wrow + (size_t)((((bank * runcap + slot) * 2 + 0) * NW + wave) * 8);
+        double *rowB = wrow + (size_t)((((bank * runcap + slot) * 2 + 1) * NW + wave) * 8);
+        switch (cur.w_nsel & ~((3u << 25) | (1u << 27))) {
         case 3 | (1 << 24): sec_reg_unapply_pair<NT, 0>(psi, lam, T, T + SEC_REG_TSTRIDE, cur, nslots, t, gwo, wd0, wd1, rowA, rowB); break;
         case 3 | (1 << 16) | (1 << 24): sec_reg_unapply_pair<NT, 1>(psi, lam, T, T + SEC_REG_TSTRIDE, cur, nslots, t, gwo, wd0, wd1, rowA, rowB); break;
         case 4: sec_reg_unapply<NT, 4, 0>(psi, lam, T, cur, nslots, t, gwo, wd0, wd1, rowA); break;
@@ -2245,16 +2250,40 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint_reg(const double *__restr
         case 1 | (1 << 16): sec_reg_unapply<NT, 1, 1>(psi, lam, T, cur, nslots, t, gwo, wd0, wd1, rowA); break;
         default: sec_reg_unapply<NT, 1, 2>(psi, lam, T, cur, nslots, t, gwo, wd0, wd1, rowA); break;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // the waves' rows of this block meet: wave 0 stores the tile's sums (the rows of the other parity take the next block)
-        if (threadIdx.x < 8u * (pair ? 2u : 1u)) {
-            const uint32_t which = threadIdx.x >> 3, e = threadIdx.x & 7u;
-            double sum = 0.0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) sum += wrow[(size_t)((parity * 2 + which) * NW + w) * 8 + e];
-            wp[(size_t)(ob + which) * 8 + e] = sum;
+        // does the unit before this one (the next to be undone) run on without a barrier?  (its first op carries the flag)
+        bool sync = true;
+        if (ob > 0 && slot + 1 < runcap) {
+            const int pb = (ob > 1 && ((reinterpret_cast<const SecRegHead *>(ops + (ob - 2))->w_nsel >> 24) & 1u)) ? ob - 2 : ob - 1;
+            sync = !((reinterpret_cast<const SecRegHead *>(ops + pb)->w_nsel >> 27) & 1u);
         }
-        parity ^= 1;
+        if (sync) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // the run's units, earliest op first: unit u sits in slot (slot - u); thread -> (unit, op of the block, entry)
+            const int nu = slot + 1;
+            const int mine = (int)(threadIdx.x >> 4);
+            int idx = ob, my_op = -1;
+            bool my_pair = false;
+            for (int u = 0; u < nu; ++u) {
+                const bool pr = (reinterpret_cast<const SecRegHead *>(ops + idx)->w_nsel >> 24) & 1u;
+                if (u == mine) {
+                    my_op = idx;
+                    my_pair = pr;
+                }
+                idx += pr ? 2 : 1;
+            }
+            const uint32_t which = (threadIdx.x >> 3) & 1u, e = threadIdx.x & 7u;
+            if (my_op >= 0 && (which == 0u || my_pair)) {
+                const int sl = slot - mine;
+                double sum = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += wrow[(size_t)((((bank * runcap + sl) * 2 + (int)which) * NW + w) * 8) + e];
+                wp[(size_t)(my_op + (int)which) * 8 + e] = sum;
+            }
+            bank ^= 1;   // (the next run's rows go to the other bank: no second barrier)
+            slot = 0;
+        } else {
+            ++slot;
+        }
         o = ob - 1;
     }
     if (srcpad) {

@@ -36,6 +36,60 @@ import torch
 import torch.distributed as dist
 
 
+class DistWatchdog:
+    """Deadline over the collective waits of a multi-rank run.  RCCL's `Work.wait()` only orders streams and the stream
+    synchronisation that follows cannot time out, so a rank whose partner never posts its half of an exchange would sit there
+    until somebody kills the job.  A daemon thread checks a deadline that every progress point of the sharded register
+    (`kick`: each half-shard exchange, each chunk of a partner read, each all-reduce) pushes `timeout_s` into the future; when
+    it passes, `on_expire(phase, seconds)` runs on that thread (the blocked main thread has released the GIL inside the wait)
+    and the process leaves with `exit_code` through `os._exit` — no exec, no clean-up that could block again.
+    `OVQE_DIST_TIMEOUT_S` (default 120) sets the time."""
+
+    def __init__(self, on_expire=None, timeout_s=None, exit_code=3):
+        import os
+        import threading
+        self.timeout_s = float(os.environ.get("OVQE_DIST_TIMEOUT_S", "120")) if timeout_s is None else float(timeout_s)
+        self.on_expire = on_expire
+        self.exit_code = exit_code
+        self.phase = "start"
+        self.expired = False
+        self._deadline = time.monotonic() + self.timeout_s
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, name="ovqe-dist-watchdog", daemon=True)
+        self._thread.start()
+
+    def kick(self, phase=None):
+        if phase is not None:
+            self.phase = phase
+        self._deadline = time.monotonic() + self.timeout_s
+
+    def stop(self):
+        self._stop.set()
+
+    def _run(self):
+        import os
+        while not self._stop.wait(min(0.25, self.timeout_s / 4)):
+            late = time.monotonic() - self._deadline
+            if late > 0:
+                self.expired = True
+                try:
+                    if self.on_expire is not None:
+                        self.on_expire(self.phase, self.timeout_s + late)
+                finally:
+                    if self.exit_code is not None:
+                        os._exit(self.exit_code)
+                return
+
+
+#: the watchdog of this process, if the launcher installed one (bench.py does for every multi-rank run)
+watchdog = None
+
+
+def _progress(phase=None):
+    if watchdog is not None:
+        watchdog.kick(phase)
+
+
 def permute_mask(mask, perm):
     out = 0
     m = int(mask)
@@ -221,6 +275,7 @@ class ShardedStatevector:
         for p, w in enumerate(works):
             w.wait()
             on_arrival(p)
+            _progress()
 
     def _swap(self, gbit, lbit):
         """exchange physical global bit ``gbit`` with physical local bit ``lbit``: each rank sends the half of its shard
@@ -245,6 +300,7 @@ class ShardedStatevector:
         starts = [sum(sizes[:p]) for p in range(P)]
         recv_pieces = [recv[starts[p]:starts[p] + sizes[p]] for p in range(P)]
         self.engine.sync()
+        _progress("half-shard exchange")
         t_swap = time.perf_counter()
 
         real = self.real and self.real_transfers      # (the same on every rank: the flag follows the rotation list)
@@ -269,6 +325,7 @@ class ShardedStatevector:
         self._exchange(partner, pack, recv_pieces, unpack)
         self.engine.sync()
         self.stats["swap_s"] += time.perf_counter() - t_swap
+        _progress("local sweeps")
         # the logical qubits living on these two physical bits trade places
         la, lb = self.perm.index(gbit), self.perm.index(lbit)
         self.perm[la], self.perm[lb] = lbit, gbit
@@ -455,8 +512,10 @@ class ShardedStatevector:
             return self._post_multi([(own, self._chunk_bufs[c & 1][k * csize:(k + 1) * csize], self.rank ^ d, 2 * d + (c & 1))
                                      for k, d in enumerate(partners)])
 
+        _progress("partner-shard read")
         pending = post(0)
         for c in range(nchunks):
+            _progress()
             t0 = time.perf_counter()
             pending.wait()
             if hasattr(self.engine, "stream"):
@@ -520,9 +579,12 @@ class ShardedStatevector:
                                                       np.array([t[0] for t in terms], np.uint64),
                                                       np.array([t[1] for t in terms], np.uint64), cs)
         val = torch.tensor([total.real], dtype=torch.float64, device=self.engine.tensor.device)
+        _progress("all-reduce of the energy")
         if self._dist:
             dist.all_reduce(val, group=self.group)
-        return float(val.item())
+        out = float(val.item())
+        _progress("local sweeps")
+        return out
 
     # -- ADAPT gradient screen on the sharded register ("ADAPT screen identical with sigma also sharded")
     def apply_hamiltonian(self, xs, zs, coeffs, constant=0.0):
@@ -633,7 +695,8 @@ class ShardedStatevector:
             final_perm = list(self.perm)
             prog = {"steps": steps, "coeff": np.asarray(rot_coeffs, np.float64), "pidx": np.asarray(rot_pidx, np.int64),
                     "hf": int(hf_index), "perm": final_perm, "real": all(bin(x & z).count("1") & 1 for x, z in zip(xs, zs)),
-                    "swaps": sum(1 for st in steps if st[0] == "swap"), "ham": None}
+                    "swaps": sum(1 for st in steps if st[0] == "swap"), "ham": None,
+                    "n_params": int(np.asarray(rot_pidx, np.int64).max(initial=-1)) + 1}
             if hamiltonian is not None:
                 hx, hz, hc, const = hamiltonian
                 groups = self._group_by_partner(hx, hz, hc)        # under the final permutation (self.perm right now)
@@ -644,11 +707,14 @@ class ShardedStatevector:
 
     def run_program(self, prog, theta):
         """|hf> -> the program's state at ``theta`` (the plan's exchanges and local sweeps; no planning)"""
-        theta = np.asarray(theta, np.float64)
+        theta = np.asarray(theta, np.float64).reshape(-1)
+        if theta.size < prog["n_params"]:
+            raise ValueError(f"expected {prog['n_params']} parameters, got {theta.size}")
         self.perm = list(range(self.n))
         self.init_basis(prog["hf"])
         self.real = prog["real"]      # (a list with one even-Y string anywhere travels complex from the start: the flag is per program)
-        phis = prog["coeff"] * np.where(prog["pidx"] >= 0, theta[np.clip(prog["pidx"], 0, max(len(theta) - 1, 0))] if len(theta) else 0.0, 1.0)
+        pidx = prog["pidx"]
+        phis = prog["coeff"] * (np.where(pidx >= 0, theta[np.maximum(pidx, 0)], 1.0) if theta.size else 1.0)
         for st in prog["steps"]:
             if st[0] == "swap":
                 self._swap(st[1], st[2])

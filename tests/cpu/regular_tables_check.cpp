@@ -66,7 +66,7 @@ int main(int argc, char **argv) {
     const int cases = argc > 1 ? std::atoi(argv[1]) : 300;
     std::mt19937_64 rng(argc > 2 ? std::atoll(argv[2]) : 12345);
     auto rnd = [&](uint64_t m) { return (uint64_t)(rng() % m); };
-    int checked = 0, blocks_seen = 0, selectors_seen = 0, declined = 0;
+    int checked = 0, blocks_seen = 0, selectors_seen = 0, declined = 0, runs_joined = 0;
     double worst = 0.0;
     for (int cs = 0; cs < cases; ++cs) {
         Case C;
@@ -178,7 +178,10 @@ int main(int argc, char **argv) {
         std::vector<SecRegOp> rops;
         std::vector<uint32_t> emap, gwords;
         const bool pairs = rnd(4) != 0;
-        if (!build_reg_ops(sops, C.pats, S, all, C.hf, dep, depG, M - t, pairs, rops, emap, gwords)) { ++declined; continue; }
+        // runs without barriers: "waves" of 2^lane_bits groups, 2^wave_bits of them (the product: 6 and 2; small here so that the tiles of
+        // these registers have several waves); 0 wave bits = a barrier after every unit
+        const int lane_bits = 1 + (int)rnd(2), wave_bits = (int)rnd(3), run_cap = 1 + (int)rnd(6);
+        if (!build_reg_ops(sops, C.pats, S, all, C.hf, dep, depG, M - t, pairs, rops, emap, gwords, lane_bits, wave_bits, run_cap)) { ++declined; continue; }
         // ---- the coset, a random real state on it
         std::map<uint64_t, double> psi;
         for (uint64_t i = 0; i <= all; ++i)
@@ -214,6 +217,9 @@ int main(int argc, char **argv) {
                 if (!psi.count(i)) { std::printf("case %d: slot (%u, %u) is not a member\n", cs, tile, k); return 1; }
                 lds[sec_reg_swz(k)] = psi.at(i);
             }
+            // who wrote a slot last since the last barrier (-1: nobody): inside a run a wave may only touch slots that no OTHER wave wrote
+            std::vector<int> writer(nslots + 64, -1);
+            int run_len = 1;
             for (size_t o = 0; o < rops.size();) {
                 const SecRegOp &r = rops[o];
                 const uint32_t *gw = gwords.data() + o * SEC_REG_GSTRIDE;
@@ -227,7 +233,16 @@ int main(int argc, char **argv) {
                 for (uint32_t g = 0; g < (nslots >> nbits); ++g) {
                     const uint32_t wd = gw[g], sb = wd & 0xffffu;
                     double a[16];
-                    for (int e = 0; e < na; ++e) a[e] = lds.at((sb ^ depo[e]) >> 3);
+                    const int wave_of_g = (int)((g >> lane_bits) & ((1u << wave_bits) - 1u));
+                    for (int e = 0; e < na; ++e) {
+                        const size_t at = (sb ^ depo[e]) >> 3;
+                        if (writer.at(at) >= 0 && writer[at] != wave_of_g) {
+                            std::printf("case %d: op %zu, group %u (wave %d) touches a slot wave %d wrote since the last barrier\n", cs, o, g, wave_of_g, writer[at]);
+                            return 1;
+                        }
+                        writer[at] = wave_of_g;
+                        a[e] = lds.at(at);
+                    }
                     if (!block) {
                         const uint32_t neg = ((wd >> 16) & 1u) ^ tz;
                         uint32_t sel = 0;
@@ -270,6 +285,14 @@ int main(int argc, char **argv) {
                     }
                     for (int e = 0; e < na; ++e) lds.at((sb ^ depo[e]) >> 3) = a[e];
                 }
+                if ((r.w_nsel >> 27) & 1u) {   // the next unit follows without a barrier
+                    ++runs_joined;
+                    if (++run_len > run_cap) { std::printf("case %d: a run longer than run_cap\n", cs); return 1; }
+                    if (wave_bits == 0 || o + (block ? 2 : 1) >= rops.size()) { std::printf("case %d: run flag where no run can be\n", cs); return 1; }
+                } else {
+                    std::fill(writer.begin(), writer.end(), -1);   // barrier
+                    run_len = 1;
+                }
                 o += block ? 2 : 1;
             }
             for (uint32_t k = 0; k < nslots; ++k) got[member(tile, k)] = lds[sec_reg_swz(k)];
@@ -285,7 +308,7 @@ int main(int argc, char **argv) {
         }
         ++checked;
     }
-    std::printf("regular tables ok: %d sweeps replayed (%d blocks of two ops, %d ops with selectors), %d declined, worst |delta| %.1e\n", checked,
-                blocks_seen, selectors_seen, declined, worst);
+    std::printf("regular tables ok: %d sweeps replayed (%d blocks of two ops, %d ops with selectors, %d barriers left out), %d declined, worst |delta| %.1e\n", checked,
+                blocks_seen, selectors_seen, runs_joined, declined, worst);
     return checked >= cases / 5 ? 0 : 2;
 }

@@ -425,3 +425,70 @@ def test_compiled_program_on_the_sharded_register(world, n, chunk_bits):
     assert abs(e_plain - es[2]) < 1e-12
     assert swaps_per_run == plain_swaps == planned >= 1          # the plan IS what the uncompiled path does, made once
     assert t_plan < 5.0 and nsteps > 0, t_plan
+
+
+# ---- the deadline over the collective waits (task 6a) -------------------------------------------------------
+def test_watchdog_fires_only_without_progress():
+    import time
+
+    from openvqe_amd.distributed import DistWatchdog
+    fired = []
+    wd = DistWatchdog(on_expire=lambda phase, s: fired.append((phase, s)), timeout_s=0.4, exit_code=None)
+    for _ in range(6):            # progress every 0.15 s: 0.9 s without firing
+        time.sleep(0.15)
+        wd.kick("exchange")
+    assert not fired and not wd.expired
+    time.sleep(1.0)               # ... then silence
+    assert fired and fired[0][0] == "exchange" and fired[0][1] >= 0.4 and wd.expired
+    wd.stop()
+
+
+def _stalled_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OVQE_DIST_TIMEOUT_S"] = "3"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+
+    from openvqe_amd import distributed as dd
+
+    def expired(phase, seconds):
+        out.put((rank, phase, seconds))
+        time.sleep(0.2)           # (let the queue's feeder thread write before os._exit)
+
+    dd.watchdog = dd.DistWatchdog(on_expire=expired)       # exit code 3 through os._exit
+    sv = dd.ShardedStatevector(6, engine_factory=lambda nl, ng, r: OracleShardEngine(nl, ng, r))
+    sv.init_basis(5)
+    if rank == 1:
+        time.sleep(10 ** 6)       # never posts its half of the exchange
+    sv.apply_pauli_rotations([1 << 5], [0], [0.3])          # X on the rank bit: a half-shard exchange with the stalled partner
+    out.put((rank, "finished", 0.0))
+
+
+def test_stalled_partner_ends_the_wait_with_exit_code_3():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stalled_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(out.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 3
+    assert [g[0] for g in got] == [0, 1]
+    assert got[0][1] == "half-shard exchange" and got[0][2] >= 3.0      # rank 0 sat in the exchange's wait
+    assert got[1][1] == "start"                                           # rank 1 never made a step
+
+
+def test_compiled_program_refuses_a_short_parameter_vector():
+    """run_program clipped the parameter index instead of raising (the single-GPU path raises)"""
+    from openvqe_amd.distributed import ShardedStatevector
+    sv = ShardedStatevector(5, engine_factory=lambda nl, ng, r: OracleShardEngine(nl, ng, r))
+    prog = sv.compile_program([0b00011, 0b01100, 0b10001], [0b00001, 0b00100, 0b10000], [1.0, 0.5, -1.0], [0, 1, 2], 0b00101)
+    assert prog["n_params"] == 3
+    sv.run_program(prog, [0.1, 0.2, 0.3])
+    with pytest.raises(ValueError, match="expected 3 parameters"):
+        sv.run_program(prog, [0.1, 0.2])
+    with pytest.raises(ValueError, match="expected 3 parameters"):
+        sv.run_program(prog, [])

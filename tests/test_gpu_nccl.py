@@ -115,8 +115,10 @@ def test_bench_distributed_path_over_rccl_at_world_size_one(gpu_lib):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 4096
     out = json.loads(last)
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0
-    sh = out["sharded"]
+    assert out["sharded"]["weak_qubits"] == 24
+    sh = json.load(open(os.path.join(ROOT, out["extra"])))["sharded"]     # the legs' detail is in bench_extra.json
     assert sh["weak"]["n_qubits"] == 24 and sh["weak"]["swaps"] == 0 and abs(sh["weak"]["norm2"] - 1.0) < 1e-10
     assert sh["strong"]["energy"] == sh["weak"]["energy"]
