@@ -1871,12 +1871,13 @@ __device__ __forceinline__ void sec_reg_apply(double *__restrict__ tile, const d
 #pragma unroll
         for (int q = 0; q < NP; ++q) r[q] = Tl[q];
         // the group's sign on the second members: (u, sigma v) rotates by the plain (c, s)
+        // the group's sign sigma on the second members: (u, sigma v) rotated by (c, s) and signed back = (u, v) rotated by (c, sigma s)
         if (dbg != 2)   // (measurement: 2 = no arithmetic, 3 = no stores)
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            const double u = a[q], v = sec_flip(a[NA - 1 - q], neg);
-            a[q] = r[q].x * u + r[q].y * v;
-            a[NA - 1 - q] = sec_flip(r[q].x * v - r[q].y * u, neg);
+            const double u = a[q], v = a[NA - 1 - q], sn = sec_flip(r[q].y, neg);
+            a[q] = r[q].x * u + sn * v;
+            a[NA - 1 - q] = r[q].x * v - sn * u;
         }
         if (dbg != 3)
 #pragma unroll
@@ -1923,9 +1924,9 @@ __device__ __forceinline__ void sec_reg_apply_pair(double *__restrict__ tile, co
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const double2 r = (NSEL && MOVE_A && v) ? r1[q] : r0[q];
-                        const double u = a[8 * v + q], w = sec_flip(a[8 * v + 7 - q], neg);
-                        a[8 * v + q] = r.x * u + r.y * w;
-                        a[8 * v + 7 - q] = sec_flip(r.x * w - r.y * u, neg);
+                        const double u = a[8 * v + q], w = a[8 * v + 7 - q], sn = sec_flip(r.y, neg);
+                        a[8 * v + q] = r.x * u + sn * w;
+                        a[8 * v + 7 - q] = r.x * w - sn * u;
                     }
                 }
             }
@@ -1944,9 +1945,9 @@ __device__ __forceinline__ void sec_reg_apply_pair(double *__restrict__ tile, co
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const double2 r = (NSEL && MOVE_B && v) ? r1[q] : r0[q];
-                        const double u = a[4 * v + q], w = sec_flip(a[4 * v + 11 - q], neg);
-                        a[4 * v + q] = r.x * u + r.y * w;
-                        a[4 * v + 11 - q] = sec_flip(r.x * w - r.y * u, neg);
+                        const double u = a[4 * v + q], w = a[4 * v + 11 - q], sn = sec_flip(r.y, neg);
+                        a[4 * v + q] = r.x * u + sn * w;
+                        a[4 * v + 11 - q] = r.x * w - sn * u;
                     }
                 }
             }
@@ -2106,14 +2107,14 @@ __device__ __forceinline__ void sec_reg_unapply(double *__restrict__ psi, double
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const double2 r = Tl[q];
-            const double u = a[q], v = sec_flip(a[NA - 1 - q], neg), lu = l[q], lv = sec_flip(l[NA - 1 - q], neg);
-            const double cq = lu * v - lv * u;
+            const double u = a[q], v = a[NA - 1 - q], lu = l[q], lv = l[NA - 1 - q], sn = sec_flip(r.y, neg);
+            const double cq = sec_flip(lu * v - lv * u, neg);   // (sigma on the second members: folded into s and into the sum)
 #pragma unroll
             for (int vs = 0; vs < (1 << NSEL); ++vs) acc[vs * NP + q] += (NSEL == 0 || sel == (uint32_t)vs) ? cq : 0.0;
-            a[q] = r.x * u - r.y * v;
-            a[NA - 1 - q] = sec_flip(r.x * v + r.y * u, neg);
-            l[q] = r.x * lu - r.y * lv;
-            l[NA - 1 - q] = sec_flip(r.x * lv + r.y * lu, neg);
+            a[q] = r.x * u - sn * v;
+            a[NA - 1 - q] = r.x * v + sn * u;
+            l[q] = r.x * lu - sn * lv;
+            l[NA - 1 - q] = r.x * lv + sn * lu;
         }
 #pragma unroll
         for (int e = 0; e < NA; ++e) {
@@ -2158,14 +2159,14 @@ __device__ __forceinline__ void sec_reg_unapply_pair(double *__restrict__ psi, d
             for (int q = 0; q < 4; ++q) {
                 const double2 r = Tl[q];
                 const int i = 4 * v + q, j = 4 * v + 11 - q;
-                const double u = a[i], w = sec_flip(a[j], neg), lu = l[i], lw = sec_flip(l[j], neg);
-                const double cq = lu * w - lw * u;
+                const double u = a[i], w = a[j], lu = l[i], lw = l[j], sn = sec_flip(r.y, neg);
+                const double cq = sec_flip(lu * w - lw * u, neg);
                 accB[q] += (NSEL == 0 || sel == 0u) ? cq : 0.0;
                 if (NSEL) accB[4 + q] += sel ? cq : 0.0;
-                a[i] = r.x * u - r.y * w;
-                a[j] = sec_flip(r.x * w + r.y * u, neg);
-                l[i] = r.x * lu - r.y * lw;
-                l[j] = sec_flip(r.x * lw + r.y * lu, neg);
+                a[i] = r.x * u - sn * w;
+                a[j] = r.x * w + sn * u;
+                l[i] = r.x * lu - sn * lw;
+                l[j] = r.x * lw + sn * lu;
             }
         }
 #pragma unroll
@@ -2177,14 +2178,14 @@ __device__ __forceinline__ void sec_reg_unapply_pair(double *__restrict__ psi, d
             for (int q = 0; q < 4; ++q) {
                 const double2 r = Tl[q];
                 const int i = 8 * v + q, j = 8 * v + 7 - q;
-                const double u = a[i], w = sec_flip(a[j], neg), lu = l[i], lw = sec_flip(l[j], neg);
-                const double cq = lu * w - lw * u;
+                const double u = a[i], w = a[j], lu = l[i], lw = l[j], sn = sec_flip(r.y, neg);
+                const double cq = sec_flip(lu * w - lw * u, neg);
                 accA[q] += (NSEL == 0 || sel == 0u) ? cq : 0.0;
                 if (NSEL) accA[4 + q] += sel ? cq : 0.0;
-                a[i] = r.x * u - r.y * w;
-                a[j] = sec_flip(r.x * w + r.y * u, neg);
-                l[i] = r.x * lu - r.y * lw;
-                l[j] = sec_flip(r.x * lw + r.y * lu, neg);
+                a[i] = r.x * u - sn * w;
+                a[j] = r.x * w + sn * u;
+                l[i] = r.x * lu - sn * lw;
+                l[j] = r.x * lw + sn * lu;
             }
         }
 #pragma unroll
