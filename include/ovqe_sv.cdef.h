@@ -21,6 +21,7 @@ const char *ovqe_last_error(ovqe_handle h);
 int ovqe_device_count(int *count);
 int ovqe_create(int n_qubits, int device, ovqe_handle *out);
 int ovqe_create_shard(int n_local, int n_global, uint64_t shard_index, int device, ovqe_handle *out);
+int ovqe_create_view(int n_qubits, int device, void *dev_ptr, ovqe_handle *out);
 int ovqe_destroy(ovqe_handle h);
 int ovqe_set_stream(ovqe_handle h, void *hip_stream);
 int ovqe_set_option(ovqe_handle h, const char *name, int64_t value);
@@ -70,3 +71,5 @@ int ovqe_time_pauli_rotation(ovqe_handle h, uint64_t x, uint64_t z, double phi, 
 int ovqe_last_batch_ms(ovqe_handle h, double *ms);
 int ovqe_last_support(ovqe_handle h, int32_t which, int64_t *support);
 int ovqe_program_info(ovqe_handle h, int64_t *info, int count);
+int ovqe_get_rotation_program(ovqe_handle h, int64_t capacity, uint64_t *x, uint64_t *z, double *coeff, double *phi0,
+                              int32_t *pidx, int64_t *count);

@@ -68,6 +68,11 @@ int ovqe_device_count(int *count);
 int ovqe_create(int n_qubits, int device, ovqe_handle *out);
 /* one shard of a distributed state: n_local local bits, n_global rank bits, this shard's index */
 int ovqe_create_shard(int n_local, int n_global, uint64_t shard_index, int device, ovqe_handle *out);
+/* a handle whose state IS the caller's device buffer of 2^n_qubits amplitudes (16 bytes each) from the start: nothing of that
+ * size is allocated (ovqe_create + ovqe_adopt_state would allocate a state and drop it).  The sharded register contracts CHUNKS of
+ * partner shards through such views (the chunk contractions of <psi|H|psi> / sigma = H psi over a partitioned register, the
+ * multi-device form of ref:openvqe/adapt/fermionic_adapt_vqe.py:114 and get_energy_ucc.py:47-48); the buffer must outlive the handle. */
+int ovqe_create_view(int n_qubits, int device, void *dev_ptr, ovqe_handle *out);
 int ovqe_destroy(ovqe_handle h);
 /* run this handle's kernels on a caller-owned hipStream_t (NULL = default stream) */
 int ovqe_set_stream(ovqe_handle h, void *hip_stream);
@@ -94,7 +99,7 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  *   "compact" (1)     compact cover: from the second evaluation of a (program, Hamiltonian) pair, <H> of a real-amplitude streaming
  *                     energy runs over a compact copy of the state's support
  *   "sector" (1)      sector path: from the second energy evaluation (the first gradient call; the first evaluation for programs of at most
- *                     "sector_eager_rots" = 2048 rotations) a real-amplitude program whose states occupy at most 1/"sector_sparsity" (4) of
+ *                     2048 rotations) a real-amplitude program whose states occupy at most 1/"sector_sparsity" (4) of
  *                     the register runs entirely on that support: circuit over compact tiles, <H> from the Hamiltonian materialised on
  *                     the support; tables in device memory up to "sector_max_gb" (128; and 60 % of the free memory) — beyond it <H> goes
  *                     through the compact cover; "sector_min_qubits" (18); "sector_h" 0: never materialise <H>.  When an evaluation meets
@@ -112,39 +117,38 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  *                     within 5 ms: the stream is synchronised after all
  *   "sector_fused_reduce" (1)  the final reduction of a lone evaluation on the sector tables writes energy and orphan flag into mapped
  *                     host memory; 0: reduction launch + two copies
- *   "screen_sparse" (16) / "screen_sector" (1) / "screen_sector_min" (1024) / "screen_tables" (1)  ADAPT screens: bilinear forms summed over
+ *   "screen_sparse" (16) / "screen_sector" (1) / "screen_sector_min" (1024)  ADAPT screens: bilinear forms summed over
  *                     the listed non-zero amplitudes of psi while they are at most 1/value of the register (0: never); sigma = H psi from the
  *                     materialised Hamiltonian of psi's symmetry sector once psi lists that many amplitudes; pattern tables for the pool's
  *                     same-x runs (see ovqe_pool_gradients, ovqe_last_support); ovqe_apply_exp_pauli_sum runs its Taylor steps over the
  *                     closure of the support under the operator's x-groups within the same bound (bit-identical amplitudes)
  *   "lanczos_keep_gb" (160) ovqe_ground_state keeps its Lanczos vectors in HBM up to this many GB (and 60 % of the free memory): one pass of
  *                     the recurrence gives the Ritz vector; 0 or vectors that do not fit: the recurrence runs twice
- *   "expect_sparse" (4) tiled <H>: a tile with at most 1/value non-zero amplitudes is evaluated over its compacted list (0: never)
  *
- * (B) GEOMETRY — defaults are the measured optimum on MI355X; for experiments
- *   streaming path: "tile_bits" (-1 automatic: 12 for n >= 25, else 11; 0 = one sweep per op), "tile_low" (4), "ham_tile_low" (2; -1 =
- *                     "tile_low"), "apply_min_tiles" (256), "expect_streams", "index_streams", "persist_blocks", "unroll", "compact_cpp"
- *   fused / support-compacted kernels: "small_max_qubits", "small_batch_max_qubits", "small_threads", "sparse_rows" (1), "sparse_wg" (1),
- *                     "sparse_grad" (1), "sparse_renumber" (1), "sparse_spw", "sparse_dealias"
+ * (B) GEOMETRY — defaults are the measured optimum on MI355X
+ *   streaming path: "tile_bits" (-1 automatic: 12 for n >= 25, else 11; 0 = one sweep per op), "tile_low" (4), "apply_min_tiles" (256),
+ *                     "index_streams"
+ *   fused / support-compacted kernels: "small_max_qubits", "small_batch_max_qubits"
  *   sector path: "sector_bits" / "sector_h_bits" (index bits per circuit / <H> tile, 0 automatic), "sector_tile_cap" (6500 amplitudes per
  *                     circuit tile so that gradients fit; up to 14000 for energies only), "sector_threads" (0 automatic, 64, 256, 512,
- *                     1024), "sector_sweep" (2: second sweep form, 64-bit pair words in registers; 1: first form), "sector_chunk" (1024,
- *                     2048, 4096), "sector_adjoint" (2 / 1), "sector_depth2", "sector_dict" (1: dictionary-coded matrix elements, dictionary from a sample of the stream
- *                     first; 2: from all values; 3: from a sample too thin to be complete — the fall-back, tests; 0: explicit values), "sector_many_tiles", "sector_h_lpt",
- *                     "sector_h_threads", "sector_h_groups", "sector_apply_threads", "sector_row_banks", "sector_batch_threads" /
- *                     "sector_batch_nb" / "sector_batch_sweep_threads" / "sector_batch_dst_lds" / "sector_batch_zfast" (1024 / 2 / 512 / 0 / 1),
- *                     "sector_reg_threads" (256; 128, 512, 1024), "sector_reg_pairs" (1: blocks of two three-bit ops),
- *                     "sector_pairs_form" (2: pair-table builder with the ops staged in LDS and no barrier per op; 1: first form).  Combinations the
- *                     second sweep form has no kernel for fall back to the first form / to one evaluation at a time.
+ *                     1024), "sector_adjoint" (2 / 1), "sector_dict" (1: dictionary-coded matrix elements, dictionary from a sample of the
+ *                     stream first; 2: from all values; 3: from a sample too thin to be complete — the fall-back, tests; 0: explicit values),
+ *                     "sector_reg_threads" (256; 128, 512, 1024), "sector_reg_pairs" (1: blocks of two three-bit ops), "sector_reg_runs"
+ *                     (1: runs of ops whose waves stay inside their own slots run without barriers), "sector_pairs_form" (2: pair-table
+ *                     builder with the ops staged in LDS; 1: first form).  Combinations the second sweep form has no kernel for fall back to
+ *                     the first form / to one evaluation at a time.
+ *   "sector_profile"  HIP-event times of the two halves of a sector evaluation in ovqe_program_info
  *
- * (C) MEASUREMENT AND TESTS — not for production use
- *   "sector_profile" (HIP-event times of the two halves of a sector evaluation in ovqe_program_info), "sector_debug" (1: measurement;
- *   2: say on stderr why a program was left to the dense kernels or its tables dropped; 4: wall time of the build's phases and of the
- *   stages of every evaluation above 3 ms),
- *   "sector_sweep_dbg" / "sector_h_dbg" (kernels truncated after a given phase: launch only, loads only, no arithmetic, no stores),
- *   "sparse_dbg" (the support-compacted throughput kernel without its sincos / circuit rows / Hamiltonian entries), "rot_variant" (one launch
- *   geometry of the streaming pair sweep), "fault_inject" (1: the next term-list build throws std::bad_alloc:
- *   the exception barrier's test) */
+ * (C) MEASUREMENT AND TESTS — accepted ONLY by the testing build of this same source (-DOVQE_TESTING: libovqe_sv_testing.so, loaded by
+ *   tests/test_gpu_abi.py and, through OVQE_LIB=testing, by the scripts under tools/); the product library answers OVQE_ERR_INVALID
+ *   "unknown option" and runs every one of them at its default:
+ *   "fault_inject" (1: the next term-list build throws std::bad_alloc: the exception barrier's test), "sector_debug" (2: say on stderr why a
+ *   program was left to the dense kernels; 4: wall time of the build's phases), "sector_sweep_dbg" / "sector_h_dbg" / "sparse_dbg" (kernels
+ *   truncated after a given phase), "rot_variant", and the launch geometries and superseded forms kept for comparison: "unroll",
+ *   "ham_tile_low", "expect_sparse", "expect_streams", "persist_blocks", "compact_cpp", "small_threads", "sparse_rows", "sparse_wg",
+ *   "sparse_grad", "sparse_renumber", "sparse_spw", "sparse_dealias", "sector_sweep", "sector_chunk", "sector_depth2", "sector_many_tiles",
+ *   "sector_h_lpt", "sector_h_threads", "sector_h_groups", "sector_apply_threads", "sector_row_banks", "sector_eager_rots",
+ *   "screen_tables", "sector_batch_threads" / "_nb" / "_sweep_threads" / "_dst_lds" / "_zfast" */
 int ovqe_set_option(ovqe_handle h, const char *name, int64_t value);
 /* device pointer to the 2^n_local amplitudes (for RCCL exchange by the host layer) */
 int ovqe_state_ptr(ovqe_handle h, void **dev_ptr);
@@ -329,6 +333,16 @@ int ovqe_last_support(ovqe_handle h, int32_t which, int64_t *support);
  *   the register that the reference's QUCCSD templates populate; option "sector_regular", default 1): slot bits of a circuit
  *   tile — the sweeps then run from bit arithmetic, without pair words — and the number of free (dependent) index bits; 0 else */
 int ovqe_program_info(ovqe_handle h, int64_t *info, int count);
+/* The stored program as its sequence of Pauli rotations exp(-i (coeff[r] theta[pidx[r]] + phi0[r]) P_r), P_r = (x[r], z[r]) in
+ * index-bit space, in execution order (pidx < 0: a constant angle) — for a gate program in Clifford-frame form
+ * (ovqe_set_gate_program, option "clifford_frame") the rotations with their CONJUGATED strings, i.e. what the reference's
+ * template list (ref:openvqe/common_files/circuit.py:13-106, executed by ref:openvqe/ucc_family/get_energy_qucc.py:47-52) becomes
+ * once its Clifford gates are moved to the end; for ovqe_set_program the rotations as given.  *count receives the number of
+ * rotations; up to `capacity` of them are written (arrays may be NULL when capacity is 0).  OVQE_ERR_STATE when no program is set
+ * or the program still holds literal X / H / CNOT ops (a literal list, an open or forced frame).  Diagnostics / tests: lets a
+ * checker evaluate the very sequence the kernels run with an independent simulator. */
+int ovqe_get_rotation_program(ovqe_handle h, int64_t capacity, uint64_t *x, uint64_t *z, double *coeff, double *phi0,
+                              int32_t *pidx, int64_t *count);
 
 #ifdef __cplusplus
 }

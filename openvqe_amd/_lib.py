@@ -8,6 +8,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libovqe_sv.so")
+#: the same source built with -DOVQE_TESTING: it also accepts the measurement / fault-injection options (tests/test_gpu_abi.py, tools/)
+TESTING_LIB_PATH = os.path.join(_HERE, "lib", "libovqe_sv_testing.so")
+if os.environ.get("OVQE_LIB"):     # measurement scripts: OVQE_LIB=testing (or a path) selects the library to load
+    LIB_PATH = TESTING_LIB_PATH if os.environ["OVQE_LIB"] == "testing" else os.environ["OVQE_LIB"]
 
 _u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
@@ -35,6 +39,7 @@ SIGNATURES = {
     "ovqe_device_count": (_int, [ctypes.POINTER(_int)]),
     "ovqe_create": (_int, [_int, _int, ctypes.POINTER(_H)]),
     "ovqe_create_shard": (_int, [_int, _int, _u64, _int, ctypes.POINTER(_H)]),
+    "ovqe_create_view": (_int, [_int, _int, ctypes.c_void_p, ctypes.POINTER(_H)]),
     "ovqe_destroy": (_int, [_H]),
     "ovqe_set_stream": (_int, [_H, _vp]),
     "ovqe_set_option": (_int, [_H, ctypes.c_char_p, _i64]),
@@ -72,6 +77,8 @@ SIGNATURES = {
     "ovqe_sector_ground_state": (_int, [_H, _dbl, _int, _u64, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl),
                                         ctypes.POINTER(_int)]),
     "ovqe_program_info": (_int, [_H, ctypes.POINTER(ctypes.c_int64), _int]),
+    "ovqe_get_rotation_program": (_int, [_H, _i64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.POINTER(ctypes.c_int64)]),
 }
 
 _lib = None

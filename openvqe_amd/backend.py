@@ -46,7 +46,9 @@ def compile_ucc_program(nbqbits, generators, n_params=None):
 class Statevector:
     """n-qubit complex128 state resident on one MI355X (or one shard of a distributed state)."""
 
-    def __init__(self, n_qubits, device=0, n_global=0, shard_index=0):
+    def __init__(self, n_qubits, device=0, n_global=0, shard_index=0, view_of=None):
+        """``view_of``: device pointer of a caller-owned buffer of 2^n_qubits amplitudes that IS the state (ovqe_create_view: no
+        allocation of that size; the buffer must outlive the object)"""
         self._L = _lib.lib()
         self._h = ctypes.c_void_p()
         self._energy_io = None
@@ -54,7 +56,11 @@ class Statevector:
         self.n_local = int(n_qubits)
         self.n_global = int(n_global)
         self.shard_index = int(shard_index)
-        if n_global:
+        if view_of is not None:
+            if n_global:
+                raise ValueError("a view is a single-device handle")
+            rc = self._L.ovqe_create_view(n_qubits, device, ctypes.c_void_p(int(view_of)), ctypes.byref(self._h))
+        elif n_global:
             rc = self._L.ovqe_create_shard(n_qubits, n_global, shard_index, device, ctypes.byref(self._h))
         else:
             rc = self._L.ovqe_create(n_qubits, device, ctypes.byref(self._h))
@@ -358,6 +364,18 @@ class Statevector:
                 "sector_circuit_us", "sector_expect_us", "sector_h_stream_bytes", "sector_fci_block",
                 "sp_conflicts_discovery_order", "sp_conflicts", "sector_regular_slot_bits", "sector_free_bits")
         return dict(zip(keys, [int(v) for v in out]))
+
+    def rotation_program(self):
+        """the stored program as its Pauli-rotation sequence (ovqe_get_rotation_program): a gate program in Clifford-frame form
+        comes back with its conjugated strings.  -> (xs, zs, coeffs, phi0s, pidx) numpy arrays in execution order"""
+        n = ctypes.c_int64()
+        self._ck(self._L.ovqe_get_rotation_program(self._h, 0, None, None, None, None, None, ctypes.byref(n)))
+        R = n.value
+        xs, zs = np.empty(R, np.uint64), np.empty(R, np.uint64)
+        cs, p0, pi = np.empty(R, np.float64), np.empty(R, np.float64), np.empty(R, np.int32)
+        self._ck(self._L.ovqe_get_rotation_program(self._h, R, xs.ctypes.data, zs.ctypes.data, cs.ctypes.data, p0.ctypes.data,
+                                                   pi.ctypes.data, ctypes.byref(n)))
+        return xs, zs, cs, p0, pi
 
     # -- ADAPT ----------------------------------------------------------------------------------
     def pool_gradients(self, pool_ops, mode):

@@ -27,22 +27,18 @@ RANK_TWO_FROM = 256
 
 
 def _line_search():
-    try:   # scipy's own: Wolfe search of MINPACK2 (dcsrch), falling back on the Python one — what its BFGS calls
+    """scipy's own Wolfe search (MINPACK2's dcsrch, falling back on its Python search) — what scipy's BFGS calls, and what the
+    "same iterates" claim above rests on.  It is a private name (validated on scipy 1.9 ... 1.15): where a scipy release no longer
+    has it, -> None and `minimize_bfgs` hands the whole minimisation to scipy's BFGS (dense update, same iterates) rather than
+    running on a DIFFERENT line search without saying so."""
+    try:
         from scipy.optimize._optimize import _LineSearchError, _line_search_wolfe12
         return _line_search_wolfe12, _LineSearchError
-    except ImportError:   # the public search (strong Wolfe, Python)
-        from scipy.optimize import line_search
+    except ImportError:
+        return None
 
-        class _LineSearchError(RuntimeError):
-            pass
 
-        def search(f, fprime, xk, pk, gfk, old_fval, old_old_fval, **kwargs):
-            ret = line_search(f, fprime, xk, pk, gfk, old_fval, old_old_fval, c1=kwargs.get("c1", 1e-4), c2=kwargs.get("c2", 0.9))
-            if ret[0] is None:
-                raise _LineSearchError()
-            return ret
-
-        return search, _LineSearchError
+_warned = []
 
 
 def minimize_bfgs(fun, x0, jac, tol=None, maxiter=None, disp=False, c1=1e-4, c2=0.9):
@@ -51,6 +47,17 @@ def minimize_bfgs(fun, x0, jac, tol=None, maxiter=None, disp=False, c1=1e-4, c2=
     call, and the device calls that follow — a hundred kernel launches each — then take three times as long (measured on the
     MI355X box, N2 QUCCSD gradient: 31 ms -> 89 ms with 10 ms of threaded numpy between the calls, tools/exp_mirror_eval_n2.py)."""
     with one_blas_thread():
+        if _line_search() is None:
+            if not _warned:
+                import warnings
+                warnings.warn("scipy.optimize._optimize._line_search_wolfe12 is not importable in this scipy release: the rank-two BFGS "
+                              "is bypassed and scipy's own BFGS (dense inverse-Hessian update) runs instead", RuntimeWarning, stacklevel=2)
+                _warned.append(True)
+            from scipy.optimize import minimize
+            opts = {"disp": disp, "c1": c1, "c2": c2}
+            if maxiter is not None:
+                opts["maxiter"] = maxiter
+            return minimize(fun, x0, jac=jac, method="BFGS", tol=tol, options=opts)
         return _minimize_bfgs(fun, x0, jac, tol, maxiter, disp, c1, c2)
 
 

@@ -2274,7 +2274,7 @@ bool mapped_io(ovqe_handle h, int64_t B) {
     // measured: zero-copy wins up to the 64-KiB buffer (H2O: 16 evaluations 63 us against 89 us through copies)
     if ((size_t)B * (size_t)(h->K + 1) > ovqe_sv::IO_DOUBLES || B > 1024) return false;
     if (!h->h_io) {
-        if (hipHostMalloc((void **)&h->h_io, ovqe_sv::IO_DOUBLES * sizeof(double), hipHostMallocMapped) != hipSuccess) {
+        if (hipHostMalloc((void **)&h->h_io, ovqe_sv::IO_DOUBLES * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
             h->h_io = nullptr;
             (void)hipGetLastError();
             return false;
@@ -2995,7 +2995,7 @@ int check_theta(ovqe_handle h, const double *theta, int32_t K) {
     return OVQE_OK;
 }
 
-int create_common(int n_local, int n_global, uint64_t shard, int device, ovqe_handle *out) {
+int create_common(int n_local, int n_global, uint64_t shard, int device, ovqe_handle *out, void *adopt = nullptr) {
     if (!out) return fail(nullptr, OVQE_ERR_INVALID, "out is NULL");
     *out = nullptr;
     // 33 local qubits (128 GiB) is what the sweep launchers cover (four pairs per thread keep a launch below 2^32
@@ -3022,14 +3022,19 @@ int create_common(int n_local, int n_global, uint64_t shard, int device, ovqe_ha
     h->shard = shard;
     h->namps = 1ull << n_local;
     h->base = shard << n_local;
-    e = hipMalloc((void **)&h->state, h->namps * sizeof(amp_t));
-    if (e != hipSuccess) {
-        delete h;
-        return fail(nullptr, OVQE_ERR_ALLOC, std::string("hipMalloc state: ") + hipGetErrorString(e));
+    if (adopt) {   // a view: the caller's buffer is the state, nothing of that size is allocated here
+        h->state = (amp_t *)adopt;
+        h->own_state = false;
+    } else {
+        e = hipMalloc((void **)&h->state, h->namps * sizeof(amp_t));
+        if (e != hipSuccess) {
+            delete h;
+            return fail(nullptr, OVQE_ERR_ALLOC, std::string("hipMalloc state: ") + hipGetErrorString(e));
+        }
     }
     if (hipHostMalloc((void **)&h->h_result, 64 * sizeof(double2), hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
-        (void)hipFree(h->state);
+        if (h->own_state) (void)hipFree(h->state);
         delete h;
         return fail(nullptr, OVQE_ERR_ALLOC, "host staging / event creation failed");
     }
@@ -3060,6 +3065,11 @@ int ovqe_create(int n_qubits, int device, ovqe_handle *out) try {
 
 int ovqe_create_shard(int n_local, int n_global, uint64_t shard_index, int device, ovqe_handle *out) try {
     return create_common(n_local, n_global, shard_index, device, out);
+} OVQE_CATCH(nullptr)
+
+int ovqe_create_view(int n_qubits, int device, void *dev_ptr, ovqe_handle *out) try {
+    if (!dev_ptr) return fail(nullptr, OVQE_ERR_INVALID, "dev_ptr is NULL");
+    return create_common(n_qubits, 0, 0, device, out, dev_ptr);
 } OVQE_CATCH(nullptr)
 
 int ovqe_destroy(ovqe_handle h) try {
@@ -3109,10 +3119,16 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     OVQE_ENTER(h);
     if (!h || !name) return OVQE_ERR_INVALID;
     const std::string k(name);
+    // Keys between `#ifdef OVQE_TESTING` lines exist only in the testing build of this same source (libovqe_sv_testing.so, built by
+    // __graft_entry__.build() with -DOVQE_TESTING, loaded through OVQE_LIB by tests/test_gpu_abi.py and the measurement scripts under
+    // tools/): fault injection, kernels with phases switched off, superseded kernel forms and launch geometries.  The product
+    // library refuses them as unknown options and runs every one of them at its default.
     if (k == "force_path") h->opt_force_path = (int)value;
     else if (k == "small_max_qubits") h->opt_small_max = (int)value;
     else if (k == "small_batch_max_qubits") h->opt_small_batch_max = (int)value;
+#ifdef OVQE_TESTING
     else if (k == "unroll") h->opt_unroll = (int)value;
+#endif
     else if (k == "real_mode") {
         h->opt_real_mode = (int)value;
         h->sp_tried = false;
@@ -3120,8 +3136,11 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     else if (k == "sparse") {
         h->opt_sparse = (int)value;
         h->sp_tried = false;
-    } else if (k == "sparse_spw") h->opt_sparse_spw = (int)value;
+    }
+#ifdef OVQE_TESTING
+    else if (k == "sparse_spw") h->opt_sparse_spw = (int)value;
     else if (k == "sparse_dbg") h->opt_sparse_dbg = (int)value;
+#endif
     else if (k == "clifford_phase_host") h->opt_clifford_phase_host = (int)value;
     else if (k == "index_streams") {
         h->opt_index_streams = (int)value;
@@ -3136,16 +3155,23 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
         h->sec.disabled = false;
         h->sec.seen = 0;
         h->sec.prog_version = -1;
-    } else if (k == "sector_threads") h->opt_sector_threads = (value == 0 || value == 64 || value == 512 || value == 1024) ? (int)value : 256;
+    }
+    else if (k == "sector_threads") h->opt_sector_threads = (value == 0 || value == 64 || value == 512 || value == 1024) ? (int)value : 256;
+#ifdef OVQE_TESTING
     else if (k == "sector_h_groups") h->opt_sector_h_groups = (int)value;
     else if (k == "sector_h_dbg") h->opt_sector_h_dbg = (int)value;
+#endif
     else if (k == "sector_adjoint") h->opt_sector_adjoint = value == 1 ? 1 : 2;
+#ifdef OVQE_TESTING
     else if (k == "sector_apply_threads") h->opt_sector_apply_threads = value == 1024 ? 1024 : (value == 512 ? 512 : 0);
     else if (k == "sector_h_threads") h->opt_sector_h_threads = value == 1024 ? 1024 : 512;
+#endif
     else if (k == "sector_batch") h->opt_sector_batch = (int)value;
+#ifdef OVQE_TESTING
     else if (k == "sector_h_lpt") h->opt_sector_h_lpt = (int)value;
     else if (k == "sector_many_tiles") h->opt_sector_many_tiles = (int)value;
     else if (k == "sector_depth2") h->opt_sector_depth2 = (int)value;
+#endif
     else if (k == "sector_regular") {
         h->opt_sector_regular = (int)value;
         free_sector(h->sec);
@@ -3166,13 +3192,18 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
         h->sec.prog_version = -1;
     }
     else if (k == "sector_reg_threads") h->opt_sector_reg_threads = value == 512 ? 512 : (value == 1024 ? 1024 : (value == 128 ? 128 : 256));
+#ifdef OVQE_TESTING
     else if (k == "sector_eager_rots") h->opt_sector_eager_rots = (int)value;
+#endif
     else if (k == "sector_fused_reduce") h->opt_sector_fused_reduce = (int)value;
     else if (k == "poll_result") h->opt_poll_result = (int)value;
     else if (k == "sector_pairs_form") h->opt_sector_pairs_form = (int)value;
     else if (k == "screen_sector") h->opt_screen_sector = (int)value;
+#ifdef OVQE_TESTING
     else if (k == "screen_tables") h->opt_screen_tables = (int)value;
+#endif
     else if (k == "screen_sector_min") h->opt_screen_sector_min = (int)value;
+#ifdef OVQE_TESTING
     else if (k == "sector_batch_sweep_threads") h->opt_sector_batch_sweep_threads = value == 512 ? 512 : (value == 256 ? 256 : 1024);
     else if (k == "sector_batch_dst_lds") h->opt_sector_batch_dst_lds = (int)value;
     else if (k == "sector_batch_zfast") h->opt_sector_batch_zfast = (int)value;
@@ -3182,6 +3213,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     else if (k == "sector_debug") h->opt_sector_debug = (int)value;
     else if (k == "sector_sweep") h->opt_sector_sweep = value == 1 ? 1 : 2;
     else if (k == "sector_sweep_dbg") h->opt_sector_sweep_dbg = (int)value;
+#endif
     else if (k == "sector_reg_runs") {   // runs of ops without barriers (planned at build time: the tables are rebuilt)
         h->opt_sector_reg_runs = (int)value;
         free_sector(h->sec);
@@ -3189,7 +3221,9 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
         h->sec.seen = 0;
         h->sec.prog_version = -1;
     }
+#ifdef OVQE_TESTING
     else if (k == "sector_chunk") h->opt_sector_chunk = (value == 1024 || value == 4096) ? (int)value : 2048;
+#endif
     else if (k == "sector_profile") h->opt_sector_profile = (int)value;
     else if (k == "sector_sparsity" || k == "sector_tile_cap") {
         (k == "sector_sparsity" ? h->opt_sector_sparsity : h->opt_sector_tile_cap) = (int)value;
@@ -3200,17 +3234,22 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     }
     else if (k == "lanczos_keep_gb") h->opt_lanczos_keep_gb = (int)value;
     else if (k == "screen_sparse") h->opt_screen_sparse = (int)std::max<int64_t>(0, value);
+#ifdef OVQE_TESTING
     else if (k == "rot_variant") h->opt_rot_variant = (int)value;
     else if (k == "fault_inject") h->fault_inject = (int)value;
+#endif
     else if (k == "real_stream") h->opt_real_stream = (int)value;
     else if (k == "apply_min_tiles") h->opt_apply_min_tiles = (int)value;
     else if (k == "clifford_frame") h->opt_clifford_frame = (int)value;  // applies to the next ovqe_set_gate_program
+#ifdef OVQE_TESTING
     else if (k == "ham_tile_low") h->opt_ham_tile_low = (int)value;
+#endif
     else if (k == "tile_bits" || k == "tile_low") {
         (k == "tile_bits" ? h->opt_tile_bits : h->opt_tile_low) = (int)value;
         h->tp_real_built = false;  // the real-amplitude plan follows on its next use
         if (h->prog_set) return build_tile_program(h);
     }
+#ifdef OVQE_TESTING
     else if (k == "sparse_dealias") {
         h->opt_sparse_dealias = value ? 1 : 0;
         h->sp_tried = false;
@@ -3228,17 +3267,20 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     else if (k == "expect_sparse") h->opt_expect_sparse = (int)std::max<int64_t>(0, value);
     else if (k == "expect_streams") h->opt_expect_streams = value >= 2 ? 2 : 1;
     else if (k == "compact_cpp") h->opt_compact_cpp = (int)std::min<int64_t>(4, std::max<int64_t>(1, value));
+#endif
     else if (k == "compact") {
         h->opt_compact = value ? 1 : 0;
         h->cc.valid = false;
         h->cc.disabled = false;
         h->cc.seen = 0;
     }
+#ifdef OVQE_TESTING
     else if (k == "persist_blocks") h->opt_persist_blocks = (int)value;
     else if (k == "small_threads") {
         h->opt_small_threads = (int)value;
         h->exp_lbits = -1;
     }
+#endif
     else if (k == "table_fusion") {
         if (h->opt_table_fusion != (int)value && h->prog_set) {
             h->opt_table_fusion = (int)value;
@@ -3949,9 +3991,9 @@ static int list_support(ovqe_handle h, uint64_t *support, bool *listed, uint64_t
 // of the sector path, sector_host.inc build_sector_h, without a circuit) and sigma is one pass over it (k_sector_apply).  Real
 // Hamiltonians and real states only; anything else takes the register path.
 static int build_screen_sector(ovqe_handle h, uint64_t support) {
-    DevBlockScope kept_blocks(h->kept_blocks);
     SectorEngine &E = h->scr;
-    free_sector(E);
+    free_sector(E);   // (before the build's block cache opens: sector_host.inc build_sector)
+    DevBlockScope kept_blocks(h->kept_blocks);
     E.ham_version = h->ham.version;
     h->scr_failed_version = h->ham.version;   // until everything below succeeded
     if (h->n_global != 0 || h->n_local > 32 || h->n_local < 12) return OVQE_OK;
@@ -4794,6 +4836,29 @@ int ovqe_program_info(ovqe_handle h, int64_t *info, int count) try {
                             (E.valid && E.regular && h->opt_sector_regular) ? (int64_t)E.reg_m : 0,
                             (E.valid && E.regular) ? (int64_t)__builtin_popcount(E.freemask) : 0};
     for (int i = 16; i < count && i < 30; ++i) info[i] = sv[i - 16];
+    return OVQE_OK;
+} OVQE_CATCH(h)
+
+int ovqe_get_rotation_program(ovqe_handle h, int64_t capacity, uint64_t *x, uint64_t *z, double *coeff, double *phi0,
+                              int32_t *pidx, int64_t *count) try {
+    OVQE_ENTER(h);
+    if (!h || !count || capacity < 0 || (capacity > 0 && (!x || !z || !coeff || !phi0 || !pidx))) return OVQE_ERR_INVALID;
+    if (!h->prog_set) return fail(h, OVQE_ERR_STATE, "no program set");
+    if (h->frame_open) return fail(h, OVQE_ERR_STATE, "the program's Clifford frame is open: the rotations alone are not the circuit");
+    int64_t n = 0;
+    for (const SmallOp &op : h->ops) {
+        if (op.kind != OP_PAIR && op.kind != OP_DIAG) return fail(h, OVQE_ERR_STATE, "the program holds literal X / H / CNOT ops");
+        for (int32_t r = op.first; r < op.first + op.count; ++r, ++n) {
+            if (n >= capacity) continue;
+            const SmallRot &sr = h->rots[r];
+            x[n] = op.x;
+            z[n] = sr.z;
+            coeff[n] = sr.coeff;
+            phi0[n] = sr.phi0;
+            pidx[n] = sr.pidx;
+        }
+    }
+    *count = n;
     return OVQE_OK;
 } OVQE_CATCH(h)
 

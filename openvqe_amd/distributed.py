@@ -169,8 +169,8 @@ class HipShardEngine:
     def _sub(self, m):
         if m not in self._subs:
             from .backend import Statevector
-            sub = Statevector(m, device=self.device.index)
-            sub.adopt_state(self.tensor.data_ptr())      # never used as a state: drops the handle's own 2^m-amplitude allocation
+            # (never used as a state — bra and ket pointers come with every call: a view of the shard, no 2^m-amplitude allocation)
+            sub = Statevector(m, device=self.device.index, view_of=self.tensor.data_ptr())
             sub.set_stream(self.stream.cuda_stream)
             self._subs[m] = sub
         return self._subs[m]
@@ -499,6 +499,7 @@ class ShardedStatevector:
         real = self.real and self.real_transfers
         if real and (self._chunk_real is None or self._chunk_real[0].numel() < np_ * csize):
             self._chunk_real = [torch.empty(np_ * csize, dtype=torch.float64, device=self.engine.tensor.device) for _ in range(2)]
+        if real and (self._chunk_send is None or self._chunk_send[0].numel() != csize):   # (sized by the chunk alone: its own test)
             self._chunk_send = [torch.empty(csize, dtype=torch.float64, device=self.engine.tensor.device) for _ in range(2)]
 
         def post(c):

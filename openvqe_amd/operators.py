@@ -248,10 +248,15 @@ def pack_terms(nbqbits, terms):
     total = int(lens.sum())
     if total == 0:
         return xs, zs, cs
-    chars = np.frombuffer("".join([t.op for t in terms]).encode("latin-1"), dtype=np.uint8)
+    qlens = np.fromiter((len(t.qbits) for t in terms), np.int64, T)
+    if not np.array_equal(qlens, lens):   # (a flat array would shift every later term's qubits: checked before anything is flattened)
+        k = int(np.argmax(qlens != lens))
+        raise ValueError(f"term {k}: {int(lens[k])} Pauli characters on {int(qlens[k])} qubits")
+    try:
+        chars = np.frombuffer("".join([t.op for t in terms]).encode("latin-1"), dtype=np.uint8)
+    except UnicodeEncodeError as exc:
+        raise ValueError(f"unknown Pauli '{exc.object[exc.start]}'") from None
     qubits = np.fromiter((q for t in terms for q in t.qbits), np.int64, total)
-    if chars.size != total:
-        raise ValueError("Pauli string with characters outside Latin-1")
     if qubits.min() < 0 or qubits.max() >= nbqbits:
         raise ValueError("qubit index out of range")
     is_x, is_y, is_z, is_i = chars == ord("X"), chars == ord("Y"), chars == ord("Z"), chars == ord("I")

@@ -123,7 +123,20 @@ class OracleStatevector:
             for name, qubits, sc, co, p in gates:
                 self.apply_gate(name, qubits, co + (sc * theta[p] if p >= 0 else 0.0))
 
+    #: True: Pauli-rotation programs are evaluated by the C restatement of the same oracle (oracle/c/ovqe_oracle.c, fused mask sweeps —
+    #: what tests/test_oracle.py pins against this class's numpy form) instead of the numpy loops: ~100 x faster at 14 qubits, for the
+    #: flows that evaluate hundreds of energies (tests/test_gpu_flows.py, H2O ADAPT)
+    use_c_oracle = False
+
     def energy(self, theta):
+        if self.use_c_oracle and self._prog[0] == "rot" and not np.any(self._prog[4]):
+            from oracle import cref
+            _, xs, zs, cs, _, pi, hf = self._prog
+            hx, hz, hc, const = self._ham
+            e, psi = cref.ucc_energy(self.nbqbits, hf, xs, zs, cs, np.asarray(pi, np.int32), np.asarray(theta, float).reshape(-1),
+                                     hx, hz, hc, const, 0)
+            self.psi = psi
+            return float(e)
         self.prepare_state(theta)
         xs, zs, cs, const = self._ham
         return masks.expectation(self.psi, xs, zs, cs, const)

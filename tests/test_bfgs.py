@@ -46,3 +46,25 @@ def test_printed_summary_has_scipy_s_lines(capsys):
     out = capsys.readouterr().out
     assert "Optimization terminated successfully." in out and "Current function value:" in out
     assert f"Iterations: {res.nit}" in out and f"Function evaluations: {res.nfev}" in out and f"Gradient evaluations: {res.njev}" in out
+
+
+def test_missing_private_line_search_hands_over_to_scipy(monkeypatch):
+    """without scipy's private Wolfe search the rank-two BFGS must not run on another line search silently"""
+    import warnings
+
+    import scipy.optimize
+
+    from openvqe_amd.common_files import bfgs
+    monkeypatch.setattr(bfgs, "_line_search", lambda: None)
+    monkeypatch.setattr(bfgs, "_warned", [])
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(12, 12))
+    A = A @ A.T + 12 * np.eye(12)
+    b = rng.normal(size=12)
+    f, g = (lambda x: 0.5 * x @ A @ x - b @ x), (lambda x: A @ x - b)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        res = bfgs.minimize_bfgs(f, np.zeros(12), g, tol=1e-8)
+    assert any("scipy's own BFGS" in str(w.message) for w in seen)
+    ref = scipy.optimize.minimize(f, np.zeros(12), jac=g, method="BFGS", tol=1e-8)
+    assert np.array_equal(res.x, ref.x) and res.nit == ref.nit

@@ -12,9 +12,29 @@ from tests.util import random_hamiltonian, random_state
 pytestmark = pytest.mark.gpu
 
 
-def test_host_allocation_failure_is_a_status_not_a_dead_process(gpu_lib):
+@pytest.fixture
+def testing_lib(gpu_lib, monkeypatch):
+    """the OVQE_TESTING build of the same source (fault injection lives only there): handles created inside the test bind to it"""
+    from openvqe_amd import _lib
+    monkeypatch.setattr(_lib, "LIB_PATH", _lib.TESTING_LIB_PATH)
+    monkeypatch.setattr(_lib, "_lib", None)
+    return _lib.lib()
+
+
+def test_product_library_refuses_the_testing_options(gpu_lib):
     from openvqe_amd._lib import BackendError
     from openvqe_amd.backend import Statevector
+    with Statevector(6) as sv:
+        for name in ("fault_inject", "sector_sweep_dbg", "sector_h_dbg", "sparse_dbg", "sector_debug"):
+            with pytest.raises(BackendError, match="unknown option"):
+                sv.set_option(name, 1)
+        sv.set_option("sector", 1)      # a product option
+
+
+def test_host_allocation_failure_is_a_status_not_a_dead_process(testing_lib):
+    from openvqe_amd._lib import BackendError
+    from openvqe_amd.backend import Statevector
+    gpu_lib = testing_lib
     n = 10
     rng = np.random.default_rng(5)
     ham = random_hamiltonian(rng, n, 12)

@@ -388,3 +388,47 @@ def test_stand_in_qpu_caches_literal_gate_templates(gpu_lib, monkeypatch):
     _reset()
     l1 = float(np.abs(ham.packed()[2]).sum())
     assert np.abs(np.array(got) - np.array(want)).max() < 1e-11 * max(1.0, l1)
+
+
+def test_h2o_fermionic_adapt_five_iterations_select_the_same_operators_as_the_oracle_engine(gpu_lib, monkeypatch):
+    """BASELINE configs[2] on ITS molecule (north_star: "ADAPT gradient ranking identical"): five macro-iterations of the
+    fermionic-ADAPT mirror (ref:openvqe/adapt/fermionic_adapt_vqe.py:371-593) on H2O/STO-3G — 14 qubits, the 1246-operator
+    spin-complemented pool, one operator per iteration, COBYLA — on the HIP engine and on the oracle engine underneath the SAME host
+    code: the selected pool indices must be identical iteration by iteration and the energies equal to 1e-9.  (The fidelity's reference vector is not the object of this test: both runs get the same ARPACK eigenpair of the sparse
+    matrix, so that the oracle side does not spend a minute in a numpy Lanczos.)"""
+    import io
+    import re
+
+    import scipy.sparse.linalg as sla
+
+    import openvqe_amd.adapt.fermionic_adapt_vqe as fa
+    from openvqe_amd import chem, pools
+    mol = chem.molecule("H2O")
+    e_hf = mol.rhf()
+    ham = mol.jw_hamiltonian()
+    size, pool = pools.spin_complement_gsd(mol.n_elec, mol.nao)
+    assert size == 1246 and ham.nbqbits == 14
+    hf = mol.hf_init()
+    vals, vecs = sla.eigsh(ham.get_matrix(sparse=True), k=1, which="SA", tol=1e-10)
+    monkeypatch.setattr(fa, "_ground_space", lambda *a, **k: (vals, vecs))
+    monkeypatch.setattr(OracleStatevector, "use_c_oracle", True)
+    runs = {}
+    for kind in ("hip", "oracle"):
+        text = io.StringIO()
+        with engine(kind), contextlib.redirect_stdout(text):
+            trace, _ = fa.fermionic_adapt_vqe(None, None, None, ham, pool, hf, 1, float(vals[0]), "COBYLA", 1e-6, "norm", 1e-2,
+                                              max_external_iterations=5)
+        picks = [int(v) for v in re.findall(r"sorted_index1:\s+\[(\d+)\]", text.getvalue())]
+        runs[kind] = (picks, trace)
+    (picks_h, tr_h), (picks_o, tr_o) = runs["hip"], runs["oracle"]
+    assert len(picks_h) == 5 and picks_h == picks_o, (picks_h, picks_o)
+    assert len(set(picks_h)) == 5
+    assert np.abs(np.array(tr_h["energies"]) - np.array(tr_o["energies"])).max() < 1e-9
+    # the first screen is taken at the same point (|hf>): equal to rounding.  Later screens are taken at each run's OWN optimum, which
+    # COBYLA (tol 1e-6) fixes to ~1e-6 in theta — the energy is stationary there (differences ~1e-12), gradients of the pool are not
+    assert abs(tr_h["norms"][0] - tr_o["norms"][0]) < 1e-10 and abs(tr_h["Max_gradients"][0] - tr_o["Max_gradients"][0]) < 1e-10
+    for key in ("norms", "Max_gradients", "fidelity"):
+        assert np.abs(np.array(tr_h[key]) - np.array(tr_o[key])).max() < 2e-4, key
+    assert all(a > b for a, b in zip(tr_h["energies"], tr_h["energies"][1:])) and tr_h["energies"][0] < e_hf
+    for key in ("CNOTs", "Hadamard"):
+        assert tr_h[key] == tr_o[key]

@@ -285,6 +285,100 @@ def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
     assert np.abs(out[0][1] - out[1][1]).max() < 1e-11
 
 
+def test_24_qubit_full_quccsd_list_against_c_oracle(gpu_lib):
+    """configs[3] UN-THINNED: the reference's whole QUCCSD list on N2 / cc-pVDZ (10e,12o) — 1715 parameters, 62 852 literal gates
+    (ref:openvqe/common_files/circuit.py:13-106 through ref:openvqe/ucc_family/get_energy_qucc.py:47-52) — on the full 6464-term
+    Hamiltonian against ONE oracle number.  Gate by gate the oracle would take an hour (62 852 passes over 256 MiB); instead the
+    backend hands out the rotation sequence it compiled the list to (ovqe_get_rotation_program: 13 300 Pauli rotations with their
+    Clifford-conjugated strings) and the plain-C oracle evaluates THAT with its own fused mask sweeps and x-grouped expectation.
+    What this pins: every kernel between the compiled sequence and the energy (sector tables on the 2^22 coset, bit-arithmetic
+    sweeps, materialised <H>) at full size; what it takes from the product is the frame compiler's output, whose equivalence to the
+    literal list the test above checks (frame form == literal form on the same full list, and the thinned list gate by gate)."""
+    from openvqe_amd import chem
+    from openvqe_amd.backend import Statevector
+    from openvqe_amd.common_files.circuit import quccsd_gate_list
+    from oracle import cref
+    mol = chem.molecule("N2-CCPVDZ")
+    mol.rhf()
+    prob = chem.cas_problem(mol, 2, 12)
+    n = prob.nbqbits
+    size, cluster_ops, _, theta_mp2, hf = prob.uccsd()
+    gates, K, _ = quccsd_gate_list(12, 5, 1, excitations=[op.terms[0].qbits for op in cluster_ops])
+    assert K == size == 1715 and len(gates) > 60000
+    ham = prob.jw_hamiltonian()
+    hx, hz, hc = ham.packed()
+    hc = np.ascontiguousarray(hc.real)
+    l1 = float(np.abs(hc).sum())
+    rng = np.random.default_rng(2425)
+    theta = np.array(theta_mp2) + rng.uniform(-0.05, 0.05, K)
+    with Statevector(n) as sv:
+        sv.set_hamiltonian(ham)
+        sv.set_gate_program(gates, K, hf)
+        assert sv.program_info()["literal_gates"] == 0
+        rx, rz, rc, p0, pidx = sv.rotation_program()
+        es = [sv.energy(theta) for _ in range(3)]
+        info = sv.program_info()
+    assert len(rx) == 13300 and int(pidx.max()) == K - 1
+    # the oracle takes phi = coeff * theta[pidx]: constant parts / constant rotations ride on one extra parameter fixed at 1
+    # (two rotations by the same string commute, so coeff * theta + phi0 splits exactly)
+    ext = np.append(theta, 1.0)
+    ox, oz, oc, op_ = [], [], [], []
+    for x, z, c, c0, p in zip(rx, rz, rc, p0, pidx):
+        if p >= 0 and c != 0.0:
+            ox.append(x); oz.append(z); oc.append(c); op_.append(p)
+        if c0 != 0.0:
+            ox.append(x); oz.append(z); oc.append(c0); op_.append(K)
+    psi = np.empty(1 << n, dtype=np.complex128)
+    e_ref, _ = cref.ucc_energy(n, hf, np.array(ox, np.uint64), np.array(oz, np.uint64), np.array(oc), np.array(op_, np.int32), ext,
+                               hx, hz, hc, ham.constant_coeff, psi=psi)
+    assert info["sector_support"] == 1 << 22 and info["sector_regular_slot_bits"] > 0 and info["sector_free_bits"] == 2
+    for e in es:       # streaming path (first call), table build (second), sector tables (third)
+        assert abs(e - e_ref) < 1e-10 * max(1.0, l1), (e, e_ref)
+    assert abs(np.vdot(psi, psi).real - 1.0) < 1e-11
+
+
+def test_rotation_program_export_round_trip(gpu_lib):
+    """ovqe_get_rotation_program: a Pauli-rotation program comes back as given; a literal gate list is refused; a small QUCCSD
+    template list in frame form comes back as rotations whose oracle evaluation equals the oracle's gate-by-gate energy"""
+    from openvqe_amd import chem, fermion
+    from openvqe_amd._lib import BackendError
+    from openvqe_amd.backend import Statevector, compile_ucc_program
+    from openvqe_amd.common_files.circuit import quccsd_gate_list
+    from tests.oracle_backend import OracleStatevector
+    mol = chem.molecule("H4")
+    mol.rhf()
+    ham = mol.jw_hamiltonian()
+    n = ham.nbqbits
+    gens = fermion.uccsd_generators(mol.nao, mol.n_elec // 2)
+    hf = mol.hf_init()
+    rx, rz, rc, pidx, K = compile_ucc_program(n, gens)
+    gates, Kq, hfq = quccsd_gate_list(mol.nao, mol.n_elec // 2, 1)
+    rng = np.random.default_rng(8)
+    with Statevector(n) as sv:
+        sv.set_hamiltonian(ham)
+        with pytest.raises(BackendError):
+            sv.rotation_program()                   # no program yet
+        sv.set_ucc_program(gens, hf)
+        gx, gz, gc, g0, gp = sv.rotation_program()
+        assert (gx == rx).all() and (gz == rz).all() and np.array_equal(gc, rc) and not g0.any() and (gp == pidx).all()
+        sv.set_option("clifford_frame", 0)
+        sv.set_gate_program(gates, Kq, hfq)
+        with pytest.raises(BackendError, match="literal"):
+            sv.rotation_program()
+        sv.set_option("clifford_frame", 1)
+        sv.set_gate_program(gates, Kq, hfq)
+        fx, fz, fc, f0, fp = sv.rotation_program()
+        theta = rng.uniform(-0.3, 0.3, Kq)
+        e_gpu = sv.energy(theta)
+    o = OracleStatevector(n)
+    o.set_hamiltonian(ham)
+    o.set_gate_program(gates, Kq, hfq)
+    e_gates = o.energy(theta)
+    o.set_rotation_program(fx, fz, fc, fp, Kq, hfq, phi0=f0)
+    e_rots = o.energy(theta)
+    assert abs(e_rots - e_gates) < 1e-11 and abs(e_gpu - e_gates) < 1e-11
+
+
 def test_24_qubit_uccsd_sector_path_on_n2(gpu_lib):
     """N2 / cc-pVDZ (10e, 12o), UCCSD in the reference's operator order (1715 cluster operators, 6464-term JW Hamiltonian) through
     the sector path: (5 alpha, 5 beta) sector = 627 264 amplitudes, against the dense-state kernels on the same handle inputs,

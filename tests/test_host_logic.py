@@ -404,3 +404,18 @@ def test_remaining_qubit_pool_kinds_have_the_expected_shape():
         pools.qubit_pool("eight", n)
     with pytest.raises(KeyError):
         pools.qubit_pool("no such pool", n)
+
+
+def test_pack_terms_refuses_ragged_and_non_pauli_input():
+    """the vectorised packer flattens all qubits side by side — a term with more qubits than characters would shift
+    every later term's masks; characters outside Latin-1 must end in the same ValueError as any other non-Pauli character"""
+    from types import SimpleNamespace as T
+
+    from openvqe_amd.operators import pack_terms
+    with pytest.raises(ValueError, match="term 0: 2 Pauli characters on 1 qubits"):
+        pack_terms(4, [T(coeff=1.0, op="XY", qbits=[0]), T(coeff=1.0, op="Z", qbits=[1, 2])])
+    for text in ("X中", "Xé", "XQ"):
+        with pytest.raises(ValueError, match="unknown Pauli"):
+            pack_terms(4, [T(coeff=1.0, op=text, qbits=[0, 1])])
+    xs, zs, cs = pack_terms(4, [T(coeff=1.0, op="XY", qbits=[0, 3]), T(coeff=2.0, op="", qbits=[]), T(coeff=0.5, op="Z", qbits=[2])])
+    assert xs.tolist() == [0b1001, 0, 0] and zs.tolist() == [0b0001, 0, 0b0010]
