@@ -269,7 +269,14 @@ __global__ __launch_bounds__(NT) void k_sparse_vqe_wg(SparseArgs A, const double
     double2 *cs = reinterpret_cast<double2 *>(st + A.mpad);        // [ntab + 1]: the last entry is the identity
     __shared__ double2 red[NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef OVQE_TESTING
+    uint64_t stamp[6] = {};   // "sparse_dbg" = 9: phase times of the first evaluation of workgroup 0 (s_memrealtime ticks of 10 ns)
+#define OVQE_STAMP(k) do { if (A.dbg == 9) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define OVQE_STAMP(k) do { } while (0)
+#endif
     for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+        OVQE_STAMP(0);
         const double *th = theta + b * A.K;
         // Hamiltonian entries of this thread: in flight from here on
         SpEntry ent[EPT];
@@ -289,7 +296,9 @@ __global__ __launch_bounds__(NT) void k_sparse_vqe_wg(SparseArgs A, const double
             cs[e] = make_double2(c, sn);
         }
         if (tid == 0) cs[A.ntab] = make_double2(1.0, 0.0);
+        OVQE_STAMP(1);
         __syncthreads();
+        OVQE_STAMP(2);
         if (wave == 0) {
             auto apply = [&](uint64_t word) {
                 const uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
@@ -311,7 +320,9 @@ __global__ __launch_bounds__(NT) void k_sparse_vqe_wg(SparseArgs A, const double
                 }
             }
         }
+        OVQE_STAMP(3);
         __syncthreads();
+        OVQE_STAMP(4);
         double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < EPT; ++k)
@@ -322,7 +333,16 @@ __global__ __launch_bounds__(NT) void k_sparse_vqe_wg(SparseArgs A, const double
         }
         const double2 tot = block_sum<NT>(make_double2(acc, 0.0), red);
         if (tid == 0) energies[b] = tot.x + A.constant;
+#ifdef OVQE_TESTING
+        if (A.dbg == 9 && tid == 0 && blockIdx.x == 0 && b == 0) {
+            stamp[5] = __builtin_amdgcn_s_memrealtime();
+            printf("k_sparse_vqe_wg phases (10-ns ticks): prologue %llu, barrier %llu, circuit (wave 0) %llu, barrier %llu, <H> + reduce %llu; rows %d entries %d\n",
+                   (unsigned long long)(stamp[1] - stamp[0]), (unsigned long long)(stamp[2] - stamp[1]), (unsigned long long)(stamp[3] - stamp[2]),
+                   (unsigned long long)(stamp[4] - stamp[3]), (unsigned long long)(stamp[5] - stamp[4]), nrows8, A.nent);
+        }
+#endif
     }
+#undef OVQE_STAMP
 }
 
 // ---- exact gradient on the compact support (round 3) ---------------------------------------------------------------------

@@ -587,3 +587,21 @@ def test_sector_ground_state_on_a_hopping_chain_needs_more_than_64_rounds(SV):
     occ = np.flatnonzero(np.abs(vec) > 0)
     assert len(occ) <= comb(n, p) and all(bin(int(i)).count("1") == p for i in occ[:: max(1, len(occ) // 500)])
     assert abs(np.linalg.norm(vec) - 1.0) < 1e-10
+
+
+def test_differential_fuzz_of_the_sector_path(gpu_lib):
+    """tools/fuzz_sector.py, 40 cases: random UCC-type programs and QUCCSD template lists at 14-20 qubits under random tile geometry,
+    workgroup sizes, coding and sweep forms (pair words / bit arithmetic / blocks of two ops / runs without barriers): energies and all
+    gradient components of the sector path against the dense-state kernels of the same handle (1e-11 / 1e-10 |H|_1).  The superseded
+    kernel forms that no default selects are reached only through these option draws."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_sector.py"), "40", "2025"], capture_output=True, text=True,
+                       timeout=900, cwd=root)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-2000:]
+    assert r.returncode == 0 and "MISMATCH" not in r.stdout, tail
+    assert "bit-arithmetic sweeps" in tail
+    regular = int(tail.split("(")[1].split(" ")[0])
+    assert regular >= 5, tail      # the regular-support kernels were among the draws

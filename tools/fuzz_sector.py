@@ -1,4 +1,4 @@
-"""Differential fuzzing of the sector path (not part of the test suite: minutes of GPU time): random UCC-type programs at 14..20
+"""Differential fuzzing of the sector path (tests/test_gpu_sector.py runs 40 cases of it; more by hand): random UCC-type programs at 14..20
 qubits (subsets and random orders of UCCSD generators, single-string generators on few supports, multi-term generators that
 fuse to several patterns), JW two-body or random low-weight Hamiltonians, random tile geometry / workgroup sizes / coding:
 energies and gradients of the sector path against the dense-state kernels of the same handle.
@@ -82,7 +82,8 @@ for case in range(cases):
             "sector_tile_cap": int(rng.choice([6500, 6500, 700, 150])), "sector_min_qubits": 8,
             # regular supports (full cosets of the program's Z2 symmetries: the single-string kinds produce them): bit-arithmetic sweeps
             "sector_reg_pairs": int(rng.random() < 0.7), "sector_reg_threads": int(rng.choice([128, 256, 512])),
-            "sector_reg_adjoint": int(rng.random() < 0.8), "sector_regular": int(rng.choice([1, 1, 1, 3, 0]))}
+            "sector_reg_adjoint": int(rng.random() < 0.8), "sector_regular": int(rng.choice([1, 1, 1, 3, 0])),
+            "sector_reg_runs": int(rng.random() < 0.75)}
     scale = max(1.0, float(np.abs(ham.packed()[2]).sum()))
     with Statevector(n) as sv:
         sv.set_option("force_path", 2)
@@ -110,3 +111,5 @@ for case in range(cases):
     print(f"case {case}: n={n} o={o} {kind} K={K} opts={opts} support={info['sector_support']} sweeps={info['sector_sweeps']} "
           f"h_sweeps={info['sector_h_sweeps']} regular={info['sector_regular_slot_bits']}/{info['sector_free_bits']} dE={de:.1e} dG={dg:.1e}{flag}", flush=True)
 print(f"worst dE/|H|_1 = {worst_e:.2e}, worst dG/|H|_1 = {worst_g:.2e}; sector path used in {used} cases ({regular} of them on bit-arithmetic sweeps), declined in {declined}")
+if worst_e >= 1e-11 or worst_g >= 1e-10 or used == 0:
+    sys.exit(1)
