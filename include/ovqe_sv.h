@@ -128,7 +128,8 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  * (B) GEOMETRY — defaults are the measured optimum on MI355X
  *   streaming path: "tile_bits" (-1 automatic: 12 for n >= 25, else 11; 0 = one sweep per op), "tile_low" (4), "apply_min_tiles" (256),
  *                     "index_streams"
- *   fused / support-compacted kernels: "small_max_qubits", "small_batch_max_qubits"
+ *   fused / support-compacted kernels: "small_max_qubits", "small_batch_max_qubits", "sparse_grad" (1: all derivatives of a register of at most
+ *                     16 qubits in one fused launch on the compact support; 0: the streaming adjoint pass), "sparse_renumber" (1)
  *   sector path: "sector_bits" / "sector_h_bits" (index bits per circuit / <H> tile, 0 automatic), "sector_tile_cap" (6500 amplitudes per
  *                     circuit tile so that gradients fit; up to 14000 for energies only), "sector_threads" (0 automatic, 64, 256, 512,
  *                     1024), "sector_adjoint" (2 / 1), "sector_dict" (1: dictionary-coded matrix elements, dictionary from a sample of the
@@ -146,7 +147,7 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  *   program was left to the dense kernels; 4: wall time of the build's phases), "sector_sweep_dbg" / "sector_h_dbg" / "sparse_dbg" (kernels
  *   truncated after a given phase), "rot_variant", and the launch geometries and superseded forms kept for comparison: "unroll",
  *   "ham_tile_low", "expect_sparse", "expect_streams", "persist_blocks", "compact_cpp", "small_threads", "sparse_rows", "sparse_wg",
- *   "sparse_grad", "sparse_renumber", "sparse_spw", "sparse_dealias", "sector_sweep", "sector_chunk", "sector_depth2", "sector_many_tiles",
+ *   "sparse_spw", "sparse_dealias", "sector_sweep", "sector_chunk", "sector_depth2", "sector_many_tiles",
  *   "sector_h_lpt", "sector_h_threads", "sector_h_groups", "sector_apply_threads", "sector_row_banks", "sector_eager_rots",
  *   "screen_tables", "sector_batch_threads" / "_nb" / "_sweep_threads" / "_dst_lds" / "_zfast" */
 int ovqe_set_option(ovqe_handle h, const char *name, int64_t value);

@@ -3141,6 +3141,11 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
         h->opt_sparse = (int)value;
         h->sp_tried = false;
     }
+    else if (k == "sparse_grad") h->opt_sparse_grad = value ? 1 : 0;
+    else if (k == "sparse_renumber") {
+        h->opt_sparse_renumber = value ? 1 : 0;
+        h->sp_tried = false;
+    }
 #ifdef OVQE_TESTING
     else if (k == "sparse_spw") h->opt_sparse_spw = (int)value;
     else if (k == "sparse_dbg") h->opt_sparse_dbg = (int)value;
@@ -3258,14 +3263,9 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
         h->opt_sparse_dealias = value ? 1 : 0;
         h->sp_tried = false;
     }
-    else if (k == "sparse_grad") h->opt_sparse_grad = value ? 1 : 0;
     else if (k == "sparse_wg") h->opt_sparse_wg = value ? 1 : 0;
     else if (k == "sparse_rows") {
         h->opt_sparse_rows = value ? 1 : 0;
-        h->sp_tried = false;
-    }
-    else if (k == "sparse_renumber") {
-        h->opt_sparse_renumber = value ? 1 : 0;
         h->sp_tried = false;
     }
     else if (k == "expect_sparse") h->opt_expect_sparse = (int)std::max<int64_t>(0, value);

@@ -2048,32 +2048,53 @@ __global__ __launch_bounds__(NT) void k_sector_sweep_reg(const double *__restric
 // is twice that), then both states are rotated back.  A lane's eight per-entry sums are reduced over the wave by a reduce-scatter
 // (three exchange-and-halve steps, then three butterfly steps: ten additions instead of forty-eight), the four waves' totals meet in
 // LDS and lanes 0..7 of wave 0 store the tile's partial sums of the op: wpart[tile][op][8].
-__device__ __forceinline__ double sec_reduce8(const double (&c)[8]) {   // -> the wave's total of entry 4 b0 + 2 b1 + b2 (b = lane bits)
+// lane l <- lane l ^ 1, ^ 2, ^ 4 by DPP (quad permutations; a row shift by four lanes each way under complementary bank masks): no
+// LDS crossbar — the __shfl_xor these replace were 20 ds_bpermute per reduction on the pipe the kernel is bound by (round 5)
+template <int CTRL>
+__device__ __forceinline__ double sec_dpp_quad(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sec_dpp_xor4(double v) {
+    // row_shr:4 (lane i <- i - 4) into the lanes with bit 2 set (banks 1 and 3), then row_shl:4 (lane i <- i + 4) into the others
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x114, 0xf, 0xa, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x114, 0xf, 0xa, false);
+    lo = __builtin_amdgcn_update_dpp(lo, __double2loint(v), 0x104, 0xf, 0x5, false);
+    hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(v), 0x104, 0xf, 0x5, false);
+    return __hiloint2double(hi, lo);
+}
+// -> in the lanes with bit 3 clear: the total over the lane's ROW of 16 of entry 4 b0 + 2 b1 + b2 (b = lane bits): a reduce-scatter
+// (three exchange-and-halve steps: ten additions instead of forty-eight) and one row shift by eight lanes
+__device__ __forceinline__ double sec_reduce8(const double (&c)[8]) {
     const int lane = threadIdx.x & 63;
     double t4[4], t2[2], t1;
     {
         const bool hi = lane & 1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t4[j] = (hi ? c[4 + j] : c[j]) + __shfl_xor(hi ? c[j] : c[4 + j], 1, 64);
+        for (int j = 0; j < 4; ++j) t4[j] = (hi ? c[4 + j] : c[j]) + sec_dpp_quad<0xB1>(hi ? c[j] : c[4 + j]);   // quad_perm [1,0,3,2]
     }
     {
         const bool hi = lane & 2;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) t2[j] = (hi ? t4[2 + j] : t4[j]) + __shfl_xor(hi ? t4[j] : t4[2 + j], 2, 64);
+        for (int j = 0; j < 2; ++j) t2[j] = (hi ? t4[2 + j] : t4[j]) + sec_dpp_quad<0x4E>(hi ? t4[j] : t4[2 + j]);   // quad_perm [2,3,0,1]
     }
     {
         const bool hi = lane & 4;
-        t1 = (hi ? t2[1] : t2[0]) + __shfl_xor(hi ? t2[0] : t2[1], 4, 64);
+        t1 = (hi ? t2[1] : t2[0]) + sec_dpp_xor4(hi ? t2[0] : t2[1]);
     }
-    t1 += __shfl_xor(t1, 8, 64);
-    t1 += __shfl_xor(t1, 16, 64);
-    t1 += __shfl_xor(t1, 32, 64);
+    {   // row_shl:8: lane i <- i + 8 (the upper half of a row reads nothing: zero)
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(t1), 0x108, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(t1), 0x108, 0xf, 0xf, false);
+        t1 += __hiloint2double(hi, lo);
+    }
     return t1;
 }
-__device__ __forceinline__ void sec_reg_wstore(double *__restrict__ wslot, const double (&acc)[8]) {   // this wave's row of 8 totals
+constexpr int SEC_REG_WROWS = 4;   // rows of 16 lanes per wave: each stores its own eight totals (summed over rows and waves at the flush)
+__device__ __forceinline__ void sec_reg_wstore(double *__restrict__ wslot, const double (&acc)[8]) {   // this wave's 4 x 8 totals
     const double tot = sec_reduce8(acc);
     const int lane = threadIdx.x & 63;
-    if (lane < 8) wslot[((lane & 1) << 2) | (lane & 2) | ((lane & 4) >> 2)] = tot;
+    if (!(lane & 8)) wslot[(lane >> 4) * 8 + (((lane & 1) << 2) | (lane & 2) | ((lane & 4) >> 2))] = tot;
 }
 
 template <int NT, int W, int NSEL>
@@ -2213,7 +2234,7 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint_reg(const double *__restr
     const uint32_t nslots = 1u << mbits, t = blockIdx.x;
     double *psi = reinterpret_cast<double *>(sec_smem), *lam = psi + nslots;
     double2 *cs = reinterpret_cast<double2 *>(lam + nslots);                       // [nops][8]
-    double *wrow = reinterpret_cast<double *>(cs + (size_t)nops * SEC_REG_TSTRIDE);   // [2 banks][runcap units][2 ops of a block][NW][8]
+    double *wrow = reinterpret_cast<double *>(cs + (size_t)nops * SEC_REG_TSTRIDE);   // [2 banks][runcap units][2 ops of a block][NW][4 rows of lanes][8]
     const size_t e0 = (size_t)t * nslots;
     for (uint32_t j = threadIdx.x; j < nslots; j += NT) {
         const uint32_t k = sec_reg_swz(oslot ? (uint32_t)oslot[j] : j);
@@ -2236,8 +2257,8 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint_reg(const double *__restr
         const uint32_t *gwo = gw + (size_t)ob * SEC_REG_GSTRIDE;
         const uint32_t wd0 = gwo[threadIdx.x], wd1 = gwo[threadIdx.x + NT];
         const double2 *T = cs + (size_t)ob * SEC_REG_TSTRIDE;
-        double *rowA = wrow + (size_t)((((bank * runcap + slot) * 2 + 0) * NW + wave) * 8);
-        double *rowB = wrow + (size_t)((((bank * runcap + slot) * 2 + 1) * NW + wave) * 8);
+        double *rowA = wrow + (size_t)((((bank * runcap + slot) * 2 + 0) * NW + wave) * (8 * SEC_REG_WROWS));
+        double *rowB = wrow + (size_t)((((bank * runcap + slot) * 2 + 1) * NW + wave) * (8 * SEC_REG_WROWS));
         switch (cur.w_nsel & ~((3u << 25) | (1u << 27))) {
         case 3 | (1 << 24): sec_reg_unapply_pair<NT, 0>(psi, lam, T, T + SEC_REG_TSTRIDE, cur, nslots, t, gwo, wd0, wd1, rowA, rowB); break;
         case 3 | (1 << 16) | (1 << 24): sec_reg_unapply_pair<NT, 1>(psi, lam, T, T + SEC_REG_TSTRIDE, cur, nslots, t, gwo, wd0, wd1, rowA, rowB); break;
@@ -2277,7 +2298,8 @@ __global__ __launch_bounds__(NT) void k_sector_adjoint_reg(const double *__restr
                 const int sl = slot - mine;
                 double sum = 0.0;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) sum += wrow[(size_t)((((bank * runcap + sl) * 2 + (int)which) * NW + w) * 8) + e];
+                for (int w = 0; w < NW * SEC_REG_WROWS; ++w)   // (waves x rows of lanes, in a fixed order)
+                    sum += wrow[(size_t)(((bank * runcap + sl) * 2 + (int)which) * NW * SEC_REG_WROWS + w) * 8 + e];
                 wp[(size_t)(my_op + (int)which) * 8 + e] = sum;
             }
             bank ^= 1;   // (the next run's rows go to the other bank: no second barrier)
