@@ -346,6 +346,7 @@ struct ovqe_sv {
     int opt_screen_sector = 1;        // ADAPT screens: sigma = H psi from the materialised Hamiltonian of psi's symmetry sector (real states)
     int opt_screen_sector_min = 1024; // ... once psi lists at least this many amplitudes
     bool prog_from_gates = false;     // the stored program came from ovqe_set_gate_program (frame form): sector tables at the first evaluation
+    int opt_tile_flat = 1;            // tiled <H>: entries of one or two merged terms as per-LANE items (1), per-wave entries (0), items for real states only (2)
     int opt_sector_eager_rots = 2048; // programs of at most this many rotations build their sector tables at the FIRST evaluation (else the second)
     int opt_sector_regular = 1;       // supports that are a full coset of the program's Z2 symmetries: sweeps from bit arithmetic, no pair words (k_sector_sweep_reg); 2: such engines build no pair tables at all (energies only)
     int opt_sector_reg_threads = 256; // workgroup size of those sweeps
@@ -912,7 +913,7 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
                 }
                 if (mt.empty()) continue;
                 const int nk_total = 1 << (M - w);
-                if (mt.size() <= 2 && nk_total >= 2) {  // one lane per TILE_ITEM_PAIRS pairs (sv_tile.hpp)
+                if (mt.size() <= 2 && nk_total >= 2 && (h->opt_tile_flat == 1 || (h->opt_tile_flat == 2 && real))) {  // one lane per TILE_ITEM_PAIRS pairs (sv_tile.hpp)
                     ExFlatT fe = {};
                     fe.x = xl;
                     fe.ibits = ibits;
@@ -3245,6 +3246,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     else if (k == "screen_sparse") h->opt_screen_sparse = (int)std::max<int64_t>(0, value);
 #ifdef OVQE_TESTING
     else if (k == "rot_variant") h->opt_rot_variant = (int)value;
+    else if (k == "tile_flat") h->opt_tile_flat = (int)value;
     else if (k == "fault_inject") h->fault_inject = (int)value;
 #endif
     else if (k == "real_stream") h->opt_real_stream = (int)value;

@@ -475,7 +475,10 @@ def test_batched_evaluations_on_the_sector_tables_match_c_oracle(SV, m, o):
     thetas[5] = 0.0
     rx, rz, rc, pidx, _ = compile_ucc_program(n, gens)
     hx, hz, hc = ham.packed()
-    want = cref.ucc_energy_batch(n, hf, rx, rz, rc, pidx, thetas, hx, hz, hc.real.copy(), ham.constant_coeff)
+    # the oracle sees every vector at 16 and 18 qubits; at 20 qubits (141 evaluations = three minutes of the suite's budget) the first 24,
+    # the rest of the big batch is held against one evaluation at a time on the same handle (the serial path has its own oracle tests)
+    n_oracle = 141 if m < 10 else 24
+    want = cref.ucc_energy_batch(n, hf, rx, rz, rc, pidx, thetas[:n_oracle], hx, hz, hc.real.copy(), ham.constant_coeff)
     l1 = float(np.abs(hc).sum())
     with SV(n) as sv:
         sv.set_option("force_path", 2)
@@ -486,6 +489,7 @@ def test_batched_evaluations_on_the_sector_tables_match_c_oracle(SV, m, o):
         info = sv.program_info()
         got = {B: sv.energy_batch(thetas[:B]) for B in (1, 3, 8, 141)}
         serial = np.array([sv.energy(t) for t in thetas[:9]])
+        serial_rest = np.array([sv.energy(t) for t in thetas[n_oracle:]])
         # parameters and energies resident on the device (ovqe_energy_batch_device beyond the fused kernels' 16 qubits): the same
         # batched passes with nothing crossing PCIe; an odd batch (ragged last pair of states) and, with batches switched off, the
         # route through the host
@@ -508,7 +512,8 @@ def test_batched_evaluations_on_the_sector_tables_match_c_oracle(SV, m, o):
     assert info["sector_support"] == comb(m, o) ** 2
     assert np.abs(first - want[:8]).max() < 1e-10 * max(1.0, l1)
     for B, e in got.items():
-        assert e.shape == (B,) and np.abs(e - want[:B]).max() < 1e-10 * max(1.0, l1), B
+        assert e.shape == (B,) and np.abs(e[:n_oracle] - want[:B]).max() < 1e-10 * max(1.0, l1), B
+    assert np.abs(got[141][n_oracle:] - serial_rest).max(initial=0.0) < 1e-12 * max(1.0, l1)
     assert np.abs(got[141][:9] - serial).max() < 1e-12 * max(1.0, l1)
     assert np.abs(unbatched - serial).max() < 1e-13 * max(1.0, l1)
 
