@@ -346,7 +346,11 @@ struct ovqe_sv {
     int opt_screen_sector = 1;        // ADAPT screens: sigma = H psi from the materialised Hamiltonian of psi's symmetry sector (real states)
     int opt_screen_sector_min = 1024; // ... once psi lists at least this many amplitudes
     bool prog_from_gates = false;     // the stored program came from ovqe_set_gate_program (frame form): sector tables at the first evaluation
-    int opt_tile_flat = 1;            // tiled <H>: entries of one or two merged terms as per-LANE items (1), per-wave entries (0), items for real states only (2)
+    int opt_expect_dense = 1;         // tiled <H> of dense complex registers (25+ qubits): census of the first sweep, then two workgroups per CU
+    DevBuf d_tile_cnt;
+    int opt_tile_flat = 2;            // tiled <H>: entries of one or two merged terms as per-LANE items (1), per-wave entries (0), items for real
+                                      // states only (2, default: on dense complex tiles the items' LDS reads conflict 16 ways — 78 % of the LDS cycles,
+                                      // profiles/r5_tilexp — and the per-wave entries are 10 % faster once two workgroups share a CU)
     int opt_sector_eager_rots = 2048; // programs of at most this many rotations build their sector tables at the FIRST evaluation (else the second)
     int opt_sector_regular = 1;       // supports that are a full coset of the program's Z2 symmetries: sweeps from bit arithmetic, no pair words (k_sector_sweep_reg); 2: such engines build no pair tables at all (energies only)
     int opt_sector_reg_threads = 256; // workgroup size of those sweeps
@@ -1011,23 +1015,31 @@ inline int expect_ysplit(ovqe_handle h, int M) {  // workgroups per tile: fill t
     return y;
 }
 
+// dense_only: the caller knows that no tile of this state is sparse (census of the evaluation's first sweep, run_expectation_tiled):
+// the staging area of the sparse-tile path and the tile's non-zero list (38 KB beside a 64-KB tile: ONE workgroup per CU) are left
+// out of the launch, and two workgroups share a CU — one loads its tile while the other computes
 template <int M, bool REAL>
 int launch_tile_expect(ovqe_handle h, const HamDev &H, const ExSweep &sw, double2 *partials, int accumulate,
-                       hipStream_t stream) {
+                       hipStream_t stream, bool dense_only = false, int *census = nullptr) {
     constexpr int NT = 1 << TILE_EXPECT_LOG_NT;
     static_assert(TILE_SPARSE_TERMS >= 2 * TILE_TERM_CAP && TILE_SPARSE_GROUPS >= 2 * TILE_APPLY_GROUPS, "two host chunks per pass");
-    const size_t smem = ((size_t)(REAL ? 8 : 16) << M) + TILE_SPARSE_TERMS * sizeof(ExTermLds) +
-                        TILE_SPARSE_GROUPS * sizeof(ExAGroupT) + (NT / 64) * sizeof(double2) + (NT / 64 + 2) * sizeof(int) +
-                        ((size_t)2 << M);
+    const size_t smem_full = ((size_t)(REAL ? 8 : 16) << M) + TILE_SPARSE_TERMS * sizeof(ExTermLds) +
+                             TILE_SPARSE_GROUPS * sizeof(ExAGroupT) + (NT / 64) * sizeof(double2) + (NT / 64 + 2) * sizeof(int) +
+                             ((size_t)2 << M);
+    // (dense path: the term table of a chunk, TILE_TERM_CAP entries, lives at the start of the staging bytes; the reduction slots
+    // sit behind the whole staging area in the kernel's layout, so the dense launch keeps the area's address range up to them)
+    const size_t smem_dense = ((size_t)(REAL ? 8 : 16) << M) + TILE_TERM_CAP * sizeof(ExTermLds) + (NT / 64) * sizeof(double2) +
+                              (NT / 64 + 2) * sizeof(int);
+    const size_t smem = dense_only ? smem_dense : smem_full;
     const dim3 grid((unsigned)(h->namps >> M), (unsigned)expect_ysplit(h, M));
-    const int sparse_den = H.d_agroups.p && sw.a1 > sw.a0 ? h->opt_expect_sparse : 0;
+    const int sparse_den = dense_only ? -1 : ((H.d_agroups.p && sw.a1 > sw.a0) ? h->opt_expect_sparse : 0);
     static bool attr_done_dev[64] = {};  // function attributes are per device
     bool &attr_done = attr_done_dev[h->device & 63];
     if (!attr_done) {
         HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_expect<M, NT, true, REAL>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_full));
         HIPC(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_expect<M, NT, false, REAL>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_full));
         attr_done = true;
     }
     if (h->n_local >= 25) {
@@ -1035,13 +1047,13 @@ int launch_tile_expect(ovqe_handle h, const HamDev &H, const ExSweep &sw, double
                            (const ExChunkT *)H.d_tchunks.p, (const ExEntryT *)H.d_tgroups.p,
                            (const ExTermT *)H.d_tterms.p, (const ExFlatT *)H.d_tflats.p, (const ExItemT *)H.d_titems.p, partials,
                            accumulate, (const ExChunkT *)H.d_achunks.p, (const ExAGroupT *)H.d_agroups.p,
-                           (const ExTermT *)H.d_aterms.p, sparse_den);
+                           (const ExTermT *)H.d_aterms.p, sparse_den, census);
     } else {
         hipLaunchKernelGGL((k_tile_expect<M, NT, false, REAL>), grid, dim3(NT), smem, stream, (const void *)h->state, h->base, sw,
                            (const ExChunkT *)H.d_tchunks.p, (const ExEntryT *)H.d_tgroups.p,
                            (const ExTermT *)H.d_tterms.p, (const ExFlatT *)H.d_tflats.p, (const ExItemT *)H.d_titems.p, partials,
                            accumulate, (const ExChunkT *)H.d_achunks.p, (const ExAGroupT *)H.d_agroups.p,
-                           (const ExTermT *)H.d_aterms.p, sparse_den);
+                           (const ExTermT *)H.d_aterms.p, sparse_den, census);
     }
     HIPC(h, hipGetLastError());
     return OVQE_OK;
@@ -1074,6 +1086,28 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bo
         HIPC(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     }
     std::vector<char> on_second(ns, 0);
+    int acc[2] = {0, 0};
+    // Dense complex registers of 25+ qubits (a shard of the partitioned register, a random state): the LDS that the sparse-tile path
+    // needs beside a 64-KB tile leaves ONE workgroup per CU, which then loads, waits and computes in turn (31 qubits: 62 sweeps at
+    // 1.1 TB/s).  The first sweep of an evaluation counts the tiles that took the sparse path; when none did, the state is dense
+    // under every tile bit set and the remaining sweeps run without that area: two workgroups per CU, of either stream.  (One stream
+    // synchronisation per evaluation: only where there are at least four sweeps of at least half a gigabyte.)
+    const bool try_dense = !real && M == 12 && h->n_local >= 25 && ns >= 4 && h->opt_expect_sparse > 0 && h->opt_expect_dense;
+    bool dense_only = false;
+    int k_start = 0;
+    if (try_dense) {
+        rc = ensure(h, h->d_tile_cnt, sizeof(int));
+        if (rc) return rc;
+        HIPC(h, hipMemsetAsync(h->d_tile_cnt.p, 0, sizeof(int), h->stream));
+        rc = launch_tile_expect<12, false>(h, H, H.tsweeps[0], partials, 0, h->stream, false, (int *)h->d_tile_cnt.p);
+        if (rc) return rc;
+        int census = 1;
+        HIPC(h, hipMemcpyAsync(&census, h->d_tile_cnt.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPC(h, hipStreamSynchronize(h->stream));
+        dense_only = census == 0;
+        acc[0] = 1;
+        k_start = 1;
+    }
     if (dual) {
         const double mem = 16.0 * (double)h->namps * (real ? 0.5 : 1.0) / 2.8e6;        // us at ~2.8 TB/s
         const double per_term = 0.23 * (double)h->namps / (double)(1ull << 24);       // us, measured at 24 qubits
@@ -1089,8 +1123,7 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bo
         HIPC(h, hipEventRecord(h->ev_fork, h->stream));
         HIPC(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
     }
-    int acc[2] = {0, 0};
-    for (int k = 0; k < ns; ++k) {
+    for (int k = k_start; k < ns; ++k) {
         const ExSweep &sw = H.tsweeps[k];
         const int which = on_second[k];
         hipStream_t strm = which ? h->stream2 : h->stream;
@@ -1105,7 +1138,7 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bo
             switch (M) {
             case 10: rc = launch_tile_expect<10, false>(h, H, sw, part, acc[which], strm); break;
             case 11: rc = launch_tile_expect<11, false>(h, H, sw, part, acc[which], strm); break;
-            default: rc = launch_tile_expect<12, false>(h, H, sw, part, acc[which], strm); break;
+            default: rc = launch_tile_expect<12, false>(h, H, sw, part, acc[which], strm, dense_only); break;
             }
         }
         if (rc) return rc;
@@ -3085,7 +3118,7 @@ int ovqe_destroy(ovqe_handle h) try {
     if (h->own_state && h->state) (void)hipFree(h->state);
     for (int k = 0; k < 2; ++k)
         if (h->scratch[k]) (void)hipFree(h->scratch[k]);
-    std::vector<DevBuf *> bufs = {&h->d_partials, &h->d_result, &h->d_rp, &h->d_ops, &h->d_rots, &h->d_rots_seq, &h->d_segs,
+    std::vector<DevBuf *> bufs = {&h->d_tile_cnt, &h->d_partials, &h->d_result, &h->d_rp, &h->d_ops, &h->d_rots, &h->d_rots_seq, &h->d_segs,
                                   &h->d_stream,
                                   &h->d_theta, &h->d_energies, &h->d_workspace, &h->d_egroups, &h->d_eterms, &h->d_echunks,
                                   &h->d_eflat, &h->d_sp_ops, &h->d_sp_rows, &h->d_sp_rows64, &h->d_sp_prim, &h->d_sp_pairs, &h->d_sp_entries, &h->d_pg_off, &h->d_pg_xs, &h->d_pg_terms, &h->d_pg_runs, &h->d_pg_tabs,
@@ -3247,6 +3280,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
 #ifdef OVQE_TESTING
     else if (k == "rot_variant") h->opt_rot_variant = (int)value;
     else if (k == "tile_flat") h->opt_tile_flat = (int)value;
+    else if (k == "expect_dense") h->opt_expect_dense = (int)value;
     else if (k == "fault_inject") h->fault_inject = (int)value;
 #endif
     else if (k == "real_stream") h->opt_real_stream = (int)value;

@@ -292,7 +292,8 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
                                                     const ExItemT *__restrict__ items, double2 *__restrict__ partials,
                                                     int accumulate, const ExChunkT *__restrict__ achunks,
                                                     const ExAGroupT *__restrict__ agroups,
-                                                    const ExTermT *__restrict__ aterms, int sparse_den) {
+                                                    const ExTermT *__restrict__ aterms, int sparse_den,
+                                                    int *__restrict__ sparse_tiles = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Amp<REAL>::T amp;
     constexpr uint32_t NEL = 1u << M;
@@ -302,10 +303,13 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
     const amp *tile = reinterpret_cast<const amp *>(smem);
     double2 *tilev = reinterpret_cast<double2 *>(smem);
     // [tile][dense path: term table | sparse path: staged terms + pieces (same bytes)][reduction][scan][non-zero list]
+    // sparse_den < 0: DENSE layout — the launch left the sparse path's staging area and non-zero list out (launch_tile_expect):
+    // [tile][term table of one chunk][reduction]
+    const bool dense_layout = sparse_den < 0;
     ExTermLds *lt = reinterpret_cast<ExTermLds *>(smem + (size_t)NELV * sizeof(double2));
     ExTermLds *spt = lt;                                             // sparse path: staged terms ...
-    ExAGroupT *spg = reinterpret_cast<ExAGroupT *>(spt + TILE_SPARSE_TERMS);  // ... and pieces of a pass
-    double2 *red = reinterpret_cast<double2 *>(spg + TILE_SPARSE_GROUPS);
+    ExAGroupT *spg = reinterpret_cast<ExAGroupT *>(spt + (dense_layout ? TILE_TERM_CAP : TILE_SPARSE_TERMS));  // ... and pieces of a pass
+    double2 *red = reinterpret_cast<double2 *>(spg + (dense_layout ? 0 : TILE_SPARSE_GROUPS));
     int *scan = reinterpret_cast<int *>(red + NT / 64);             // NT / 64 wave totals + the tile's count
     uint16_t *nz = reinterpret_cast<uint16_t *>(scan + NT / 64 + 2);  // tile-local indices of the non-zero amplitudes
     static_assert(TILE_SPARSE_TERMS >= TILE_TERM_CAP, "the dense term table lives in the sparse staging bytes");
@@ -365,6 +369,7 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
             total += c;
         }
         if ((int64_t)total * sparse_den <= (int64_t)NEL) {
+            if (sparse_tiles && threadIdx.x == 0 && blockIdx.y == 0) atomicAdd(sparse_tiles, 1);   // (the host's census of the first sweep)
             int pos = before + incl - cnt;
 #pragma unroll
             for (int k = 0; k < K; ++k)
@@ -425,21 +430,32 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
         const double c0r = s0 ? -fe.c0r : fe.c0r, c1r = s1 ? -fe.c1r : fe.c1r;
         const double c0i = s0 ? -fe.c0i : fe.c0i, c1i = s1 ? -fe.c1i : fe.c1i;
         const uint32_t x = fe.x, keep = ~fe.x;
+        // (round 5: 69 -> ~50 vector instructions per pair — the kernel is bound by their issue, SQ counters in profiles/r5_tilexp.
+        // The swizzle is linear over XOR, so the partner's LDS address is one XOR away from the own one; a term's sign is one XOR on
+        // the high word of its coefficient, the parity shifted into the sign bit, instead of a compare and two selects.)
+        const uint32_t sx = tile_swz<REAL>(x);
+        const uint32_t c0rh = (uint32_t)__double2hiint(c0r), c0rl = (uint32_t)__double2loint(c0r);
+        const uint32_t c1rh = (uint32_t)__double2hiint(c1r), c1rl = (uint32_t)__double2loint(c1r);
+        const uint32_t c0ih = (uint32_t)__double2hiint(c0i), c0il = (uint32_t)__double2loint(c0i);
+        const uint32_t c1ih = (uint32_t)__double2hiint(c1i), c1il = (uint32_t)__double2loint(c1i);
         uint32_t i = it.istart;
         double part = 0.0;
         for (uint32_t c = 0; c < it.count; c += 2) {
             const uint32_t i0 = i, j0 = i0 ^ x;
             const uint32_t i1 = ((((i0 | x) + 1u) & keep) | fe.ibits) & (NEL - 1u), j1 = i1 ^ x;
             i = ((((i1 | x) + 1u) & keep) | fe.ibits) & (NEL - 1u);
-            const amp a0 = tile[tile_swz<REAL>(i0)], b0 = tile[tile_swz<REAL>(j0)];
-            const amp a1 = tile[tile_swz<REAL>(i1)], b1 = tile[tile_swz<REAL>(j1)];
-            const bool n00 = __popc(j0 & fe.zin0) & 1, n01 = __popc(j0 & fe.zin1) & 1;
-            const bool n10 = __popc(j1 & fe.zin0) & 1, n11 = __popc(j1 & fe.zin1) & 1;
-            const double d0 = (n00 ? -c0r : c0r) + (n01 ? -c1r : c1r), d1 = (n10 ? -c0r : c0r) + (n11 ? -c1r : c1r);
+            const uint32_t p0 = tile_swz<REAL>(i0), p1 = tile_swz<REAL>(i1);
+            const amp a0 = tile[p0], b0 = tile[p0 ^ sx];
+            const amp a1 = tile[p1], b1 = tile[p1 ^ sx];
+            const uint32_t n00 = (uint32_t)__popc(j0 & fe.zin0) << 31, n01 = (uint32_t)__popc(j0 & fe.zin1) << 31;
+            const uint32_t n10 = (uint32_t)__popc(j1 & fe.zin0) << 31, n11 = (uint32_t)__popc(j1 & fe.zin1) << 31;
+            const double d0 = __hiloint2double((int)(c0rh ^ n00), (int)c0rl) + __hiloint2double((int)(c1rh ^ n01), (int)c1rl);
+            const double d1 = __hiloint2double((int)(c0rh ^ n10), (int)c0rl) + __hiloint2double((int)(c1rh ^ n11), (int)c1rl);
             if constexpr (REAL) {
                 part += d0 * (a0 * b0) + d1 * (a1 * b1);
             } else {
-                const double e0 = (n00 ? -c0i : c0i) + (n01 ? -c1i : c1i), e1 = (n10 ? -c0i : c0i) + (n11 ? -c1i : c1i);
+                const double e0 = __hiloint2double((int)(c0ih ^ n00), (int)c0il) + __hiloint2double((int)(c1ih ^ n01), (int)c1il);
+                const double e1 = __hiloint2double((int)(c0ih ^ n10), (int)c0il) + __hiloint2double((int)(c1ih ^ n11), (int)c1il);
                 part += d0 * (a0.x * b0.x + a0.y * b0.y) - e0 * (a0.x * b0.y - a0.y * b0.x);
                 part += d1 * (a1.x * b1.x + a1.y * b1.y) - e1 * (a1.x * b1.y - a1.y * b1.x);
             }
@@ -478,31 +494,39 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
                 const uint32_t dlane = deposit_index((uint32_t)en.k0 + lane, en.x) | en.ibits;
                 const uint32_t d64 = deposit_index(64u, en.x);  // k -> k + 64 never carries into lane bits
                 uint32_t i = dlane;
+                // (round 5: the swizzle is linear over XOR — the partner's address is one XOR from the own one; a term's sign is one XOR
+                // on the high word of its coefficient instead of a compare and two selects)
+                const uint32_t sx = tile_swz<REAL>(en.x);
+                const uint32_t c0rh = (uint32_t)__double2hiint(l0.cr), c0rl = (uint32_t)__double2loint(l0.cr);
+                const uint32_t c1rh = (uint32_t)__double2hiint(l1.cr), c1rl = (uint32_t)__double2loint(l1.cr);
+                const uint32_t c0ih = (uint32_t)__double2hiint(l0.ci), c0il = (uint32_t)__double2loint(l0.ci);
+                const uint32_t c1ih = (uint32_t)__double2hiint(l1.ci), c1il = (uint32_t)__double2loint(l1.ci);
                 // four trips at a time: the eight LDS reads are issued before the first result is needed
                 for (uint32_t k = lane; k < (uint32_t)en.nk; k += 256u) {
                     uint32_t ii[4];
                     amp a[4], c[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        ii[q] = i;
+                        ii[q] = i & (NEL - 1u);
                         i = (((i | en.x) + d64) & ~en.x) | en.ibits;  // next free index, x positions skipped
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        a[q] = tile[tile_swz<REAL>(ii[q] & (NEL - 1u))];
-                        c[q] = tile[tile_swz<REAL>((ii[q] ^ en.x) & (NEL - 1u))];
+                        const uint32_t pa = tile_swz<REAL>(ii[q]);
+                        a[q] = tile[pa];
+                        c[q] = tile[pa ^ sx];
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const uint32_t j = ii[q] ^ en.x;
-                        const bool n0 = __popc(j & l0.zin) & 1, n1 = __popc(j & l1.zin) & 1;
-                        const double dr = (n0 ? -l0.cr : l0.cr) + (n1 ? -l1.cr : l1.cr);
+                        const uint32_t n0 = (uint32_t)__popc(j & l0.zin) << 31, n1 = (uint32_t)__popc(j & l1.zin) << 31;
+                        const double dr = __hiloint2double((int)(c0rh ^ n0), (int)c0rl) + __hiloint2double((int)(c1rh ^ n1), (int)c1rl);
                         double v;
                         if constexpr (REAL) {
                             v = dr * (a[q] * c[q]);
                         } else {
                             const double wx = a[q].x * c[q].x + a[q].y * c[q].y, wy = a[q].x * c[q].y - a[q].y * c[q].x;
-                            const double di = (n0 ? -l0.ci : l0.ci) + (n1 ? -l1.ci : l1.ci);
+                            const double di = __hiloint2double((int)(c0ih ^ n0), (int)c0il) + __hiloint2double((int)(c1ih ^ n1), (int)c1il);
                             v = dr * wx - di * wy;
                         }
                         part += (k + 64u * q < (uint32_t)en.nk) ? v : 0.0;
