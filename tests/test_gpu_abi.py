@@ -84,3 +84,38 @@ def test_polled_results_equal_synchronised_ones(gpu_lib):
                 batch = sv.energy_batch(thetas[:64])
             assert np.abs(batch - got[poll][:64]).max() < 1e-11
         assert np.array_equal(got[0], got[1])
+
+
+def test_tiled_expectation_of_a_dense_complex_register_census_and_forms(testing_lib):
+    """<psi|H|psi> of a DENSE complex 26-qubit state (a shard of the partitioned register, a random state) through the tile cover:
+    the first sweep's census finds no sparse tile, the remaining sweeps run in the dense LDS layout (two workgroups per CU) — against
+    the same cover with the census off, with per-lane items instead of per-wave entries, and against the kernels that take one pass
+    per x-group (tile_bits = 0); testing build: the switches are measurement options"""
+    from openvqe_amd.backend import Statevector
+    from openvqe_amd.operators import Hamiltonian, Term
+    n = 26
+    rng = np.random.default_rng(26)
+    terms = []
+    for _ in range(60):
+        qs = sorted(rng.choice(n, int(rng.choice([1, 2, 4])), replace=False).tolist())
+        ops = "".join(rng.choice(list("XYZ"), len(qs)))
+        if ops.count("Y") & 1:          # keep H real-symmetric: even number of Y
+            ops = ops.replace("Y", "X", 1)
+        terms.append(Term(float(rng.normal()), ops, qs))
+    H = Hamiltonian(n, terms, 0.5, do_clean_up=False)
+    l1 = sum(abs(t.coeff) for t in terms)
+    got, passes = {}, {}
+    for label, opts in (("census_entries", {}), ("no_census", {"expect_dense": 0}), ("items", {"tile_flat": 1}),
+                        ("items_no_census", {"tile_flat": 1, "expect_dense": 0}), ("one_pass_per_group", {"tile_bits": 0})):
+        with Statevector(n) as sv:
+            for k, v in opts.items():
+                sv.set_option(k, v)
+            sv.randomize(2626, 1.0)
+            got[label] = sv.expectation(H)
+            passes[label] = sv.last_passes()[0]
+    for label in got:
+        if label != "one_pass_per_group":     # a cover of at least four sweeps (the census applies), fewer than one per x-group
+            assert 4 <= passes[label] < passes["one_pass_per_group"], passes
+    ref = got["one_pass_per_group"]
+    for label, e in got.items():
+        assert abs(e - ref) < 1e-12 * l1, (label, e, ref)
