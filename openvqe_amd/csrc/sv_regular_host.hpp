@@ -3,6 +3,7 @@
 // sv_sector.hpp, and compiled on its own under AddressSanitizer + UBSan by tests/cpu/regular_tables_check.cpp, which replays a
 // sweep from these tables on the host and compares it with the pair-by-pair definition (tests/test_sanitizer.py).
 #pragma once
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <vector>
@@ -40,10 +41,23 @@ struct SecRegHead {       // the kernel's view of a record
 };
 static_assert(sizeof(SecRegOp) == 128, "SecRegOp is read as 32 dwords");
 // LDS bank swizzle of a tile of doubles, linear over XOR (swz(a ^ b) = swz(a) ^ swz(b)): a group's members are base ^ spread(e).
-// Slot bit p lands on bank bit p mod 5 (8-byte slots: 32 per LDS cycle for reads, 16 for writes).  The host numbers the groups
-// so that bits 0..4 of the group number — the lanes of a read group — sit on positions of residues 0..4 mod 5 wherever the op's
-// mixing bits leave one free (bits 0..3, the 16 lanes of a write group, on residues 0..3): conflict-free whatever the x mask.
-constexpr inline uint32_t sec_reg_swz(uint32_t v) { return v ^ ((v >> 5) & 31u) ^ ((v >> 10) & 31u); }
+// The bank of an 8-byte slot is its low five address bits (32 slots per LDS cycle for reads, 16 for writes).  Slot bit p < 5 IS bank
+// bit p; slot bit p >= 5 adds the 5-bit COLUMN SEC_REG_SWZ_COL[p - 5] to the bank bits.  The 32 lanes of a read group reach 32 different
+// banks iff the columns of the five slot positions that carry the lane bits are linearly independent over GF(2), and the 16 lanes of a
+// write group 16 different slots of the 16 that one write cycle serves iff the columns of the first four are independent in their low four
+// bits; the host picks those positions per op among the positions the op does not mix (build_reg_ops: group_order).  Round 4's swizzle used the columns
+// e_(p mod 5): an op that mixes both members of a residue class of two (positions {2,7}, {3,8}, {4,9}) left no independent five — 17 % of the
+// ops of the reference's QUCCSD list ran with two-way conflicts on every access (SQ_LDS_BANK_CONFLICT: 30 k cycles per CU and sweep,
+// profiles/r5_quccsd24).  These columns were searched (4000 random draws) for the fewest position sets whose complement fails either test: of
+// the 495 ways to mix four of twelve positions ONE does (round 4: 150), of the 220 three-position sets none (32).
+constexpr uint32_t SEC_REG_SWZ_COL[8] = {28u, 14u, 11u, 5u, 19u, 31u, 21u, 7u};   // slot positions 5 .. 12
+constexpr inline uint32_t sec_reg_bank_column(int p) { return p < 5 ? (1u << p) : SEC_REG_SWZ_COL[p - 5]; }
+constexpr inline uint32_t sec_reg_swz(uint32_t v) {
+    uint32_t low = v & 31u;
+    for (int k = 0; k < 8; ++k)
+        if ((v >> (5 + k)) & 1u) low ^= SEC_REG_SWZ_COL[k];
+    return (v & ~31u) | low;
+}
 
 
 constexpr uint32_t SEC_REG_GSTRIDE = 2048;   // words per op: the groups of a one-bit op in a 4096-slot tile
@@ -184,21 +198,41 @@ inline bool build_reg_ops(const std::vector<SecBuildOp> &sops, const std::vector
             ++i;
         }
     }
-    // numbering of the groups: bits 0..4 of the group number on slot positions of residues 0..4 mod 5 (sec_reg_swz), lowest first;
-    // `wave` (a run without barriers): those positions, ascending, become bits lane_bits.. of the group number
+    // numbering of the groups: bits 0..4 of the group number (the lanes of a read group) on five slot positions whose bank columns are
+    // linearly independent (sec_reg_swz), lowest first; `wave` (a run without barriers): those positions, ascending, become bits
+    // lane_bits.. of the group number
+    auto reduce_by = [](const uint32_t (&basis)[5], uint32_t v) {
+        for (int b = 4; b >= 0; --b)
+            if (basis[b] && ((v >> b) & 1u)) v ^= basis[b];
+        return v;
+    };
     auto group_order = [&](uint32_t mixing, uint32_t wave) {
         std::vector<int> free_pos, order;
         for (int p = 0; p < mbits; ++p)
             if (!(((mixing | wave) >> p) & 1u)) free_pos.push_back(p);
         std::vector<char> used(free_pos.size(), 0);
-        for (int res = 0; res < 5; ++res)
-            for (size_t k = 0; k < free_pos.size(); ++k)
-                if (!used[k] && free_pos[k] % 5 == res) {
-                    used[k] = 1;
-                    order.push_back(free_pos[k]);
-                    break;
-                }
-        // (a residue without a free position: its lane bit takes the lowest position left — a two-way conflict at worst)
+        uint32_t basis4[5] = {}, basis[5] = {};   // basis[b]: a vector whose highest set bit is b
+        // lane bits 0..3 (a write group): columns independent in their low four bits
+        for (size_t k = 0; k < free_pos.size() && order.size() < 4; ++k) {
+            const uint32_t v = reduce_by(basis4, sec_reg_bank_column(free_pos[k]) & 15u);
+            if (!v) continue;
+            basis4[31 - __builtin_clz(v)] = v;
+            const uint32_t f = reduce_by(basis, sec_reg_bank_column(free_pos[k]));   // (independent in four bits => independent in five)
+            basis[31 - __builtin_clz(f)] = f;
+            used[k] = 1;
+            order.push_back(free_pos[k]);
+        }
+        // lane bit 4 (the other half of a read group): a column outside the span of those four
+        for (size_t k = 0; k < free_pos.size() && order.size() == 4; ++k) {
+            if (used[k]) continue;
+            const uint32_t v = reduce_by(basis, sec_reg_bank_column(free_pos[k]));
+            if (!v) continue;
+            basis[31 - __builtin_clz(v)] = v;
+            used[k] = 1;
+            order.push_back(free_pos[k]);
+        }
+        // (fewer than five independent columns among the free positions: the remaining lane bits take the lowest positions left — a
+        // two-way conflict per missing dimension)
         for (size_t k = 0; k < free_pos.size(); ++k)
             if (!used[k]) order.push_back(free_pos[k]);
         if (wave) {
@@ -208,12 +242,25 @@ inline bool build_reg_ops(const std::vector<SecBuildOp> &sops, const std::vector
         }
         return order;
     };
-    // residues 0..4 that the read lanes of an op would miss (each costs a two-way bank conflict on its accesses)
+    // dimensions of the bank space that the read lanes of an op would miss (each costs a two-way bank conflict on its accesses)
     auto missing_residues = [&](uint32_t mixing, uint32_t wave) {
-        uint32_t have = 0;
-        for (int p = 0; p < mbits; ++p)
-            if (!(((mixing | wave) >> p) & 1u)) have |= 1u << (p % 5);
-        return 5 - __builtin_popcount(have & 31u);
+        uint32_t basis[5] = {}, basis4[5] = {};
+        int rank = 0, rank4 = 0, nfree = 0;
+        for (int p = 0; p < mbits; ++p) {
+            if (((mixing | wave) >> p) & 1u) continue;
+            ++nfree;
+            const uint32_t v = reduce_by(basis, sec_reg_bank_column(p));
+            if (v) {
+                basis[31 - __builtin_clz(v)] = v;
+                ++rank;
+            }
+            const uint32_t v4 = reduce_by(basis4, sec_reg_bank_column(p) & 15u);
+            if (v4) {
+                basis4[31 - __builtin_clz(v4)] = v4;
+                ++rank4;
+            }
+        }
+        return nfree >= 5 ? (5 - rank) + (4 - rank4) : 0;   // (fewer than five free positions: the groups do not fill a read cycle anyway)
     };
     // units (a block of two ops or one op), their mixing positions, and the runs that need no barrier inside
     std::vector<uint32_t> wave_of(n, 0u);
