@@ -283,13 +283,20 @@ inline bool build_reg_ops(const std::vector<SecBuildOp> &sops, const std::vector
             if (u1 <= u0) return;
             uint32_t best = 0;
             int best_score = 1 << 30;
-            for (uint32_t sub = 0; sub <= allpos; ++sub) {
-                if ((sub & ~avail) || __builtin_popcount(sub) != wave_bits) continue;
+            // every wave_bits-subset of the unmixed positions (Gosper's walk over the masks of that weight, filtered to `avail`)
+            for (uint32_t sub = (1u << wave_bits) - 1u; sub <= allpos;) {
+                const uint32_t cur = sub;
+                {   // next mask of the same weight
+                    const uint32_t c = sub & (0u - sub), r = sub + c;
+                    sub = r ? (((r ^ sub) >> 2) / c) | r : allpos + 1u;
+                }
+                if (cur & ~avail) continue;
+                const uint32_t sub_mask = cur;
                 int score = 0;
-                for (size_t u = u0; u < u1; ++u) score += missing_residues(units[u].mixing, sub) - missing_residues(units[u].mixing, 0u);
-                if (score < best_score || (score == best_score && sub > best)) {
+                for (size_t u = u0; u < u1; ++u) score += missing_residues(units[u].mixing, sub_mask) - missing_residues(units[u].mixing, 0u);
+                if (score < best_score || (score == best_score && sub_mask > best)) {
                     best_score = score;
-                    best = sub;
+                    best = sub_mask;
                 }
             }
             for (size_t u = u0; u < u1; ++u) {
