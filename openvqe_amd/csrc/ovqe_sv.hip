@@ -179,6 +179,8 @@ struct SectorEngine {
     bool regular = false;         // the support is a full coset of the program's Z2 symmetries and every sweep has its SecRegOp list
     int reg_m = 0;                // slot bits of a tile then (tile bits minus the free bits)
     int reg_plan_threads = 0;     // workgroup size the barrier-free runs were planned for (0: none planned)
+    bool coset_assumed = false;   // the support is the coset of the program's Z2 symmetries, taken without a probe (gate lists)
+    bool coset_rejected = false;  // ... and the check of the first build found it mostly empty: this program is probed
     uint32_t freemask = 0;        // the free (dependent) index bits of the coset
     DevBuf d_regmap, d_regtab;    // table-entry map of all sweeps (angle-table entry | sign << 31, or none), the (c, s) table of the evaluation
     uint32_t nregtab = 0;
@@ -356,6 +358,7 @@ struct ovqe_sv {
     int opt_sector_reg_threads = 256; // workgroup size of those sweeps
     int opt_sector_reg_adjoint = 1;   // ovqe_energy_gradient on a regular support: backward sweeps from bit arithmetic too (0: pair-word sweeps)
     int opt_sector_reg_pairs = 1;     // two consecutive three-bit ops that share two bits run as one 16-slot block
+    int opt_sector_coset_first = 1;   // gate lists in frame form: the coset of their Z2 symmetries as support, no probe run (checked afterwards)
     int opt_sector_reg_runs = 1;      // runs of consecutive ops whose waves stay inside their own slots: no barrier inside a run
     int opt_sector_depth2 = 1;        // first form of the sweeps: two chunks of pair words ahead where every op of a tile fits a staging buffer
     int opt_sector_many_tiles = 1;    // single evaluations with >= 768 tiles: the workgroup shape of the batches (512 threads, scatter indices from memory)
@@ -1723,6 +1726,7 @@ int sector_prepare(ovqe_handle h, bool eager = false) {
         E.disabled = false;
         E.seen = 0;
         E.probe_mode = 0;
+        E.coset_rejected = false;
         E.prog_version = h->prog_version;
         E.ham_version = h->ham.version;
     }
@@ -3280,6 +3284,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
 #ifdef OVQE_TESTING
     else if (k == "rot_variant") h->opt_rot_variant = (int)value;
     else if (k == "tile_flat") h->opt_tile_flat = (int)value;
+    else if (k == "sector_coset_first") h->opt_sector_coset_first = (int)value;
     else if (k == "expect_dense") h->opt_expect_dense = (int)value;
     else if (k == "fault_inject") h->fault_inject = (int)value;
 #endif
@@ -4715,6 +4720,7 @@ extern "C" int ovqe_sector_ground_state(ovqe_handle h, double tol, int max_iter,
         E.disabled = false;
         E.seen = 0;
         E.probe_mode = 0;
+        E.coset_rejected = false;
         E.prog_version = h->prog_version;
         E.ham_version = h->ham.version;
     }

@@ -122,6 +122,28 @@ __global__ __launch_bounds__(256) void k_sec_fill_nz(const double *__restrict__ 
         if (i0 + k < namps && st[i0 + k] != 0.0) sup[pos++] = (uint32_t)(i0 + k);
 }
 
+// the coset of a program's Z2 symmetries through |hf>, ascending: member k has the kept bits pdep(k, kept) and every free bit f set to
+// s_f ^ parity(member & G_f) (G_f: kept bits above f; sv_regular_host.hpp z2_symmetries)
+struct SecCoset {
+    uint32_t kept;
+    int32_t nfree;
+    uint32_t fbit[8], G[8], s[8];
+};
+__global__ __launch_bounds__(256) void k_sec_coset(SecCoset c, uint32_t K, uint32_t *__restrict__ sup) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= K) return;
+    uint32_t i = 0, m = c.kept, q = k;
+    while (m) {   // pdep (the mask is uniform)
+        const uint32_t low = m & (0u - m);
+        if (q & 1u) i |= low;
+        q >>= 1;
+        m &= m - 1u;
+    }
+    for (int f = c.nfree - 1; f >= 0; --f)   // (G_f holds kept bits only: the order does not matter)
+        if ((c.s[f] ^ (uint32_t)__popc(i & c.G[f])) & 1u) i |= 1u << c.fbit[f];
+    sup[k] = i;
+}
+
 // ---- layouts ----------------------------------------------------------------------------------------------------------
 // key = (index bits outside the tile set) << M | (index bits inside): sorting the keys sorts the support by tile
 __global__ __launch_bounds__(256) void k_sec_keys(const uint32_t *__restrict__ sup, uint32_t K, uint32_t smask, uint32_t outside,

@@ -610,3 +610,57 @@ def test_differential_fuzz_of_the_sector_path(gpu_lib):
     assert "bit-arithmetic sweeps" in tail
     regular = int(tail.split("(")[1].split(" ")[0])
     assert regular >= 5, tail      # the regular-support kernels were among the draws
+
+
+def test_gate_list_takes_the_coset_without_a_probe_and_is_checked(SV):
+    """A gate list in frame form gets its sector tables on the coset of its Z2 symmetries WITHOUT a probe run (the reference's QUCCSD
+    templates fill that coset: ref:openvqe/common_files/circuit.py:13-106); the build then checks with one evaluation at generic
+    angles that the coset is populated.  (a) QUCCSD templates at 18 qubits: support = the spin-parity quarter, sweeps from bit arithmetic;
+    (b) a NUMBER-CONSERVING gate list — UCCSD generators synthesised as CNOT staircases (what myQLM's build_ucc_ansatz emits) — populates
+    (9 choose 4)^2 of the 2^16 coset members: the check rejects the coset and the tables come from a probe.  Energies of both against
+    the dense-state kernels of the same handle."""
+    import math
+
+    from openvqe_amd import fermion
+    from openvqe_amd.common_files.circuit import quccsd_gate_list
+    m, o = 9, 4
+    n = 2 * m
+    ham, gens, hf = fermion.synthetic_molecule(m, o, seed=909)
+    l1 = float(np.abs(ham.packed()[2]).sum())
+    rng = np.random.default_rng(99)
+    # (b) literal gates of every 6th generator: basis changes, CNOT staircase, RZ(2 c theta), uncompute
+    picked = gens[::6]
+    gates = []
+    for k, g in enumerate(picked):
+        for t in g.terms:
+            act = [(q, p) for q, p in zip(t.qbits, t.op) if p != "I"]
+            pre = [("H", [q], 0.0, 0.0, -1) if p == "X" else ("RX", [q], 0.0, math.pi / 2, -1) for q, p in act if p in "XY"]
+            post = [("H", [q], 0.0, 0.0, -1) if p == "X" else ("RX", [q], 0.0, -math.pi / 2, -1) for q, p in act if p in "XY"]
+            ladder = [("CNOT", [a[0], b[0]], 0.0, 0.0, -1) for a, b in zip(act[:-1], act[1:])]
+            gates += pre + ladder + [("RZ", [act[-1][0]], 2.0 * float(np.real(t.coeff)), 0.0, k)] + ladder[::-1] + post
+    theta_b = rng.uniform(-0.4, 0.4, len(picked))
+    qgates, Kq, hfq = quccsd_gate_list(m, o, 1)
+    theta_a = rng.uniform(-0.3, 0.3, Kq)
+    out = {}
+    for label, glist, K, hf0, theta in (("quccsd", qgates, Kq, hfq, theta_a), ("staircase_uccsd", gates, len(picked), hf, theta_b)):
+        with SV(n) as sv:
+            sv.set_option("force_path", 2)
+            sv.set_hamiltonian(ham)
+            sv.set_gate_program(glist, K, hf0)
+            assert sv.program_info()["literal_gates"] == 0
+            e = [sv.energy(theta) for _ in range(3)]
+            info = sv.program_info()
+            sv.set_option("sector", 0)
+            e_dense = sv.energy(theta)
+        out[label] = (e, e_dense, info)
+    for label, (e, e_dense, info) in out.items():
+        assert np.abs(np.array(e) - e_dense).max() < 1e-11 * max(1.0, l1), (label, e, e_dense)
+    assert out["quccsd"][2]["sector_support"] == 1 << (n - 2) and out["quccsd"][2]["sector_regular_slot_bits"] > 0
+    # (every 6th generator does not reach all of the (4 alpha, 4 beta) sector: a probed support inside it, far below the 2^16 coset)
+    assert 1000 < out["staircase_uccsd"][2]["sector_support"] <= comb(m, o) ** 2 and out["staircase_uccsd"][2]["sector_regular_slot_bits"] == 0
+    # the same rotation sequence as a Pauli-rotation program gives the same energy (the frame compiler saw through the staircases)
+    with SV(n) as sv:
+        sv.set_option("force_path", 2)
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(picked, hf)
+        assert abs(sv.energy(theta_b) - out["staircase_uccsd"][1]) < 1e-11 * max(1.0, l1)
