@@ -350,6 +350,7 @@ struct ovqe_sv {
     bool prog_from_gates = false;     // the stored program came from ovqe_set_gate_program (frame form): sector tables at the first evaluation
     int opt_expect_dense = 1;         // tiled <H> of dense complex registers (25+ qubits): census of the first sweep, then two workgroups per CU
     DevBuf d_tile_cnt;
+    int opt_tile_unsplit = 1;         // tiled <H> of complex states: groups of one or two terms as unsplit entries (see build_ham_tiles)
     int opt_tile_flat = 2;            // tiled <H>: entries of one or two merged terms as per-LANE items (1), per-wave entries (0), items for real
                                       // states only (2, default: on dense complex tiles the items' LDS reads conflict 16 ways — 78 % of the LDS cycles,
                                       // profiles/r5_tilexp — and the per-wave entries are 10 % faster once two workgroups share a CU)
@@ -889,6 +890,44 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
             const int w = __builtin_popcount(xl);
             int xpos[16], np = 0;
             for (uint32_t mk2 = xl; mk2; mk2 &= mk2 - 1u) xpos[np++] = __builtin_ctz(mk2);
+            // UNSPLIT entries (round 5): a group of one or two raw terms on a complex state — no pattern of its x bits cancels, so
+            // cutting it into 2^(w-1) pattern entries only multiplies the per-entry set-up (a quarter of the kernel's instructions at
+            // w = 4: 25 per pair).  Its 2^(M-1) pairs (pivot bit of i clear) are walked in pieces of 512 with the x part of z left in
+            // the terms' masks; en.x = the pivot bit alone (what the index walk skips), en.pad = the mask that leads to the partner.
+            if (!real && w >= 2 && gr.t1 - gr.t0 <= 2 && h->opt_tile_unsplit && M - 1 >= 9) {
+                if ((int)tterms.size() - ck.t0 + (gr.t1 - gr.t0) > TILE_TERM_CAP) {
+                    ck.g1 = (int32_t)tgroups.size();
+                    ck.t1 = (int32_t)tterms.size();
+                    chunks.push_back(ck);
+                    ck = {ck.g1, ck.g1, ck.t1, ck.t1};
+                }
+                const int32_t t0 = (int32_t)tterms.size();
+                bool real_only = true;
+                for (int t = gr.t0; t < gr.t1; ++t) {
+                    const HTerm &ht = H.terms[t];
+                    ExTermT et = {};
+                    et.zin = extract_bits(ht.z, S);
+                    et.zout = ht.z & ~S;
+                    et.cr = ht.cr;
+                    et.ci = ht.ci;
+                    if (et.ci != 0.0) real_only = false;
+                    tterms.push_back(et);
+                }
+                const int npairs = 1 << (M - 1);
+                for (int k0 = 0; k0 < npairs; k0 += 512) {
+                    ExEntryT en = {};
+                    en.x = 1u << xpos[w - 1];
+                    en.ibits = 0;
+                    en.t0 = t0;
+                    en.t1 = (int32_t)tterms.size();
+                    en.k0 = k0;
+                    en.nk = 512;
+                    en.real_only = real_only ? 1 : 0;
+                    en.pad = (int32_t)xl;
+                    tgroups.push_back(en);
+                }
+                continue;
+            }
             const uint32_t npat = w ? (1u << (w - 1)) : 1u;
             for (uint32_t e = 0; e < npat; ++e) {
                 uint32_t ibits = 0;
@@ -3284,6 +3323,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
 #ifdef OVQE_TESTING
     else if (k == "rot_variant") h->opt_rot_variant = (int)value;
     else if (k == "tile_flat") h->opt_tile_flat = (int)value;
+    else if (k == "tile_unsplit") h->opt_tile_unsplit = (int)value;
     else if (k == "sector_coset_first") h->opt_sector_coset_first = (int)value;
     else if (k == "expect_dense") h->opt_expect_dense = (int)value;
     else if (k == "fault_inject") h->fault_inject = (int)value;

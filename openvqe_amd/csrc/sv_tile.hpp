@@ -283,6 +283,62 @@ __device__ __forceinline__ double tile_sparse_pieces(const typename Amp<REAL>::T
     return part;
 }
 
+// the pairs of one (group, pattern) entry — or of a piece of an unsplit group — with one or two merged terms: lanes over the free
+// index, four trips in flight.  The swizzle is linear over XOR (the partner's address is one XOR from the own one); a term's sign is one
+// XOR on the high word of its coefficient (round 5: the kernel is bound by the issue of these instructions once two workgroups share a CU).
+template <bool REAL, uint32_t NEL, bool ONE, bool RO, bool FULL>
+__device__ __forceinline__ double tile_entry_pairs(const typename Amp<REAL>::T *tile, const ExEntryT &en, const ExTermLds &l0, const ExTermLds &l1,
+                                                   uint32_t lane) {
+    typedef typename Amp<REAL>::T amp;
+    const uint32_t d64 = deposit_index(64u, en.x);  // k -> k + 64 never carries into lane bits
+    uint32_t i = deposit_index((uint32_t)en.k0 + lane, en.x) | en.ibits;
+    const uint32_t xf = en.pad ? (uint32_t)en.pad : en.x;   // (an unsplit entry: en.x is the pivot bit, en.pad the whole x mask)
+    const uint32_t sx = tile_swz<REAL>(xf);
+    const uint32_t c0rh = (uint32_t)__double2hiint(l0.cr), c0rl = (uint32_t)__double2loint(l0.cr);
+    const uint32_t c1rh = (uint32_t)__double2hiint(l1.cr), c1rl = (uint32_t)__double2loint(l1.cr);
+    const uint32_t c0ih = (uint32_t)__double2hiint(l0.ci), c0il = (uint32_t)__double2loint(l0.ci);
+    const uint32_t c1ih = (uint32_t)__double2hiint(l1.ci), c1il = (uint32_t)__double2loint(l1.ci);
+    double part = 0.0;
+    for (uint32_t k = lane; k < (uint32_t)en.nk; k += 256u) {
+        uint32_t ii[4];
+        amp a[4], c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ii[q] = i & (NEL - 1u);
+            i = (((i | en.x) + d64) & ~en.x) | en.ibits;  // next free index, x positions skipped
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t pa = tile_swz<REAL>(ii[q]);
+            a[q] = tile[pa];
+            c[q] = tile[pa ^ sx];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t j = ii[q] ^ xf;
+            const uint32_t n0 = (uint32_t)__popc(j & l0.zin) << 31;
+            double dr = __hiloint2double((int)(c0rh ^ n0), (int)c0rl), di = 0.0;
+            if constexpr (!RO) di = __hiloint2double((int)(c0ih ^ n0), (int)c0il);
+            if constexpr (!ONE) {
+                const uint32_t n1 = (uint32_t)__popc(j & l1.zin) << 31;
+                dr += __hiloint2double((int)(c1rh ^ n1), (int)c1rl);
+                if constexpr (!RO) di += __hiloint2double((int)(c1ih ^ n1), (int)c1il);
+            }
+            double v;
+            if constexpr (REAL) {
+                v = dr * (a[q] * c[q]);
+            } else {
+                const double wx = a[q].x * c[q].x + a[q].y * c[q].y;
+                v = dr * wx;
+                if constexpr (!RO) v -= di * (a[q].x * c[q].y - a[q].y * c[q].x);
+            }
+            if constexpr (FULL) part += v;
+            else part += (k + 64u * q < (uint32_t)en.nk) ? v : 0.0;
+        }
+    }
+    return part;
+}
+
 template <int M, int NT, bool NTL, bool REAL>
 __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st, uint64_t base, ExSweep sw,
                                                     const ExChunkT *__restrict__ chunks,
@@ -483,55 +539,20 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
             const int nt = en.t1 - en.t0;
             double part = 0.0;
             if (nt <= 2) {
-                // the common case after merging (a JW double excitation leaves ONE coefficient per active pattern):
-                // the pair set-up is the cost, so no unrolling over dead lanes — one pair per lane per trip
-                const ExTermLds l0 = gt[0];
-                ExTermLds l1 = gt[nt - 1];
+                // the common case after merging (a JW double excitation leaves ONE coefficient per active pattern): one pair per lane
+                // per trip, four trips at a time; variants by what the entry does not need (uniform per entry): a second term, imaginary
+                // coefficients, the bound check of a ragged last trip
+                const ExTermLds l0 = gt[0], l1 = gt[nt - 1];
+                const bool ro = REAL || en.real_only, full = (en.nk & 255) == 0;
+#define OVQE_TEP(ONE_, RO_, FULL_) part = tile_entry_pairs<REAL, NEL, ONE_, RO_, FULL_>(tile, en, l0, l1, lane)
                 if (nt == 1) {
-                    l1.cr = 0.0;
-                    l1.ci = 0.0;
+                    if (ro) { if (full) OVQE_TEP(true, true, true); else OVQE_TEP(true, true, false); }
+                    else { if (full) OVQE_TEP(true, false, true); else OVQE_TEP(true, false, false); }
+                } else {
+                    if (ro) { if (full) OVQE_TEP(false, true, true); else OVQE_TEP(false, true, false); }
+                    else { if (full) OVQE_TEP(false, false, true); else OVQE_TEP(false, false, false); }
                 }
-                const uint32_t dlane = deposit_index((uint32_t)en.k0 + lane, en.x) | en.ibits;
-                const uint32_t d64 = deposit_index(64u, en.x);  // k -> k + 64 never carries into lane bits
-                uint32_t i = dlane;
-                // (round 5: the swizzle is linear over XOR — the partner's address is one XOR from the own one; a term's sign is one XOR
-                // on the high word of its coefficient instead of a compare and two selects)
-                const uint32_t sx = tile_swz<REAL>(en.x);
-                const uint32_t c0rh = (uint32_t)__double2hiint(l0.cr), c0rl = (uint32_t)__double2loint(l0.cr);
-                const uint32_t c1rh = (uint32_t)__double2hiint(l1.cr), c1rl = (uint32_t)__double2loint(l1.cr);
-                const uint32_t c0ih = (uint32_t)__double2hiint(l0.ci), c0il = (uint32_t)__double2loint(l0.ci);
-                const uint32_t c1ih = (uint32_t)__double2hiint(l1.ci), c1il = (uint32_t)__double2loint(l1.ci);
-                // four trips at a time: the eight LDS reads are issued before the first result is needed
-                for (uint32_t k = lane; k < (uint32_t)en.nk; k += 256u) {
-                    uint32_t ii[4];
-                    amp a[4], c[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        ii[q] = i & (NEL - 1u);
-                        i = (((i | en.x) + d64) & ~en.x) | en.ibits;  // next free index, x positions skipped
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const uint32_t pa = tile_swz<REAL>(ii[q]);
-                        a[q] = tile[pa];
-                        c[q] = tile[pa ^ sx];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const uint32_t j = ii[q] ^ en.x;
-                        const uint32_t n0 = (uint32_t)__popc(j & l0.zin) << 31, n1 = (uint32_t)__popc(j & l1.zin) << 31;
-                        const double dr = __hiloint2double((int)(c0rh ^ n0), (int)c0rl) + __hiloint2double((int)(c1rh ^ n1), (int)c1rl);
-                        double v;
-                        if constexpr (REAL) {
-                            v = dr * (a[q] * c[q]);
-                        } else {
-                            const double wx = a[q].x * c[q].x + a[q].y * c[q].y, wy = a[q].x * c[q].y - a[q].y * c[q].x;
-                            const double di = __hiloint2double((int)(c0ih ^ n0), (int)c0il) + __hiloint2double((int)(c1ih ^ n1), (int)c1il);
-                            v = dr * wx - di * wy;
-                        }
-                        part += (k + 64u * q < (uint32_t)en.nk) ? v : 0.0;
-                    }
-                }
+#undef OVQE_TEP
             } else {
             double vx[PP], vy[PP], dr[PP], di[PP];
             uint32_t jj[PP];
