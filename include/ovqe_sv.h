@@ -150,7 +150,9 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  *   "sparse_spw", "sparse_dealias", "sector_sweep", "sector_chunk", "sector_depth2", "sector_many_tiles",
  *   "sector_h_lpt", "sector_h_threads", "sector_h_groups", "sector_apply_threads", "sector_row_banks", "sector_eager_rots",
  *   "screen_tables", "sector_batch_threads" / "_nb" / "_sweep_threads" / "_dst_lds" / "_zfast", "tile_flat" (tiled <H>: entries of one
- *   or two merged terms as per-lane items 1 / per-wave entries 0 / items for real states only 2, the default), "sector_coset_first" (1: a gate list in frame form takes the coset of its Z2 symmetries as
+ *   or two merged terms as per-lane items 1 / per-wave entries 0 / items for real states only 2, the default), "sector_apply_seq" (1: lambda = H psi on the sector tables runs one launch per sweep in sequence with plain
+ *   additions where one sweep fills the chip; 0: one launch, global atomics), "tile_unsplit" (1: tiled <H> of complex states takes groups
+ *   of one or two terms as unsplit entries), "sector_coset_first" (1: a gate list in frame form takes the coset of its Z2 symmetries as
  *   its support without a probe run; the build checks afterwards that the coset is populated), "expect_dense" (1: the
  *   first sweep of a tiled <H> of a complex register of 25+ qubits counts its sparse tiles; none: the other sweeps run without the
  *   sparse path's LDS, two workgroups per CU) */

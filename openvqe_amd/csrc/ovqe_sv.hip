@@ -359,6 +359,7 @@ struct ovqe_sv {
     int opt_sector_reg_threads = 256; // workgroup size of those sweeps
     int opt_sector_reg_adjoint = 1;   // ovqe_energy_gradient on a regular support: backward sweeps from bit arithmetic too (0: pair-word sweeps)
     int opt_sector_reg_pairs = 1;     // two consecutive three-bit ops that share two bits run as one 16-slot block
+    int opt_sector_apply_seq = 1;     // lambda = H psi on the sector tables: one launch per sweep in sequence, plain additions (0: one launch, global atomics)
     int opt_sector_coset_first = 1;   // gate lists in frame form: the coset of their Z2 symmetries as support, no probe run (checked afterwards)
     int opt_sector_reg_runs = 1;      // runs of consecutive ops whose waves stay inside their own slots: no barrier inside a run
     int opt_sector_depth2 = 1;        // first form of the sweeps: two chunks of pair words ahead where every op of a tile fits a staging buffer
@@ -3325,6 +3326,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     else if (k == "tile_flat") h->opt_tile_flat = (int)value;
     else if (k == "tile_unsplit") h->opt_tile_unsplit = (int)value;
     else if (k == "sector_coset_first") h->opt_sector_coset_first = (int)value;
+    else if (k == "sector_apply_seq") h->opt_sector_apply_seq = (int)value;
     else if (k == "expect_dense") h->opt_expect_dense = (int)value;
     else if (k == "fault_inject") h->fault_inject = (int)value;
 #endif
