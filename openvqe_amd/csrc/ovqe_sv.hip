@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -147,6 +148,10 @@ struct SectorSeg {      // one sweep of the circuit
     DevBuf d_srcpad;              // gather indices of the sweep, tile-padded (k_sec_pad_src): first form of the sweep kernel
     DevBuf d_dstpad;              // scatter indices into the next sweep's tile-padded order (k_sector_sweep2)
     DevBuf d_wide, d_rounds;      // 64-bit pair words, rounds per (tile, chunk) (k_sec_widen)
+    DevBuf d_stream, d_rowhdr, d_rowinfo;   // per-wave streams of the third sweep form (k_sector_sweep3): rows of 64 pair words, cos/sin base per row, run boundaries per (tile, wave)
+    int nruns = 0;                // runs of the sweep's op list (0: no streams; the second form serves the sweep)
+    int stream_waves = 0;         // waves per workgroup that share the rows
+    uint64_t stream_rows = 0;
     DevBuf d_bdst;                // scatter indices into the PREVIOUS sweep's tile-padded order (k_sector_adjoint2)
     DevBuf d_torder;              // tiles by population, largest first (sweeps with many tiles per CU)
     uint32_t maxchunks = 0;
@@ -329,7 +334,9 @@ struct ovqe_sv {
     int opt_sector_sparsity = 4;  // the support must be at most 1/this of the register
     int opt_sector_profile = 0;   // 1: HIP events around the circuit and the <H> kernel of every sector evaluation (program_info)
     int opt_sector_debug = 0;     // measurements only (1: circuit sweeps without their ops — wrong results)
-    int opt_sector_sweep = 2;     // circuit sweep kernel: 2 = scatter-on-write, pair words in registers (k_sector_sweep2); 1 = first form
+    int opt_sector_stream_arrange = 1; // third sweep form: lanes of a row chosen for the LDS banks (0: in list order; testing builds)
+    int opt_sector_stream_waves = 0;   // third sweep form: waves that share a tile's rows (0: from the pairs per op of the sweep's largest tile); testing builds
+    int opt_sector_sweep = 3;     // circuit sweep kernel: 3 = per-wave streams, barriers at run boundaries only (k_sector_sweep3; built on the tables of 2); 2 = scatter-on-write, pair words in registers (k_sector_sweep2); 1 = first form
     int opt_sector_chunk = 2048;  // k_sector_sweep2: pair words per chunk = threads x words per thread (1024, 2048, 4096)
     int opt_sector_sweep_dbg = 0; // measurements only, k_sector_sweep2: 1 no ops, 2 empty kernel, 3 loads only — wrong results
     int opt_sector_h_groups = 256; // workgroups per <H> sweep (they share the sweep's tiles round robin)
@@ -3298,8 +3305,10 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     else if (k == "sector_batch_threads") h->opt_sector_batch_threads = value == 512 ? 512 : 1024;
     else if (k == "sector_row_banks") h->opt_sector_row_banks = (int)value;
     else if (k == "sector_debug") h->opt_sector_debug = (int)value;
-    else if (k == "sector_sweep") h->opt_sector_sweep = value == 1 ? 1 : 2;
+    else if (k == "sector_sweep") h->opt_sector_sweep = value == 1 ? 1 : (value == 2 ? 2 : 3);   // (2 on tables built under 3: the second form on the same tables)
     else if (k == "sector_sweep_dbg") h->opt_sector_sweep_dbg = (int)value;
+    else if (k == "sector_stream_waves") h->opt_sector_stream_waves = (int)value;
+    else if (k == "sector_stream_arrange") h->opt_sector_stream_arrange = (int)value;
 #endif
     else if (k == "sector_reg_runs") {   // runs of ops without barriers (planned at build time: the tables are rebuilt)
         h->opt_sector_reg_runs = (int)value;

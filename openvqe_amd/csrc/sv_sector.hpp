@@ -769,6 +769,289 @@ __global__ __launch_bounds__(NT) void k_sector_sweep2(const double *__restrict__
     }
     if (bad) atomicOr(flag, 1);
 }
+// ---- one sweep of the circuit, third form (round 5): pair words in PER-WAVE streams --------------------------------------
+// What bounds the second form is the workgroup barrier behind every round (24-qubit UCCSD: 41 rounds of 0.3 us per sweep; rocprofv3:
+// waves wait 61 % of their cycles, VALU 6.5 %, LDS 1.2 %).  Consecutive ops of a sweep mix few bits between them (UCCSD: neighbours in
+// the list differ in one orbital), so the sweep's op list is cut into RUNS whose mixing masks together leave at least log2(waves) of the
+// tile's index bits untouched: those bits split the tile's slots into classes no op of the run leaves, every class belongs to one
+// wave for the length of the run (classes dealt to waves by pair count, largest first: k_sec_wave_plan), and a wave applies its part of
+// every op of the run in op order with nothing but the in-order LDS pipe between them.  Workgroup barriers are left at the run
+// boundaries only (24-qubit UCCSD: 140 for 1715 ops).
+//   stream of (tile, wave): ROWS of 64 32-bit pair words (slot_i | slot_j << sb | pattern << 2 sb | sign << 31 — the first form's
+//   fields with the sign moved to where it is xor-ed into the sine; 0xffffffff: empty lane), one op per row (an op with more than 64
+//   pairs in the wave's classes takes several), rows in op order; rowhdr[row] = first cos/sin entry of the row's op (bit 15: the op
+//   has a word in this wave whose partner is outside the support); rowinfo[(tile, wave)][r] = first row of run r (r = nruns: the end).
+//   Rows are loaded SEC_STREAM_G at a time, the next batch in flight while this one is applied.
+constexpr int SEC_STREAM_WAVES = 16;     // waves per workgroup the streams are planned for (k_sector_sweep3<1024>)
+constexpr int SEC_STREAM_G = 8;          // rows per batch
+constexpr int SEC_STREAM_CLASS_BITS = 6; // at most 64 slot classes per run
+struct SecWaveRun {
+    int32_t op_end;       // ops [previous op_end, op_end) of the sweep
+    uint32_t cmask;       // index bits (inside the tile, outside every mixing mask of the run) that number the slot classes
+};
+// plan (FILL = false: rows per (tile, wave, op) and the class -> wave map) and fill (FILL = true: words and row headers) of the streams;
+// one workgroup per tile
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_sec_wave_plan(const uint32_t *__restrict__ sup, const uint32_t *__restrict__ cid,
+                                                       const uint32_t *__restrict__ off, const uint32_t *__restrict__ pairs,
+                                                       const uint32_t *__restrict__ poff, int nops, const int32_t *__restrict__ tab0, int rot0,
+                                                       const SecWaveRun *__restrict__ runs, int nruns, int sb, int nw, uint32_t *__restrict__ oprows,
+                                                       const uint32_t *__restrict__ rowoff, uint8_t *__restrict__ wof,
+                                                       uint32_t *__restrict__ stream, uint16_t *__restrict__ rowhdr) {
+    constexpr int NC = 1 << SEC_STREAM_CLASS_BITS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
+    uint8_t *own = sec_smem;     // [tile population]: class, then wave, of every slot
+    __shared__ uint32_t ccount[NC], wcnt[SEC_STREAM_WAVES], worph[SEC_STREAM_WAVES];
+    const int NW = nw;           // waves that work on the rows (a power of two up to SEC_STREAM_WAVES)
+    __shared__ uint8_t wofc[NC];
+    const uint32_t t = blockIdx.x, e0 = off[t], n = off[t + 1] - e0;
+    const uint32_t *po = poff + (size_t)t * (nops + 1);
+    const uint32_t mask = (1u << sb) - 1u;
+    int o0 = 0;
+    for (int r = 0; r < nruns; ++r) {
+        const int o1 = runs[r].op_end;
+        const uint32_t cmask = runs[r].cmask;
+        if (threadIdx.x < NC) ccount[threadIdx.x] = 0;
+        for (uint32_t k = threadIdx.x; k < n; k += 256u) own[k] = (uint8_t)sec_pext(sup[cid[e0 + k]], cmask);
+        __syncthreads();
+        uint8_t *wo = wof + ((size_t)t * nruns + r) * NC;
+        if (!FILL) {
+            for (uint32_t k = po[o0] + threadIdx.x; k < po[o1]; k += 256u) atomicAdd(&ccount[own[pairs[k] & mask]], 1u);
+            __syncthreads();
+            if (threadIdx.x == 0) {   // classes to waves: largest first onto the wave with the fewest pairs so far
+                uint32_t load[SEC_STREAM_WAVES];
+                for (int w = 0; w < NW; ++w) load[w] = 0;
+                for (int it = 0; it < NC; ++it) {
+                    int best = -1;
+                    uint32_t bc = 0;
+                    for (int c = 0; c < NC; ++c)
+                        if (ccount[c] != 0xffffffffu && (best < 0 || ccount[c] > bc)) {
+                            best = c;
+                            bc = ccount[c];
+                        }
+                    int w0 = 0;
+                    for (int w = 1; w < NW; ++w)
+                        if (load[w] < load[w0]) w0 = w;
+                    load[w0] += bc;
+                    wofc[best] = (uint8_t)w0;
+                    ccount[best] = 0xffffffffu;
+                }
+                for (int c = 0; c < NC; ++c) wo[c] = wofc[c];
+            }
+        } else if (threadIdx.x < NC) {
+            wofc[threadIdx.x] = wo[threadIdx.x];
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < n; k += 256u) own[k] = wofc[own[k]];
+        for (int o = o0; o < o1; ++o) {
+            if ((int)threadIdx.x < NW) {
+                wcnt[threadIdx.x] = 0;
+                worph[threadIdx.x] = 0;
+            }
+            __syncthreads();
+            for (uint32_t k = po[o] + threadIdx.x; k < po[o + 1]; k += 256u) {
+                const uint32_t pw = pairs[k], w = own[pw & mask];
+                const uint32_t rank = atomicAdd(&wcnt[w], 1u);
+                if (FILL) {
+                    stream[(size_t)rowoff[((size_t)t * NW + w) * (nops + 1) + o] * 64u + rank] =
+                        (pw & ((1u << (2 * sb)) - 1u)) | ((pw >> (2 * sb + 1)) << (2 * sb)) | (((pw >> (2 * sb)) & 1u) << 31);
+                    if (((pw >> sb) & mask) == mask) worph[w] = 1u;
+                }
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < NW) {
+                const size_t q = (size_t)t * NW + threadIdx.x;
+                if (!FILL) {
+                    oprows[q * nops + o] = (wcnt[threadIdx.x] + 63u) >> 6;
+                } else {
+                    for (uint32_t rw = rowoff[q * (nops + 1) + o]; rw < rowoff[q * (nops + 1) + o + 1]; ++rw)
+                        rowhdr[rw] = (uint16_t)((uint32_t)(tab0[o] - rot0) | (worph[threadIdx.x] ? 0x8000u : 0u));
+                }
+            }
+        }
+        __syncthreads();
+        o0 = o1;
+    }
+}
+// Lanes of a row chosen for the LDS banks (MI355X: a 64-bit read is served in two groups of 32 lanes over 64 dword banks, a 64-bit write in
+// four groups of 16 lanes over 32: slots that agree mod 32 / mod 16 inside a group cost a cycle each; the second form's counters: 83 %
+// of its LDS cycles are such conflicts).  One thread per row: every word goes to the 16-lane group where its two slots collide with
+// the fewest already placed (first fit), groups filled from their first lane.
+__global__ __launch_bounds__(256) void k_sec_row_arrange(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t rows, int sb) {
+    const uint64_t row = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (row >= rows) return;
+    const uint32_t mask = (1u << sb) - 1u;
+    const uint32_t *src = in + row * 64u;
+    uint32_t *dst = out + row * 64u;
+    uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+    uint32_t wi0 = 0, wi1 = 0, wi2 = 0, wi3 = 0, wj0 = 0, wj1 = 0, wj2 = 0, wj3 = 0;   // residues mod 16 taken in a group: first / second slot
+    uint32_t ri0 = 0, ri1 = 0, rj0 = 0, rj1 = 0;                                       // residues mod 32 taken in a half
+    for (int k = 0; k < 64; ++k) {
+        const uint32_t w = src[k];
+        if (w == 0xffffffffu) break;       // (the fill leaves the words of a row contiguous from lane 0)
+        const uint32_t si = w & mask, sj = (w >> sb) & mask;
+        const bool plain = sj != mask;
+        const uint32_t a16 = 1u << (si & 15u), a32 = 1u << (si & 31u), b16 = plain ? 1u << (sj & 15u) : 0u, b32 = plain ? 1u << (sj & 31u) : 0u;
+        const uint32_t c0 = cnt0 < 16u ? ((wi0 & a16) != 0) + ((wj0 & b16) != 0) + ((ri0 & a32) != 0) + ((rj0 & b32) != 0) : 99u;
+        const uint32_t c1 = cnt1 < 16u ? ((wi1 & a16) != 0) + ((wj1 & b16) != 0) + ((ri0 & a32) != 0) + ((rj0 & b32) != 0) : 99u;
+        const uint32_t c2 = cnt2 < 16u ? ((wi2 & a16) != 0) + ((wj2 & b16) != 0) + ((ri1 & a32) != 0) + ((rj1 & b32) != 0) : 99u;
+        const uint32_t c3 = cnt3 < 16u ? ((wi3 & a16) != 0) + ((wj3 & b16) != 0) + ((ri1 & a32) != 0) + ((rj1 & b32) != 0) : 99u;
+        uint32_t best = 0, bc = c0;
+        if (c1 < bc) { best = 1; bc = c1; }
+        if (c2 < bc) { best = 2; bc = c2; }
+        if (c3 < bc) { best = 3; bc = c3; }
+        uint32_t pos;
+        if (best == 0) { pos = cnt0++; wi0 |= a16; wj0 |= b16; ri0 |= a32; rj0 |= b32; }
+        else if (best == 1) { pos = 16u + cnt1++; wi1 |= a16; wj1 |= b16; ri0 |= a32; rj0 |= b32; }
+        else if (best == 2) { pos = 32u + cnt2++; wi2 |= a16; wj2 |= b16; ri1 |= a32; rj1 |= b32; }
+        else { pos = 48u + cnt3++; wi3 |= a16; wj3 |= b16; ri1 |= a32; rj1 |= b32; }
+        dst[pos] = w;
+    }
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void k_sector_sweep3(const double *__restrict__ in, double *__restrict__ out, size_t in_stride,
+                                                      size_t out_stride, const uint32_t *__restrict__ dstpad,
+                                                      const uint32_t *__restrict__ off, const uint32_t *__restrict__ rowinfo, int nruns, int nwave,
+                                                      const uint32_t *__restrict__ stream, const uint16_t *__restrict__ rowhdr,
+                                                      const RotParam *__restrict__ rp, size_t rp_stride, int rot0, int nrot, uint32_t tile_cap,
+                                                      uint32_t hf_pos, int *__restrict__ flag, int sb, int dst_lds, int bfast,
+                                                      const uint32_t *__restrict__ torder, int dbg) {
+    constexpr int G = SEC_STREAM_G;
+    static_assert(NT >= 64 * SEC_STREAM_WAVES, "the streams are planned for up to this many waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
+    double *tile = reinterpret_cast<double *>(sec_smem);
+    const uint32_t spare = tile_cap;     // one slot behind the tile: partner of the words whose partner is outside the support
+    double2 *cs = reinterpret_cast<double2 *>(tile + ((tile_cap + 2u) & ~1u));
+    uint32_t *dst = reinterpret_cast<uint32_t *>(cs + nrot);
+    const uint32_t tq = bfast ? blockIdx.y : blockIdx.x, b = bfast ? blockIdx.x : blockIdx.y;
+    const uint32_t t = torder ? torder[tq] : tq;
+    const uint32_t e0 = off[t];
+    const uint32_t n = off[t + 1] - e0;
+    if (n == 0) return;
+    const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the wave's run boundaries (lane r: first row of run r), then its first rows — ahead of the tile's loads
+    // (waves past the nwave the streams were planned for have no rows: they load, store and meet the others at the barriers)
+    const uint32_t myb = wv < (uint32_t)nwave ? rowinfo[((size_t)t * (uint32_t)nwave + wv) * (uint32_t)(nruns + 1) + min(lane, (uint32_t)nruns)] : 0u;
+    const uint32_t R0 = __builtin_amdgcn_readlane(myb, 0), R1 = __builtin_amdgcn_readlane(myb, nruns);
+    uint32_t cw[G], nw[G], ch, nh;
+#pragma unroll
+    for (int g = 0; g < G; ++g) cw[g] = stream[(size_t)(R0 + g) * 64u + lane];
+    ch = rowhdr[R0 + (lane & (G - 1))];
+    in += (size_t)b * in_stride;
+    out += (size_t)b * out_stride;
+    rp += (size_t)b * rp_stride;
+    const size_t tbase = (size_t)t * tile_cap;
+    constexpr int TB = 8;
+    for (uint32_t k0 = threadIdx.x; k0 < n; k0 += TB * NT) {
+        uint32_t d[TB];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) d[j] = dst_lds ? dstpad[tbase + min(k0 + (uint32_t)j * NT, n - 1u)] : 0u;
+        if (in) {
+            double v[TB];
+#pragma unroll
+            for (int j = 0; j < TB; ++j) v[j] = in[tbase + min(k0 + (uint32_t)j * NT, n - 1u)];
+#pragma unroll
+            for (int j = 0; j < TB; ++j)
+                if (k0 + (uint32_t)j * NT < n) tile[k0 + (uint32_t)j * NT] = v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < TB; ++j)
+                if (k0 + (uint32_t)j * NT < n) tile[k0 + (uint32_t)j * NT] = (e0 + k0 + (uint32_t)j * NT == hf_pos) ? 1.0 : 0.0;
+        }
+        if (dst_lds) {
+#pragma unroll
+            for (int j = 0; j < TB; ++j)
+                if (k0 + (uint32_t)j * NT < n) dst[k0 + (uint32_t)j * NT] = d[j];
+        }
+    }
+    for (int r0 = threadIdx.x; r0 < nrot; r0 += 2 * NT) {
+        const RotParam ra = rp[rot0 + r0], rb = rp[rot0 + min(r0 + NT, nrot - 1)];
+        cs[r0] = make_double2(ra.c, ra.s);
+        if (r0 + NT < nrot) cs[r0 + NT] = make_double2(rb.c, rb.s);
+    }
+    if (threadIdx.x == 0) tile[spare] = 0.0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    bool bad = false;
+    const uint32_t mask = (1u << sb) - 1u;
+    int rb = 1;      // next run boundary of this wave
+    uint32_t bnd = __builtin_amdgcn_readlane(myb, min(1, nruns));
+    if (dbg == 1) rb = nruns;
+    unsigned char *const lds = sec_smem;
+    for (uint32_t base = R0; base < R1 && dbg != 1; base += G) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) nw[g] = stream[(size_t)(base + G + g) * 64u + lane];   // (the tables end with 2 G rows of padding)
+        nh = rowhdr[base + G + (lane & (G - 1))];
+        // The batch decoded ahead of its rows: byte addresses of both slots, cos and signed sin — ten vector instructions a word (the
+        // first version decoded inside the row: 45 instructions per row, and a wave's rows are one dependent chain).  What is left
+        // per row is the chain itself: two LDS reads, four multiply-adds, two writes.  Empty lanes sit the row out (EXEC-masked lanes
+        // take no part in the LDS banking).  A word whose partner is outside the support (its row's header says so: the batch
+        // decodes with selects) rotates its amplitude against the spare slot by the identity, and the rows check that it is zero.
+        uint32_t ai[G], aj[G];
+        double qc[G], qn[G];
+        const bool slow = __ballot((ch & 0x8000u) != 0u) != 0ull;
+        const uint32_t pshift = 2u * (uint32_t)sb;
+        if (!slow) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const uint32_t w = base + g < R1 ? cw[g] : 0xffffffffu;
+                const uint32_t csb = __builtin_amdgcn_readlane(ch, g);
+                const double2 cr = cs[csb + ((w & 0x7fffffffu) >> pshift)];   // (an empty lane reads past the table: nothing it gets is used)
+                ai[g] = (w & mask) << 3;
+                aj[g] = ((w >> sb) & mask) << 3;
+                qc[g] = cr.x;
+                qn[g] = __hiloint2double(__double2hiint(cr.y) ^ (int)(w & 0x80000000u), __double2loint(cr.y));
+                asm volatile("" : "+v"(ai[g]), "+v"(aj[g]), "+v"(qc[g]), "+v"(qn[g]));
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const uint32_t w = base + g < R1 ? cw[g] : 0xffffffffu;
+                const uint32_t csb = __builtin_amdgcn_readlane(ch, g) & 0x7fffu;
+                const bool empty = w == 0xffffffffu;
+                const uint32_t sj = (w >> sb) & mask;
+                const bool plain = sj != mask;      // (an empty lane reads as a word without partner)
+                const double2 cr = cs[empty ? 0u : csb + ((w & 0x7fffffffu) >> pshift)];
+                ai[g] = (w & mask) << 3;
+                aj[g] = (plain ? sj : spare) << 3;
+                qc[g] = plain ? cr.x : 1.0;
+                qn[g] = plain ? ((w >> 31) ? -cr.y : cr.y) : 0.0;
+                asm volatile("" : "+v"(ai[g]), "+v"(aj[g]), "+v"(qc[g]), "+v"(qn[g]));
+            }
+        }
+        auto rows = [&](auto check) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (base + g < R1) {
+                    while (rb < nruns && base + g >= bnd) {
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        ++rb;
+                        bnd = __builtin_amdgcn_readlane(myb, min(rb, nruns));
+                    }
+                    if (ai[g] != (mask << 3)) {
+                        double *pu = reinterpret_cast<double *>(lds + ai[g]), *pv = reinterpret_cast<double *>(lds + aj[g]);
+                        const double u = *pu, v = *pv;
+                        *pu = qc[g] * u + qn[g] * v;
+                        *pv = qc[g] * v - qn[g] * u;
+                        if (decltype(check)::value) bad |= aj[g] == (spare << 3) && u != 0.0;
+                    }
+                }
+            }
+        };
+        if (slow) rows(std::true_type{});
+        else rows(std::false_type{});
+#pragma unroll
+        for (int g = 0; g < G; ++g) cw[g] = nw[g];
+        ch = nh;
+    }
+    for (; rb < nruns; ++rb) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (dst_lds) {
+        for (uint32_t k = threadIdx.x; k < n; k += NT) out[dst[k]] = tile[k];
+    } else {
+        for (uint32_t k = threadIdx.x; k < n; k += NT) out[dstpad[tbase + k]] = tile[k];
+    }
+    if (bad) atomicOr(flag, 1);
+}
 // scatter indices of a sweep: where every entry of its order sits in the NEXT sweep's tile-padded order
 // (dstc[p], p = position in this sweep's order; src_next / off_next / cap_next describe the next sweep) ...
 __global__ __launch_bounds__(256) void k_sec_dst_compact(const uint32_t *__restrict__ src_next, const uint32_t *__restrict__ off_next,
