@@ -341,7 +341,7 @@ struct ovqe_sv {
     int opt_sector_sweep_dbg = 0; // measurements only, k_sector_sweep2: 1 no ops, 2 empty kernel, 3 loads only — wrong results
     int opt_sector_h_groups = 256; // workgroups per <H> sweep (they share the sweep's tiles round robin)
     int opt_sector_h_dbg = 0;     // measurements only, k_sector_expect: 1 tile loads only, 2 no tile loads, 3 metadata only — wrong results
-    int opt_sector_adjoint = 2;   // backward sweeps of the gradient: 2 = on the 64-bit tables (k_sector_adjoint2) where they exist and fit; 1 = first form
+    int opt_sector_adjoint = 3;   // backward sweeps of the gradient: 3 = on the per-wave streams (k_sector_adjoint3) where a sweep has them; 2 = on the 64-bit tables (k_sector_adjoint2) where they exist and fit; 1 = first form
     int opt_sector_apply_threads = 0; // threads per workgroup of k_sector_apply (0 = automatic, 512, 1024)
     int opt_sector_h_threads = 512; // threads per workgroup of k_sector_expect (512 or 1024)
     int opt_sector_row_banks = 0; // materialised <H>: the elements of every row ordered against LDS bank conflicts (k_sec_row_banks)
@@ -3255,7 +3255,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     else if (k == "sector_h_groups") h->opt_sector_h_groups = (int)value;
     else if (k == "sector_h_dbg") h->opt_sector_h_dbg = (int)value;
 #endif
-    else if (k == "sector_adjoint") h->opt_sector_adjoint = value == 1 ? 1 : 2;
+    else if (k == "sector_adjoint") h->opt_sector_adjoint = value == 1 ? 1 : (value == 2 ? 2 : 3);
 #ifdef OVQE_TESTING
     else if (k == "sector_apply_threads") h->opt_sector_apply_threads = value == 1024 ? 1024 : (value == 512 ? 512 : 0);
     else if (k == "sector_h_threads") h->opt_sector_h_threads = value == 1024 ? 1024 : 512;

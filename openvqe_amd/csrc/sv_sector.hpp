@@ -780,7 +780,7 @@ __global__ __launch_bounds__(NT) void k_sector_sweep2(const double *__restrict__
 //   stream of (tile, wave): ROWS of 64 32-bit pair words (slot_i | slot_j << sb | pattern << 2 sb | sign << 31 — the first form's
 //   fields with the sign moved to where it is xor-ed into the sine; 0xffffffff: empty lane), one op per row (an op with more than 64
 //   pairs in the wave's classes takes several), rows in op order; rowhdr[row] = first cos/sin entry of the row's op (bit 15: the op
-//   has a word in this wave whose partner is outside the support); rowinfo[(tile, wave)][r] = first row of run r (r = nruns: the end).
+//   has a word in this wave whose partner is outside the support, bit 14: words of more than one pattern); rowinfo[(tile, wave)][r] = first row of run r (r = nruns: the end).
 //   Rows are loaded SEC_STREAM_G at a time, the next batch in flight while this one is applied.
 constexpr int SEC_STREAM_WAVES = 16;     // waves per workgroup the streams are planned for (k_sector_sweep3<1024>)
 constexpr int SEC_STREAM_G = 8;          // rows per batch
@@ -801,7 +801,7 @@ __global__ __launch_bounds__(256) void k_sec_wave_plan(const uint32_t *__restric
     constexpr int NC = 1 << SEC_STREAM_CLASS_BITS;
     extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
     uint8_t *own = sec_smem;     // [tile population]: class, then wave, of every slot
-    __shared__ uint32_t ccount[NC], wcnt[SEC_STREAM_WAVES], worph[SEC_STREAM_WAVES];
+    __shared__ uint32_t ccount[NC], wcnt[SEC_STREAM_WAVES], worph[SEC_STREAM_WAVES], wpatm[SEC_STREAM_WAVES];
     const int NW = nw;           // waves that work on the rows (a power of two up to SEC_STREAM_WAVES)
     __shared__ uint8_t wofc[NC];
     const uint32_t t = blockIdx.x, e0 = off[t], n = off[t + 1] - e0;
@@ -847,6 +847,7 @@ __global__ __launch_bounds__(256) void k_sec_wave_plan(const uint32_t *__restric
             if ((int)threadIdx.x < NW) {
                 wcnt[threadIdx.x] = 0;
                 worph[threadIdx.x] = 0;
+                wpatm[threadIdx.x] = 0;
             }
             __syncthreads();
             for (uint32_t k = po[o] + threadIdx.x; k < po[o + 1]; k += 256u) {
@@ -856,6 +857,7 @@ __global__ __launch_bounds__(256) void k_sec_wave_plan(const uint32_t *__restric
                     stream[(size_t)rowoff[((size_t)t * NW + w) * (nops + 1) + o] * 64u + rank] =
                         (pw & ((1u << (2 * sb)) - 1u)) | ((pw >> (2 * sb + 1)) << (2 * sb)) | (((pw >> (2 * sb)) & 1u) << 31);
                     if (((pw >> sb) & mask) == mask) worph[w] = 1u;
+                    atomicOr(&wpatm[w], 1u << min(pw >> (2 * sb + 1), 31u));
                 }
             }
             __syncthreads();
@@ -865,7 +867,8 @@ __global__ __launch_bounds__(256) void k_sec_wave_plan(const uint32_t *__restric
                     oprows[q * nops + o] = (wcnt[threadIdx.x] + 63u) >> 6;
                 } else {
                     for (uint32_t rw = rowoff[q * (nops + 1) + o]; rw < rowoff[q * (nops + 1) + o + 1]; ++rw)
-                        rowhdr[rw] = (uint16_t)((uint32_t)(tab0[o] - rot0) | (worph[threadIdx.x] ? 0x8000u : 0u));
+                        rowhdr[rw] = (uint16_t)((uint32_t)(tab0[o] - rot0) | (worph[threadIdx.x] ? 0x8000u : 0u) |
+                                                (__popc(wpatm[threadIdx.x]) > 1 ? 0x4000u : 0u));
                 }
             }
         }
@@ -994,7 +997,7 @@ __global__ __launch_bounds__(NT) void k_sector_sweep3(const double *__restrict__
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const uint32_t w = base + g < R1 ? cw[g] : 0xffffffffu;
-                const uint32_t csb = __builtin_amdgcn_readlane(ch, g);
+                const uint32_t csb = __builtin_amdgcn_readlane(ch, g) & 0x3fffu;
                 const double2 cr = cs[csb + ((w & 0x7fffffffu) >> pshift)];   // (an empty lane reads past the table: nothing it gets is used)
                 ai[g] = (w & mask) << 3;
                 aj[g] = ((w >> sb) & mask) << 3;
@@ -1006,7 +1009,7 @@ __global__ __launch_bounds__(NT) void k_sector_sweep3(const double *__restrict__
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const uint32_t w = base + g < R1 ? cw[g] : 0xffffffffu;
-                const uint32_t csb = __builtin_amdgcn_readlane(ch, g) & 0x7fffu;
+                const uint32_t csb = __builtin_amdgcn_readlane(ch, g) & 0x3fffu;
                 const bool empty = w == 0xffffffffu;
                 const uint32_t sj = (w >> sb) & mask;
                 const bool plain = sj != mask;      // (an empty lane reads as a word without partner)
@@ -2407,6 +2410,171 @@ __device__ __forceinline__ double sec_reduce8(const double (&c)[8]) {
         t1 += __hiloint2double(hi, lo);
     }
     return t1;
+}
+// Backward sweep on the streams of the third form (k_sector_sweep3): a wave walks its rows from the last to the first, workgroup
+// barriers at the run boundaries only.  A row is one op (usually one table entry: its header says when not), so the gradient terms
+// sigma (lambda_i psi_j - lambda_j psi_i) of a BATCH of eight rows are summed over the wave together — a reduce-scatter (ten
+// additions for eight sums, sec_reduce8) whose four partial totals per entry are added to the wave's row of partial sums by LDS
+// atomics (rows of the same op share an entry).  psi / lambda come and go as in k_sector_adjoint2.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_sector_adjoint3(const double *__restrict__ psi_in, const double *__restrict__ lam_in,
+                                                        double *__restrict__ psi_out, double *__restrict__ lam_out, int in_compact,
+                                                        const uint32_t *__restrict__ bdst, const uint32_t *__restrict__ off,
+                                                        const uint32_t *__restrict__ rowinfo, int nruns, int nwave,
+                                                        const uint32_t *__restrict__ stream, const uint16_t *__restrict__ rowhdr,
+                                                        const RotParam *__restrict__ rp, int rot0, int nrot, uint32_t tile_cap,
+                                                        double *__restrict__ wpart, int wstride, int sb) {
+    constexpr int G = SEC_STREAM_G;
+    static_assert(G == 8, "the batch's gradient terms are reduced eight rows at a time");
+    extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
+    const uint32_t capp = (tile_cap + 2u) & ~1u;
+    double *tp = reinterpret_cast<double *>(sec_smem);
+    double *tl = tp + capp;
+    double2 *cs = reinterpret_cast<double2 *>(tl + capp);
+    double *wacc = reinterpret_cast<double *>(cs + nrot);   // [nwave][nrot]
+    uint32_t *dst = reinterpret_cast<uint32_t *>(wacc + (size_t)nwave * nrot);
+    const uint32_t t = blockIdx.x;
+    const uint32_t e0 = off[t];
+    const uint32_t n = off[t + 1] - e0;
+    if (n == 0) return;
+    const uint32_t lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t myb = wv < (uint32_t)nwave ? rowinfo[((size_t)t * (uint32_t)nwave + wv) * (uint32_t)(nruns + 1) + min(lane, (uint32_t)nruns)] : 0u;
+    const uint32_t R0 = __builtin_amdgcn_readlane(myb, 0), R1 = __builtin_amdgcn_readlane(myb, nruns);
+    const int nb = (int)((R1 - R0 + (uint32_t)G - 1u) / (uint32_t)G);   // batches, aligned from the wave's first row
+    uint32_t cw[G], nw[G], ch, nh;
+    {
+        const uint32_t bs = R0 + (uint32_t)(nb ? nb - 1 : 0) * G;
+#pragma unroll
+        for (int g = 0; g < G; ++g) cw[g] = stream[(size_t)(bs + g) * 64u + lane];
+        ch = rowhdr[bs + (lane & (G - 1))];
+    }
+    const size_t tbase = (size_t)t * tile_cap, ibase = in_compact ? (size_t)e0 : tbase;
+    constexpr int TB = 4;
+    for (uint32_t k0 = threadIdx.x; k0 < n; k0 += TB * NT) {
+        uint32_t d[TB];
+        double u[TB], v[TB];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const uint32_t k = min(k0 + (uint32_t)j * NT, n - 1u);
+            d[j] = bdst ? bdst[tbase + k] : 0u;
+            u[j] = psi_in[ibase + k];
+            v[j] = lam_in[ibase + k];
+        }
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const uint32_t k = k0 + (uint32_t)j * NT;
+            if (k < n) {
+                tp[k] = u[j];
+                tl[k] = v[j];
+                dst[k] = d[j];
+            }
+        }
+    }
+    for (int r0 = threadIdx.x; r0 < nrot; r0 += NT) {
+        const RotParam ra = rp[rot0 + r0];
+        cs[r0] = make_double2(ra.c, ra.s);
+    }
+    for (int r0 = threadIdx.x; r0 < nwave * nrot; r0 += NT) wacc[r0] = 0.0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    double *mine = wacc + (size_t)min(wv, (uint32_t)nwave - 1u) * nrot;
+    const uint32_t mask = (1u << sb) - 1u, pshift = 2u * (uint32_t)sb;
+    unsigned char *const pb = reinterpret_cast<unsigned char *>(tp);
+    const uint32_t loff = capp * (uint32_t)sizeof(double);   // lambda's tile behind psi's
+    int rb = nruns - 1;      // next run boundary below this wave's current row
+    uint32_t bnd = __builtin_amdgcn_readlane(myb, max(rb, 0));
+    for (int b = nb - 1; b >= 0; --b) {
+        const uint32_t bs = R0 + (uint32_t)b * G, ps = b ? bs - G : bs;
+#pragma unroll
+        for (int g = 0; g < G; ++g) nw[g] = stream[(size_t)(ps + g) * 64u + lane];   // the batch below: in flight while this one is applied
+        nh = rowhdr[ps + (lane & (G - 1))];
+        uint32_t ai[G], aj[G];
+        double qc[G], qn[G], gq[G];
+        const bool slow = __ballot((ch & 0xc000u) != 0u) != 0ull;   // a row with words of several entries, or without partner: sums per row
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint32_t w = bs + g < R1 ? cw[g] : 0xffffffffu;
+            const uint32_t csb = __builtin_amdgcn_readlane(ch, g) & 0x3fffu;
+            const bool live = ((w >> sb) & mask) != mask;      // (an empty lane reads as a word without partner; neither has a term)
+            const double2 cr = cs[live ? csb + ((w & 0x7fffffffu) >> pshift) : 0u];
+            ai[g] = (w & mask) << 3;
+            aj[g] = ((w >> sb) & mask) << 3;
+            qc[g] = cr.x;
+            qn[g] = __hiloint2double(__double2hiint(cr.y) ^ (int)(w & 0x80000000u), __double2loint(cr.y));
+            gq[g] = 0.0;
+            asm volatile("" : "+v"(ai[g]), "+v"(aj[g]), "+v"(qc[g]), "+v"(qn[g]));
+        }
+        auto rows = [&](auto per_row) {
+#pragma unroll
+            for (int g = G - 1; g >= 0; --g) {
+                if (bs + g < R1) {
+                    while (rb >= 1 && bs + g < bnd) {
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        --rb;
+                        bnd = __builtin_amdgcn_readlane(myb, max(rb, 0));
+                    }
+                    const bool live = aj[g] != (mask << 3);
+                    double gg = 0.0;
+                    if (live) {
+                        double *pu = reinterpret_cast<double *>(pb + ai[g]), *pv = reinterpret_cast<double *>(pb + aj[g]);
+                        double *lu_ = reinterpret_cast<double *>(pb + loff + ai[g]), *lv_ = reinterpret_cast<double *>(pb + loff + aj[g]);
+                        const double u1 = *pu, v1 = *pv, lu = *lu_, lv = *lv_;
+                        const double t0 = lu * v1 - lv * u1;
+                        gg = __hiloint2double(__double2hiint(t0) ^ (int)(cw[g] & 0x80000000u), __double2loint(t0));
+                        *pu = qc[g] * u1 - qn[g] * v1;
+                        *pv = qc[g] * v1 + qn[g] * u1;
+                        *lu_ = qc[g] * lu - qn[g] * lv;
+                        *lv_ = qc[g] * lv + qn[g] * lu;
+                    }
+                    if (decltype(per_row)::value) {   // the row's terms by table entry
+                        const uint32_t ent = (__builtin_amdgcn_readlane(ch, g) & 0x3fffu) + ((cw[g] & 0x7fffffffu) >> pshift);
+                        uint64_t todo = __ballot(live);
+                        while (todo) {
+                            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ent, __ffsll((long long)todo) - 1);
+                            const bool m = live && ent == e;
+                            const double tsum = sec_wave_sum63(m ? gg : 0.0);
+                            if (lane == 63u) mine[e] += tsum;
+                            todo &= ~__ballot(m);
+                        }
+                    } else {
+                        gq[g] = gg;
+                    }
+                }
+            }
+        };
+        if (slow) {
+            rows(std::true_type{});
+        } else {
+            rows(std::false_type{});
+            // eight rows' sums at once; lane l with bit 3 clear holds, for its 16 lanes, the total of row 4 b0 + 2 b1 + b2 (b = bits of l)
+            const double tot = sec_reduce8(gq);
+            uint32_t ent = 0;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const uint32_t eg = bs + g < R1 ? (__builtin_amdgcn_readlane(ch, g) & 0x3fffu) + ((__builtin_amdgcn_readlane(cw[g], 0) & 0x7fffffffu) >> pshift) : 0u;
+                const int L = ((g & 1) << 2) | (g & 2) | ((g & 4) >> 2);   // the lanes (mod 8) that hold row g's total
+                ent = (lane & 7u) == (uint32_t)L ? eg : ent;
+            }
+            if (!(lane & 8u) && tot != 0.0) __hip_atomic_fetch_add(&mine[ent], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) cw[g] = nw[g];
+        ch = nh;
+    }
+    for (; rb >= 1; --rb) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __syncthreads();
+    double *wout = wpart + (size_t)t * wstride + rot0;   // [tile][table entry], zeroed by the host
+    for (int r = threadIdx.x; r < nrot; r += NT) {
+        double tsum = 0.0;
+        for (int w = 0; w < nwave; ++w) tsum += wacc[(size_t)w * nrot + r];
+        wout[r] = tsum;
+    }
+    if (bdst) {
+        for (uint32_t k = threadIdx.x; k < n; k += NT) {
+            const uint32_t d = dst[k];
+            psi_out[d] = tp[k];
+            lam_out[d] = tl[k];
+        }
+    }
 }
 constexpr int SEC_REG_WROWS = 4;   // rows of 16 lanes per wave: each stores its own eight totals (summed over rows and waves at the flush)
 __device__ __forceinline__ void sec_reg_wstore(double *__restrict__ wslot, const double (&acc)[8]) {   // this wave's 4 x 8 totals

@@ -40,10 +40,13 @@ for m, o in cases:
             sv.set_option("sector_sweep_dbg", 0)
         print("  energies equal bit for bit:", es[3] == es[2], es[3] - es[2])
         sv.set_option("sector_profile", 0)
+        gs = {}
         for sweep in (3, 2):
             sv.set_option("sector_sweep", sweep)
             e, g = sv.energy_gradient(theta)
+            gs[sweep] = g
             t0 = time.perf_counter()
             for _ in range(5):
                 e, g = sv.energy_gradient(theta)
             print(f"  form {sweep}: gradient {1e3 * (time.perf_counter() - t0) / 5:.3f} ms, |g| {np.linalg.norm(g):.12f}")
+        print("  gradients: max |g3 - g2| =", np.abs(gs[3] - gs[2]).max())
