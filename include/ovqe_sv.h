@@ -132,7 +132,8 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  *                     16 qubits in one fused launch on the compact support; 0: the streaming adjoint pass), "sparse_renumber" (1)
  *   sector path: "sector_bits" / "sector_h_bits" (index bits per circuit / <H> tile, 0 automatic), "sector_tile_cap" (6500 amplitudes per
  *                     circuit tile so that gradients fit; up to 14000 for energies only), "sector_threads" (0 automatic, 64, 256, 512,
- *                     1024), "sector_adjoint" (2 / 1), "sector_dict" (1: dictionary-coded matrix elements, dictionary from a sample of the
+ *                     1024), "sector_adjoint" (backward sweeps of the gradient: 3 on the per-wave streams where a sweep has them, 2 on the 64-bit
+ *                     pair tables, 1 first form), "sector_dict" (1: dictionary-coded matrix elements, dictionary from a sample of the
  *                     stream first; 2: from all values; 3: from a sample too thin to be complete — the fall-back, tests; 0: explicit values),
  *                     "sector_reg_threads" (256; 128, 512, 1024), "sector_reg_pairs" (1: blocks of two three-bit ops), "sector_reg_runs"
  *                     (1: runs of ops whose waves stay inside their own slots run without barriers), "sector_pairs_form" (2: pair-table
@@ -147,7 +148,11 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  *   program was left to the dense kernels; 4: wall time of the build's phases), "sector_sweep_dbg" / "sector_h_dbg" / "sparse_dbg" (kernels
  *   truncated after a given phase), "rot_variant", and the launch geometries and superseded forms kept for comparison: "unroll",
  *   "ham_tile_low", "expect_sparse", "expect_streams", "persist_blocks", "compact_cpp", "small_threads", "sparse_rows", "sparse_wg",
- *   "sparse_spw", "sparse_dealias", "sector_sweep", "sector_chunk", "sector_depth2", "sector_many_tiles",
+ *   "sparse_spw", "sparse_dealias", "sector_sweep" (circuit sweeps on an irregular support: 3 pair words in per-wave streams with barriers at
+ *   run boundaries only — built on top of the tables of 2 —, 2 64-bit pair words in registers with a barrier per round, 1 first form; 2 on a
+ *   handle built under 3 runs the second form on the same tables), "sector_stream_waves" (0: waves that share a tile's rows from the pairs per
+ *   op of the sweep's largest tile; 1, 2, 4, 8, 16), "sector_stream_arrange" (1: the lanes of a row chosen for the LDS banks), "sector_chunk",
+ *   "sector_depth2", "sector_many_tiles",
  *   "sector_h_lpt", "sector_h_threads", "sector_h_groups", "sector_apply_threads", "sector_row_banks", "sector_eager_rots",
  *   "screen_tables", "sector_batch_threads" / "_nb" / "_sweep_threads" / "_dst_lds" / "_zfast", "tile_flat" (tiled <H>: entries of one
  *   or two merged terms as per-lane items 1 / per-wave entries 0 / items for real states only 2, the default), "sector_apply_seq" (1: lambda = H psi on the sector tables runs one launch per sweep in sequence with plain

@@ -664,3 +664,49 @@ def test_gate_list_takes_the_coset_without_a_probe_and_is_checked(SV):
         sv.set_hamiltonian(ham)
         sv.set_ucc_program(picked, hf)
         assert abs(sv.energy(theta_b) - out["staircase_uccsd"][1]) < 1e-11 * max(1.0, l1)
+
+
+@pytest.fixture
+def testing_lib(gpu_lib, monkeypatch):
+    """the OVQE_TESTING build of the same source: it also takes the options that pick a kernel form"""
+    from openvqe_amd import _lib
+    monkeypatch.setattr(_lib, "LIB_PATH", _lib.TESTING_LIB_PATH)
+    monkeypatch.setattr(_lib, "_lib", None)
+    return _lib.lib()
+
+
+@pytest.mark.parametrize("m,o,waves,arrange", [(8, 3, 0, 1), (8, 3, 1, 0), (8, 4, 2, 1), (9, 4, 0, 1), (9, 4, 4, 0), (9, 4, 16, 1), (10, 5, 8, 1)])
+def test_per_wave_streams_equal_the_second_sweep_form_bit_for_bit(testing_lib, m, o, waves, arrange):
+    """third form of the circuit sweeps (k_sector_sweep3 / k_sector_adjoint3: pair words in per-wave streams, barriers at run boundaries
+    only) against the second form ON THE SAME TABLES: a pair is rotated by the same arithmetic in both, every slot sees its ops in
+    program order, so the energies are equal bit for bit, whatever the number of waves that share a tile's rows and whether the lanes
+    of a row were arranged for the LDS banks; the gradient's partial sums are added in another order (1e-12); both against the oracle"""
+    from openvqe_amd import fermion
+    from openvqe_amd.backend import Statevector
+    n = 2 * m
+    ham, gens, hf = fermion.synthetic_molecule(m, o, seed=300 + m)
+    rng = np.random.default_rng(31 * m + o)
+    thetas = [rng.uniform(-0.3, 0.3, len(gens)) for _ in range(3)]
+    want = _oracle_energies(n, gens, hf, ham, thetas)
+    l1 = float(np.abs(ham.packed()[2]).sum())
+    with Statevector(n) as sv:
+        sv.set_option("force_path", 2)
+        sv.set_option("sector_min_qubits", 8)
+        sv.set_option("sector_stream_waves", waves)
+        sv.set_option("sector_stream_arrange", arrange)
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, hf)
+        for th in thetas:
+            sv.energy(th)                       # (the tables are built at the second evaluation)
+        got, grad = {}, {}
+        for form in (3, 2):
+            sv.set_option("sector_sweep", form)
+            sv.set_option("sector_adjoint", form)
+            got[form] = [sv.energy(th) for th in thetas]
+            grad[form] = [sv.energy_gradient(th) for th in thetas]
+        batch = sv.energy_batch(np.stack(thetas))
+    assert got[3] == got[2]
+    for (e3, g3), (e2, g2), ew in zip(grad[3], grad[2], want):
+        assert abs(e3 - ew) < 1e-10 * max(1.0, l1) and abs(e3 - e2) < 1e-13 * max(1.0, l1)    # (the gradient's energy is a dot product with lambda)
+        assert np.abs(g3 - g2).max() < 1e-12 * max(1.0, l1)
+    assert np.abs(batch - np.array(want)).max() < 1e-10 * max(1.0, l1)
