@@ -795,85 +795,106 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void k_sec_wave_plan(const uint32_t *__restrict__ sup, const uint32_t *__restrict__ cid,
                                                        const uint32_t *__restrict__ off, const uint32_t *__restrict__ pairs,
                                                        const uint32_t *__restrict__ poff, int nops, const int32_t *__restrict__ tab0, int rot0,
-                                                       const SecWaveRun *__restrict__ runs, int nruns, int sb, int nw, uint32_t *__restrict__ oprows,
-                                                       const uint32_t *__restrict__ rowoff, uint8_t *__restrict__ wof,
-                                                       uint32_t *__restrict__ stream, uint16_t *__restrict__ rowhdr) {
+                                                       const SecWaveRun *__restrict__ runs, int nruns, int sb, int nw, uint32_t cap,
+                                                       uint32_t *__restrict__ oprows, const uint32_t *__restrict__ rowoff,
+                                                       uint8_t *__restrict__ wof, uint32_t *__restrict__ stream, uint16_t *__restrict__ rowhdr) {
     constexpr int NC = 1 << SEC_STREAM_CLASS_BITS;
+    static_assert(NC == 64, "the classes are dealt to the waves by the 64 lanes of one wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char sec_smem[];
-    uint8_t *own = sec_smem;     // [tile population]: class, then wave, of every slot
-    __shared__ uint32_t ccount[NC], wcnt[SEC_STREAM_WAVES], worph[SEC_STREAM_WAVES], wpatm[SEC_STREAM_WAVES];
     const int NW = nw;           // waves that work on the rows (a power of two up to SEC_STREAM_WAVES)
+    uint32_t *bas = reinterpret_cast<uint32_t *>(sec_smem);   // [cap] basis index of every slot
+    uint32_t *lpo = bas + cap;                                 // [nops + 1] the tile's pair offsets
+    uint32_t *wcnt = lpo + nops + 1;                           // [nops][NW] pair words of (op, wave)
+    uint32_t *wflag = wcnt + (size_t)nops * NW;                // [nops][NW] bit 31: a word without partner; bits 0..30: patterns seen (30: that or beyond)
+    uint8_t *own = reinterpret_cast<uint8_t *>(wflag + (size_t)nops * NW);   // [cap] class, then wave, of every slot
+    __shared__ uint32_t ccount[NC];
     __shared__ uint8_t wofc[NC];
     const uint32_t t = blockIdx.x, e0 = off[t], n = off[t + 1] - e0;
-    const uint32_t *po = poff + (size_t)t * (nops + 1);
     const uint32_t mask = (1u << sb) - 1u;
+    for (uint32_t k0 = threadIdx.x; k0 < n; k0 += 4u * 256u) {   // (one trip per four slots of a thread)
+        uint32_t c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = cid[e0 + min(k0 + (uint32_t)j * 256u, n - 1u)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = sup[c[j]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + (uint32_t)j * 256u < n) bas[k0 + (uint32_t)j * 256u] = c[j];
+    }
+    for (int o = threadIdx.x; o <= nops; o += 256) lpo[o] = poff[(size_t)t * (nops + 1) + o];
+    for (int i = threadIdx.x; i < nops * NW; i += 256) {
+        wcnt[i] = 0;
+        wflag[i] = 0;
+    }
+    __syncthreads();
     int o0 = 0;
     for (int r = 0; r < nruns; ++r) {
         const int o1 = runs[r].op_end;
         const uint32_t cmask = runs[r].cmask;
         if (threadIdx.x < NC) ccount[threadIdx.x] = 0;
-        for (uint32_t k = threadIdx.x; k < n; k += 256u) own[k] = (uint8_t)sec_pext(sup[cid[e0 + k]], cmask);
+        for (uint32_t k = threadIdx.x; k < n; k += 256u) own[k] = (uint8_t)sec_pext(bas[k], cmask);
         __syncthreads();
         uint8_t *wo = wof + ((size_t)t * nruns + r) * NC;
         if (!FILL) {
-            for (uint32_t k = po[o0] + threadIdx.x; k < po[o1]; k += 256u) atomicAdd(&ccount[own[pairs[k] & mask]], 1u);
+            for (uint32_t k = lpo[o0] + threadIdx.x; k < lpo[o1]; k += 256u) atomicAdd(&ccount[own[pairs[k] & mask]], 1u);
             __syncthreads();
-            if (threadIdx.x == 0) {   // classes to waves: largest first onto the wave with the fewest pairs so far
-                uint32_t load[SEC_STREAM_WAVES];
-                for (int w = 0; w < NW; ++w) load[w] = 0;
+            if (threadIdx.x < 64u) {   // classes to waves: largest first onto the wave with the fewest pairs so far (ties: lowest class, lowest wave)
+                const uint32_t lane = threadIdx.x;
+                unsigned long long key = (((unsigned long long)ccount[lane] + 1ull) << 6) | (63u - lane);   // 0 once the class has its wave
+                uint32_t load = 0, myw = 0;
                 for (int it = 0; it < NC; ++it) {
-                    int best = -1;
-                    uint32_t bc = 0;
-                    for (int c = 0; c < NC; ++c)
-                        if (ccount[c] != 0xffffffffu && (best < 0 || ccount[c] > bc)) {
-                            best = c;
-                            bc = ccount[c];
-                        }
-                    int w0 = 0;
-                    for (int w = 1; w < NW; ++w)
-                        if (load[w] < load[w0]) w0 = w;
-                    load[w0] += bc;
-                    wofc[best] = (uint8_t)w0;
-                    ccount[best] = 0xffffffffu;
+                    unsigned long long kmax = key;
+                    for (int d = 32; d; d >>= 1) {
+                        const unsigned long long other = __shfl_xor(kmax, d);
+                        kmax = other > kmax ? other : kmax;
+                    }
+                    const uint32_t best = 63u - (uint32_t)(kmax & 63ull), bc = (uint32_t)(kmax >> 6) - 1u;
+                    unsigned long long kmin = (int)lane < NW ? (((unsigned long long)load << 6) | lane) : ~0ull;
+                    for (int d = 32; d; d >>= 1) {
+                        const unsigned long long other = __shfl_xor(kmin, d);
+                        kmin = other < kmin ? other : kmin;
+                    }
+                    const uint32_t w0 = (uint32_t)(kmin & 63ull);
+                    if (lane == w0) load += bc;
+                    if (lane == best) {
+                        myw = w0;
+                        key = 0ull;
+                    }
                 }
-                for (int c = 0; c < NC; ++c) wo[c] = wofc[c];
+                wofc[lane] = (uint8_t)myw;
+                wo[lane] = (uint8_t)myw;
             }
         } else if (threadIdx.x < NC) {
             wofc[threadIdx.x] = wo[threadIdx.x];
         }
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < n; k += 256u) own[k] = wofc[own[k]];
-        for (int o = o0; o < o1; ++o) {
-            if ((int)threadIdx.x < NW) {
-                wcnt[threadIdx.x] = 0;
-                worph[threadIdx.x] = 0;
-                wpatm[threadIdx.x] = 0;
-            }
-            __syncthreads();
-            for (uint32_t k = po[o] + threadIdx.x; k < po[o + 1]; k += 256u) {
+        __syncthreads();
+        for (int o = o0; o < o1; ++o) {   // (every (op, wave) has its own counter: nothing to wait for between the ops)
+            for (uint32_t k = lpo[o] + threadIdx.x; k < lpo[o + 1]; k += 256u) {
                 const uint32_t pw = pairs[k], w = own[pw & mask];
-                const uint32_t rank = atomicAdd(&wcnt[w], 1u);
+                const uint32_t rank = atomicAdd(&wcnt[o * NW + w], 1u);
                 if (FILL) {
                     stream[(size_t)rowoff[((size_t)t * NW + w) * (nops + 1) + o] * 64u + rank] =
                         (pw & ((1u << (2 * sb)) - 1u)) | ((pw >> (2 * sb + 1)) << (2 * sb)) | (((pw >> (2 * sb)) & 1u) << 31);
-                    if (((pw >> sb) & mask) == mask) worph[w] = 1u;
-                    atomicOr(&wpatm[w], 1u << min(pw >> (2 * sb + 1), 31u));
-                }
-            }
-            __syncthreads();
-            if ((int)threadIdx.x < NW) {
-                const size_t q = (size_t)t * NW + threadIdx.x;
-                if (!FILL) {
-                    oprows[q * nops + o] = (wcnt[threadIdx.x] + 63u) >> 6;
-                } else {
-                    for (uint32_t rw = rowoff[q * (nops + 1) + o]; rw < rowoff[q * (nops + 1) + o + 1]; ++rw)
-                        rowhdr[rw] = (uint16_t)((uint32_t)(tab0[o] - rot0) | (worph[threadIdx.x] ? 0x8000u : 0u) |
-                                                (__popc(wpatm[threadIdx.x]) > 1 ? 0x4000u : 0u));
+                    atomicOr(&wflag[o * NW + w], ((((pw >> sb) & mask) == mask) ? 0x80000000u : 0u) | (1u << min(pw >> (2 * sb + 1), 30u)));
                 }
             }
         }
         __syncthreads();
         o0 = o1;
+    }
+    for (int i = threadIdx.x; i < nops * NW; i += 256) {
+        const int o = i / NW, w = i - o * NW;
+        const size_t q = (size_t)t * NW + w;
+        if (!FILL) {
+            oprows[q * nops + o] = (wcnt[i] + 63u) >> 6;
+        } else {
+            const uint32_t fl = wflag[i];
+            const uint16_t hd = (uint16_t)((uint32_t)(tab0[o] - rot0) | ((fl >> 31) ? 0x8000u : 0u) |
+                                           ((__popc(fl & 0x7fffffffu) > 1 || (fl & 0x40000000u)) ? 0x4000u : 0u));
+            for (uint32_t rw = rowoff[q * (nops + 1) + o]; rw < rowoff[q * (nops + 1) + o + 1]; ++rw) rowhdr[rw] = hd;
+        }
     }
 }
 // Lanes of a row chosen for the LDS banks (MI355X: a 64-bit read is served in two groups of 32 lanes over 64 dword banks, a 64-bit write in
