@@ -612,6 +612,20 @@ def test_differential_fuzz_of_the_sector_path(gpu_lib):
     assert regular >= 5, tail      # the regular-support kernels were among the draws
 
 
+def test_differential_fuzz_with_the_per_wave_streams_forced(gpu_lib):
+    """the same tool on the testing build (OVQE_LIB=testing), 30 cases: the draws add the third sweep form's streams forced on small
+    tiles — 1 to 16 waves per tile, lanes of a row arranged for the LDS banks or in list order, words without partner, ops of several
+    patterns (single-string and multi-term generators) — and the first / second forms, forwards and backwards"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_sector.py"), "30", "77"], capture_output=True, text=True,
+                       timeout=900, cwd=root, env=dict(os.environ, OVQE_LIB="testing"))
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-2000:]
+    assert r.returncode == 0 and "MISMATCH" not in r.stdout, tail
+
+
 def test_gate_list_takes_the_coset_without_a_probe_and_is_checked(SV):
     """A gate list in frame form gets its sector tables on the coset of its Z2 symmetries WITHOUT a probe run (the reference's QUCCSD
     templates fill that coset: ref:openvqe/common_files/circuit.py:13-106); the build then checks with one evaluation at generic

@@ -1,7 +1,8 @@
 """Differential fuzzing of the sector path (tests/test_gpu_sector.py runs 40 cases of it; more by hand): random UCC-type programs at 14..20
 qubits (subsets and random orders of UCCSD generators, single-string generators on few supports, multi-term generators that
 fuse to several patterns), JW two-body or random low-weight Hamiltonians, random tile geometry / workgroup sizes / coding:
-energies and gradients of the sector path against the dense-state kernels of the same handle.
+energies and gradients of the sector path against the dense-state kernels of the same handle.  With OVQE_LIB=testing the draws include
+the per-wave streams of the third sweep form (forced wave counts, lanes arranged or not) and the superseded sweep forms.
 usage: python tools/fuzz_sector.py [cases] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -84,6 +85,13 @@ for case in range(cases):
             "sector_reg_pairs": int(rng.random() < 0.7), "sector_reg_threads": int(rng.choice([128, 256, 512])),
             "sector_reg_adjoint": int(rng.random() < 0.8), "sector_regular": int(rng.choice([1, 1, 1, 3, 0])),
             "sector_reg_runs": int(rng.random() < 0.75)}
+    if os.environ.get("OVQE_LIB") == "testing":   # the testing build also takes the options that pick a kernel form: per-wave streams
+        # (third sweep form) forced on tiles the product would leave to the second form, over the waves that share a tile's rows
+        opts.update({"sector_stream_waves": int(rng.choice([0, 1, 2, 4, 8, 16])), "sector_stream_arrange": int(rng.random() < 0.5),
+                     "sector_sweep": int(rng.choice([3, 3, 3, 2, 1])), "sector_adjoint": int(rng.choice([3, 3, 2, 1]))})
+        if rng.random() < 0.6:
+            opts["sector_threads"] = int(rng.choice([0, 1024]))      # (the streams are for 1024-thread workgroups)
+            opts["sector_regular"] = 0
     scale = max(1.0, float(np.abs(ham.packed()[2]).sum()))
     with Statevector(n) as sv:
         sv.set_option("force_path", 2)
