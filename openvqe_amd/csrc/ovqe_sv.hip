@@ -165,6 +165,7 @@ struct SectorHSweep {   // one sweep of the materialised <H>
     SectorLayout L;
     uint64_t nnz = 0;
     int ndict = 0;          // magnitudes in the sweep's dictionary (0: the coded stream keeps explicit values)
+    int packed = 0;         // 1: the coded words are stored as 24-bit elements
     DevBuf d_cbase, d_clen, d_cwords, d_cvals, d_dict, d_xbase, d_xlen, d_xwords, d_xvals, d_order;   // row format (sv_sector.hpp)
     DevBuf d_torder;              // tiles by population, largest first
 };
@@ -339,6 +340,7 @@ struct ovqe_sv {
     int opt_sector_sweep = 3;     // circuit sweep kernel: 3 = per-wave streams, barriers at run boundaries only (k_sector_sweep3; built on the tables of 2); 2 = scatter-on-write, pair words in registers (k_sector_sweep2); 1 = first form
     int opt_sector_chunk = 2048;  // k_sector_sweep2: pair words per chunk = threads x words per thread (1024, 2048, 4096)
     int opt_sector_sweep_dbg = 0; // measurements only, k_sector_sweep2: 1 no ops, 2 empty kernel, 3 loads only — wrong results
+    int opt_sector_h_pack = 1;     // <H> tables: coded words of a sweep with at most 1023 magnitudes stored as 24-bit elements (0: 32-bit words; testing builds)
     int opt_sector_h_groups = 256; // workgroups per <H> sweep (they share the sweep's tiles round robin)
     int opt_sector_h_dbg = 0;     // measurements only, k_sector_expect: 1 tile loads only, 2 no tile loads, 3 metadata only — wrong results
     int opt_sector_adjoint = 3;   // backward sweeps of the gradient: 3 = on the per-wave streams (k_sector_adjoint3) where a sweep has them; 2 = on the 64-bit tables (k_sector_adjoint2) where they exist and fit; 1 = first form
@@ -3309,6 +3311,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     else if (k == "sector_sweep_dbg") h->opt_sector_sweep_dbg = (int)value;
     else if (k == "sector_stream_waves") h->opt_sector_stream_waves = (int)value;
     else if (k == "sector_stream_arrange") h->opt_sector_stream_arrange = (int)value;
+    else if (k == "sector_h_pack") h->opt_sector_h_pack = (int)value;
 #endif
     else if (k == "sector_reg_runs") {   // runs of ops without barriers (planned at build time: the tables are rebuilt)
         h->opt_sector_reg_runs = (int)value;

@@ -69,7 +69,30 @@ struct SecHSweep {    // one sweep of the materialised <H>: device pointers
     const double *xvals;
     int32_t ndict, ntiles;
     const uint32_t *torder;   // [ntiles] tiles by population, largest first: the order in which workgroups take them (nullptr: as numbered)
+    int32_t packed;           // 1: cwords holds the coded words as 24-bit elements (k_sec_pack24: four elements of a lane in three dwords)
 };
+constexpr int SEC_DICT_PACKED_MAX = 1023;   // magnitudes up to which a coded word fits 24 bits (slot 13, sign 1, entry 10: the null element is entry ndict)
+typedef uint32_t sec_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t sec_u32x3 __attribute__((ext_vector_type(3)));
+// four 24-bit elements of a lane from their three dwords (the layout of the 32-bit words with the empty top byte dropped)
+__device__ __forceinline__ sec_u32x4 sec_unpack24(sec_u32x3 d) {
+    sec_u32x4 w;
+    w.x = d.x & 0xffffffu;
+    w.y = __builtin_amdgcn_alignbit(d.y, d.x, 24) & 0xffffffu;
+    w.z = __builtin_amdgcn_alignbit(d.z, d.y, 16) & 0xffffffu;
+    w.w = d.z >> 8;
+    return w;
+}
+// the coded stream of a sweep in 24-bit elements: group g = four consecutive words (one lane's) -> three dwords; a quarter fewer bytes
+// for the kernels that stream the table from HBM (<H>, lambda = H psi, batches)
+__global__ __launch_bounds__(256) void k_sec_pack24(const uint32_t *__restrict__ words, uint32_t ngroups, uint32_t *__restrict__ packed) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= ngroups) return;
+    const sec_u32x4 w = *reinterpret_cast<const sec_u32x4 *>(words + 4u * (size_t)g);
+    packed[3u * (size_t)g] = w.x | (w.y << 24);
+    packed[3u * (size_t)g + 1u] = (w.y >> 8) | (w.z << 16);
+    packed[3u * (size_t)g + 2u] = (w.z >> 16) | (w.w << 8);
+}
 // which entry of an off-diagonal pair keeps its matrix element: a hash bit of the pair (lower index, x mask) — per pair, not
 // per entry, so that every row keeps about half of its elements
 __device__ __forceinline__ bool sec_low_owns(uint64_t low, uint64_t x) {
@@ -1377,10 +1400,19 @@ __device__ __forceinline__ double sec_row_sum(const SecHSweep &sw, const SecSlic
                 __hip_atomic_fetch_add(to, v * hai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             };
             uint32_t q = 0;
-            for (; q + 4u * SEC_H_INFLIGHT - 1u < L; q += 4u * SEC_H_INFLIGHT) {   // SEC_H_INFLIGHT 16-byte loads in flight per lane
+            const uint32_t *wp3 = sw.cwords + (mt.cbase >> 2) * 3u + 3u * lane;   // packed: the lane's four elements of step q / 4 are three dwords at 192 (q / 4)
+            for (; q + 4u * SEC_H_INFLIGHT - 1u < L; q += 4u * SEC_H_INFLIGHT) {   // SEC_H_INFLIGHT 16-byte (12-byte) loads in flight per lane
                 u32x4 w[SEC_H_INFLIGHT];
+                if (sw.packed) {
+                    sec_u32x3 d[SEC_H_INFLIGHT];
 #pragma unroll
-                for (int u = 0; u < SEC_H_INFLIGHT; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wp + 64u * (q + 4u * (uint32_t)u)));
+                    for (int u = 0; u < SEC_H_INFLIGHT; ++u) d[u] = __builtin_nontemporal_load(reinterpret_cast<const sec_u32x3 *>(wp3 + 48u * (q + 4u * (uint32_t)u)));
+#pragma unroll
+                    for (int u = 0; u < SEC_H_INFLIGHT; ++u) w[u] = sec_unpack24(d[u]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < SEC_H_INFLIGHT; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wp + 64u * (q + 4u * (uint32_t)u)));
+                }
                 double v[SEC_H_INFLIGHT][4];
 #pragma unroll
                 for (int u = 0; u < SEC_H_INFLIGHT; ++u) {
@@ -1404,7 +1436,7 @@ __device__ __forceinline__ double sec_row_sum(const SecHSweep &sw, const SecSlic
                 }
             }
             for (; q < L; q += 4u) {
-                const u32x4 w = *reinterpret_cast<const u32x4 *>(wp + 64u * q);
+                const u32x4 w = sw.packed ? sec_unpack24(*reinterpret_cast<const sec_u32x3 *>(wp3 + 48u * q)) : *reinterpret_cast<const u32x4 *>(wp + 64u * q);
                 const double v0 = value(w.x), v1 = value(w.y), v2 = value(w.z), v3 = value(w.w);
                 a0 += v0 * tile[w.x & SEC_HSLOT_MASK];
                 a1 += v1 * tile[w.y & SEC_HSLOT_MASK];
@@ -1594,11 +1626,21 @@ __global__ __launch_bounds__(NT) void k_sector_expect_batch(const double *__rest
                         for (int s = 0; s < NB; ++s) r[s] += v * a[s];
                     };
                     uint32_t q = 0;
+                    const uint32_t *wp3 = sw.cwords + (cur.cbase >> 2) * 3u + 3u * lane;   // packed 24-bit elements: see sec_row_sum
                     for (; q + 4u * SEC_H_INFLIGHT - 1u < L; q += 4u * SEC_H_INFLIGHT) {
                         u32x4 w[SEC_H_INFLIGHT];
+                        if (sw.packed) {
+                            sec_u32x3 d[SEC_H_INFLIGHT];
+#pragma unroll
+                            for (int u = 0; u < SEC_H_INFLIGHT; ++u) d[u] = zfast ? *reinterpret_cast<const sec_u32x3 *>(wp3 + 48u * (q + 4u * (uint32_t)u))
+                                                               : __builtin_nontemporal_load(reinterpret_cast<const sec_u32x3 *>(wp3 + 48u * (q + 4u * (uint32_t)u)));
+#pragma unroll
+                            for (int u = 0; u < SEC_H_INFLIGHT; ++u) w[u] = sec_unpack24(d[u]);
+                        } else {
 #pragma unroll
                         for (int u = 0; u < SEC_H_INFLIGHT; ++u) w[u] = zfast ? *reinterpret_cast<const u32x4 *>(wp + 64u * (q + 4u * (uint32_t)u))
                                                            : __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wp + 64u * (q + 4u * (uint32_t)u)));
+                        }
 #pragma unroll
                         for (int u = 0; u < SEC_H_INFLIGHT; ++u) {
                             term(w[u].x);
@@ -1608,7 +1650,7 @@ __global__ __launch_bounds__(NT) void k_sector_expect_batch(const double *__rest
                         }
                     }
                     for (; q < L; q += 4u) {
-                        const u32x4 w = *reinterpret_cast<const u32x4 *>(wp + 64u * q);
+                        const u32x4 w = sw.packed ? sec_unpack24(*reinterpret_cast<const sec_u32x3 *>(wp3 + 48u * q)) : *reinterpret_cast<const u32x4 *>(wp + 64u * q);
                         term(w.x);
                         term(w.y);
                         term(w.z);

@@ -724,3 +724,39 @@ def test_per_wave_streams_equal_the_second_sweep_form_bit_for_bit(testing_lib, m
         assert abs(e3 - ew) < 1e-10 * max(1.0, l1) and abs(e3 - e2) < 1e-13 * max(1.0, l1)    # (the gradient's energy is a dot product with lambda)
         assert np.abs(g3 - g2).max() < 1e-12 * max(1.0, l1)
     assert np.abs(batch - np.array(want)).max() < 1e-10 * max(1.0, l1)
+
+
+def test_packed_hamiltonian_elements_equal_the_32_bit_words_bit_for_bit(testing_lib):
+    """<H> tables of a sweep whose dictionary has at most 1023 magnitudes keep their coded words as 24-bit elements (k_sec_pack24: a
+    quarter fewer bytes for the kernels that stream them): same elements in the same order, so energies, batches and gradients equal
+    those of the 32-bit words (energies and batches bit for bit; H2O / STO-3G UCCSD, 14 qubits; a 16-qubit synthetic molecule), and the oracle"""
+    from openvqe_amd import chem, fermion
+    from openvqe_amd.backend import Statevector
+    mol = chem.molecule("H2O")
+    mol.rhf()
+    prob = mol.problem(active=False)
+    _, _, gens_w, theta_mp2, hf_w = prob.uccsd()
+    cases = [(prob.jw_hamiltonian(), gens_w, hf_w, np.array(theta_mp2))]
+    ham, gens, hf = fermion.synthetic_molecule(8, 3, seed=77)
+    cases.append((ham, gens, hf, np.random.default_rng(8).uniform(-0.3, 0.3, len(gens))))
+    for ham, gens, hf, th in cases:
+        n = ham.nbqbits
+        thetas = [th, 0.5 * th, -0.7 * th]
+        want = _oracle_energies(n, gens, hf, ham, thetas)
+        l1 = float(np.abs(ham.packed()[2]).sum())
+        got = {}
+        for pack in (1, 0):
+            with Statevector(n) as sv:
+                sv.set_option("force_path", 2)
+                sv.set_option("sector_min_qubits", 8)
+                sv.set_option("sector_h_pack", pack)
+                sv.set_hamiltonian(ham)
+                sv.set_ucc_program(gens, hf)
+                es = [sv.energy(t) for t in thetas]
+                es = [sv.energy(t) for t in thetas]           # (from the tables)
+                grads = [sv.energy_gradient(t)[1] for t in thetas]
+                got[pack] = (es, sv.energy_batch(np.stack(thetas)), grads, sv.program_info()["sector_bytes"])
+        assert got[1][0] == got[0][0] and np.array_equal(got[1][1], got[0][1])
+        assert all(np.abs(a - b).max() < 1e-12 * max(1.0, l1) for a, b in zip(got[1][2], got[0][2]))   # (lambda = H psi adds with atomics: rounding)
+        assert got[1][3] < got[0][3]                                   # the packed tables are smaller
+        assert max(abs(e - w) for e, w in zip(got[1][0], want)) < 1e-10 * max(1.0, l1)
