@@ -413,4 +413,47 @@ inline bool build_reg_ops(const std::vector<SecBuildOp> &sops, const std::vector
 }
 
 
+
+// ---- per-wave streams of the irregular supports' circuit sweeps (k_sector_sweep3, sv_sector.hpp): the host side of their plan ----
+struct SecWaveRun {
+    int32_t op_end;       // ops [previous op_end, op_end) of the sweep
+    uint32_t cmask;       // index bits (inside the tile, outside every mixing mask of the run) that number the slot classes
+};
+// Waves that share a tile's rows, from the pair words per op of the sweep's largest tile: what bounds a sweep is the LDS traffic of that
+// tile, and a row costs the same whether eight or sixty-four of its lanes hold a pair — as few waves as keep the rows of an op about
+// full (measured at 24 qubits: 16 waves = rows 40 % full = no faster than a barrier per op).  0: no streams (small tiles: a round of
+// the second sweep form costs no more than a row, and the streams take time to build).
+inline int sec_stream_wave_count(double pairs_per_op, int max_waves) {
+    if (pairs_per_op < 24.0) return 0;
+    int nw = 1;
+    while (nw < max_waves && pairs_per_op > 64.0 * nw) nw *= 2;
+    return nw;
+}
+// The sweep's op list cut into runs whose mixing masks together leave log2(nw) + 1 (nw = 1: any number) of the tile's M index bits
+// S untouched: those bits (at most class_bits of them, the highest) number slot classes that no op of the run leaves, so a wave
+// that owns a class for the length of a run needs no barrier inside it.  false: an op mixes more bits than a run may.
+inline bool sec_plan_wave_runs(const std::vector<SecBuildOp> &sops, uint64_t S, int M, int nw, int class_bits, std::vector<SecWaveRun> &runs) {
+    runs.clear();
+    const int wbits = __builtin_ctz((unsigned)nw);
+    const int U = M - wbits - (nw > 1 ? 1 : 0);      // two slot classes per wave at least
+    if (U < 2) return false;
+    const int nops = (int)sops.size();
+    for (int k = 0; k < nops;) {
+        uint64_t u = 0;
+        int l = k;
+        while (l < nops && __builtin_popcountll(u | sops[l].x) <= U) u |= sops[l++].x;
+        if (l == k) return false;
+        const uint64_t cm = S & ~u;
+        uint64_t cmask = 0;
+        for (int b = 63, c = 0; b >= 0 && c < class_bits; --b)
+            if ((cm >> b) & 1ull) {
+                cmask |= 1ull << b;
+                ++c;
+            }
+        runs.push_back({(int32_t)l, (uint32_t)cmask});
+        k = l;
+    }
+    return true;
+}
+
 }  // namespace ovqe

@@ -808,10 +808,7 @@ __global__ __launch_bounds__(NT) void k_sector_sweep2(const double *__restrict__
 constexpr int SEC_STREAM_WAVES = 16;     // waves per workgroup the streams are planned for (k_sector_sweep3<1024>)
 constexpr int SEC_STREAM_G = 8;          // rows per batch
 constexpr int SEC_STREAM_CLASS_BITS = 6; // at most 64 slot classes per run
-struct SecWaveRun {
-    int32_t op_end;       // ops [previous op_end, op_end) of the sweep
-    uint32_t cmask;       // index bits (inside the tile, outside every mixing mask of the run) that number the slot classes
-};
+// (SecWaveRun and the host side of the plan: sv_regular_host.hpp)
 // plan (FILL = false: rows per (tile, wave, op) and the class -> wave map) and fill (FILL = true: words and row headers) of the streams;
 // one workgroup per tile
 template <bool FILL>

@@ -62,6 +62,107 @@ static void reference_apply(const Case &C, const SecBuildOp &b, std::map<uint64_
     psi.swap(out);
 }
 
+// ---- per-wave streams of the irregular supports (sec_stream_wave_count, sec_plan_wave_runs): the runs partition the op list in order,
+// are maximal, their class bits lie inside the tile and outside every mixing mask of the run — and, replayed on a random sparse tile,
+// the classes are closed under the run's ops, so applying a run CLASS BY CLASS (what the waves do, each in op order on the slots of its
+// classes, no barrier) gives the amplitudes of applying it op by op, bit for bit.
+static int check_stream_plans(std::mt19937_64 &rng, int cases) {
+    auto rnd = [&](uint64_t m) { return (uint64_t)(rng() % m); };
+    int checked = 0;
+    for (int cs = 0; cs < cases; ++cs) {
+        const int n = 10 + (int)rnd(9), M = 6 + (int)rnd((uint64_t)std::min(n - 6, 11)) ;
+        uint64_t S = 0;
+        while (__builtin_popcountll(S) < M) S |= 1ull << rnd((uint64_t)n);
+        std::vector<int> sbits;
+        for (int b = 0; b < n; ++b)
+            if ((S >> b) & 1ull) sbits.push_back(b);
+        const int nops = 1 + (int)rnd(40);
+        std::vector<SecBuildOp> ops((size_t)nops);
+        uint64_t prev = 0;
+        for (int o = 0; o < nops; ++o) {
+            uint64_t x = 0;
+            const int w = rnd(3) ? 4 : 2;
+            if (prev && rnd(3)) {                       // neighbours in the list share most of their bits, as UCCSD's do
+                x = prev;
+                x &= ~(1ull << sbits[rnd((uint64_t)M)]);
+            }
+            while (__builtin_popcountll(x) < std::min(w, M)) x |= 1ull << sbits[rnd((uint64_t)M)];
+            ops[(size_t)o] = SecBuildOp{x, 0, 0, 1, 0, o};
+            prev = x;
+        }
+        const int nw = 1 << (int)rnd(5);
+        std::vector<SecWaveRun> runs;
+        const bool ok = sec_plan_wave_runs(ops, S, M, nw, 6, runs);
+        const int wbits = __builtin_ctz((unsigned)nw), U = M - wbits - (nw > 1 ? 1 : 0);
+        bool wide = U < 2;
+        for (const SecBuildOp &b : ops) wide = wide || __builtin_popcountll(b.x) > U;
+        if (!ok) {
+            if (!wide) { printf("case %d: plan declined without a wide op\n", cs); return -1; }
+            continue;
+        }
+        if (wide) { printf("case %d: plan accepted with an op wider than a run\n", cs); return -1; }
+        int o0 = 0;
+        for (size_t r = 0; r < runs.size(); ++r) {
+            const int o1 = runs[r].op_end;
+            if (o1 <= o0 || o1 > nops) { printf("case %d: run %zu does not advance\n", cs, r); return -1; }
+            uint64_t u = 0;
+            for (int o = o0; o < o1; ++o) u |= ops[(size_t)o].x;
+            const uint64_t cm = runs[r].cmask;
+            if ((cm & ~S) || (cm & u) || __builtin_popcountll(cm) > 6 || __builtin_popcountll(u) > U ||
+                (nw > 1 && __builtin_popcountll(cm) < std::min(6, wbits + 1))) { printf("case %d: class mask of run %zu\n", cs, r); return -1; }
+            if (o1 < nops && __builtin_popcountll(u | ops[(size_t)o1].x) <= U) { printf("case %d: run %zu is not maximal\n", cs, r); return -1; }
+            o0 = o1;
+        }
+        if (o0 != nops) { printf("case %d: the runs do not cover the op list\n", cs); return -1; }
+        // replay on a sparse tile: indices that agree outside S, a random half of them in the support
+        const uint64_t outside = rnd(1ull << n) & ~S;
+        std::map<uint64_t, double> amp_a, amp_b;
+        for (uint64_t k = 0; k < (1ull << M); ++k)
+            if (rnd(2)) {
+                const uint64_t i = pdep(k, S) | outside;
+                amp_a[i] = amp_b[i] = (double)rnd(1000) / 997.0 - 0.5;
+            }
+        auto rotate = [&](std::map<uint64_t, double> &amp, const SecBuildOp &b, uint64_t i, int o) {
+            const uint64_t j = i ^ b.x;
+            if (i > j) return;
+            auto pj = amp.find(j);
+            if (pj == amp.end()) return;
+            const double c = std::cos(0.3 + 0.1 * o), sn = std::sin(0.3 + 0.1 * o);
+            double &u = amp[i], &v = pj->second;
+            const double nu = c * u + sn * v, nv = c * v - sn * u;
+            u = nu;
+            v = nv;
+        };
+        o0 = 0;
+        for (size_t r = 0; r < runs.size(); ++r) {
+            const int o1 = runs[r].op_end;
+            const uint64_t cm = runs[r].cmask;
+            for (int o = o0; o < o1; ++o)                      // (a) op by op
+                for (auto &kv : amp_a) rotate(amp_a, ops[(size_t)o], kv.first, o);
+            std::map<uint64_t, std::vector<uint64_t>> by_class;   // (b) class by class, each in op order
+            for (auto &kv : amp_b) by_class[kv.first & cm].push_back(kv.first);
+            for (auto &cl : by_class)
+                for (int o = o0; o < o1; ++o)
+                    for (uint64_t i : cl.second) {
+                        if (amp_b.count(i ^ ops[(size_t)o].x) && (((i ^ ops[(size_t)o].x) & cm) != (i & cm))) { printf("case %d: a pair leaves its class\n", cs); return -1; }
+                        rotate(amp_b, ops[(size_t)o], i, o);
+                    }
+            o0 = o1;
+        }
+        for (auto &kv : amp_a)
+            if (kv.second != amp_b[kv.first]) { printf("case %d: class-by-class replay differs at %llx\n", cs, (unsigned long long)kv.first); return -1; }
+        ++checked;
+    }
+    for (double p : {0.0, 23.9, 24.0, 64.0, 64.1, 128.0, 129.0, 400.0, 1e6}) {
+        const int nw = sec_stream_wave_count(p, 16);
+        if ((p < 24.0) != (nw == 0) || (nw && (nw & (nw - 1))) || nw > 16 || (nw > 1 && p <= 32.0 * nw) || (nw && nw < 16 && p > 64.0 * nw)) {
+            printf("wave count %d for %.1f pairs per op\n", nw, p);
+            return -1;
+        }
+    }
+    return checked;
+}
+
 int main(int argc, char **argv) {
     const int cases = argc > 1 ? std::atoi(argv[1]) : 300;
     std::mt19937_64 rng(argc > 2 ? std::atoll(argv[2]) : 12345);
@@ -310,5 +411,8 @@ int main(int argc, char **argv) {
     }
     std::printf("regular tables ok: %d sweeps replayed (%d blocks of two ops, %d ops with selectors, %d barriers left out), %d declined, worst |delta| %.1e\n", checked,
                 blocks_seen, selectors_seen, runs_joined, declined, worst);
-    return checked >= cases / 5 ? 0 : 2;
+    const int plans = check_stream_plans(rng, cases);
+    if (plans < 0) return 3;
+    std::printf("stream plans ok: %d plans replayed class by class\n", plans);
+    return checked >= cases / 5 && plans >= cases / 5 ? 0 : 2;
 }

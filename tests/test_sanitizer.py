@@ -81,6 +81,7 @@ def test_regular_support_tables_under_asan_ubsan(tmp_path):
         r = subprocess.run([exe, "400", seed], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         assert "regular tables ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+        assert "stream plans ok" in r.stdout, r.stdout[-2000:]      # (the host side of the per-wave streams' plan: runs, class bits)
 
 
 def test_clifford_frame_compiler_under_asan_ubsan(tmp_path):
