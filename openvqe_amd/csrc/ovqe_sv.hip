@@ -3307,7 +3307,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     else if (k == "sector_batch_threads") h->opt_sector_batch_threads = value == 512 ? 512 : 1024;
     else if (k == "sector_row_banks") h->opt_sector_row_banks = (int)value;
     else if (k == "sector_debug") h->opt_sector_debug = (int)value;
-    else if (k == "sector_sweep") h->opt_sector_sweep = value == 1 ? 1 : (value == 2 ? 2 : 3);   // (2 on tables built under 3: the second form on the same tables)
+    else if (k == "sector_sweep") h->opt_sector_sweep = value == 1 ? 1 : (value == 2 ? 2 : (value == 4 ? 4 : 3));   // (2 on tables built under 3: the second form on the same tables; 4: the streams for batches too)
     else if (k == "sector_sweep_dbg") h->opt_sector_sweep_dbg = (int)value;
     else if (k == "sector_stream_waves") h->opt_sector_stream_waves = (int)value;
     else if (k == "sector_stream_arrange") h->opt_sector_stream_arrange = (int)value;

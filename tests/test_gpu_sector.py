@@ -718,6 +718,7 @@ def test_per_wave_streams_equal_the_second_sweep_form_bit_for_bit(testing_lib, m
             sv.set_option("sector_adjoint", form)
             got[form] = [sv.energy(th) for th in thetas]
             grad[form] = [sv.energy_gradient(th) for th in thetas]
+        sv.set_option("sector_sweep", 4)        # (the streams for the states of a batch too: the product gives batches the second form)
         batch = sv.energy_batch(np.stack(thetas))
     assert got[3] == got[2]
     for (e3, g3), (e2, g2), ew in zip(grad[3], grad[2], want):
