@@ -151,7 +151,7 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  *   "sparse_spw", "sparse_dealias", "sector_sweep" (circuit sweeps on an irregular support: 3 pair words in per-wave streams with barriers at
  *   run boundaries only — built on top of the tables of 2 —, 2 64-bit pair words in registers with a barrier per round, 1 first form; 2 on a
  *   handle built under 3 runs the second form on the same tables; 4: the streams for the states of a batch too — the product gives
- *   batches the second form, whose workgroups hide each other's barriers), "sector_stream_waves" (0: waves that share a tile's rows from the pairs per
+ *   batches the second form: their workgroups hide each other's barriers and the streams gain them nothing), "sector_stream_waves" (0: waves that share a tile's rows from the pairs per
  *   op of the sweep's largest tile; 1, 2, 4, 8, 16), "sector_stream_arrange" (1: the lanes of a row chosen for the LDS banks), "sector_h_pack" (1: <H> sweeps with at most 1023
  *   magnitudes keep their coded words as 24-bit elements), "sector_chunk",
  *   "sector_depth2", "sector_many_tiles",
