@@ -51,6 +51,7 @@ struct SecGroup {     // x-group of the Hamiltonian, global masks
 //     +- dict[index] (index == ndict: null, 0);
 //   explicit element (diagonal, single-excitation-like groups): word = slot_j, value H_ii or 2 H_ij (null: 0).
 constexpr int SEC_H_INFLIGHT = 4;   // 16-byte loads of coded words in flight per lane in the <H> kernels (8: slower, 4.0 against 4.4 TB/s)
+constexpr int SEC_H_INFLIGHT_APPLY = 2;   // ... in k_sector_apply (lambda = H psi keeps every element's value for its LDS atomic: registers)
 constexpr int SEC_HSLOT_BITS = 13;
 constexpr uint32_t SEC_HSLOT_MASK = (1u << SEC_HSLOT_BITS) - 1u;
 constexpr uint32_t SEC_HMAX_TILE = SEC_HSLOT_MASK - 1u;   // entries per <H> tile
@@ -1379,6 +1380,7 @@ __device__ __forceinline__ SecSliceMeta sec_slice_meta(const SecHSweep &sw, size
 template <bool APPLY>
 __device__ __forceinline__ double sec_row_sum(const SecHSweep &sw, const SecSliceMeta &mt, uint32_t lane, uint32_t row, double ai,
                                               const double *tile, const double *dict, double *lam) {
+    constexpr int NFL = APPLY ? SEC_H_INFLIGHT_APPLY : SEC_H_INFLIGHT;   // 16-byte (packed: 12-byte) loads in flight per lane
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     double *dummy = const_cast<double *>(dict) + sw.ndict + 2 + lane;   // APPLY only: 64 doubles behind the dictionary (sector_h_smem)
     const double hai = 0.5 * ai;
@@ -1398,21 +1400,21 @@ __device__ __forceinline__ double sec_row_sum(const SecHSweep &sw, const SecSlic
             };
             uint32_t q = 0;
             const uint32_t *wp3 = sw.cwords + (mt.cbase >> 2) * 3u + 3u * lane;   // packed: the lane's four elements of step q / 4 are three dwords at 192 (q / 4)
-            for (; q + 4u * SEC_H_INFLIGHT - 1u < L; q += 4u * SEC_H_INFLIGHT) {   // SEC_H_INFLIGHT 16-byte (12-byte) loads in flight per lane
-                u32x4 w[SEC_H_INFLIGHT];
+            for (; q + 4u * NFL - 1u < L; q += 4u * NFL) {   // NFL 16-byte (12-byte) loads in flight per lane
+                u32x4 w[NFL];
                 if (sw.packed) {
-                    sec_u32x3 d[SEC_H_INFLIGHT];
+                    sec_u32x3 d[NFL];
 #pragma unroll
-                    for (int u = 0; u < SEC_H_INFLIGHT; ++u) d[u] = __builtin_nontemporal_load(reinterpret_cast<const sec_u32x3 *>(wp3 + 48u * (q + 4u * (uint32_t)u)));
+                    for (int u = 0; u < NFL; ++u) d[u] = __builtin_nontemporal_load(reinterpret_cast<const sec_u32x3 *>(wp3 + 48u * (q + 4u * (uint32_t)u)));
 #pragma unroll
-                    for (int u = 0; u < SEC_H_INFLIGHT; ++u) w[u] = sec_unpack24(d[u]);
+                    for (int u = 0; u < NFL; ++u) w[u] = sec_unpack24(d[u]);
                 } else {
 #pragma unroll
-                    for (int u = 0; u < SEC_H_INFLIGHT; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wp + 64u * (q + 4u * (uint32_t)u)));
+                    for (int u = 0; u < NFL; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wp + 64u * (q + 4u * (uint32_t)u)));
                 }
-                double v[SEC_H_INFLIGHT][4];
+                double v[NFL][4];
 #pragma unroll
-                for (int u = 0; u < SEC_H_INFLIGHT; ++u) {
+                for (int u = 0; u < NFL; ++u) {
                     v[u][0] = value(w[u].x);
                     v[u][1] = value(w[u].y);
                     v[u][2] = value(w[u].z);
@@ -1424,7 +1426,7 @@ __device__ __forceinline__ double sec_row_sum(const SecHSweep &sw, const SecSlic
                 }
                 if (APPLY) {
 #pragma unroll
-                    for (int u = 0; u < SEC_H_INFLIGHT; ++u) {
+                    for (int u = 0; u < NFL; ++u) {
                         scatter(w[u].x, v[u][0]);
                         scatter(w[u].y, v[u][1]);
                         scatter(w[u].z, v[u][2]);
