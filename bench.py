@@ -232,7 +232,7 @@ def gate_and_midsize_workloads(device):
                     "bound": "hbm", "kernel": "k_sector_expect (materialised <H>: one pass over the table per evaluation)",
                     "achieved": hb / t_exp / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / t_exp / 1e9 / HBM_PEAK_GBS,
                     "bytes_per_launch": hb, "avg_launch_ms": 1e3 * t_exp,
-                    "traffic_source": "profiles/r2_sector/pmc_summary.txt (FETCH_SIZE x2)"}
+                    "traffic_source": newest_profile("*_sector", "pmc_summary.txt") + " (FETCH_SIZE x2)"}
                 row24[label]["circuit_sweeps_ms"] = 1e-3 * float(np.mean(circ_us))
             if sector:
                 # batched evaluations on the tables (what a finite-difference gradient of the reference's BFGS submits)
@@ -343,7 +343,7 @@ def gate_and_midsize_workloads(device):
                                    "hbm_side_GBs": (20 * sup * nsw / t_c / 1e9) if infq["sector_regular_slot_bits"] else None,
                                    "note": "8 B read + 8 B written per amplitude and sweep + 4 B of gather index; the ops of a sweep "
                                            "(46 on average) act on the tile in LDS"},
-                "traffic_source": "profiles/r4_quccsd24 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+                "traffic_source": newest_profile("*quccsd24", "pmc_summary.txt") + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
         calls = []
         t0 = time.perf_counter()
         with one_blas_thread():
@@ -470,7 +470,7 @@ SHARDED_SEED = 20250227
 SHARDED_KNOWN = {(31, 64, 1000): 0.0006064921993039994}
 
 
-def sharded_leg(n, local_rank, world, rank, rotations=64, terms=1000, barrier=None):
+def sharded_leg(n, local_rank, world, rank, rotations=64, terms=1000, barrier=None, dry_rank=None):
     """One pass of configs[4] over the index-bit-partitioned register (openvqe_amd.distributed): the synthetic state
     (recomputable on the host per global index, openvqe_amd/synth.py) -> `rotations` Pauli rotations (half-shard
     exchanges over RCCL for X/Y on global qubits) -> <H> (partner-shard reads for global-x groups).  World size 1 runs
@@ -479,7 +479,13 @@ def sharded_leg(n, local_rank, world, rank, rotations=64, terms=1000, barrier=No
     from openvqe_amd.distributed import ShardedStatevector
     g = world.bit_length() - 1
     xs, zs, phis, hx, hz, hc = sharded_workload(n, rotations, terms)
-    sv = ShardedStatevector(n, device=local_rank)
+    sv = ShardedStatevector(n, device=local_rank, dry_rank=dry_rank)
+    if dry_rank is not None:
+        world, rank = dry_rank
+        g = world.bit_length() - 1
+    if os.environ.get("OVQE_BENCH_SINGLE_DEVICE") and world > 1 and dry_rank is None:
+        # every rank's shard sits on device 0: compute sections take the device one rank at a time, so that their seconds are a rank's own
+        sv.compute_lock = os.path.join("/tmp", "ovqe_bench_compute_%s.lock" % os.environ.get("MASTER_PORT", "0"))
     sv.randomize(SHARDED_SEED)
     stall = os.environ.get("OVQE_BENCH_INJECT_STALL_RANK")      # tests: this rank never posts its half of the first exchange
     if stall is not None and int(stall) == rank:
@@ -512,7 +518,9 @@ def sharded_leg(n, local_rank, world, rank, rotations=64, terms=1000, barrier=No
     groups = len(set(hx))
     swap_bytes = st["bytes_sent"]
     read_bytes = st2["bytes_sent"] - st["bytes_sent"]
-    t_local = max(t_rot - st["swap_s"], 1e-9)
+    t_local = max(st["local_sweeps_s"], 1e-9)
+    info = sv.engine.sum_info(sv._plan_for(hx, hz, hc, 0.0)["expect"]) if hasattr(sv.engine, "sum_info") else {}
+    link = XGMI_LINK_GBS * 1e9
     out = {
         "workload": f"{rotations} JW two-body rotations + {terms}-term random JW Hamiltonian ({groups} x-groups) on the "
                     f"synthetic {n}-qubit state, index-bit partition over {world} GPU(s)",
@@ -544,9 +552,26 @@ def sharded_leg(n, local_rank, world, rank, rotations=64, terms=1000, barrier=No
         "expectation_GBs_per_gpu": (cnt2["contraction_bytes"] - cnt["contraction_bytes"]) / t_exp / 1e9,
         "expectation_x_groups_equivalent_GBs_aggregate": 16.0 * 2 ** n * groups / t_exp / 1e9,
         "energy": e, "norm2": n2, "h_norm1": float(np.abs(hc).sum()),
+        # this rank's kernel seconds by phase (every section synchronised; ranks sharing one device take it in turn)
+        "expectation_local_s": st2["expectation_local_s"], "expectation_remote_compute_s": st2["expectation_remote_s"],
+        "expectation_plan": info, "expectation_partners_read": st2["partners_per_read"],
+        "exchange_count": st["swaps"], "exchange_bytes_per_rank": swap_bytes, "shard_read_bytes_sent_per_rank": read_bytes,
     }
+    # the same rank on eight GPUs with xGMI links (153 GB/s each way): a half-shard exchange crosses ONE link; the partner reads of <H>
+    # use one link per partner at once and overlap with the contraction of the previous chunk
+    nread = max(1, st2["partners_per_read"])
+    out["projected_with_xgmi"] = {
+        "rotations_s": t_local + st["swap_s"] * (1.0 if dry_rank is not None else 0.0) + swap_bytes / link,
+        "expectation_s": st2["expectation_local_s"] + max(st2["expectation_remote_s"], (read_bytes / nread) / link if read_bytes else 0.0),
+        "assumes": "exchange = bytes / 153 GB/s on one link (+ the measured pack / unpack copies of a dry rank); partner reads: one link "
+                   "per partner concurrently, hidden behind the contraction when shorter",
+    }
+    if dry_rank is not None:
+        out["dry_rank"] = {"world": world, "rank": rank, "note": "one rank of the job alone on one GPU: own chunks stand in for the partners', "
+                           "every kernel, copy and byte count is that rank's; energy and norm are meaningless here"}
+        out.pop("energy_check", None)
     known = SHARDED_KNOWN.get((n, rotations, terms))
-    if known is not None:
+    if known is not None and dry_rank is None:
         tol = 1e-11 * out["h_norm1"]
         out["energy_check"] = {"expected": known, "abs_diff": abs(e - known), "tol": tol, "ok": bool(abs(e - known) <= tol)}
     del sv
@@ -569,6 +594,11 @@ def sharded_block(args, local_rank, world, rank, barrier):
         block["strong"] = sharded_leg(base, local_rank, world, rank, args.sharded_rotations, args.sharded_terms, barrier)
     else:
         block["strong"] = block["weak"]
+    if world == 1 and not args.no_scale_proxy:
+        # configs[4] at FULL size without eight GPUs: rank 0 of an 8-rank register of base + 3 qubits as a dry rank on this GPU (its
+        # shard is the 2^base amplitudes of the weak curve) — that rank's kernels, pack / unpack copies and link bytes, projected on
+        # 153-GB/s links.  Rank 0 contracts four partner shards (the most any rank does under the Hermitian halving).
+        block["scale_proxy"] = sharded_leg(base + 3, local_rank, 1, 0, args.sharded_rotations, args.sharded_terms, None, dry_rank=(8, 0))
     checks = [(leg, block[leg]["energy_check"]) for leg in ("strong", "weak") if "energy_check" in block[leg]]
     if not checks:
         block["energy_check"] = "no value on record for these sizes"
@@ -619,6 +649,13 @@ def mirror_leg():
                                         "E2": float(it["minimum_energy_result2_guess"][0]),
                                         "E1_minus_FCI": float(res["energies1_substracted_from_FCI"])}
     return out
+
+
+def newest_profile(dir_glob, name):
+    """the newest committed `profiles/<dir_glob>/<name>` (round directories sort by name: r2_…, r3_…, …) as a repo-relative path"""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", dir_glob, name)))
+    return os.path.relpath(hits[-1], ROOT) if hits else "(no committed profile)"
 
 
 def pmc_traffic_per_launch():
@@ -672,7 +709,8 @@ def cpu_baseline_leg(ham, gens, hf, thetas, budget_s=12.0):
             dt = time.perf_counter() - t0
             if dt > budget_s / 2:
                 break
-        out[label] = {"evals_per_s": cnt / dt, "evals": cnt, "seconds": dt, "threads": cores, "energy0": float(e[0])}
+        out[label] = {"evals_per_s": cnt / dt, "evals": cnt, "seconds": dt, "threads": cores, "energy0": float(e[0]),
+                      "energies": np.asarray(e, np.float64).copy()}
     # the fused CPU sweep beside the GPU's single-Pauli-string sweep (26 qubits = 1 GiB, OpenMP over the cores)
     from openvqe_amd.operators import pack_string
     nq = 26
@@ -719,7 +757,8 @@ def compact_line(out, extra_path):
     if "cpu_baseline" in out:
         cb = out["cpu_baseline"]
         line["cpu_baseline"] = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "kind", "sample",
-                                                           "gate_level_evals_per_s", "gpu_minus_cpu_energy")}
+                                                           "gate_level_evals_per_s", "gpu_minus_cpu_energy",
+                                                           "batch_kernel_max_abs_diff_vs_oracle")}
     side = {}
     for k in ("single_call_evals_per_s", "fd_gradient_evals_per_s", "mirror_ucc_action_evals_per_s"):
         if k in out:
@@ -745,6 +784,18 @@ def compact_line(out, extra_path):
                 "weak_rotations_s": _r(sh["weak"]["rotations_s"]), "weak_expectation_s": _r(sh["weak"]["expectation_s"]),
                 "strong_rotations_s": _r(sh["strong"]["rotations_s"]), "strong_expectation_s": _r(sh["strong"]["expectation_s"]),
                 "energy_check": sh.get("energy_check")}
+            for leg in ("weak", "strong"):
+                line["sharded"][leg + "_compute_s"] = [_r(sh[leg].get(k), 4) for k in ("local_sweeps_s", "expectation_local_s", "expectation_remote_compute_s")]
+            px = sh.get("scale_proxy")
+            if px is not None:
+                line["sharded"]["scale_proxy"] = {
+                    "what": "rank 0 of 8 at %d qubits, alone on this GPU (dry rank)" % px["n_qubits"],
+                    "local_sweeps_s": _r(px["local_sweeps_s"], 4), "expectation_local_s": _r(px["expectation_local_s"], 4),
+                    "expectation_remote_compute_s": _r(px["expectation_remote_compute_s"], 4),
+                    "exchanges": px["exchange_count"], "exchanged_GiB": _r(px["exchanged_GiB_per_rank"], 4),
+                    "shard_read_GiB": _r(px["shard_read_GiB_per_rank"], 4), "partners_read": px["expectation_partners_read"],
+                    "projected_8gpu_rotations_s": _r(px["projected_with_xgmi"]["rotations_s"], 4),
+                    "projected_8gpu_expectation_s": _r(px["projected_with_xgmi"]["expectation_s"], 4)}
     line["extra"] = extra_path
     return line
 
@@ -821,6 +872,7 @@ def main():
     ap.add_argument("--no-sharded", action="store_true", help="skip the index-bit-partitioned configs[4] block")
     ap.add_argument("--sharded-qubits", type=int, default=int(os.environ.get("OVQE_BENCH_SHARDED_QUBITS", "31")),
                     help="configs[4]: qubits per GPU of the weak curve = register of the strong curve (31: 32-GiB shards)")
+    ap.add_argument("--no-scale-proxy", action="store_true", help="skip the dry 8-rank leg of configs[4] (one rank of 34 qubits on this GPU)")
     ap.add_argument("--sharded-rotations", type=int, default=64)
     ap.add_argument("--sharded-terms", type=int, default=1000)
     args = ap.parse_args()
@@ -1078,8 +1130,15 @@ def main():
                     "n2_fermionic_adapt_30_iterations": n2.get("fermionic_adapt_30_iterations"),
                 }
         if not args.no_cpu and world == 1:
-            cpu, cores = cpu_baseline_leg(ham, gens, hf, thetas_host[0], args.cpu_seconds)
-            e_gpu0 = energy_check(ham, gens, hf, thetas_host[0, 0], local_rank)
+            # the oracle evaluates the first `cores` parameter vectors of the FIRST TIMED step; the energies the timed launch
+            # (k_sparse_vqe_rows, B-wide) left in HBM for those vectors are compared with them: the kernel behind `value` is
+            # checked in the run that times it (the single-call kernel keeps its own check beside it)
+            kt = args.warmup
+            cpu, cores = cpu_baseline_leg(ham, gens, hf, thetas_host[kt], args.cpu_seconds)
+            e_gpu0 = energy_check(ham, gens, hf, thetas_host[kt, 0], local_rank)
+            nchk = min(cores, B)
+            e_timed = energies_dev[kt, :nchk].cpu().numpy()
+            batch_diff = {lab: float(np.abs(e_timed - cpu[lab].pop("energies")[:nchk]).max()) for lab in ("fused", "gate_level")}
             out["cpu_baseline"] = {
                 "value": cpu["fused"]["evals_per_s"],
                 "unit": "evals/s",
@@ -1094,6 +1153,9 @@ def main():
                 "gate_level_evals_per_s": cpu["gate_level"]["evals_per_s"],
                 "single_string_sweep_26_qubits": cpu["sweep_26q"],
                 "gpu_minus_cpu_energy": e_gpu0 - cpu["fused"]["energy0"],
+                "batch_kernel_max_abs_diff_vs_oracle": batch_diff["fused"],
+                "batch_kernel_max_abs_diff_vs_gate_level_oracle": batch_diff["gate_level"],
+                "batch_kernel_checked": f"energies of the timed step {kt} (launch of {B}), first {nchk} parameter vectors",
             }
     if use_dist:
         dist.barrier()

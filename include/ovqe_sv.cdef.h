@@ -46,6 +46,16 @@ int ovqe_apply_pauli_sum(ovqe_handle h, const void *ket_dev, void *out_dev, int6
 int ovqe_bilinear_batch(ovqe_handle h, const void *bra_dev, const void *ket_dev, int64_t n_ops, const int64_t *offsets,
                         const uint64_t *x, const uint64_t *z, const double *coeff_re, const double *coeff_im,
                         double *out_re_im);
+int ovqe_xsum_create(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff_re, const double *coeff_im,
+                     int chunk_bits, int32_t *id);
+int ovqe_xsum_destroy(ovqe_handle h, int32_t id);
+int ovqe_xsum_partners(ovqe_handle h, int32_t id, int64_t capacity, uint64_t *d, int64_t *passes, int64_t *count);
+int ovqe_xsum_info(ovqe_handle h, int32_t id, int64_t *info, int count);
+int ovqe_xsum_expect_local(ovqe_handle h, int32_t id, double *out);
+int ovqe_xsum_expect_remote(ovqe_handle h, int32_t id, uint64_t d, uint64_t chunk, const void *ket_chunk);
+int ovqe_xsum_expect_finish(ovqe_handle h, int32_t id, double *out_re_im);
+int ovqe_xsum_apply_local(ovqe_handle h, int32_t id, void *out_dev, double ident);
+int ovqe_xsum_apply_remote(ovqe_handle h, int32_t id, uint64_t d, uint64_t chunk, const void *ket_chunk, void *out_dev);
 int ovqe_set_hamiltonian(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff,
                          double constant);
 int ovqe_set_program(ovqe_handle h, int64_t R, const uint64_t *x, const uint64_t *z, const double *coeff,

@@ -224,6 +224,35 @@ int ovqe_bilinear_batch(ovqe_handle h, const void *bra_dev, const void *ket_dev,
                         const uint64_t *x, const uint64_t *z, const double *coeff_re, const double *coeff_im,
                         double *out_re_im);
 
+/* ---- Pauli sums planned once for a shard of the partitioned register ("group terms by x_g ... exchange
+ * (read-only) + local partial sums"; the observable of ref:openvqe/ucc_family/get_energy_ucc.py:46-48 and the sigma = H psi of
+ * ref:openvqe/adapt/fermionic_adapt_vqe.py:114 on a register that no single device holds).  Masks live in the PHYSICAL index-bit space
+ * of the whole register (n_local + n_global bits).  d = x >> n_local names the shard (this shard's index ^ d) a term reads its ket
+ * amplitudes from; the host layer (openvqe_amd/distributed.py) receives that shard in chunks of 2^chunk_bits amplitudes and hands
+ * every chunk to the calls below.  The plan — d = 0 terms as a tile cover of the shard, the others as LDS-tiled passes over
+ * (chunk, own shard) pairs, csrc/sv_cross.hpp — is made once; an evaluation uploads nothing.  *_remote calls only enqueue work on the
+ * handle's stream (ovqe_set_stream: order them behind the transfer of the chunk); expect_local / expect_finish synchronise. */
+int ovqe_xsum_create(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff_re, const double *coeff_im,
+                     int chunk_bits, int32_t *id);
+int ovqe_xsum_destroy(ovqe_handle h, int32_t id);
+/* the rank differences d != 0 the sum has terms for (ascending) and the passes one chunk of each costs; *count = how many */
+int ovqe_xsum_partners(ovqe_handle h, int32_t id, int64_t capacity, uint64_t *d, int64_t *passes, int64_t *count);
+/* info[0..10): local x-groups, local terms, local tile sweeps (0 until the first evaluation), local groups outside the cover,
+ * partners, remote x-groups, remote terms, remote passes per chunk summed over the partners, tile bits of the passes, 1 when the
+ * chunks are too small to tile (streaming kernel) */
+int ovqe_xsum_info(ovqe_handle h, int32_t id, int64_t *info, int count);
+/* Re <shard| H_0 |shard> of the d = 0 terms (real coefficients only) */
+int ovqe_xsum_expect_local(ovqe_handle h, int32_t id, double *out);
+/* accumulate <shard| H_d |ket> for chunk `chunk` of the shard of (this shard's index ^ d): ket_chunk = 2^chunk_bits amplitudes on
+ * this device */
+int ovqe_xsum_expect_remote(ovqe_handle h, int32_t id, uint64_t d, uint64_t chunk, const void *ket_chunk);
+/* the accumulated remote contractions (re, im) since the last finish; resets the accumulator */
+int ovqe_xsum_expect_finish(ovqe_handle h, int32_t id, double *out_re_im);
+/* out = ident * psi + H_0 psi on this shard's state (out: 2^n_local amplitudes, != the state) */
+int ovqe_xsum_apply_local(ovqe_handle h, int32_t id, void *out_dev, double ident);
+/* out += H_d ket for one received chunk (out: the 2^n_local-amplitude buffer being accumulated) */
+int ovqe_xsum_apply_remote(ovqe_handle h, int32_t id, uint64_t d, uint64_t chunk, const void *ket_chunk, void *out_dev);
+
 /* ---- compiled evaluation: E(theta) of a whole ansatz circuit */
 /* observable H = constant + sum_t coeff[t] P_t (real coefficients; ref:...get_energy_ucc.py:47) */
 int ovqe_set_hamiltonian(ovqe_handle h, int64_t T, const uint64_t *x, const uint64_t *z, const double *coeff,

@@ -58,6 +58,15 @@ SIGNATURES = {
     "ovqe_bilinear": (_int, [_H, _vp, _vp, _i64, _u64p, _u64p, _f64p, _OptF64, _f64p]),
     "ovqe_apply_pauli_sum": (_int, [_H, _vp, _vp, _i64, _u64p, _u64p, _f64p, _OptF64, _int]),
     "ovqe_bilinear_batch": (_int, [_H, _vp, _vp, _i64, _i64p, _u64p, _u64p, _f64p, _OptF64, _f64p]),
+    "ovqe_xsum_create": (_int, [_H, _i64, _u64p, _u64p, _f64p, _OptF64, _int, ctypes.POINTER(ctypes.c_int32)]),
+    "ovqe_xsum_destroy": (_int, [_H, ctypes.c_int32]),
+    "ovqe_xsum_partners": (_int, [_H, ctypes.c_int32, _i64, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(_i64)]),
+    "ovqe_xsum_info": (_int, [_H, ctypes.c_int32, ctypes.POINTER(_i64), _int]),
+    "ovqe_xsum_expect_local": (_int, [_H, ctypes.c_int32, ctypes.POINTER(_dbl)]),
+    "ovqe_xsum_expect_remote": (_int, [_H, ctypes.c_int32, _u64, _u64, _vp]),
+    "ovqe_xsum_expect_finish": (_int, [_H, ctypes.c_int32, _f64p]),
+    "ovqe_xsum_apply_local": (_int, [_H, ctypes.c_int32, _vp, _dbl]),
+    "ovqe_xsum_apply_remote": (_int, [_H, ctypes.c_int32, _u64, _u64, _vp, _vp]),
     "ovqe_set_hamiltonian": (_int, [_H, _i64, _u64p, _u64p, _f64p, _dbl]),
     "ovqe_set_program": (_int, [_H, _i64, _u64p, _u64p, _f64p, _OptF64, _i32p, ctypes.c_int32, _u64]),
     "ovqe_set_gate_program": (_int, [_H, _i64, _i32p, _i32p, _i32p, _f64p, _f64p, _i32p, ctypes.c_int32, _u64]),

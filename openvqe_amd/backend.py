@@ -198,6 +198,59 @@ class Statevector:
                                              np.ascontiguousarray(coeff.imag if len(coeff) else [0.0]), out))
         return out[0:2 * n_ops:2] + 1j * out[1:2 * n_ops:2]
 
+    # -- Pauli sums planned once for a shard of the partitioned register (ovqe_xsum_*, csrc/cross_host.inc) -------------------
+    def xsum_create(self, xs, zs, coeff, chunk_bits):
+        """plan of sum_t c_t P_t (masks in the physical index-bit space of the WHOLE register) on this shard -> id"""
+        coeff = np.asarray(coeff, np.complex128)
+        sid = ctypes.c_int32()
+        n = len(xs)
+        one = np.zeros(1)
+        self._ck(self._L.ovqe_xsum_create(self._h, n, np.ascontiguousarray(xs if n else [0], np.uint64),
+                                          np.ascontiguousarray(zs if n else [0], np.uint64),
+                                          np.ascontiguousarray(coeff.real) if n else one,
+                                          (np.ascontiguousarray(coeff.imag) if n else one) if np.any(coeff.imag != 0.0) else None,
+                                          int(chunk_bits), ctypes.byref(sid)))
+        return sid.value
+
+    def xsum_destroy(self, sid):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.ovqe_xsum_destroy(self._h, int(sid))
+
+    def xsum_partners(self, sid):
+        """[(rank difference d, passes one chunk of that partner costs)]"""
+        n = ctypes.c_int64()
+        self._ck(self._L.ovqe_xsum_partners(self._h, int(sid), 0, None, None, ctypes.byref(n)))
+        d, p = np.zeros(max(n.value, 1), np.uint64), np.zeros(max(n.value, 1), np.int64)
+        self._ck(self._L.ovqe_xsum_partners(self._h, int(sid), n.value, d.ctypes.data, p.ctypes.data, ctypes.byref(n)))
+        return [(int(d[k]), int(p[k])) for k in range(n.value)]
+
+    def xsum_info(self, sid):
+        out = (ctypes.c_int64 * 10)()
+        self._ck(self._L.ovqe_xsum_info(self._h, int(sid), out, 10))
+        keys = ("local_groups", "local_terms", "local_tile_sweeps", "local_untiled_groups", "partners", "remote_groups",
+                "remote_terms", "remote_passes_per_chunk", "tile_bits", "streaming_fallback")
+        return dict(zip(keys, [int(v) for v in out]))
+
+    def xsum_expect_local(self, sid):
+        out = ctypes.c_double()
+        self._ck(self._L.ovqe_xsum_expect_local(self._h, int(sid), ctypes.byref(out)))
+        return out.value
+
+    def xsum_expect_remote(self, sid, d, chunk, ket_ptr):
+        self._ck(self._L.ovqe_xsum_expect_remote(self._h, int(sid), int(d), int(chunk), ctypes.c_void_p(ket_ptr)))
+
+    def xsum_expect_finish(self, sid):
+        out = np.zeros(2, np.float64)
+        self._ck(self._L.ovqe_xsum_expect_finish(self._h, int(sid), out))
+        return complex(out[0], out[1])
+
+    def xsum_apply_local(self, sid, out_ptr, ident=0.0):
+        self._ck(self._L.ovqe_xsum_apply_local(self._h, int(sid), ctypes.c_void_p(out_ptr), float(ident)))
+
+    def xsum_apply_remote(self, sid, d, chunk, ket_ptr, out_ptr):
+        self._ck(self._L.ovqe_xsum_apply_remote(self._h, int(sid), int(d), int(chunk), ctypes.c_void_p(ket_ptr),
+                                                ctypes.c_void_p(out_ptr)))
+
     # -- compiled evaluation --------------------------------------------------------------------
     def set_hamiltonian(self, hamiltonian):
         xs, zs, cs = pack_terms(self.nbqbits, hamiltonian.terms)

@@ -12,6 +12,7 @@
 #include <complex>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -23,6 +24,7 @@
 #include "sv_sparse.hpp"
 #include "sv_tile.hpp"
 #include "sv_sector.hpp"
+#include "sv_cross.hpp"
 #include "sv_frame_host.hpp"
 #include <hipcub/hipcub.hpp>
 #include <unordered_map>
@@ -118,6 +120,29 @@ struct HamDev {  // grouped Pauli sum resident on the device
     DevBuf d_achunks, d_agroups, d_aterms;  // operator-application form of the cover (k_tile_apply, sparse tiles)
     std::vector<ExChunkT> h_achunks;        // host copy (launch geometry of the compact cover)
     int cover_id = 0;                       // bumped whenever the cover is rebuilt
+};
+
+// Pauli sum planned ONCE for a shard of the partitioned register (sv_cross.hpp, cross_host.inc): the terms without an x part on the
+// rank bits as a HamDev of their own (tile cover, pair trick), the others grouped by partner shard with a pass list each
+struct CrossCover {          // the groups of one partner (rank difference d)
+    uint64_t d = 0;
+    int ngroups = 0, nterms = 0;
+    bool small = false;      // chunks below the tile sizes: k_cross_small, one launch per class of high x bits
+    int M = 0;               // tile bits of the passes
+    std::vector<CrossPass> passes;
+    DevBuf d_achunks, d_agroups, d_aterms;          // tile form
+    std::vector<uint64_t> class_h;                   // small form: x bits above the chunk per class ...
+    std::vector<std::pair<int, int>> class_groups;   // ... and its group range
+    DevBuf d_groups, d_terms;
+};
+struct CrossSum {
+    int chunk_bits = 0;
+    bool hermitian = false;  // every coefficient real: expectation values allowed
+    HamDev local;            // d = 0
+    bool has_local = false;
+    std::vector<CrossCover> partners;
+    DevBuf d_part;           // per-workgroup partial sums of the remote contractions of one expectation value
+    size_t part_slots = 0;
 };
 
 // compact cover (sv_tile.hpp k_tile_expect_compact): the support of the program's states, sorted by tile for every sweep
@@ -411,6 +436,7 @@ struct ovqe_sv {
                                   // compacted list of those amplitudes (0 = always the dense entry walks)
     HamDev ham_real;              // tile cover of the stored Hamiltonian for the real-amplitude state
     TilePlan tp_adhoc;            // of the rotation list of the current ovqe_apply_pauli_rotations call
+    std::vector<CrossSum *> xsums;   // ovqe_xsum_create (slots of destroyed sums are nullptr)
 };
 
 namespace {
@@ -459,6 +485,25 @@ int translate_exception(ovqe_handle h) noexcept {
         if (e_ != hipSuccess)                                                                           \
             return fail(h, OVQE_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));            \
     } while (0)
+
+void free_hamdev(HamDev &H) {
+    for (DevBuf *b : {&H.d_groups, &H.d_terms, &H.d_tchunks, &H.d_tgroups, &H.d_tterms, &H.d_tflats, &H.d_titems, &H.d_rest, &H.d_achunks,
+                      &H.d_agroups, &H.d_aterms})
+        if (b->p) {
+            (void)hipFree(b->p);
+            *b = DevBuf{};
+        }
+}
+
+void free_cross_sum(CrossSum *X) {
+    if (!X) return;
+    free_hamdev(X->local);
+    for (CrossCover &C : X->partners)
+        for (DevBuf *b : {&C.d_achunks, &C.d_agroups, &C.d_aterms, &C.d_groups, &C.d_terms})
+            if (b->p) (void)hipFree(b->p);
+    if (X->d_part.p) (void)hipFree(X->d_part.p);
+    delete X;
+}
 
 void release_block(void *p, size_t cap) {
     if (!p) return;
@@ -1131,7 +1176,9 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bo
     // two streams when the cover has enough sweeps: the sweeps are taken heaviest-first by the main stream and
     // lightest-first by the second one until they meet (estimated duration: one read of the state + compute per term)
     const int ns = (int)H.tsweeps.size();
-    const bool dual = h->opt_expect_streams >= 2 && ns >= 8 && h->n_local >= 20 && h->n_global == 0;
+    // (shards too: the second stream forks from and joins the handle's stream by events, so what the caller ordered behind that
+    // stream — the RCCL transfers of the partitioned register — stays ordered behind both)
+    const bool dual = h->opt_expect_streams >= 2 && ns >= 8 && h->n_local >= 20;
     if (dual && !h->stream2) {
         HIPC(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
         HIPC(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -1418,8 +1465,8 @@ int launch_tile_apply(ovqe_handle h, const HamDev &H, const ExSweep &sw, const a
 // in_idx / in_count: the ascending list of the non-zero amplitudes of `in` when the caller has it (the ADAPT screen of a
 // state of a few determinants): every sweep then only visits the tiles that hold one of them
 int apply_hamiltonian(ovqe_handle h, amp_t *out, const amp_t *in, double ident, const uint64_t *in_idx = nullptr,
-                      uint64_t in_count = 0) {
-    HamDev &H = h->ham;
+                      uint64_t in_count = 0, HamDev *which = nullptr) {
+    HamDev &H = which ? *which : h->ham;   // (which: the local part of a planned cross-shard sum, cross_host.inc)
     if (H.tile_bits != tile_bits(h, false) || H.tile_low != ham_tile_low(h, false) || H.tile_real) {
         int rc = build_ham_tiles(h, H, false);
         if (rc) return rc;
@@ -3184,6 +3231,7 @@ int ovqe_destroy(ovqe_handle h) try {
         if (b->p) (void)hipFree(b->p);
     free_sector(h->sec);
     free_sector(h->scr);
+    for (CrossSum *X : h->xsums) free_cross_sum(X);
     h->kept_blocks.flush();
     if (h->h_rp) (void)hipHostFree(h->h_rp);
     if (h->h_result) (void)hipHostFree(h->h_result);
@@ -4983,3 +5031,5 @@ int ovqe_last_batch_ms(ovqe_handle h, double *ms) try {
 } OVQE_CATCH(h)
 
 }  // extern "C"
+
+#include "cross_host.inc"

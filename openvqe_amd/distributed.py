@@ -152,20 +152,44 @@ class HipShardEngine:
         self.sv.apply_pauli_rotations(xs, zs, phis)
         self._count("rotation", self.sv, len(xs))
 
-    def bilinear(self, xs, zs, coeffs, ket=None):
-        out = self.sv.bilinear(xs, zs, coeffs, ket_ptr=None if ket is None else ket.data_ptr())
-        self._count("contraction", self.sv)
-        return out
-
-    def apply_sum(self, xs, zs, coeffs, out, ket=None, accumulate=False):
-        self.sv.apply_pauli_sum(xs, zs, coeffs, out.data_ptr(), None if ket is None else ket.data_ptr(), accumulate)
-
     def bilinear_batch(self, offsets, xs, zs, coeffs, bra, ket=None):
         return self.sv.bilinear_batch(offsets, xs, zs, coeffs, bra_ptr=bra.data_ptr(),
                                       ket_ptr=None if ket is None else ket.data_ptr())
 
-    # -- the same three contractions on CHUNKS: 2^m consecutive amplitudes of a shard-sized buffer against a received chunk
-    # of the partner's shard; masks live on the m low bits (the host layer folds everything above them into the coefficients)
+    # -- Pauli sums planned once per (Hamiltonian, permutation): ovqe_xsum_* (csrc/cross_host.inc, csrc/sv_cross.hpp).  Masks in the
+    # physical bit space of the whole register; the remote calls only enqueue kernels on the engine's stream
+    def plan_sum(self, xs, zs, coeffs, chunk_bits):
+        return self.sv.xsum_create(xs, zs, coeffs, chunk_bits)
+
+    def free_sum(self, sid):
+        self.sv.xsum_destroy(sid)
+
+    def sum_info(self, sid):
+        return self.sv.xsum_info(sid)
+
+    def sum_partners(self, sid):
+        return self.sv.xsum_partners(sid)
+
+    def sum_expect_local(self, sid):
+        out = self.sv.xsum_expect_local(sid)
+        self._count("contraction", self.sv)
+        return out
+
+    def sum_expect_remote(self, sid, d, chunk, ket):
+        self.sv.xsum_expect_remote(sid, d, chunk, ket.data_ptr())
+        self._count("contraction", self.sv)
+
+    def sum_expect_finish(self, sid):
+        return self.sv.xsum_expect_finish(sid)
+
+    def sum_apply_local(self, sid, out, ident=0.0):
+        self.sv.xsum_apply_local(sid, out.data_ptr(), ident)
+
+    def sum_apply_remote(self, sid, d, chunk, ket, out):
+        self.sv.xsum_apply_remote(sid, d, chunk, ket.data_ptr(), out.data_ptr())
+
+    # -- the pool contraction on CHUNKS: 2^m consecutive amplitudes of a shard-sized buffer against a received chunk of the
+    # partner's shard; masks live on the m low bits (the host layer folds everything above them into the coefficients)
     def _sub(self, m):
         if m not in self._subs:
             from .backend import Statevector
@@ -175,14 +199,6 @@ class HipShardEngine:
             self._subs[m] = sub
         return self._subs[m]
 
-    def sub_bilinear(self, m, bra, bra_off, ket, xs, zs, coeffs):
-        out = self._sub(m).bilinear(xs, zs, coeffs, bra_ptr=bra.data_ptr() + 16 * bra_off, ket_ptr=ket.data_ptr())
-        self._count("contraction", self._sub(m))
-        return out
-
-    def sub_apply_sum(self, m, out, out_off, ket, xs, zs, coeffs):
-        self._sub(m).apply_pauli_sum(xs, zs, coeffs, out.data_ptr() + 16 * out_off, ket.data_ptr(), True)
-
     def sub_bilinear_batch(self, m, offsets, xs, zs, coeffs, bra, bra_off, ket):
         return self._sub(m).bilinear_batch(offsets, xs, zs, coeffs, bra_ptr=bra.data_ptr() + 16 * bra_off, ket_ptr=ket.data_ptr())
 
@@ -190,10 +206,19 @@ class HipShardEngine:
 class ShardedStatevector:
     """n-qubit state over ``dist.get_world_size()`` ranks (a power of two)."""
 
-    def __init__(self, n_qubits, engine_factory=None, group=None, device=None):
+    def __init__(self, n_qubits, engine_factory=None, group=None, device=None, dry_rank=None):
+        """``dry_rank`` = (world, rank): ONE rank of a ``world``-rank register without the others — no process group; a half-shard
+        exchange packs, "receives" its own packed half and unpacks, a partner-shard read hands out this rank's own chunks.  The
+        amplitudes are then meaningless, but every kernel launch, every pack / unpack copy and every byte that would cross a link
+        is what that rank of the real job executes and counts: the per-rank compute time of configs[4] at full shard size, measured
+        on one GPU (bench.py ``scale_proxy``)."""
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.dry = dry_rank is not None
+        if self.dry:
+            self.world, self.rank = int(dry_rank[0]), int(dry_rank[1])
+        else:
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+            self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         g = self.world.bit_length() - 1
         if (1 << g) != self.world:
             raise ValueError("world size must be a power of two")
@@ -205,9 +230,14 @@ class ShardedStatevector:
             dev = device if device is not None else torch.cuda.current_device()
             engine_factory = lambda nl, ng, r: HipShardEngine(nl, ng, r, dev)  # noqa: E731
         self.engine = engine_factory(self.n_local, self.g, self.rank)
-        self._dist = dist.is_initialized()
+        self._dist = dist.is_initialized() and not self.dry
         self.stats = {"swaps": 0, "bytes_sent": 0, "full_shard_reads": 0, "chunk_reads": 0, "partners_per_read": 0, "pieces": 0,
-                      "swap_s": 0.0, "shard_read_s": 0.0, "real_exchanges": 0, "real_chunk_reads": 0}
+                      "swap_s": 0.0, "shard_read_s": 0.0, "real_exchanges": 0, "real_chunk_reads": 0,
+                      # seconds this rank's kernels ran, by phase (each section ends with a device synchronisation)
+                      "local_sweeps_s": 0.0, "expectation_local_s": 0.0, "expectation_remote_s": 0.0, "apply_s": 0.0}
+        # Several ranks on ONE device (the gloo runs of the tests and of bench.py's single-device mode) would time each other's
+        # kernels: with a lock file every compute section takes the device alone (flock), so its seconds are this rank's own
+        self.compute_lock = None
         self._tmp = None
         self._chunk_bufs = None
         self._chunk_real = None
@@ -221,6 +251,30 @@ class ShardedStatevector:
         self.real_transfers = True
 
     # -- helpers ----------------------------------------------------------------------------
+    def _compute(self, phase):
+        """context of one compute section: its wall time (device synchronised on both sides) goes to stats[phase + "_s"]"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def section():
+            lock = None
+            if self.compute_lock:
+                import fcntl
+                lock = open(self.compute_lock, "a+")
+                fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                self.engine.sync()
+                t0 = time.perf_counter()
+                yield
+                self.engine.sync()
+                self.stats[phase + "_s"] += time.perf_counter() - t0
+            finally:
+                if lock is not None:
+                    import fcntl
+                    fcntl.flock(lock, fcntl.LOCK_UN)
+                    lock.close()
+        return section()
+
     def _phys(self, mask):
         return permute_mask(mask, self.perm)
 
@@ -271,6 +325,14 @@ class ShardedStatevector:
         for p, rcv in enumerate(recv_pieces):
             snd = make_send(p)
             keep.append(snd)
+            if self.dry:     # (one rank alone: the piece it would send stands in for the piece it would receive)
+                rcv.copy_(snd.view(rcv.shape))
+
+                class _Done:
+                    def wait(_self):
+                        pass
+                works.append(_Done())
+                continue
             works.append(self._post_pair(snd, rcv, partner, tag=p))   # one tag per piece: gloo matches by tag
         for p, w in enumerate(works):
             w.wait()
@@ -415,8 +477,9 @@ class ShardedStatevector:
 
         def flush():
             if batch_x:
-                self.engine.rotations(np.array(batch_x, np.uint64), np.array(batch_z, np.uint64),
-                                      np.array(batch_p, np.float64))
+                with self._compute("local_sweeps"):
+                    self.engine.rotations(np.array(batch_x, np.uint64), np.array(batch_z, np.uint64),
+                                          np.array(batch_p, np.float64))
                 batch_x.clear(); batch_z.clear(); batch_p.clear()
 
         uses = self._use_lists(xs, self.n) if len(xs) > 8 else None
@@ -443,8 +506,9 @@ class ShardedStatevector:
             groups.setdefault(xp >> self.n_local, []).append((xp, zp, complex(c), t))
         return [(xg, groups[xg]) for xg in sorted(groups)]
 
-    #: log2 of the amplitudes per chunk of a partner-shard read (26: 1 GiB); OVQE_SHARD_CHUNK_BITS overrides it (tests)
-    CHUNK_BITS = 26
+    #: log2 of the amplitudes per chunk of a partner-shard read (27: 2 GiB; the x bits of a term above the chunk cost extra passes of
+    #: the cross-shard kernels, so chunks are as large as the double buffers allow); OVQE_SHARD_CHUNK_BITS overrides it (tests)
+    CHUNK_BITS = 27
 
     def _chunk_bits(self):
         import os
@@ -452,66 +516,94 @@ class ShardedStatevector:
         return max(1, min(self.n_local, m))
 
     def _post_multi(self, items):
-        """post every (send tensor, receive tensor, partner rank, tag) of ``items`` as ONE batch -> object with ``wait()``.
-        RCCL runs the pairs of a batch concurrently — one xGMI link per partner — and takes the device tensors as they are;
-        gloo (tests; CPU engines) talks to raw host pointers, so device tensors travel through host copies there."""
-        staged = items[0][0].is_cuda and dist.get_backend(self.group) == "gloo"
-        if items[0][0].is_cuda and not staged and hasattr(self.engine, "check_stream"):
+        """post every (send tensor or None, receive tensor or None, partner rank, tag) of ``items`` as ONE batch -> object with
+        ``wait()``.  RCCL runs the transfers of a batch concurrently — one xGMI link per partner — and takes the device tensors as
+        they are; gloo (tests; CPU engines) talks to raw host pointers, so device tensors travel through host copies there."""
+        some = next(t for it in items for t in it[:2] if t is not None)
+        staged = some.is_cuda and dist.get_backend(self.group) == "gloo"
+        if some.is_cuda and not staged and hasattr(self.engine, "check_stream"):
             self.engine.check_stream()
         ops, keep = [], []
+        sent = {}
         for snd, rcv, partner, tag in items:
-            s_buf = snd.cpu() if staged else snd
-            r_buf = torch.empty(rcv.shape, dtype=rcv.dtype, device="cpu") if staged else rcv
-            keep.append((s_buf, r_buf, rcv))
-            pair = [dist.P2POp(dist.isend, s_buf, partner, self.group, tag=tag), dist.P2POp(dist.irecv, r_buf, partner, self.group, tag=tag)]
-            if self.rank > partner:   # lower rank sends first in a pair (gloo needs an order)
+            pair = []
+            if snd is not None:
+                if staged and id(snd) not in sent:
+                    sent[id(snd)] = snd.cpu()          # (one host copy of the own chunk serves every destination)
+                s_buf = sent[id(snd)] if staged else snd
+                pair.append(dist.P2POp(dist.isend, s_buf, partner, self.group, tag=tag))
+            if rcv is not None:
+                r_buf = torch.empty(rcv.shape, dtype=rcv.dtype, device="cpu") if staged else rcv
+                keep.append((r_buf, rcv))
+                pair.append(dist.P2POp(dist.irecv, r_buf, partner, self.group, tag=tag))
+            if len(pair) == 2 and self.rank > partner:   # lower rank sends first in a pair (gloo needs an order)
                 pair.reverse()
             ops += pair
-        works = dist.batch_isend_irecv(ops)
+        works = dist.batch_isend_irecv(ops) if ops else []
+        hold = list(sent.values())
 
         class _Pending:
             def wait(_self):
                 for w in works:
                     w.wait()
                 if staged:
-                    for _, r_buf, rcv in keep:
+                    for r_buf, rcv in keep:
                         rcv.copy_(r_buf)
                 keep.clear()
+                hold.clear()
 
         return _Pending()
 
-    def _partner_chunks(self, partners):
+    def _partner_chunks(self, partners, send_to=None):
         """generator over the chunks of the partners' psi shards: yields (c, [chunk c of the shard of rank ^ d for d in
-        ``partners``]).  Chunk c + 1 of ALL partners is posted as one batch before chunk c is handed out (double buffering:
-        2 x len(partners) x 2^m amplitudes instead of two whole shards), so every link of the group list carries traffic at
-        once while the previous chunk is contracted ("several partners concurrently in chunks")."""
-        if not partners:
+        ``partners``]); this rank's own chunk c goes to rank ^ d for d in ``send_to`` (default: the same list — a symmetric read;
+        the Hermitian halving of <H> reads from some partners and sends to others).  Chunk c + 1 of ALL partners is posted as one
+        batch before chunk c is handed out (double buffering: 2 x len(partners) x 2^m amplitudes instead of two whole shards), so
+        every link of the list carries traffic at once while the previous chunk is contracted ("several
+        partners concurrently in chunks")."""
+        send_to = list(partners) if send_to is None else list(send_to)
+        partners = list(partners)
+        if not partners and not send_to:
             return
         m = self._chunk_bits()
         csize = 1 << m
         nchunks = 1 << (self.n_local - m)
         np_ = len(partners)
-        if self._chunk_bufs is None or self._chunk_bufs[0].numel() < np_ * csize:
+        real = self.real and self.real_transfers
+        if self.dry:     # one rank alone: its own chunks stand in for the partners' (same kernels, same bytes counted)
+            for c in range(nchunks):
+                own = self.engine.tensor[c * csize:(c + 1) * csize]
+                self.stats["chunk_reads"] += np_
+                self.stats["bytes_sent"] += len(send_to) * csize * (8 if real else 16)
+                yield c, [own] * np_
+                self.engine.sync()
+            self.stats["full_shard_reads"] += np_
+            self.stats["partners_per_read"] = max(self.stats["partners_per_read"], np_)
+            return
+        if np_ and (self._chunk_bufs is None or self._chunk_bufs[0].numel() < np_ * csize):
             self._chunk_bufs = None
             self._chunk_bufs = [self.engine.new_buffer(np_ * csize), self.engine.new_buffer(np_ * csize)]
         self.engine.sync()
 
-        real = self.real and self.real_transfers
-        if real and (self._chunk_real is None or self._chunk_real[0].numel() < np_ * csize):
+        if real and np_ and (self._chunk_real is None or self._chunk_real[0].numel() < np_ * csize):
             self._chunk_real = [torch.empty(np_ * csize, dtype=torch.float64, device=self.engine.tensor.device) for _ in range(2)]
-        if real and (self._chunk_send is None or self._chunk_send[0].numel() != csize):   # (sized by the chunk alone: its own test)
+        if real and send_to and (self._chunk_send is None or self._chunk_send[0].numel() != csize):   # (sized by the chunk alone: its own test)
             self._chunk_send = [torch.empty(csize, dtype=torch.float64, device=self.engine.tensor.device) for _ in range(2)]
 
         def post(c):
+            # one tag per (chunk parity, partner difference): gloo matches by tag, and both ends of a pair agree on it
             own = self.engine.tensor[c * csize:(c + 1) * csize]
-            if real:   # real parts only over the links; the complex chunks are rebuilt when the transfer has landed
+            if real and send_to:   # real parts only over the links; the complex chunks are rebuilt when the transfer has landed
                 send = self._chunk_send[c & 1]
                 send.copy_(torch.view_as_real(own)[:, 0])
-                return self._post_multi([(send, self._chunk_real[c & 1][k * csize:(k + 1) * csize], self.rank ^ d, 2 * d + (c & 1))
-                                         for k, d in enumerate(partners)])
-            # one tag per (chunk parity, partner difference): gloo matches by tag, and both ends of a pair agree on it
-            return self._post_multi([(own, self._chunk_bufs[c & 1][k * csize:(k + 1) * csize], self.rank ^ d, 2 * d + (c & 1))
-                                     for k, d in enumerate(partners)])
+                own = send
+            into = self._chunk_real if real else self._chunk_bufs
+            items = {}
+            for d in send_to:
+                items[d] = [own, None]
+            for k, d in enumerate(partners):
+                items.setdefault(d, [None, None])[1] = into[c & 1][k * csize:(k + 1) * csize]
+            return self._post_multi([(sr[0], sr[1], self.rank ^ d, 2 * d + (c & 1)) for d, sr in sorted(items.items())])
 
         _progress("partner-shard read")
         pending = post(0)
@@ -522,14 +614,14 @@ class ShardedStatevector:
             if hasattr(self.engine, "stream"):
                 self.engine.stream.synchronize()      # the transfers themselves, for the link rates of the bench line
             self.stats["shard_read_s"] += time.perf_counter() - t0
-            if real:
+            if real and np_:
                 dst = torch.view_as_real(self._chunk_bufs[c & 1][:np_ * csize])
                 dst[:, 0].copy_(self._chunk_real[c & 1][:np_ * csize])
                 dst[:, 1].zero_()
             pending = post(c + 1) if c + 1 < nchunks else None
             self.stats["chunk_reads"] += np_
             self.stats["real_chunk_reads"] += np_ if real else 0
-            self.stats["bytes_sent"] += np_ * csize * (8 if real else 16)
+            self.stats["bytes_sent"] += len(send_to) * csize * (8 if real else 16)
             yield c, [self._chunk_bufs[c & 1][k * csize:(k + 1) * csize] for k in range(np_)]
             self.engine.sync()   # the buffers of this parity are posted again two chunks later
         self.stats["full_shard_reads"] += np_
@@ -557,38 +649,95 @@ class ShardedStatevector:
         remote = [(xg, self._split_by_chunk(terms, xg)) for xg, terms in groups if xg]
         return remote, [xg for xg, _ in remote]
 
+    # -- Hermitian sums: planned once per (term list, permutation) ----------------------------------------------------------------
+    @staticmethod
+    def share_of(rank, d, world, x_groups):
+        """Which x-groups of the cross terms between ``rank`` and ``rank ^ d`` this RANK contracts.  A Hermitian term gives the pair
+        (i on rank, j on rank ^ d) and its mirror image conjugate contributions, so ONE of the two ranks evaluates
+        2 Re <shard|P|partner shard> and the other neither computes nor receives anything for it: half the contractions AND half the
+        xGMI traffic of <H>.  The pairs are oriented like a round-robin tournament — rank r takes the partners s with
+        1 <= (s - r) mod W < W/2: (W - 2)/2 each — and the diametric pair (d = W/2) shares its groups alternately.
+        -> the sub-list of ``x_groups`` (sorted physical x masks)"""
+        s = rank ^ d
+        k = (s - rank) % world
+        if 2 * k == world:
+            return x_groups[0::2] if rank < s else x_groups[1::2]
+        return list(x_groups) if 1 <= k < world / 2 else []
+
+    def plan_hamiltonian(self, xs, zs, coeffs, constant=0.0):
+        """plan of H = constant + sum_t c_t P_t (real c_t; logical masks) under the CURRENT permutation: the terms this rank
+        evaluates for <H> — its d = 0 terms and, doubled, its share of the cross terms — as one engine sum; the partners it reads
+        from / sends its shard to; the full list for sigma = H psi (planned at its first use)"""
+        m = self._chunk_bits()
+        phys = [(self._phys(int(x)), self._phys(int(z)), complex(c)) for x, z, c in zip(xs, zs, coeffs)]
+        by_d = {}
+        for xp, zp, c in phys:
+            by_d.setdefault(xp >> self.n_local, {}).setdefault(xp, []).append((zp, c))
+        ex, read_from, send_to = [], [], []
+        for d in sorted(by_d):
+            groups = sorted(by_d[d])
+            if d == 0:
+                ex += [(xp, zp, c) for xp in groups for zp, c in by_d[d][xp]]
+                continue
+            mine = self.share_of(self.rank, d, self.world, groups)
+            ex += [(xp, zp, 2.0 * c) for xp in mine for zp, c in by_d[d][xp]]
+            if mine:
+                read_from.append(d)
+            if self.share_of(self.rank ^ d, d, self.world, groups):
+                send_to.append(d)
+        plan = {"m": m, "perm": tuple(self.perm), "const": float(np.real(constant)), "terms": phys,
+                "read_from": read_from, "send_to": send_to, "partners": sorted(d for d in by_d if d),
+                "expect": self.engine.plan_sum(np.array([t[0] for t in ex], np.uint64), np.array([t[1] for t in ex], np.uint64),
+                                               np.array([t[2] for t in ex], np.complex128), m),
+                "apply": None}
+        return plan
+
+    def free_plan(self, plan):
+        for key in ("expect", "apply"):
+            if plan.get(key) is not None:
+                self.engine.free_sum(plan[key])
+                plan[key] = None
+
+    def _plan_for(self, xs, zs, coeffs, constant):
+        """ad-hoc calls: the plans of the last few (term list, permutation) pairs are kept"""
+        key = (tuple(self.perm), self._chunk_bits(), np.asarray(xs, np.uint64).tobytes(), np.asarray(zs, np.uint64).tobytes(),
+               np.asarray(coeffs, np.complex128).tobytes())
+        cache = self.__dict__.setdefault("_plans", {})
+        plan = cache.pop(key, None)
+        if plan is None:
+            plan = self.plan_hamiltonian(xs, zs, coeffs, 0.0)
+            while len(cache) >= 4:
+                self.free_plan(cache.pop(next(iter(cache))))
+        cache[key] = plan        # (most recently used last)
+        plan["const"] = float(np.real(constant))
+        return plan
+
     def expectation(self, xs, zs, coeffs, constant=0.0):
         """Re sum_t c_t <psi|P_t|psi> + constant over the whole register (same value on every rank)"""
-        groups = self._group_by_partner(xs, zs, coeffs)
-        remote, partners = self._remote_plan(groups)
-        return self._expectation_grouped(groups, remote, partners) + float(np.real(constant))
+        return self._expectation_planned(self._plan_for(xs, zs, coeffs, constant))
 
-    def _expectation_grouped(self, groups, remote, partners):
-        total = 0.0 + 0.0j
-        for xg, terms in groups:
-            if xg == 0:
-                total += self.engine.bilinear(np.array([t[0] for t in terms], np.uint64),
-                                              np.array([t[1] for t in terms], np.uint64),
-                                              np.array([t[2] for t in terms], np.complex128), None)
-        m = self._chunk_bits()
-        for c, chunks in self._partner_chunks(partners):
-            for (xg, by_h), ket in zip(remote, chunks):
-                ket_high = ((self.rank ^ xg) << (self.n_local - m)) | c     # the ket chunk's global index above the chunk bits
-                for h, terms in sorted(by_h.items()):
-                    cs = np.array([t[2] * self._ket_sign(t[3], ket_high) for t in terms], np.complex128)
-                    total += self.engine.sub_bilinear(m, self.engine.tensor, (c ^ h) << m, ket,
-                                                      np.array([t[0] for t in terms], np.uint64),
-                                                      np.array([t[1] for t in terms], np.uint64), cs)
-        val = torch.tensor([total.real], dtype=torch.float64, device=self.engine.tensor.device)
+    def _expectation_planned(self, plan):
+        if plan["perm"] != tuple(self.perm):
+            raise ValueError("the Hamiltonian was planned under another qubit permutation")
+        sid = plan["expect"]
+        with self._compute("expectation_local"):
+            total = self.engine.sum_expect_local(sid)
+        for c, chunks in self._partner_chunks(plan["read_from"], plan["send_to"]):
+            with self._compute("expectation_remote"):
+                for d, ket in zip(plan["read_from"], chunks):
+                    self.engine.sum_expect_remote(sid, d, c, ket)
+        if plan["read_from"]:
+            total += self.engine.sum_expect_finish(sid).real
+        val = torch.tensor([total], dtype=torch.float64, device=self.engine.tensor.device)
         _progress("all-reduce of the energy")
         if self._dist:
             dist.all_reduce(val, group=self.group)
-        out = float(val.item())
+        out = float(val.item()) + plan["const"]
         _progress("local sweeps")
         return out
 
     # -- ADAPT gradient screen on the sharded register (SURVEY.md section 8e: "ADAPT screen identical with sigma also sharded")
-    def apply_hamiltonian(self, xs, zs, coeffs, constant=0.0):
+    def apply_hamiltonian(self, xs, zs, coeffs, constant=0.0, plan=None):
         """sigma = (H + constant) psi, sharded like psi: the x_g = 0 terms act inside the shard; the other rank differences
         are accumulated chunk by chunk from the partners' psi shards (all partners of a chunk in flight at once).
         -> this rank's sigma shard (device buffer owned by the caller until the next call)"""
@@ -596,21 +745,21 @@ class ShardedStatevector:
         if getattr(self, "_sigma", None) is None or self._sigma.numel() < size:
             self._sigma = self.engine.new_buffer(size)
         sigma = self._sigma[:size]
-        groups = self._group_by_partner(xs, zs, coeffs)
-        local = [t for xg, terms in groups if xg == 0 for t in terms]
-        tx = np.array([t[0] for t in local] + [0], np.uint64)        # + constant * identity
-        tz = np.array([t[1] for t in local] + [0], np.uint64)
-        tc = np.array([t[2] for t in local] + [complex(constant)], np.complex128)
-        self.engine.apply_sum(tx, tz, tc, sigma, None, accumulate=False)
-        remote, partners = self._remote_plan(groups)
-        m = self._chunk_bits()
-        for c, chunks in self._partner_chunks(partners):
-            for (xg, by_h), ket in zip(remote, chunks):
-                ket_high = ((self.rank ^ xg) << (self.n_local - m)) | c
-                for h, terms in sorted(by_h.items()):
-                    cs = np.array([t[2] * self._ket_sign(t[3], ket_high) for t in terms], np.complex128)
-                    self.engine.sub_apply_sum(m, sigma, (c ^ h) << m, ket, np.array([t[0] for t in terms], np.uint64),
-                                              np.array([t[1] for t in terms], np.uint64), cs)
+        plan = plan if plan is not None else self._plan_for(xs, zs, coeffs, constant)
+        if plan["perm"] != tuple(self.perm):
+            raise ValueError("the Hamiltonian was planned under another qubit permutation")
+        if plan["apply"] is None:
+            t = plan["terms"]
+            plan["apply"] = self.engine.plan_sum(np.array([v[0] for v in t], np.uint64), np.array([v[1] for v in t], np.uint64),
+                                                 np.array([v[2] for v in t], np.complex128), plan["m"])
+        sid = plan["apply"]
+        with self._compute("apply"):
+            self.engine.sum_apply_local(sid, sigma, float(np.real(constant)))
+        for c, chunks in self._partner_chunks(plan["partners"]):
+            with self._compute("apply"):
+                for d, ket in zip(plan["partners"], chunks):
+                    self.engine.sum_apply_remote(sid, d, c, ket, sigma)
+        self.engine.sync()
         return sigma
 
     def pool_gradients(self, ham, pool, mode="fermionic"):
@@ -700,8 +849,7 @@ class ShardedStatevector:
                     "n_params": int(np.asarray(rot_pidx, np.int64).max(initial=-1)) + 1}
             if hamiltonian is not None:
                 hx, hz, hc, const = hamiltonian
-                groups = self._group_by_partner(hx, hz, hc)        # under the final permutation (self.perm right now)
-                prog["ham"] = (groups, self._remote_plan(groups), float(np.real(const)))
+                prog["ham"] = self.plan_hamiltonian(hx, hz, hc, const)   # under the final permutation (self.perm right now)
         finally:
             self.perm = saved
         return prog
@@ -720,7 +868,8 @@ class ShardedStatevector:
             if st[0] == "swap":
                 self._swap(st[1], st[2])
             else:
-                self.engine.rotations(st[1], st[2], phis[st[3]])
+                with self._compute("local_sweeps"):
+                    self.engine.rotations(st[1], st[2], phis[st[3]])
         assert self.perm == prog["perm"]
 
     def program_energy(self, prog, theta):
@@ -728,8 +877,7 @@ class ShardedStatevector:
         if prog["ham"] is None:
             raise ValueError("compile_program was called without a Hamiltonian")
         self.run_program(prog, theta)
-        groups, (remote, partners), const = prog["ham"]
-        return self._expectation_grouped(groups, remote, partners) + const
+        return self._expectation_planned(prog["ham"])
 
     def energy(self, ham_xs, ham_zs, ham_coeffs, constant, rot_xs, rot_zs, rot_phis, hf_index):
         """one whole evaluation: |hf> -> rotations -> <H>"""

@@ -62,23 +62,60 @@ class OracleShardEngine:
             total += complex(c) * ph * np.vdot(bra, sign * src[j.astype(np.int64)])
         return total
 
+    # -- planned sums (the engine protocol of openvqe_amd.distributed: masks in the physical bit space of the whole register) -------
+    def plan_sum(self, xs, zs, coeffs, chunk_bits):
+        sums = self.__dict__.setdefault("_sums", {})
+        sid = max(sums, default=-1) + 1
+        sums[sid] = {"terms": [(int(x), int(z), complex(c)) for x, z, c in zip(xs, zs, coeffs)], "m": int(chunk_bits), "acc": 0j}
+        return sid
 
-    def apply_sum(self, xs, zs, coeffs, out, ket=None, accumulate=False):
-        src = self._np() if ket is None else ket.numpy()
+    def free_sum(self, sid):
+        self._sums.pop(sid)
+
+    def _chunk_form(self, m, d, chunk, x, z):
+        """ket index j of chunk `chunk` of the shard of (rank ^ d) -> (own local index i = j ^ x_local, sign, i^ny)"""
         lm = (1 << self.n_local) - 1
-        acc = np.zeros(1 << self.n_local, complex)
-        i = np.arange(1 << self.n_local, dtype=np.uint64)
-        for x, z, c in zip(xs, zs, coeffs):
-            x, z = int(x), int(z)
-            off = (self.base ^ x) & ~lm
-            j = i ^ np.uint64(x & lm)
-            par = (j | np.uint64(off)) & np.uint64(z)
-            for s in (32, 16, 8, 4, 2, 1):
-                par ^= par >> np.uint64(s)
-            sign = 1.0 - 2.0 * (par & np.uint64(1)).astype(float)
-            acc += complex(c) * (1j) ** (bin(x & z).count("1") % 4) * sign * src[j.astype(np.int64)]
-        o = out.numpy()
-        o[:] = (o if accumulate else 0) + acc
+        jl = (np.arange(1 << m, dtype=np.uint64) | np.uint64(chunk << m))
+        gj = jl | np.uint64((self.base ^ (d << self.n_local)) & ~lm)
+        par = gj & np.uint64(z)
+        for s in (32, 16, 8, 4, 2, 1):
+            par ^= par >> np.uint64(s)
+        sign = 1.0 - 2.0 * (par & np.uint64(1)).astype(float)
+        return (jl ^ np.uint64(x & lm)).astype(np.int64), sign, (1j) ** (bin(x & z).count("1") % 4)
+
+    def sum_expect_local(self, sid):
+        t = [v for v in self._sums[sid]["terms"] if v[0] >> self.n_local == 0]
+        return self.bilinear([v[0] for v in t], [v[1] for v in t], [v[2] for v in t]).real if t else 0.0
+
+    def sum_expect_remote(self, sid, d, chunk, ket):
+        S = self._sums[sid]
+        bra, k = self._np(), ket.numpy()
+        for x, z, c in S["terms"]:
+            if x >> self.n_local != d:
+                continue
+            i, sign, ph = self._chunk_form(S["m"], d, chunk, x, z)
+            S["acc"] += c * ph * np.vdot(bra[i], sign * k)
+
+    def sum_expect_finish(self, sid):
+        out, self._sums[sid]["acc"] = self._sums[sid]["acc"], 0j
+        return out
+
+    def sum_apply_local(self, sid, out, ident=0.0):
+        psi = self._np()
+        acc = ident * psi
+        for x, z, c in self._sums[sid]["terms"]:
+            if x >> self.n_local == 0:
+                acc = acc + c * masks.pauli_apply(psi, x, z, index_offset=self.base)
+        out.numpy()[:] = acc
+
+    def sum_apply_remote(self, sid, d, chunk, ket, out):
+        S = self._sums[sid]
+        o, k = out.numpy(), ket.numpy()
+        for x, z, c in S["terms"]:
+            if x >> self.n_local != d:
+                continue
+            i, sign, ph = self._chunk_form(S["m"], d, chunk, x, z)
+            o[i] += c * ph * sign * k
 
     def bilinear_batch(self, offsets, xs, zs, coeffs, bra, ket=None):
         saved = self.tensor
@@ -109,13 +146,6 @@ class OracleShardEngine:
             i, sign, ph = self._low_form(m, int(x), int(z))
             total += complex(c) * ph * np.vdot(b[i], sign * k)        # <bra|P|ket> = sum_j conj(bra_{j^x}) i^ny (-1)^{|j&z|} ket_j
         return total
-
-    def sub_apply_sum(self, m, out, out_off, ket, xs, zs, coeffs):
-        o, k = out.numpy()[out_off:out_off + (1 << m)], ket.numpy()
-        for x, z, c in zip(xs, zs, coeffs):
-            assert int(x) >> m == 0 and int(z) >> m == 0
-            i, sign, ph = self._low_form(m, int(x), int(z))
-            o[i] += complex(c) * ph * sign * k
 
     def sub_bilinear_batch(self, m, offsets, xs, zs, coeffs, bra, bra_off, ket):
         return np.array([self.sub_bilinear(m, bra, bra_off, ket, xs[a:b], zs[a:b], coeffs[a:b])
@@ -188,8 +218,11 @@ def test_sharded_state_matches_single_process_oracle(world, n, chunk_bits):
         p.join(timeout=120)
         assert p.exitcode == 0
     if world == 8:
-        assert stats["partners_per_read"] == 7                      # all seven partner groups in one chunked read
-        assert stats["chunk_reads"] == 7 * (1 << (n - 3 - chunk_bits))
+        # Hermitian halving (ShardedStatevector.share_of): of the seven partner groups rank 0 contracts the cross terms with ranks
+        # 1, 2, 3 and its alternate share of the diametric rank 4 — four shards read in one chunked pass, the other three partners
+        # read rank 0's shard instead
+        assert stats["partners_per_read"] == 4
+        assert stats["chunk_reads"] == 4 * (1 << (n - 3 - chunk_bits))
     psi = np.zeros(1 << n, complex)
     psi[hf] = 1
     for x, z, p in zip(xs, zs, phis):
@@ -203,6 +236,22 @@ def test_sharded_state_matches_single_process_oracle(world, n, chunk_bits):
     glob = sum(1 for x in xs if x >> (n - g))
     # (one rotation can need an exchange per rank bit its x touches: the multi-bit masks of the world-8 cases)
     assert stats["swaps"] <= (glob if world < 8 else g * glob)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8, 16])
+def test_hermitian_halving_orients_every_pair_once_and_balances_the_ranks(world):
+    """ShardedStatevector.share_of: of the two ranks of a pair exactly one contracts each cross x-group (the other neither computes
+    nor receives for it), and no rank takes more than W/2 of its W - 1 partners"""
+    from openvqe_amd.distributed import ShardedStatevector as S
+    groups = list(range(100, 111))          # 11 x-groups per partner
+    for d in range(1, world):
+        for r in range(world):
+            mine, theirs = S.share_of(r, d, world, groups), S.share_of(r ^ d, d, world, groups)
+            assert sorted(mine + theirs) == groups          # every group exactly once over the pair
+    for r in range(world):
+        full = sum(1 for d in range(1, world) if len(S.share_of(r, d, world, groups)) == len(groups))
+        part = sum(1 for d in range(1, world) if 0 < len(S.share_of(r, d, world, groups)) < len(groups))
+        assert full == world // 2 - 1 and part == 1          # (W - 2) / 2 whole partners + its share of the diametric one
 
 
 def test_permute_mask():

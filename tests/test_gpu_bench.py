@@ -82,6 +82,10 @@ def test_two_process_sharded_block_against_oracle(gpu_lib):
         assert abs(leg["norm2"] - 1.0) < 1e-12
         assert leg["n_gpus"] == 2 and leg["swaps"] >= 1 and leg["exchanged_GiB_per_rank"] > 0
         assert leg["xgmi_link_GBs_exchange"] > 0 and leg["full_shard_reads"] >= 1
+        # the per-rank compute seconds of the scaling proxy (ranks on one device take their compute sections in turn)
+        assert leg["local_sweeps_s"] > 0 and leg["expectation_local_s"] > 0 and leg["expectation_remote_compute_s"] >= 0
+        assert leg["exchange_count"] == leg["swaps"] and leg["projected_with_xgmi"]["rotations_s"] > 0
+    assert len(out["sharded"]["weak_compute_s"]) == 3
 
 
 def test_stalled_rank_ends_the_sharded_leg_with_a_line_and_exit_code_3(gpu_lib):

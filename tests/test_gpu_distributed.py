@@ -13,10 +13,11 @@ from tests.test_distributed import _free_port, _screen_worker, _worker
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world,n,chunk_bits", [(2, 14, None), (4, 15, 10), (2, 17, 12), (8, 16, 10)])
+@pytest.mark.parametrize("world,n,chunk_bits", [(2, 14, None), (4, 15, 10), (2, 17, 12), (8, 16, 10), (2, 12, 8), (4, 16, 11)])
 def test_sharded_state_on_hip_shards(gpu_lib, world, n, chunk_bits):
-    """(8, 16, 10): eight HIP shards of 13 local qubits on the one GPU — x on two and three rank bits, all seven partner
-    groups of <H> read in 8 chunks of 2^10 amplitudes each (the m-bit sub-register contractions of the product engine)"""
+    """(8, 16, 10): eight HIP shards of 13 local qubits on the one GPU — x on two and three rank bits, the partner groups of <H> read
+    in 8 chunks of 2^10 amplitudes each and contracted by the LDS-tiled cross-shard passes (k_tile_cross: tiles of 2^10, 2^11 and
+    2^12 amplitudes over the cases; (2, 12, 8): chunks below the tile sizes, k_cross_small)"""
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
@@ -36,8 +37,8 @@ def test_sharded_state_on_hip_shards(gpu_lib, world, n, chunk_bits):
     assert abs(e - masks.expectation(psi, hx, hz, hc, 0.25)) < 1e-11
     g = world.bit_length() - 1
     assert 1 <= stats["swaps"] <= (1 if world < 8 else g) * sum(1 for x in xs if x >> (n - g)) and stats["full_shard_reads"] >= 1
-    if world == 8:
-        assert stats["partners_per_read"] == 7 and stats["chunk_reads"] == 7 * (1 << (n - 3 - chunk_bits))
+    if world == 8:   # Hermitian halving: rank 0 contracts four of its seven partner shards (ShardedStatevector.share_of)
+        assert stats["partners_per_read"] == 4 and stats["chunk_reads"] == 4 * (1 << (n - 3 - chunk_bits))
 
 
 @pytest.mark.parametrize("world,n,chunk_bits", [(2, 13, 9), (4, 14, None), (8, 15, 9)])
