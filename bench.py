@@ -519,7 +519,7 @@ def sharded_leg(n, local_rank, world, rank, rotations=64, terms=1000, barrier=No
     swap_bytes = st["bytes_sent"]
     read_bytes = st2["bytes_sent"] - st["bytes_sent"]
     t_local = max(st["local_sweeps_s"], 1e-9)
-    info = sv.engine.sum_info(sv._plan_for(hx, hz, hc, 0.0)["expect"]) if hasattr(sv.engine, "sum_info") else {}
+    info = sv.engine.sum_info(sv._plan_sum(sv._plan_for(hx, hz, hc, 0.0), "expect")) if hasattr(sv.engine, "sum_info") else {}
     link = XGMI_LINK_GBS * 1e9
     out = {
         "workload": f"{rotations} JW two-body rotations + {terms}-term random JW Hamiltonian ({groups} x-groups) on the "

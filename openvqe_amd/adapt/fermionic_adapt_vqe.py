@@ -18,7 +18,9 @@ from ..backend import GRAD_FERMIONIC, Statevector
 from ..common_files.circuit import count
 from ..common_files.host_threads import on_one_blas_thread, usable_blas_threads
 from ..common_files.sorted_gradient import abs_sort_desc, corresponding_index, index_without_0, value_without_0
+from .. import replicas
 from ..evaluator import UCCEvaluator
+from ..partitioned import make_backend
 from .driver import AdaptEngine, Flavour, rank_gradients
 from ..qat_compat import Program, X, build_ucc_ansatz, get_default_qpu
 
@@ -28,8 +30,15 @@ _screens = {}
 
 def _screen_backend(nbqbits):
     if nbqbits not in _screens:
-        _screens[nbqbits] = Statevector(nbqbits)
+        _screens[nbqbits] = make_backend(nbqbits)    # this rank's GPU, or the partitioned register (partitioned.make_backend)
     return _screens[nbqbits]
+
+
+def _pool_gradients(screen, pool, mode):
+    """the device screen; with several GPUs and the register on each of them, the pool's operators are shared between the ranks"""
+    if replicas.active(screen.nbqbits):
+        return replicas.pool_gradients(screen, pool, mode)
+    return screen.pool_gradients(pool, mode)
 
 
 def prepare_adapt_state(hf_init_sp, pool_ops_sp, parameters, hamiltonian_sp=None):
@@ -48,7 +57,7 @@ def return_gradient_list(cluster_ops_sp, hamiltonian_sp, screen):
     if getattr(screen, "_ham_token", None) is not hamiltonian_sp:
         screen.set_hamiltonian(hamiltonian_sp)
         screen._ham_token = hamiltonian_sp
-    grads = screen.pool_gradients(cluster_ops_sp, GRAD_FERMIONIC)
+    grads = _pool_gradients(screen, cluster_ops_sp, GRAD_FERMIONIC)
     list_grad = []
     curr_norm = 0
     next_deriv = 0
@@ -68,7 +77,7 @@ def return_signed_gradients(cluster_ops_sp, hamiltonian_sp, screen):
     if getattr(screen, "_ham_token", None) is not hamiltonian_sp:
         screen.set_hamiltonian(hamiltonian_sp)
         screen._ham_token = hamiltonian_sp
-    return [float(g) for g in screen.pool_gradients(cluster_ops_sp, GRAD_FERMIONIC)]
+    return [float(g) for g in _pool_gradients(screen, cluster_ops_sp, GRAD_FERMIONIC)]
 
 
 _evaluators = {}
@@ -129,6 +138,8 @@ def get_statevector(result, nbqbits):
 
 def fun_fidelity(circ, eigenvalues, eigenvectors, nbqbits):
     """|<ground|psi>|^2 with the ansatz state read back from the device (fermionic_adapt_vqe.py:331-361)."""
+    if eigenvectors is None:
+        return float("nan")
     ee = eigenvectors[:, np.argmin(eigenvalues)]
     res = get_default_qpu().submit(circ.to_job())
     if getattr(res, "indices", None) is not None:   # samples as arrays: the overlap only has these terms
@@ -154,6 +165,10 @@ def _ground_space(hamiltonian_sp, cluster_ops_sp=None, hf_init_sp=None):
         with usable_blas_threads():
             return np.linalg.eigh(hamiltonian_sp.get_matrix())
     sv = _screen_backend(hamiltonian_sp.nbqbits)
+    if replicas.partitioned(hamiltonian_sp.nbqbits):
+        # a register no single device holds: neither the reference's dense eigh (fermionic_adapt_vqe.py:474) nor the one-device
+        # Lanczos exists at this size; the fidelity column of the trace is then not-a-number
+        return None, None
     if getattr(sv, "_ham_token", None) is not hamiltonian_sp:
         sv.set_hamiltonian(hamiltonian_sp)
         sv._ham_token = hamiltonian_sp

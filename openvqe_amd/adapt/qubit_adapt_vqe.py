@@ -12,7 +12,9 @@ from numpy import binary_repr
 from ..backend import GRAD_QUBIT, Statevector
 from ..common_files.circuit import count
 from ..common_files.host_threads import on_one_blas_thread
+from .. import replicas
 from ..evaluator import UCCEvaluator
+from ..partitioned import make_backend
 from .driver import AdaptEngine, Flavour, iterated_root_norm, rank_gradients
 from ..qat_compat import Program, X, build_ucc_ansatz, get_default_qpu
 
@@ -22,8 +24,15 @@ _evaluators = {}
 
 def _screen_backend(nbqbits):
     if nbqbits not in _screens:
-        _screens[nbqbits] = Statevector(nbqbits)
+        _screens[nbqbits] = make_backend(nbqbits)    # this rank's GPU, or the partitioned register (partitioned.make_backend)
     return _screens[nbqbits]
+
+
+def _pool_gradients(screen, pool, mode):
+    """the device screen; with several GPUs and the register on each of them, the pool's operators are shared between the ranks"""
+    if replicas.active(screen.nbqbits):
+        return replicas.pool_gradients(screen, pool, mode)
+    return screen.pool_gradients(pool, mode)
 
 
 def prepare_adapt_state(hf_init_sp, ansatz, coefficients, nbqbits=None):
@@ -42,7 +51,7 @@ def calculate_gradients(pool_mix, hamiltonian_sp, screen):
     if getattr(screen, "_ham_token", None) is not hamiltonian_sp:
         screen.set_hamiltonian(hamiltonian_sp)
         screen._ham_token = hamiltonian_sp
-    return [float(g) for g in screen.pool_gradients(pool_mix, GRAD_QUBIT)]
+    return [float(g) for g in _pool_gradients(screen, pool_mix, GRAD_QUBIT)]
 
 
 def prepare_state_ansatz(cluster_ops_sp, hf_init_sp, parameters):

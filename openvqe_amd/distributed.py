@@ -685,12 +685,16 @@ class ShardedStatevector:
                 read_from.append(d)
             if self.share_of(self.rank ^ d, d, self.world, groups):
                 send_to.append(d)
-        plan = {"m": m, "perm": tuple(self.perm), "const": float(np.real(constant)), "terms": phys,
-                "read_from": read_from, "send_to": send_to, "partners": sorted(d for d in by_d if d),
-                "expect": self.engine.plan_sum(np.array([t[0] for t in ex], np.uint64), np.array([t[1] for t in ex], np.uint64),
-                                               np.array([t[2] for t in ex], np.complex128), m),
-                "apply": None}
-        return plan
+        # (the engine sums are made at their first use: an ADAPT screen never needs "expect", an energy never "apply")
+        return {"m": m, "perm": tuple(self.perm), "const": float(np.real(constant)), "terms": phys, "expect_terms": ex,
+                "read_from": read_from, "send_to": send_to, "partners": sorted(d for d in by_d if d), "expect": None, "apply": None}
+
+    def _plan_sum(self, plan, which):
+        if plan[which] is None:
+            t = plan["expect_terms" if which == "expect" else "terms"]
+            plan[which] = self.engine.plan_sum(np.array([v[0] for v in t], np.uint64), np.array([v[1] for v in t], np.uint64),
+                                               np.array([v[2] for v in t], np.complex128), plan["m"])
+        return plan[which]
 
     def free_plan(self, plan):
         for key in ("expect", "apply"):
@@ -719,7 +723,7 @@ class ShardedStatevector:
     def _expectation_planned(self, plan):
         if plan["perm"] != tuple(self.perm):
             raise ValueError("the Hamiltonian was planned under another qubit permutation")
-        sid = plan["expect"]
+        sid = self._plan_sum(plan, "expect")
         with self._compute("expectation_local"):
             total = self.engine.sum_expect_local(sid)
         for c, chunks in self._partner_chunks(plan["read_from"], plan["send_to"]):
@@ -748,11 +752,7 @@ class ShardedStatevector:
         plan = plan if plan is not None else self._plan_for(xs, zs, coeffs, constant)
         if plan["perm"] != tuple(self.perm):
             raise ValueError("the Hamiltonian was planned under another qubit permutation")
-        if plan["apply"] is None:
-            t = plan["terms"]
-            plan["apply"] = self.engine.plan_sum(np.array([v[0] for v in t], np.uint64), np.array([v[1] for v in t], np.uint64),
-                                                 np.array([v[2] for v in t], np.complex128), plan["m"])
-        sid = plan["apply"]
+        sid = self._plan_sum(plan, "apply")
         with self._compute("apply"):
             self.engine.sum_apply_local(sid, sigma, float(np.real(constant)))
         for c, chunks in self._partner_chunks(plan["partners"]):
@@ -809,7 +809,7 @@ class ShardedStatevector:
 
     # -- compiled programs: the exchange plan of a rotation list is made ONCE (ref:openvqe/ucc_family/get_energy_ucc.py:42-45 runs the
     # same list with new angles at every optimiser step) -----------------------------------------------------------------------
-    def compile_program(self, rot_xs, rot_zs, rot_coeffs, rot_pidx, hf_index, hamiltonian=None):
+    def compile_program(self, rot_xs, rot_zs, rot_coeffs, rot_pidx, hf_index, hamiltonian=None, rot_phi0=None):
         """plan of `|hf> -> prod_r exp(-i coeff_r theta[pidx_r] P_r)` on this partition, from the identity permutation: the
         half-shard exchanges (Belady victims over the whole list, next uses by bisection: O(R n log R) instead of the O(R^2 n) scan)
         and, between them, the local rotations with their masks already in PHYSICAL bit space; with ``hamiltonian`` =
@@ -844,6 +844,7 @@ class ShardedStatevector:
             flush()
             final_perm = list(self.perm)
             prog = {"steps": steps, "coeff": np.asarray(rot_coeffs, np.float64), "pidx": np.asarray(rot_pidx, np.int64),
+                    "phi0": None if rot_phi0 is None else np.asarray(rot_phi0, np.float64),
                     "hf": int(hf_index), "perm": final_perm, "real": all(bin(x & z).count("1") & 1 for x, z in zip(xs, zs)),
                     "swaps": sum(1 for st in steps if st[0] == "swap"), "ham": None,
                     "n_params": int(np.asarray(rot_pidx, np.int64).max(initial=-1)) + 1}
@@ -863,7 +864,12 @@ class ShardedStatevector:
         self.init_basis(prog["hf"])
         self.real = prog["real"]      # (a list with one even-Y string anywhere travels complex from the start: the flag is per program)
         pidx = prog["pidx"]
-        phis = prog["coeff"] * (np.where(pidx >= 0, theta[np.maximum(pidx, 0)], 1.0) if theta.size else 1.0)
+        # rotation r: exp(-i (coeff_r theta[pidx_r] + phi0_r) P_r); pidx_r < 0: a constant angle — phi0_r when the program carries
+        # constants (ovqe_set_program's convention), else coeff_r
+        fixed = 1.0 if prog.get("phi0") is None else 0.0
+        phis = prog["coeff"] * (np.where(pidx >= 0, theta[np.maximum(pidx, 0)], fixed) if theta.size else fixed)
+        if prog.get("phi0") is not None:
+            phis = phis + prog["phi0"]
         for st in prog["steps"]:
             if st[0] == "swap":
                 self._swap(st[1], st[2])

@@ -6,16 +6,19 @@ from __future__ import annotations
 
 import numpy as np
 
-from .backend import Statevector
+from . import replicas
+from .backend import Statevector  # noqa: F401  (the one-device handle: what make_backend builds on a single GPU)
+from .partitioned import make_backend
 
 _BACKENDS = {}
 
 
-def shared_backend(nbqbits, device=0):
-    """one resident statevector handle per register size"""
-    key = (int(nbqbits), int(device))
+def shared_backend(nbqbits, device=None):
+    """one resident statevector per register size: the one-device handle on this rank's GPU, or — several ranks and a register of
+    ``replicas.partition_min_qubits()`` qubits or more — the index-bit-partitioned register (partitioned.PartitionedStatevector)"""
+    key = (int(nbqbits), -1 if device is None else int(device))
     if key not in _BACKENDS:
-        _BACKENDS[key] = Statevector(nbqbits, device=device)
+        _BACKENDS[key] = make_backend(nbqbits, device)
     return _BACKENDS[key]
 
 
@@ -29,7 +32,7 @@ def release_backends():
 class _Evaluator:
     _owner = {}  # backend key -> evaluator whose program/Hamiltonian are loaded
 
-    def __init__(self, hamiltonian, device=0):
+    def __init__(self, hamiltonian, device=None):
         self.hamiltonian = hamiltonian
         self.nbqbits = hamiltonian.nbqbits
         self.device = device
@@ -61,7 +64,10 @@ class _Evaluator:
 
     def energy_batch(self, thetas):
         self._activate()
-        return self.sv.energy_batch(np.asarray(thetas, dtype=np.float64)[:, : self.n_params])
+        thetas = np.asarray(thetas, dtype=np.float64)[:, : self.n_params]
+        if replicas.active(self.nbqbits):     # several GPUs, register on each of them: the rows of the batch shared between the ranks
+            return replicas.energy_batch(self.sv, thetas)
+        return self.sv.energy_batch(thetas)
 
     def energy_gradient(self, theta):
         """(E, dE/dtheta) by the adjoint method on the device (ovqe_energy_gradient)"""
@@ -77,7 +83,7 @@ class _Evaluator:
 class UCCEvaluator(_Evaluator):
     """E(theta) = <HF| U(theta)^+ H U(theta) |HF>, U = prod_k prod_j exp(-i theta_k c_kj P_kj)."""
 
-    def __init__(self, hamiltonian, generators, hf_init, n_params=None, device=0):
+    def __init__(self, hamiltonian, generators, hf_init, n_params=None, device=None):
         super().__init__(hamiltonian, device)
         self.generators = list(generators)
         self.hf_init = int(hf_init)
@@ -90,7 +96,7 @@ class UCCEvaluator(_Evaluator):
 class GateEvaluator(_Evaluator):
     """E(theta) of a traced literal gate circuit (QUCCSD templates)."""
 
-    def __init__(self, hamiltonian, gates, n_params, hf_init, device=0):
+    def __init__(self, hamiltonian, gates, n_params, hf_init, device=None):
         super().__init__(hamiltonian, device)
         self.gates, self.n_params, self.hf_init = gates, int(n_params), int(hf_init)
 

@@ -349,16 +349,16 @@ class HipQPU:
     names, qubits, quarter-turn angles — with every other rotation gate as a parameter of its own, so the second submission
     of a template only passes its angles (and the Clifford-frame / sector paths keep their tables)."""
 
-    def __init__(self, device=0):
-        self.device = device
+    def __init__(self, device=None):
+        self.device = device    # None: this rank's GPU (replicas.device()); registers too large for one device are partitioned
         self._sv = {}
         self._compiled = {}   # nbqbits -> (skeleton key, operator objects kept alive, n_params)
         self._observable = {}  # nbqbits -> (observable object uploaded last, its content fingerprint)
 
     def _backend(self, n):
-        from .backend import Statevector
+        from .partitioned import make_backend
         if n not in self._sv:
-            self._sv[n] = Statevector(n, device=self.device)
+            self._sv[n] = make_backend(n, self.device)
         return self._sv[n]
 
     @staticmethod

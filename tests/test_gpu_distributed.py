@@ -115,3 +115,19 @@ def test_compiled_program_on_hip_shards(gpu_lib):
         assert abs(e - masks.expectation(psi, hx, hz, hc, 0.75)) < 1e-11
     assert np.abs(np.asarray(full) - psi).max() < 1e-12 and abs(e_plain - es[2]) < 1e-12
     assert swaps_per_run == plain_swaps == planned >= 1
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_reference_entry_points_on_hip_shards(gpu_lib, world):
+    """EnergyUCC.ucc_action, fermionic_adapt_vqe and qubit_adapt_vqe (two macro-iterations each) and exact exponentials with the
+    register partitioned over HIP shards (threshold forced to 6 qubits; every rank's shard on this GPU, gloo): same picks, energies
+    and norms as the single-process oracle engine"""
+    from tests.test_partitioned_api import FLOWS, _launch, _single_process_oracle, check_partitioned
+    check_partitioned(_launch(world, "hip", FLOWS, 6), _single_process_oracle(FLOWS))
+
+
+def test_replicas_share_batches_and_pools_on_hip(gpu_lib):
+    """below the threshold every rank holds the register on its GPU (here: two one-device handles on this GPU) and the ranks share
+    the rows of a batch and the operators of a pool"""
+    from tests.test_partitioned_api import _launch, _single_process_oracle, check_replicas
+    check_replicas(_launch(2, "hip", ("replicas",), 31), _single_process_oracle(("replicas",)))
