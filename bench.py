@@ -470,7 +470,7 @@ SHARDED_SEED = 20250227
 SHARDED_KNOWN = {(31, 64, 1000): 0.0006064921993039994}
 
 
-def sharded_leg(n, local_rank, world, rank, rotations=64, terms=1000, barrier=None, dry_rank=None):
+def sharded_leg(n, local_rank, world, rank, rotations=64, terms=1000, barrier=None, dry_rank=None, real_state=False):
     """One pass of configs[4] over the index-bit-partitioned register (openvqe_amd.distributed): the synthetic state
     (recomputable on the host per global index, openvqe_amd/synth.py) -> `rotations` Pauli rotations (half-shard
     exchanges over RCCL for X/Y on global qubits) -> <H> (partner-shard reads for global-x groups).  World size 1 runs
@@ -487,6 +487,12 @@ def sharded_leg(n, local_rank, world, rank, rotations=64, terms=1000, barrier=No
         # every rank's shard sits on device 0: compute sections take the device one rank at a time, so that their seconds are a rank's own
         sv.compute_lock = os.path.join("/tmp", "ovqe_bench_compute_%s.lock" % os.environ.get("MASTER_PORT", "0"))
     sv.randomize(SHARDED_SEED)
+    if real_state:
+        # the workload's rotation strings all carry an odd number of Y — what every UCC / ADAPT generator does — so a REAL state stays
+        # real: the real parts of the synthetic state, renormalised, on float64 shards (8-byte amplitudes: half the bytes of every sweep)
+        sv.engine.set_real(True)
+        sv.real = True
+        sv.engine.tensor.mul_(1.0 / sv.norm2() ** 0.5)
     stall = os.environ.get("OVQE_BENCH_INJECT_STALL_RANK")      # tests: this rank never posts its half of the first exchange
     if stall is not None and int(stall) == rank:
         time.sleep(10 ** 6)
@@ -570,8 +576,11 @@ def sharded_leg(n, local_rank, world, rank, rotations=64, terms=1000, barrier=No
         out["dry_rank"] = {"world": world, "rank": rank, "note": "one rank of the job alone on one GPU: own chunks stand in for the partners', "
                            "every kernel, copy and byte count is that rank's; energy and norm are meaningless here"}
         out.pop("energy_check", None)
+    out["amplitude_bytes"] = 8 if real_state else 16
+    if real_state:
+        out["real_storage_through_the_leg"] = bool(sv._storage_real())
     known = SHARDED_KNOWN.get((n, rotations, terms))
-    if known is not None and dry_rank is None:
+    if known is not None and dry_rank is None and not real_state:
         tol = 1e-11 * out["h_norm1"]
         out["energy_check"] = {"expected": known, "abs_diff": abs(e - known), "tol": tol, "ok": bool(abs(e - known) <= tol)}
     del sv
@@ -595,6 +604,8 @@ def sharded_block(args, local_rank, world, rank, barrier):
     else:
         block["strong"] = block["weak"]
     if world == 1 and not args.no_scale_proxy:
+        # the same leg on a REAL state (float64 shard: the real-amplitude sweeps and <H> kernels)
+        block["real_state"] = sharded_leg(base, local_rank, 1, 0, args.sharded_rotations, args.sharded_terms, None, real_state=True)
         # configs[4] at FULL size without eight GPUs: rank 0 of an 8-rank register of base + 3 qubits as a dry rank on this GPU (its
         # shard is the 2^base amplitudes of the weak curve) — that rank's kernels, pack / unpack copies and link bytes, projected on
         # 153-GB/s links.  Rank 0 contracts four partner shards (the most any rank does under the Hermitian halving).
@@ -786,6 +797,9 @@ def compact_line(out, extra_path):
                 "energy_check": sh.get("energy_check")}
             for leg in ("weak", "strong"):
                 line["sharded"][leg + "_compute_s"] = [_r(sh[leg].get(k), 4) for k in ("local_sweeps_s", "expectation_local_s", "expectation_remote_compute_s")]
+            if sh.get("real_state"):
+                line["sharded"]["real_state_rotations_s"] = _r(sh["real_state"]["rotations_s"], 4)
+                line["sharded"]["real_state_expectation_s"] = _r(sh["real_state"]["expectation_s"], 4)
             px = sh.get("scale_proxy")
             if px is not None:
                 line["sharded"]["scale_proxy"] = {

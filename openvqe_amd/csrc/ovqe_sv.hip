@@ -135,12 +135,18 @@ struct CrossCover {          // the groups of one partner (rank difference d)
     std::vector<std::pair<int, int>> class_groups;   // ... and its group range
     DevBuf d_groups, d_terms;
 };
+struct CrossRawGroup {
+    uint64_t x;                 // local x mask
+    std::vector<HTerm> terms;   // full z masks, i^ny folded
+};
 struct CrossSum {
     int chunk_bits = 0;
     bool hermitian = false;  // every coefficient real: expectation values allowed
     HamDev local;            // d = 0
     bool has_local = false;
-    std::vector<CrossCover> partners;
+    std::vector<std::pair<uint64_t, std::vector<CrossRawGroup>>> raw;   // the terms of every rank difference d != 0, ascending
+    std::vector<CrossCover> partners[2];   // their pass lists: [0] complex amplitudes, [1] real amplitudes (option "real_state"); built at first use
+    bool built[2] = {false, false};
     DevBuf d_part;           // per-workgroup partial sums of the remote contractions of one expectation value
     size_t part_slots = 0;
 };
@@ -339,6 +345,9 @@ struct ovqe_sv {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int opt_expect_streams = 2;
+    int opt_real_state = 0;       // option "real_state": the state buffer holds 2^n_local DOUBLES (a shard of the partitioned register while
+                                  // every applied rotation has an odd number of Y): ovqe_apply_pauli_rotations, ovqe_init_basis, ovqe_norm2
+                                  // and the ovqe_xsum_expect_* calls work on 8-byte amplitudes
     CompactCover cc;              // of (current program, ham_real)
     int opt_compact = 1;          // allow the compact cover (real-amplitude streaming energies, 18..28 qubits)
     int opt_compact_cpp = 1;      // host chunks (512 terms each) staged in LDS per pass of the compact-cover kernel
@@ -498,9 +507,10 @@ void free_hamdev(HamDev &H) {
 void free_cross_sum(CrossSum *X) {
     if (!X) return;
     free_hamdev(X->local);
-    for (CrossCover &C : X->partners)
-        for (DevBuf *b : {&C.d_achunks, &C.d_agroups, &C.d_aterms, &C.d_groups, &C.d_terms})
-            if (b->p) (void)hipFree(b->p);
+    for (int f = 0; f < 2; ++f)
+        for (CrossCover &C : X->partners[f])
+            for (DevBuf *b : {&C.d_achunks, &C.d_agroups, &C.d_aterms, &C.d_groups, &C.d_terms})
+                if (b->p) (void)hipFree(b->p);
     if (X->d_part.p) (void)hipFree(X->d_part.p);
     delete X;
 }
@@ -3263,6 +3273,7 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     // tools/): fault injection, kernels with phases switched off, superseded kernel forms and launch geometries.  The product
     // library refuses them as unknown options and runs every one of them at its default.
     if (k == "force_path") h->opt_force_path = (int)value;
+    else if (k == "real_state") h->opt_real_state = value ? 1 : 0;
     else if (k == "small_max_qubits") h->opt_small_max = (int)value;
     else if (k == "small_batch_max_qubits") h->opt_small_batch_max = (int)value;
 #ifdef OVQE_TESTING
@@ -3463,7 +3474,15 @@ int ovqe_init_basis(ovqe_handle h, uint64_t index) try {
     if (!h) return OVQE_ERR_INVALID;
     const int ntot = h->n_local + h->n_global;
     if (ntot < 64 && (index >> ntot)) return fail(h, OVQE_ERR_INVALID, "basis index out of range");
-    int rc = init_basis(h, index);
+    int rc = OVQE_OK;
+    if (h->opt_real_state) {   // 2^n_local doubles; the 1.0 lives on the shard whose rank bits match
+        const uint64_t lmask = local_mask(h);
+        hipLaunchKernelGGL(k_init_basis_real, dim3(reduce_blocks(h->namps)), dim3(256), 0, h->stream, (double *)h->state, h->namps,
+                           (index & ~lmask) == h->base ? (index & lmask) : ~0ull);
+        HIPC(h, hipGetLastError());
+    } else {
+        rc = init_basis(h, index);
+    }
     if (rc) return rc;
     HIPC(h, hipStreamSynchronize(h->stream));
     return OVQE_OK;
@@ -3539,7 +3558,9 @@ int ovqe_norm2(ovqe_handle h, double *out) try {
     int rc = ensure(h, h->d_partials, (size_t)nb * sizeof(double2));
     if (!rc) rc = ensure(h, h->d_result, 64 * sizeof(double2));
     if (rc) return rc;
-    hipLaunchKernelGGL(k_norm2, dim3(nb), dim3(256), 0, h->stream, h->state, h->namps, (double2 *)h->d_partials.p);
+    // (real state: the 2^n_local doubles read as 2^(n_local - 1) complex numbers have the same sum of squares)
+    hipLaunchKernelGGL(k_norm2, dim3(nb), dim3(256), 0, h->stream, h->state, h->opt_real_state ? std::max<uint64_t>(h->namps >> 1, 1) : h->namps,
+                       (double2 *)h->d_partials.p);
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->stream, (const double2 *)h->d_partials.p, (int64_t)nb,
                        (double2 *)h->d_result.p, 0);
     HIPC(h, hipGetLastError());
@@ -3584,9 +3605,19 @@ int ovqe_apply_pauli_rotations(ovqe_handle h, int64_t R, const uint64_t *x, cons
         for (int64_t r = r0; r < r1; ++r) rots[(size_t)r].z = z[r];
         r0 = r1;
     }
+    // option "real_state": the buffer holds doubles — every string must keep a real state real (odd number of Y, x != 0): the
+    // real-amplitude tile sweeps (k_tile_sweep<REAL>: 2^13 amplitudes per 64-KB tile, one more mixing bit per sweep) and pair sweeps
+    const bool real = h->opt_real_state != 0;
+    if (real) {
+        if (h->n_local < 2) return fail(h, OVQE_ERR_INVALID, "real_state needs at least two local qubits");
+        for (int64_t r = 0; r < R; ++r)
+            if (x[r] == 0 || !(__builtin_popcountll(x[r] & z[r]) & 1))
+                return fail(h, OVQE_ERR_INVALID, "real_state: a rotation with an even number of Y (or a diagonal one) makes the amplitudes "
+                                                 "complex — clear the option and widen the buffer first");
+    }
     TilePlan &tp = h->tp_adhoc;
     if (ops.size() >= 2 && R < (1ll << 30)) {
-        rc = build_tile_plan(h, ops, rots, std::vector<uint64_t>(ops.size(), 0), tp);
+        rc = build_tile_plan(h, ops, rots, std::vector<uint64_t>(ops.size(), 0), tp, real);
         if (rc) return rc;
     } else {
         tp.plan.assign(ops.size(), 0);
@@ -3594,16 +3625,23 @@ int ovqe_apply_pauli_rotations(ovqe_handle h, int64_t R, const uint64_t *x, cons
     }
     for (const int32_t step : tp.plan) {
         if (step >= 0) {
-            rc = launch_tile_segment(h, tp, tp.tsegs[step]);
+            rc = launch_tile_segment(h, tp, tp.tsegs[step], real);
         } else {
             const SmallOp &op = ops[-1 - step];
-            rc = launch_rot_run(h, op.x, (const RotParam *)h->d_rp.p + op.first, op.count);
+            if (real) {
+                hipLaunchKernelGGL(k_rot_pairs_real, dim3(reduce_blocks(h->namps)), dim3(256), 0, h->stream, (double *)h->state, h->namps >> 1,
+                                   op.pivot, op.x, h->base, (const RotParam *)h->d_rp.p + op.first, op.count);
+                HIPC(h, hipGetLastError());
+                rc = OVQE_OK;
+            } else {
+                rc = launch_rot_run(h, op.x, (const RotParam *)h->d_rp.p + op.first, op.count);
+            }
         }
         if (rc) return rc;
     }
     HIPC(h, hipStreamSynchronize(h->stream));
     h->last_passes = (int64_t)tp.plan.size();               // every step reads and writes the shard once
-    h->last_pass_bytes = (int64_t)(32.0 * (double)h->namps * (double)tp.plan.size());
+    h->last_pass_bytes = (int64_t)((real ? 16.0 : 32.0) * (double)h->namps * (double)tp.plan.size());
     return OVQE_OK;
 } OVQE_CATCH(h)
 

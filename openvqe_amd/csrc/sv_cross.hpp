@@ -149,10 +149,134 @@ __global__ __launch_bounds__(NT) void k_tile_cross(const amp_t *__restrict__ ket
     }
 }
 
+// REAL amplitudes (2^n doubles: a basis state under rotations whose strings all carry an odd number of Y — every UCC / ADAPT
+// generator): the expectation value on 8-byte amplitudes.  As in k_tile_sweep<REAL> the 16-byte element is a PAIR of amplitudes and
+// the pass's masks live in the index space of the pairs (index bit 0 is always inside the tile, d_out never has it); the tile holds
+// 2^M doubles (M <= 13: the same 64 KB).  Terms with an imaginary folded coefficient (odd number of Y) vanish between real vectors
+// and are left out by the host; partials take the real part only.
+template <int M, int NT, bool NTL>
+__global__ __launch_bounds__(NT) void k_tile_cross_real(const double *__restrict__ ket, const double *__restrict__ bra, uint64_t ket_gbase,
+                                                        uint64_t chunk_off, CrossPass ps, const ExChunkT *__restrict__ chunks,
+                                                        const ExAGroupT *__restrict__ groups, const ExTermT *__restrict__ terms,
+                                                        double2 *__restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t NEL = 1u << M;          // amplitudes per tile
+    constexpr uint32_t NELV = NEL / 2;         // 16-byte elements
+    constexpr int TRIPS = NELV / NT;
+    double *tile = reinterpret_cast<double *>(smem);
+    double2 *tilev = reinterpret_cast<double2 *>(smem);
+    ExTermLds *lt = reinterpret_cast<ExTermLds *>(smem + (size_t)NEL * sizeof(double));
+    ExAGroupT *lg = reinterpret_cast<ExAGroupT *>(lt + TILE_TERM_CAP);
+    double2 *red = reinterpret_cast<double2 *>(lg + TILE_APPLY_GROUPS);
+    const v2d *p = reinterpret_cast<const v2d *>(ket);
+    const v2d *q = reinterpret_cast<const v2d *>(bra);
+
+    uint64_t tb = blockIdx.x;   // pair-index space
+    for (uint64_t mk = ps.smask; mk; mk &= mk - 1ull) tb = insert_zero(tb, __ffsll((long long)mk) - 1);
+    const uint64_t glow = spread_bits(threadIdx.x, ps.mask_lo);
+    const uint64_t gbase = ket_gbase | (tb << 1);
+    const uint64_t ob = ((chunk_off >> 1) | tb) ^ (ps.d_out >> 1);
+    v2d breg[TRIPS];
+    double acc0[TRIPS], acc1[TRIPS];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < TRIPS; ++j) {
+        const uint64_t hi = spread_bits((uint32_t)j, ps.mask_hi);
+        const v2d r = NTL ? __builtin_nontemporal_load(&p[tb | glow | hi]) : p[tb | glow | hi];
+        breg[j] = NTL ? __builtin_nontemporal_load(&q[ob | glow | hi]) : q[ob | glow | hi];
+        tilev[tile_swz_v(threadIdx.x + j * NT)] = make_double2(r.x, r.y);
+        any |= r.x != 0.0 || r.y != 0.0;
+        acc0[j] = 0.0;
+        acc1[j] = 0.0;
+    }
+    if (!__syncthreads_or(any)) return;
+    for (int ch = ps.a0; ch < ps.a1; ++ch) {
+        const ExChunkT ck = chunks[ch];
+        __syncthreads();
+        for (int t = ck.t0 + (int)threadIdx.x; t < ck.t1; t += NT) {
+            const ExTermT et = terms[t];
+            ExTermLds l;
+            l.cr = parity64(gbase & et.zout) ? -et.cr : et.cr;
+            l.ci = 0.0;
+            l.zin = et.zin;
+            l.pad = 0;
+            lt[t - ck.t0] = l;
+        }
+        for (int g = ck.g0 + (int)threadIdx.x; g < ck.g1; g += NT) lg[g - ck.g0] = groups[g];
+        __syncthreads();
+        for (int g = ck.g0; g < ck.g1; ++g) {
+            const ExAGroupT gr = lg[g - ck.g0];
+            const uint32_t xl = __builtin_amdgcn_readfirstlane(gr.x);
+            const int t0 = __builtin_amdgcn_readfirstlane(gr.t0) - ck.t0, t1 = __builtin_amdgcn_readfirstlane(gr.t1) - ck.t0;
+            uint32_t je0[TRIPS], je1[TRIPS];
+            double k0[TRIPS], k1[TRIPS], d0[TRIPS], d1[TRIPS];
+#pragma unroll
+            for (int j = 0; j < TRIPS; ++j) {
+                const uint32_t e = (threadIdx.x + j * NT) << 1;
+                je0[j] = e ^ xl;
+                je1[j] = (e | 1u) ^ xl;
+                k0[j] = tile[tile_swz<true>(je0[j])];
+                k1[j] = tile[tile_swz<true>(je1[j])];
+                d0[j] = 0.0;
+                d1[j] = 0.0;
+            }
+            for (int t = t0; t < t1; ++t) {
+                const ExTermLds l = lt[t];
+#pragma unroll
+                for (int j = 0; j < TRIPS; ++j) {
+                    d0[j] = fma(l.cr, parity_sign(je0[j] & l.zin), d0[j]);
+                    d1[j] = fma(l.cr, parity_sign(je1[j] & l.zin), d1[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TRIPS; ++j) {
+                acc0[j] = fma(d0[j], k0[j], acc0[j]);
+                acc1[j] = fma(d1[j], k1[j], acc1[j]);
+            }
+        }
+    }
+    double part = 0.0;
+#pragma unroll
+    for (int j = 0; j < TRIPS; ++j) part += breg[j].x * acc0[j] + breg[j].y * acc1[j];
+    __syncthreads();
+    const double2 t = block_sum<NT>(make_double2(part, 0.0), red);
+    if (threadIdx.x == 0) {
+        const double2 o = partials[blockIdx.x];
+        partials[blockIdx.x] = make_double2(o.x + t.x, o.y);
+    }
+}
+
 // Registers below the tile sizes.  Groups [g0, g1) share the part of their x mask above the chunk bits (the host launches one
 // class at a time), so output amplitude i of the class's output chunk `other` takes ket_{i ^ x_low} of the received chunk from
 // every group; a thread owns its outputs.  HGroup::x = the x mask on the chunk bits, HTerm::z = the full z mask (the sign is read
 // off the ket's GLOBAL index ket_gbase | j).
+__global__ __launch_bounds__(256) void k_cross_small_real(const double *__restrict__ ket, const double *__restrict__ bra, uint64_t csize,
+                                                          uint64_t ket_gbase, const HGroup *__restrict__ groups, int g0, int g1,
+                                                          const HTerm *__restrict__ terms, double2 *__restrict__ partials) {
+    __shared__ double2 red[4];
+    double part = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < csize; i += (uint64_t)gridDim.x * 256u) {
+        double s = 0.0;
+        for (int g = g0; g < g1; ++g) {
+            const HGroup gr = groups[g];
+            const uint64_t j = i ^ gr.x;
+            const uint64_t gj = ket_gbase | j;
+            double dr = 0.0;
+            for (int t = gr.t0; t < gr.t1; ++t) {
+                const HTerm ht = terms[t];
+                dr = fma(ht.cr, parity_sign64(gj & ht.z), dr);
+            }
+            s = fma(dr, ket[j], s);
+        }
+        part = fma(bra[i], s, part);
+    }
+    const double2 t = block_sum<256>(make_double2(part, 0.0), red);
+    if (threadIdx.x == 0) {
+        const double2 o = partials[blockIdx.x];
+        partials[blockIdx.x] = make_double2(o.x + t.x, o.y);
+    }
+}
+
 template <bool DOT>
 __global__ __launch_bounds__(256) void k_cross_small(const amp_t *__restrict__ ket, amp_t *__restrict__ other, uint64_t csize,
                                                      uint64_t ket_gbase, const HGroup *__restrict__ groups, int g0, int g1,

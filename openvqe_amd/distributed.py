@@ -127,8 +127,36 @@ class HipShardEngine:
             raise RuntimeError("ShardedStatevector was created under another torch stream: its shard kernels would not be "
                                "ordered behind RCCL transfers waited for on this one")
 
-    def new_buffer(self, count):
-        return torch.empty(count, dtype=torch.complex128, device=self.device)
+    def new_buffer(self, count, dtype=None):
+        """scratch of ``count`` amplitudes in the shard's current storage (complex128, or float64 under real storage)"""
+        return torch.empty(count, dtype=self.tensor.dtype if dtype is None else dtype, device=self.device)
+
+    @property
+    def is_real(self):
+        return self.tensor.dtype == torch.float64
+
+    def set_real(self, flag, discard=False):
+        """Storage of the shard: 2^n_local complex128 (16 B) or — while every applied rotation keeps a real state real — float64
+        (8 B: half the HBM bytes of every sweep, of <H> and of every transfer; option "real_state" of the handle).  The amplitudes
+        are converted unless ``discard`` (an initialisation follows)."""
+        flag = bool(flag)
+        if flag == self.is_real:
+            return
+        size = self.tensor.numel()
+        if discard:
+            self.tensor = None
+            new = torch.zeros(size, dtype=torch.float64 if flag else torch.complex128, device=self.device)
+        elif flag:
+            new = torch.view_as_real(self.tensor)[:, 0].contiguous()
+        else:
+            new = torch.complex(self.tensor, torch.zeros_like(self.tensor))
+        self.sync()
+        self.tensor = new
+        self.sv.adopt_state(new.data_ptr())
+        self.sv.set_option("real_state", 1 if flag else 0)
+        for sub in self._subs.values():
+            sub.close()
+        self._subs = {}
 
     def sync(self):
         torch.cuda.synchronize(self.device)
@@ -249,6 +277,10 @@ class ShardedStatevector:
         # complex layout; the imaginary parts are exact zeros and are rebuilt as such on arrival.)
         self.real = False
         self.real_transfers = True
+        # Real STORAGE (engines that offer it: the HIP engine): a compiled program whose strings all have an odd number of Y runs on
+        # float64 shards — local sweeps, <H> and transfers on 8-byte amplitudes; anything that needs complex amplitudes (a rotation
+        # with an even number of Y, sigma = H psi, the gradient screens) widens the shard back first
+        self.real_storage = True
 
     # -- helpers ----------------------------------------------------------------------------
     def _compute(self, phase):
@@ -278,11 +310,30 @@ class ShardedStatevector:
     def _phys(self, mask):
         return permute_mask(mask, self.perm)
 
+    def _storage_real(self):
+        return self.engine.tensor.dtype == torch.float64
+
+    def _choose_storage(self, real_program):
+        """before an initialisation: 8-byte amplitudes for a rotation list that keeps them real (engines that offer it)"""
+        if hasattr(self.engine, "set_real"):
+            want = bool(real_program and self.real_storage and self.n_local >= 2)
+            if want != self._storage_real():
+                self.engine.set_real(want, discard=True)
+                self._tmp = None
+                self._chunk_bufs = None
+
+    def _complex_storage(self):
+        if self._storage_real():
+            self.engine.set_real(False)
+            self._tmp = None
+            self._chunk_bufs = None
+
     def _local_mask(self):
         return (1 << self.n_local) - 1
 
     def _tmp_buffer(self, count):
-        if self._tmp is None or self._tmp.numel() < count:
+        if self._tmp is None or self._tmp.numel() < count or self._tmp.dtype != self.engine.tensor.dtype:
+            self._tmp = None
             self._tmp = self.engine.new_buffer(count)
         return self._tmp[:count]
 
@@ -365,7 +416,8 @@ class ShardedStatevector:
         _progress("half-shard exchange")
         t_swap = time.perf_counter()
 
-        real = self.real and self.real_transfers      # (the same on every rank: the flag follows the rotation list)
+        stored_real = self._storage_real()             # float64 shards travel as they are
+        real = self.real and self.real_transfers and not stored_real     # (the same on every rank: the flag follows the rotation list)
         if real:
             rrecv = torch.view_as_real(recv).reshape(-1)[:half]        # the receive buffer's first half, as doubles
             recv_pieces = [rrecv[starts[p]:starts[p] + sizes[p]] for p in range(P)]
@@ -392,8 +444,8 @@ class ShardedStatevector:
         la, lb = self.perm.index(gbit), self.perm.index(lbit)
         self.perm[la], self.perm[lb] = lbit, gbit
         self.stats["swaps"] += 1
-        self.stats["bytes_sent"] += half * (8 if real else 16)
-        self.stats["real_exchanges"] += 1 if real else 0
+        self.stats["bytes_sent"] += half * (8 if (real or stored_real) else 16)
+        self.stats["real_exchanges"] += 1 if (real or stored_real) else 0
         self.stats["pieces"] += P
 
     @staticmethod
@@ -453,6 +505,7 @@ class ShardedStatevector:
         """synthetic state defined on PHYSICAL indices (bench/scaling use; permutation reset)"""
         self.perm = list(range(self.n))
         self.real = False
+        self._complex_storage()
         self.engine.randomize(seed, 1.0)
         n2 = torch.tensor([self.engine.norm2()], dtype=torch.float64, device=self.engine.tensor.device)
         if self._dist:
@@ -473,6 +526,8 @@ class ShardedStatevector:
         zs = [int(v) for v in zs]
         if self.real and any(not (bin(x & z).count("1") & 1) for x, z in zip(xs, zs)):
             self.real = False     # a string with an even number of Y (or a diagonal one) makes the amplitudes complex
+        if not self.real:
+            self._complex_storage()
         batch_x, batch_z, batch_p = [], [], []
 
         def flush():
@@ -569,18 +624,20 @@ class ShardedStatevector:
         csize = 1 << m
         nchunks = 1 << (self.n_local - m)
         np_ = len(partners)
-        real = self.real and self.real_transfers
+        stored_real = self._storage_real()
+        real = self.real and self.real_transfers and not stored_real
         if self.dry:     # one rank alone: its own chunks stand in for the partners' (same kernels, same bytes counted)
             for c in range(nchunks):
                 own = self.engine.tensor[c * csize:(c + 1) * csize]
                 self.stats["chunk_reads"] += np_
-                self.stats["bytes_sent"] += len(send_to) * csize * (8 if real else 16)
+                self.stats["real_chunk_reads"] += np_ if (real or stored_real) else 0
+                self.stats["bytes_sent"] += len(send_to) * csize * (8 if (real or stored_real) else 16)
                 yield c, [own] * np_
                 self.engine.sync()
             self.stats["full_shard_reads"] += np_
             self.stats["partners_per_read"] = max(self.stats["partners_per_read"], np_)
             return
-        if np_ and (self._chunk_bufs is None or self._chunk_bufs[0].numel() < np_ * csize):
+        if np_ and (self._chunk_bufs is None or self._chunk_bufs[0].numel() < np_ * csize or self._chunk_bufs[0].dtype != self.engine.tensor.dtype):
             self._chunk_bufs = None
             self._chunk_bufs = [self.engine.new_buffer(np_ * csize), self.engine.new_buffer(np_ * csize)]
         self.engine.sync()
@@ -620,8 +677,8 @@ class ShardedStatevector:
                 dst[:, 1].zero_()
             pending = post(c + 1) if c + 1 < nchunks else None
             self.stats["chunk_reads"] += np_
-            self.stats["real_chunk_reads"] += np_ if real else 0
-            self.stats["bytes_sent"] += len(send_to) * csize * (8 if real else 16)
+            self.stats["real_chunk_reads"] += np_ if (real or stored_real) else 0
+            self.stats["bytes_sent"] += len(send_to) * csize * (8 if (real or stored_real) else 16)
             yield c, [self._chunk_bufs[c & 1][k * csize:(k + 1) * csize] for k in range(np_)]
             self.engine.sync()   # the buffers of this parity are posted again two chunks later
         self.stats["full_shard_reads"] += np_
@@ -746,6 +803,7 @@ class ShardedStatevector:
         are accumulated chunk by chunk from the partners' psi shards (all partners of a chunk in flight at once).
         -> this rank's sigma shard (device buffer owned by the caller until the next call)"""
         size = 1 << self.n_local
+        self._complex_storage()       # (sigma = H psi and the screens built on it work on complex amplitudes)
         if getattr(self, "_sigma", None) is None or self._sigma.numel() < size:
             self._sigma = self.engine.new_buffer(size)
         sigma = self._sigma[:size]
@@ -861,6 +919,7 @@ class ShardedStatevector:
         if theta.size < prog["n_params"]:
             raise ValueError(f"expected {prog['n_params']} parameters, got {theta.size}")
         self.perm = list(range(self.n))
+        self._choose_storage(prog["real"])
         self.init_basis(prog["hf"])
         self.real = prog["real"]      # (a list with one even-Y string anywhere travels complex from the start: the flag is per program)
         pidx = prog["pidx"]
@@ -888,6 +947,7 @@ class ShardedStatevector:
     def energy(self, ham_xs, ham_zs, ham_coeffs, constant, rot_xs, rot_zs, rot_phis, hf_index):
         """one whole evaluation: |hf> -> rotations -> <H>"""
         self.perm = list(range(self.n))
+        self._choose_storage(all(bin(int(x) & int(z)).count("1") & 1 for x, z in zip(rot_xs, rot_zs)) and len(rot_xs) > 0)
         self.init_basis(hf_index)
         self.apply_pauli_rotations(rot_xs, rot_zs, rot_phis)
         return self.expectation(ham_xs, ham_zs, ham_coeffs, constant)
@@ -895,6 +955,8 @@ class ShardedStatevector:
     # -- read-back (tests / small registers) ------------------------------------------------------
     def gather_state(self):
         """full state in LOGICAL index order on every rank (small n only)"""
+        if self._storage_real():
+            self._complex_storage()
         shard = self.engine.tensor.detach().to("cpu")
         if self.world > 1:
             parts = [torch.empty_like(shard) for _ in range(self.world)]

@@ -163,6 +163,7 @@ class PartitionedStatevector:
         import torch
         import torch.distributed as dist
         sh = self.sharded
+        sh._complex_storage()
         state = sh.engine.tensor
         acc = state.clone()
         real_before = sh.real

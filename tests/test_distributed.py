@@ -362,12 +362,17 @@ def _real_worker(rank, world, port, n, seed, out, engine="oracle", chunk_bits=No
         hc = rng.normal(size=T)
         hf = int(rng.integers(0, 1 << n))
         res = {}
-        for real_transfers in (True, False):
+        # "stored": real STORAGE where the engine offers it (HIP shards: float64 amplitudes, real-amplitude kernels); True / False:
+        # complex shards with / without real parts only on the wire
+        for variant in ("stored", True, False):
             sv = (ShardedStatevector(n, device=0) if engine == "hip" else
                   ShardedStatevector(n, engine_factory=lambda nl, ng, r: OracleShardEngine(nl, ng, r)))
-            sv.real_transfers = real_transfers
+            sv.real_storage = variant == "stored"
+            sv.real_transfers = variant is not False
             e = sv.energy(hx, hz, hc, 0.5, list(xs), list(zs), phis, hf)
-            res[real_transfers] = (e, sv.gather_state(), dict(sv.stats), sv.real)
+            stored = sv._storage_real()                               # (before the read-back widens the shard)
+            counters = dict(getattr(sv.engine, "counters", {}))
+            res[variant] = (e, sv.gather_state(), dict(sv.stats), sv.real, stored, counters)
         if rank == 0:
             out.put((res, (xs, zs, phis, hx, hz, hc, hf)))
     finally:
@@ -392,7 +397,9 @@ def test_real_amplitude_transfers_halve_the_exchanged_bytes(world, n, chunk_bits
         psi = masks.rotate(psi, int(x), int(z), p)
     assert np.abs(psi.imag).max() < 1e-15                     # the premise: odd-Y strings keep a basis state real
     want = masks.expectation(psi, hx, hz, hc, 0.5)
-    (e1, full1, st1, real1), (e0, full0, st0, _) = res[True], res[False]
+    (e1, full1, st1, real1, _, _), (e0, full0, st0, _, _, _) = res[True], res[False]
+    es, fulls, sts, _, stored, _ = res["stored"]
+    assert not stored and abs(es - want) < 1e-11 and sts["bytes_sent"] == st1["bytes_sent"]    # (the CPU engine has complex shards only)
     assert real1 and np.abs(full1 - psi).max() < 1e-12 and np.abs(full0 - psi).max() < 1e-12
     assert abs(e1 - want) < 1e-11 and abs(e0 - want) < 1e-11
     assert st1["swaps"] == st0["swaps"] >= 1 and st1["real_exchanges"] == st1["swaps"] and st0["real_exchanges"] == 0

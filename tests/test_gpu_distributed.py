@@ -66,10 +66,11 @@ def test_sharded_adapt_screen_on_hip_shards(gpu_lib, world, n, chunk_bits):
     assert stats["full_shard_reads"] >= 2
 
 
-@pytest.mark.parametrize("world,n,chunk_bits", [(4, 15, 10), (8, 16, 10)])
+@pytest.mark.parametrize("world,n,chunk_bits", [(4, 15, 10), (8, 16, 10), (2, 17, 13), (2, 15, 12)])
 def test_real_amplitude_transfers_on_hip_shards(gpu_lib, world, n, chunk_bits):
-    """odd-Y rotations from a basis state: the half-shard exchanges and the chunked partner reads carry real parts only (half the
-    bytes), the HIP shard kernels see complex shards with exact-zero imaginary parts — state and <H> against the oracle"""
+    """odd-Y rotations from a basis state, three ways: float64 shards (real-amplitude kernels: tiles of 2^13 / 2^12 / 2^11 doubles and
+    the streaming fall-back over the cases), complex shards with real parts only on the wire, complex shards and complex wire —
+    state and <H> against the oracle"""
     from tests.test_distributed import _real_worker
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
@@ -86,11 +87,20 @@ def test_real_amplitude_transfers_on_hip_shards(gpu_lib, world, n, chunk_bits):
     for x, z, p in zip(xs, zs, phis):
         psi = masks.rotate(psi, int(x), int(z), p)
     want = masks.expectation(psi, hx, hz, hc, 0.5)
-    (e1, full1, st1, real1), (e0, full0, st0, _) = res[True], res[False]
+    (e1, full1, st1, real1, stored1, cnt1), (e0, full0, st0, _, stored0, cnt0) = res[True], res[False]
     assert real1 and np.abs(np.asarray(full1) - psi).max() < 1e-12 and np.abs(np.asarray(full0) - psi).max() < 1e-12
-    assert abs(e1 - want) < 1e-11 and abs(e0 - want) < 1e-11
+    assert abs(e1 - want) < 1e-11 and abs(e0 - want) < 1e-11 and not stored1 and not stored0
     assert st1["real_exchanges"] == st1["swaps"] >= 1 and st1["real_chunk_reads"] == st1["chunk_reads"] > 0
     assert st1["bytes_sent"] * 2 == st0["bytes_sent"]
+    # real STORAGE (the default on HIP shards): the shard held 2^n_local doubles through the sweeps and <H> — the real-amplitude
+    # kernels ran (k_tile_sweep<REAL> / k_rot_pairs_real, k_tile_expect<REAL>, k_tile_cross_real), every sweep and every pass of
+    # <H> moved half the bytes of the complex run, the wire carried 8 bytes per amplitude; state and energy against the oracle
+    es, fulls, sts, reals, stored, cnts = res["stored"]
+    assert stored and reals and np.abs(np.asarray(fulls) - psi).max() < 1e-12
+    assert abs(es - want) < 1e-10 * np.abs(hc).sum()
+    assert sts["bytes_sent"] == st1["bytes_sent"] and sts["real_exchanges"] == sts["swaps"] == st1["swaps"]
+    assert 0 < cnts["rotation_bytes"] * 2 <= cnt0["rotation_bytes"] * 1.01 + 1     # 16 instead of 32 B per amplitude and sweep (fewer sweeps too: bigger tiles)
+    assert 0 < cnts["contraction_bytes"] <= 0.6 * cnt0["contraction_bytes"]
 
 
 def test_compiled_program_on_hip_shards(gpu_lib):
