@@ -289,11 +289,11 @@ def test_24_qubit_full_quccsd_list_against_c_oracle(gpu_lib):
     """configs[3] UN-THINNED: the reference's whole QUCCSD list on N2 / cc-pVDZ (10e,12o) — 1715 parameters, 62 852 literal gates
     (ref:openvqe/common_files/circuit.py:13-106 through ref:openvqe/ucc_family/get_energy_qucc.py:47-52) — on the full 6464-term
     Hamiltonian against ONE oracle number.  Gate by gate the oracle would take an hour (62 852 passes over 256 MiB); instead the
-    backend hands out the rotation sequence it compiled the list to (ovqe_get_rotation_program: 13 300 Pauli rotations with their
-    Clifford-conjugated strings) and the plain-C oracle evaluates THAT with its own fused mask sweeps and x-grouped expectation.
-    What this pins: every kernel between the compiled sequence and the energy (sector tables on the 2^22 coset, bit-arithmetic
-    sweeps, materialised <H>) at full size; what it takes from the product is the frame compiler's output, whose equivalence to the
-    literal list the test above checks (frame form == literal form on the same full list, and the thinned list gate by gate)."""
+    ORACLE's own Clifford-frame pass (oracle/frame.py: tableau form on the host, pinned against gate-by-gate simulation in
+    tests/test_oracle.py) turns the literal list into 13 300 Pauli rotations about Clifford-conjugated strings — the frame closes —
+    and the plain-C oracle evaluates that sequence with its fused mask sweeps and x-grouped expectation.  Nothing on the oracle's side
+    comes from the product.  The product's compiled sequence (ovqe_get_rotation_program) must equal the oracle's rotation for
+    rotation; its energies (streaming path, table build, sector tables on the 2^22 coset) must equal the oracle's number."""
     from openvqe_amd import chem
     from openvqe_amd.backend import Statevector
     from openvqe_amd.common_files.circuit import quccsd_gate_list
@@ -319,11 +319,17 @@ def test_24_qubit_full_quccsd_list_against_c_oracle(gpu_lib):
         es = [sv.energy(theta) for _ in range(3)]
         info = sv.program_info()
     assert len(rx) == 13300 and int(pidx.max()) == K - 1
+    from oracle import frame
+    fx, fz, fc, f0, fp, closed = frame.rotation_sequence(n, gates)
+    assert closed and len(fx) == 13300
+    # the product's frame compiler against the oracle's, rotation for rotation (same order, Hermitian strings, signs in the coefficients)
+    assert np.array_equal(fx, rx) and np.array_equal(fz, rz) and np.array_equal(fp, pidx)
+    assert np.abs(fc - rc).max() == 0.0 and np.abs(f0 - p0).max() == 0.0
     # the oracle takes phi = coeff * theta[pidx]: constant parts / constant rotations ride on one extra parameter fixed at 1
     # (two rotations by the same string commute, so coeff * theta + phi0 splits exactly)
     ext = np.append(theta, 1.0)
     ox, oz, oc, op_ = [], [], [], []
-    for x, z, c, c0, p in zip(rx, rz, rc, p0, pidx):
+    for x, z, c, c0, p in zip(fx, fz, fc, f0, fp):
         if p >= 0 and c != 0.0:
             ox.append(x); oz.append(z); oc.append(c); op_.append(p)
         if c0 != 0.0:

@@ -200,3 +200,71 @@ def test_oracle_engine_ground_state_matches_dense_eigh():
     w, v = np.linalg.eigh(H.get_matrix())
     assert abs(e - w[0]) < 1e-10 and res < 1e-8
     assert abs(abs(np.vdot(v[:, 0], o.get_state())) - 1.0) < 1e-8
+
+
+def _run_gates(psi, n, gates, theta, only_clifford=False):
+    """the literal list gate by gate on the bit-mask oracle (only_clifford: the rotations of the frame form left out)"""
+    import math
+    for name, qubits, scale, const, p in gates:
+        if name == "CNOT":
+            psi = masks.gate_cnot(psi, n, qubits[0], qubits[1])
+            continue
+        angle = const + (scale * theta[p] if p >= 0 else 0.0)
+        quarter = p < 0 and (name in ("X", "H") or angle / (0.5 * math.pi) == round(angle / (0.5 * math.pi)))
+        if only_clifford and not quarter:
+            continue
+        psi = masks.gate_1q(psi, n, qubits[0], dense.gate_matrix(name, angle))
+    return psi
+
+
+def test_clifford_frame_pass_against_gate_by_gate_simulation():
+    """oracle/frame.py — the tableau restatement of 'literal gate list = Pauli rotations about Clifford-conjugated strings, then the
+    net Clifford operator' — against the gate-by-gate oracle: (a) the reference's QUCCSD templates on H4 (8 qubits, 26 excitations,
+    ref:openvqe/common_files/circuit.py:13-106): the frame closes and the rotation sequence reproduces the state up to a global
+    phase; (b) random lists of Clifford gates and rotations whose frame stays OPEN: rotations first, then the Clifford gates in
+    order, reproduce the state"""
+    from openvqe_amd.common_files.circuit import quccsd_gate_list
+    from oracle import frame
+    gates, K, hf = quccsd_gate_list(4, 2)
+    n = 8
+    rng = np.random.default_rng(11)
+    theta = rng.uniform(-0.7, 0.7, K)
+    xs, zs, cs, p0, pi, closed = frame.rotation_sequence(n, gates)
+    assert closed and len(xs) == 2 * 8 + 8 * 18          # 2 parametrised gates per single, 8 per double excitation
+    assert np.all(pi >= 0) and np.all(p0 == 0.0)
+    psi = np.zeros(1 << n, complex)
+    psi[hf] = 1
+    want = _run_gates(psi.copy(), n, gates, theta)
+    got = psi.copy()
+    for x, z, c, c0, p in zip(xs, zs, cs, p0, pi):
+        got = masks.rotate(got, int(x), int(z), c * theta[p] + c0)
+    assert abs(abs(np.vdot(got, want)) - 1.0) < 1e-12
+    # (b) open frames, every gate kind, constant non-Clifford angles too
+    for trial in range(6):
+        n = 5
+        glist = []
+        for _ in range(60):
+            kind = rng.choice(["X", "H", "CNOT", "RX", "RY", "RZ", "RYp", "RZc", "RXq"])
+            q = int(rng.integers(0, n))
+            if kind == "CNOT":
+                t = int((q + 1 + rng.integers(0, n - 1)) % n)
+                glist.append(("CNOT", [q, t], 0.0, 0.0, -1))
+            elif kind in ("X", "H"):
+                glist.append((kind, [q], 0.0, 0.0, -1))
+            elif kind in ("RX", "RY", "RZ"):       # quarter turns: Clifford
+                glist.append((kind, [q], 0.0, float(rng.integers(-3, 4)) * 0.5 * np.pi, -1))
+            elif kind == "RYp":                     # parametrised, with a constant part
+                glist.append(("RY", [q], float(rng.choice([1.0, -1.0, -2.0])), float(rng.choice([0.0, 0.3])), int(rng.integers(0, 4))))
+            elif kind == "RZc":                     # constant generic angle: a rotation without a parameter
+                glist.append(("RZ", [q], 0.0, 0.37, -1))
+            else:
+                glist.append(("RX", [q], 1.0, 0.0, int(rng.integers(0, 4))))
+        th = rng.uniform(-1, 1, 4)
+        xs, zs, cs, p0, pi, closed = frame.rotation_sequence(n, glist)
+        psi = random_state(rng, n)
+        want = _run_gates(psi.copy(), n, glist, th)
+        got = psi.copy()
+        for x, z, c, c0, p in zip(xs, zs, cs, p0, pi):
+            got = masks.rotate(got, int(x), int(z), (c * th[p] if p >= 0 else 0.0) + c0)
+        got = _run_gates(got, n, glist, th, only_clifford=True)
+        assert abs(abs(np.vdot(got, want)) - 1.0) < 1e-12, trial
