@@ -1024,7 +1024,9 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
                 }
                 if (mt.empty()) continue;
                 const int nk_total = 1 << (M - w);
-                if (mt.size() <= 2 && nk_total >= 2 && (h->opt_tile_flat == 1 || (h->opt_tile_flat == 2 && real))) {  // one lane per TILE_ITEM_PAIRS pairs (sv_tile.hpp)
+                // (round 6: the float64 shards of the partitioned register are DENSE real states of 25+ qubits: per-wave entries there too —
+                // 31 qubits, 1000-term <H>: 1.09 s with items, 0.94 s with entries, tools/exp_real_shard.py)
+                if (mt.size() <= 2 && nk_total >= 2 && (h->opt_tile_flat == 1 || (h->opt_tile_flat == 2 && real && h->n_local < 25))) {  // one lane per TILE_ITEM_PAIRS pairs (sv_tile.hpp)
                     ExFlatT fe = {};
                     fe.x = xl;
                     fe.ibits = ibits;
@@ -1201,14 +1203,16 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bo
     // 1.1 TB/s).  The first sweep of an evaluation counts the tiles that took the sparse path; when none did, the state is dense
     // under every tile bit set and the remaining sweeps run without that area: two workgroups per CU, of either stream.  (One stream
     // synchronisation per evaluation: only where there are at least four sweeps of at least half a gigabyte.)
-    const bool try_dense = !real && M == 12 && h->n_local >= 25 && ns >= 4 && h->opt_expect_sparse > 0 && h->opt_expect_dense;
+    // (round 6: real states too — the float64 shards of the partitioned register: tiles of 2^13 doubles)
+    const bool try_dense = ((!real && M == 12) || (real && M == 13)) && h->n_local >= 25 && ns >= 4 && h->opt_expect_sparse > 0 && h->opt_expect_dense;
     bool dense_only = false;
     int k_start = 0;
     if (try_dense) {
         rc = ensure(h, h->d_tile_cnt, sizeof(int));
         if (rc) return rc;
         HIPC(h, hipMemsetAsync(h->d_tile_cnt.p, 0, sizeof(int), h->stream));
-        rc = launch_tile_expect<12, false>(h, H, H.tsweeps[0], partials, 0, h->stream, false, (int *)h->d_tile_cnt.p);
+        rc = real ? launch_tile_expect<13, true>(h, H, H.tsweeps[0], partials, 0, h->stream, false, (int *)h->d_tile_cnt.p)
+                  : launch_tile_expect<12, false>(h, H, H.tsweeps[0], partials, 0, h->stream, false, (int *)h->d_tile_cnt.p);
         if (rc) return rc;
         int census = 1;
         HIPC(h, hipMemcpyAsync(&census, h->d_tile_cnt.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1241,7 +1245,7 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bo
             switch (M) {
             case 11: rc = launch_tile_expect<11, true>(h, H, sw, part, acc[which], strm); break;
             case 12: rc = launch_tile_expect<12, true>(h, H, sw, part, acc[which], strm); break;
-            default: rc = launch_tile_expect<13, true>(h, H, sw, part, acc[which], strm); break;
+            default: rc = launch_tile_expect<13, true>(h, H, sw, part, acc[which], strm, dense_only); break;
             }
         } else {
             switch (M) {

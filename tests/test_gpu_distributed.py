@@ -99,8 +99,10 @@ def test_real_amplitude_transfers_on_hip_shards(gpu_lib, world, n, chunk_bits):
     assert stored and reals and np.abs(np.asarray(fulls) - psi).max() < 1e-12
     assert abs(es - want) < 1e-10 * np.abs(hc).sum()
     assert sts["bytes_sent"] == st1["bytes_sent"] and sts["real_exchanges"] == sts["swaps"] == st1["swaps"]
-    assert 0 < cnts["rotation_bytes"] * 2 <= cnt0["rotation_bytes"] * 1.01 + 1     # 16 instead of 32 B per amplitude and sweep (fewer sweeps too: bigger tiles)
-    assert 0 < cnts["contraction_bytes"] <= 0.6 * cnt0["contraction_bytes"]
+    assert cnts["rotation_bytes"] > 0 and cnts["contraction_bytes"] > 0
+    if n - (world.bit_length() - 1) >= 15:    # shards large enough for the real tile sweeps (2^12 doubles from 14 local qubits on):
+        assert cnts["rotation_bytes"] * 2 <= cnt0["rotation_bytes"] * 1.01 + 1     # 16 instead of 32 B per amplitude and sweep
+        assert cnts["contraction_bytes"] <= 0.6 * cnt0["contraction_bytes"]
 
 
 def test_compiled_program_on_hip_shards(gpu_lib):
