@@ -181,19 +181,82 @@ QRoutine = Program
 
 class OpList(list):
     """the list ``Circuit.ops`` returns: a plain list of ``Op`` that also knows how many instructions carry each gate name, so
-    that ``common_files.circuit.count`` answers its four questions per ADAPT iteration from ONE pass instead of formatting
-    every instruction as text four times (76 000 instructions at the 30th iteration of the N2 run: 0.4 of its 3.1 s)"""
+    that ``common_files.circuit.count`` answers its four questions per ADAPT iteration without formatting every instruction as text
+    four times (76 000 instructions at the 30th iteration of the N2 run: 0.4 of its 3.1 s).  Round 6: the list is LAZY — the counts
+    of a circuit of Pauli evolutions follow from the strings (2 #X Hadamards, 2 #Y RX, 2 (w - 1) CNOT, one RZ per string), cached per
+    operator object, so an ADAPT iteration that only counts gates (ref:openvqe/adapt/fermionic_adapt_vqe.py:520-527) never builds the
+    76 000 ``Op`` objects; anything that looks at the instructions themselves fills the list first."""
+
+    def __init__(self, circuit=None):
+        super().__init__()
+        self._circuit = circuit          # pending synthesis
+
+    def _fill(self):
+        if self._circuit is not None:
+            circuit, self._circuit = self._circuit, None
+            super().extend(circuit._synthesise())
 
     def gate_count(self, gate):
+        if self._circuit is not None:
+            counts = self._circuit.gate_counts()
+            if counts is not None:
+                return counts.get(gate, 0)
+            self._fill()
         counts = getattr(self, "_gate_counts", None)
-        if counts is None or self._counted_len != len(self):
+        if counts is None or self._counted_len != list.__len__(self):
             counts = {}
-            for op in self:
+            for op in list.__iter__(self):
                 if type(op) is not Op:
                     return None   # foreign elements: the caller formats them
                 counts[op.gate] = counts.get(op.gate, 0) + 1
-            self._gate_counts, self._counted_len = counts, len(self)
+            self._gate_counts, self._counted_len = counts, list.__len__(self)
         return counts.get(gate, 0)
+
+
+def _lazy(name):
+    method = getattr(list, name)
+
+    def wrapper(self, *args, **kwargs):
+        self._fill()
+        return method(self, *args, **kwargs)
+    wrapper.__name__ = name
+    return wrapper
+
+
+for _name in ("__len__", "__iter__", "__getitem__", "__setitem__", "__delitem__", "__contains__", "__reversed__", "__eq__", "__ne__",
+              "__add__", "__iadd__", "__mul__", "__repr__", "append", "extend", "insert", "pop", "remove", "index", "count", "copy",
+              "sort", "reverse", "clear"):
+    setattr(OpList, _name, _lazy(_name))
+OpList.__hash__ = None
+
+_string_counts = {}   # id(operator) -> (operator, number of terms, {gate: count})
+
+
+def _operator_gate_counts(op):
+    """gates of the CNOT-staircase synthesis of every string of ``op`` (what ``Circuit._synthesise`` emits for it)"""
+    hit = _string_counts.get(id(op))
+    terms = op.terms
+    if hit is not None and hit[0] is op and hit[1] == len(terms):
+        return hit[2]
+    h = rx = cnot = rz = 0
+    for term in terms:
+        c = complex(term.coeff)
+        if abs(c.imag) > 1e-12 * max(1.0, abs(c.real)):
+            return None          # (PauliEvolution.rotations raises for it: let the synthesis do so)
+        s = term.op
+        nx, ny = s.count("X"), s.count("Y")
+        w = len(s) - s.count("I")
+        if w == 0:
+            continue
+        h += 2 * nx
+        rx += 2 * ny
+        cnot += 2 * (w - 1)
+        rz += 1
+    counts = {"H": h, "RX": rx, "CNOT": cnot, "RZ": rz}
+    if len(_string_counts) > 4096:
+        _string_counts.clear()
+    _string_counts[id(op)] = (op, len(terms), counts)
+    return counts
 
 
 class Circuit:
@@ -202,8 +265,30 @@ class Circuit:
 
     @property
     def ops(self):
-        """Gate list after synthesis of the Pauli evolutions (CNOT staircase), for ``count``."""
-        out = OpList()
+        """Gate list after synthesis of the Pauli evolutions (CNOT staircase), for ``count`` — synthesised when first looked at"""
+        return OpList(self)
+
+    def gate_counts(self):
+        """{gate name: instructions} of ``ops`` without building them; None when a string cannot be counted from its text"""
+        total = {}
+        for kind, what, qubits in self.items:
+            if kind == "gate":
+                total[what.name] = total.get(what.name, 0) + 1
+                continue
+            nx = bin(what.init & ((1 << what.arity) - 1)).count("1")
+            if nx:
+                total["X"] = total.get("X", 0) + nx
+            for op, _ in zip(what.operators, what.thetas):
+                counts = _operator_gate_counts(op)
+                if counts is None:
+                    return None
+                for g, c in counts.items():
+                    if c:
+                        total[g] = total.get(g, 0) + c
+        return total
+
+    def _synthesise(self):
+        out = []
         for kind, what, qubits in self.items:
             if kind == "gate":
                 out.append(Op(what.name, qubits, what.angle))
