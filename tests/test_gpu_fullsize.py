@@ -262,27 +262,9 @@ def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
     assert abs(e_g - e_ref) < 1e-10 * max(1.0, l1)
     for k, want_g in g_ref.items():
         assert abs(g_gpu[k] - want_g) < 2e-7 * max(1.0, l1), (k, g_gpu[k], want_g)
-    # the whole list (1715 parameters, ~63 k gates): its Clifford part is ~49 k gates long and still has to be recognised as
-    # closed (the rounding of that many quarter turns once sent it down the literal path); frame form == literal form
-    gates, K, _ = quccsd_gate_list(12, 5, 1, excitations=[op.terms[0].qbits for op in cluster_ops])
-    assert K == size == 1715
-    theta = np.array(theta_mp2)
-    idx = idx[:2000]
-    full = ham
-    with Statevector(n) as sv:
-        sv.set_hamiltonian(full)
-        out = {}
-        for frame in (0, 1):
-            sv.set_option("clifford_frame", frame)
-            sv.set_gate_program(gates, K, hf)
-            info = sv.program_info()
-            e = sv.energy(theta)
-            sv.prepare_state(theta)
-            out[frame] = (e, sv.get_amplitudes(idx), info)
-    assert out[0][2]["literal_gates"] > 40000
-    assert out[1][2]["literal_gates"] == 0 and out[1][2]["real_stream"] == 1
-    assert abs(out[0][0] - out[1][0]) < 1e-10 * float(np.abs(full.packed()[2]).sum())
-    assert np.abs(out[0][1] - out[1][1]).max() < 1e-11
+    # (the WHOLE list — 1715 parameters, 62 852 gates, a Clifford part of ~49 k gates that has to be recognised as closed — is the next
+    # test: since round 6 its rotation sequence comes from the oracle's own frame pass, which replaces the product-against-product
+    # comparison "frame form == literal form" that used to run here for half a minute)
 
 
 def test_24_qubit_full_quccsd_list_against_c_oracle(gpu_lib):
@@ -462,7 +444,7 @@ def test_24_qubit_sector_path_against_c_oracle(gpu_lib):
         assert sv.program_info()["sector_support"] > 0
     assert abs(e8 - e8_ref) < 1e-10 * max(1.0, l1) and abs(e8g - e8_ref) < 1e-10 * max(1.0, l1)
     h = 1e-4
-    for k in (0, K8 // 3, K8 - 1):
+    for k in (0, K8 - 1):       # (two components: each costs the oracle two 24-qubit circuits)
         tp, tm = th8.copy(), th8.copy()
         tp[k] += h
         tm[k] -= h

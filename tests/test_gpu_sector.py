@@ -475,9 +475,9 @@ def test_batched_evaluations_on_the_sector_tables_match_c_oracle(SV, m, o):
     thetas[5] = 0.0
     rx, rz, rc, pidx, _ = compile_ucc_program(n, gens)
     hx, hz, hc = ham.packed()
-    # the oracle sees every vector at 16 and 18 qubits; at 20 qubits (141 evaluations = three minutes of the suite's budget) the first 24,
+    # the oracle sees every vector at 16 qubits, the first 48 at 18 and the first 24 at 20 (141 evaluations there = three minutes of the suite's budget),
     # the rest of the big batch is held against one evaluation at a time on the same handle (the serial path has its own oracle tests)
-    n_oracle = 141 if m < 10 else 24
+    n_oracle = 141 if m < 9 else (48 if m < 10 else 24)
     want = cref.ucc_energy_batch(n, hf, rx, rz, rc, pidx, thetas[:n_oracle], hx, hz, hc.real.copy(), ham.constant_coeff)
     l1 = float(np.abs(hc).sum())
     with SV(n) as sv:
