@@ -47,21 +47,21 @@ __global__ __launch_bounds__(NT) void k_tile_cross(const amp_t *__restrict__ ket
     const uint64_t glow = spread_bits(threadIdx.x, ps.mask_lo);
     const uint64_t gbase = ket_gbase | tb;                 // global index of the ket tile (z bits outside the tile: a sign per tile)
     const uint64_t ob = (chunk_off | tb) ^ ps.d_out;       // the other buffer's tile, local index space of the shard
-    double2 self[TRIPS], acc[TRIPS];
-    v2d oreg[TRIPS];
-#pragma unroll
-    for (int j = 0; j < TRIPS; ++j) {
-        const uint64_t hi = spread_bits((uint32_t)j, ps.mask_hi);
-        const v2d r = NTL ? __builtin_nontemporal_load(&p[tb | glow | hi]) : p[tb | glow | hi];
-        if (DOT) oreg[j] = NTL ? __builtin_nontemporal_load(&q[ob | glow | hi]) : q[ob | glow | hi];
-        self[j] = make_double2(r.x, r.y);
-        acc[j] = make_double2(0.0, 0.0);
-    }
+    double2 acc[TRIPS];
     bool any = false;
+    {
+        v2d reg[TRIPS];
 #pragma unroll
-    for (int j = 0; j < TRIPS; ++j) {
-        tile[tile_swz_v(threadIdx.x + j * NT)] = self[j];
-        any |= self[j].x != 0.0 || self[j].y != 0.0;
+        for (int j = 0; j < TRIPS; ++j) {
+            const uint64_t hi = spread_bits((uint32_t)j, ps.mask_hi);
+            reg[j] = NTL ? __builtin_nontemporal_load(&p[tb | glow | hi]) : p[tb | glow | hi];
+            acc[j] = make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int j = 0; j < TRIPS; ++j) {
+            tile[tile_swz_v(threadIdx.x + j * NT)] = make_double2(reg[j].x, reg[j].y);
+            any |= reg[j].x != 0.0 || reg[j].y != 0.0;
+        }
     }
     // a ket tile of zeros contributes nothing (a UCC / ADAPT state lives on a particle-number sector: most tiles of the register)
     if (!__syncthreads_or(any)) return;
@@ -84,58 +84,36 @@ __global__ __launch_bounds__(NT) void k_tile_cross(const amp_t *__restrict__ ket
             const ExAGroupT gr = lg[g - ck.g0];
             const uint32_t xl = __builtin_amdgcn_readfirstlane(gr.x);
             const int t0 = __builtin_amdgcn_readfirstlane(gr.t0) - ck.t0, t1 = __builtin_amdgcn_readfirstlane(gr.t1) - ck.t0;
-            // The ket's tile-local index of trip j is je = (tid ^ x_lo) | ((j NT) ^ x_hi): a THREAD part on the low log2(NT) bits and a
-            // wave-uniform TRIP part above them.  The bank swizzle only moves bits 3..5 into 0..2 (inside the thread part) and a term's
-            // sign (-1)^{|je & z|} is linear over XOR, so address and sign are prepared once per group for the thread and per trip on
-            // the scalar unit: a trip costs one OR (address), one XOR (sign into the coefficient's high word) and the multiply-adds.
-            const uint32_t jt = threadIdx.x ^ (xl & (uint32_t)(NT - 1));
-            const uint32_t al = tile_swz_v(jt) * 16u;
-            const uint32_t xhi = xl & ~(uint32_t)(NT - 1);
-            const char *tb8 = reinterpret_cast<const char *>(tile);
-            const bool real_c = __builtin_amdgcn_readfirstlane(gr.pad) & 1;   // real folded coefficients only (every group of a real-symmetric H)
-            if (t1 - t0 == 1) {     // one term: nearly every group of a JW Hamiltonian's cross terms
-                const ExTermLds l = lt[t0];
-                const uint32_t zin = __builtin_amdgcn_readfirstlane(l.zin);
-                const uint32_t gl = (uint32_t)__popc(jt & zin) << 31;
-                const uint32_t crh = (uint32_t)__double2hiint(l.cr) ^ gl, crl = (uint32_t)__double2loint(l.cr);
-                const uint32_t cih = (uint32_t)__double2hiint(l.ci) ^ gl, cil = (uint32_t)__double2loint(l.ci);
-#pragma unroll
-                for (int j = 0; j < TRIPS; ++j) {
-                    const uint32_t hj = ((uint32_t)(j * NT)) ^ xhi;
-                    const uint32_t su = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_popcount(hj & zin) << 31);
-                    const double2 k = *reinterpret_cast<const double2 *>(tb8 + (al | (hj << 4)));
-                    const double dr = __hiloint2double((int)(crh ^ su), (int)crl);
-                    acc[j].x = fma(dr, k.x, acc[j].x);
-                    acc[j].y = fma(dr, k.y, acc[j].y);
-                    if (!real_c) {
-                        const double di = __hiloint2double((int)(cih ^ su), (int)cil);
-                        acc[j].x = fma(-di, k.y, acc[j].x);
-                        acc[j].y = fma(di, k.x, acc[j].y);
-                    }
-                }
-                continue;
-            }
+            uint32_t je[TRIPS];
             double2 k[TRIPS];
             double dr[TRIPS], di[TRIPS];
-            uint32_t hj[TRIPS];
 #pragma unroll
             for (int j = 0; j < TRIPS; ++j) {
-                hj[j] = ((uint32_t)(j * NT)) ^ xhi;
-                k[j] = *reinterpret_cast<const double2 *>(tb8 + (al | (hj[j] << 4)));
+                je[j] = (threadIdx.x + j * NT) ^ xl;   // the ket's tile-local index: the sign of a term is read off IT
+                k[j] = tile[tile_swz_v(je[j])];
                 dr[j] = 0.0;
                 di[j] = 0.0;
             }
-            for (int t = t0; t < t1; ++t) {
-                const ExTermLds l = lt[t];
-                const uint32_t zin = __builtin_amdgcn_readfirstlane(l.zin);
-                const uint32_t gl = (uint32_t)__popc(jt & zin) << 31;
-                const uint32_t crh = (uint32_t)__double2hiint(l.cr) ^ gl, crl = (uint32_t)__double2loint(l.cr);
-                const uint32_t cih = (uint32_t)__double2hiint(l.ci) ^ gl, cil = (uint32_t)__double2loint(l.ci);
+            if (__builtin_amdgcn_readfirstlane(gr.pad) & 1) {   // real folded coefficients only (every group of a real-symmetric H)
+                for (int t = t0; t < t1; ++t) {
+                    const ExTermLds l = lt[t];
+#pragma unroll
+                    for (int j = 0; j < TRIPS; ++j) dr[j] = fma(l.cr, parity_sign(je[j] & l.zin), dr[j]);
+                }
 #pragma unroll
                 for (int j = 0; j < TRIPS; ++j) {
-                    const uint32_t su = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_popcount(hj[j] & zin) << 31);
-                    dr[j] += __hiloint2double((int)(crh ^ su), (int)crl);
-                    if (!real_c) di[j] += __hiloint2double((int)(cih ^ su), (int)cil);
+                    acc[j].x += dr[j] * k[j].x;
+                    acc[j].y += dr[j] * k[j].y;
+                }
+                continue;
+            }
+            for (int t = t0; t < t1; ++t) {
+                const ExTermLds l = lt[t];
+#pragma unroll
+                for (int j = 0; j < TRIPS; ++j) {
+                    const double sg = parity_sign(je[j] & l.zin);
+                    dr[j] = fma(l.cr, sg, dr[j]);
+                    di[j] = fma(l.ci, sg, di[j]);
                 }
             }
 #pragma unroll
@@ -146,6 +124,12 @@ __global__ __launch_bounds__(NT) void k_tile_cross(const amp_t *__restrict__ ket
         }
     }
     if constexpr (DOT) {
+        // (the bra tile is fetched HERE, behind the groups: 32 registers less while they run — two workgroups per CU instead of one —
+        // and the other workgroup's arithmetic hides the fetch)
+        v2d oreg[TRIPS];
+#pragma unroll
+        for (int j = 0; j < TRIPS; ++j) oreg[j] = NTL ? __builtin_nontemporal_load(&q[ob | glow | spread_bits((uint32_t)j, ps.mask_hi)])
+                                                      : q[ob | glow | spread_bits((uint32_t)j, ps.mask_hi)];
         double2 part = make_double2(0.0, 0.0);   // conj(bra_i) s_i
 #pragma unroll
         for (int j = 0; j < TRIPS; ++j) {
@@ -198,18 +182,21 @@ __global__ __launch_bounds__(NT) void k_tile_cross_real(const double *__restrict
     const uint64_t glow = spread_bits(threadIdx.x, ps.mask_lo);
     const uint64_t gbase = ket_gbase | (tb << 1);
     const uint64_t ob = ((chunk_off >> 1) | tb) ^ (ps.d_out >> 1);
-    v2d breg[TRIPS];
     double acc0[TRIPS], acc1[TRIPS];
     bool any = false;
+    {
+        v2d reg[TRIPS];
 #pragma unroll
-    for (int j = 0; j < TRIPS; ++j) {
-        const uint64_t hi = spread_bits((uint32_t)j, ps.mask_hi);
-        const v2d r = NTL ? __builtin_nontemporal_load(&p[tb | glow | hi]) : p[tb | glow | hi];
-        breg[j] = NTL ? __builtin_nontemporal_load(&q[ob | glow | hi]) : q[ob | glow | hi];
-        tilev[tile_swz_v(threadIdx.x + j * NT)] = make_double2(r.x, r.y);
-        any |= r.x != 0.0 || r.y != 0.0;
-        acc0[j] = 0.0;
-        acc1[j] = 0.0;
+        for (int j = 0; j < TRIPS; ++j) {
+            reg[j] = NTL ? __builtin_nontemporal_load(&p[tb | glow | spread_bits((uint32_t)j, ps.mask_hi)]) : p[tb | glow | spread_bits((uint32_t)j, ps.mask_hi)];
+            acc0[j] = 0.0;
+            acc1[j] = 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < TRIPS; ++j) {
+            tilev[tile_swz_v(threadIdx.x + j * NT)] = make_double2(reg[j].x, reg[j].y);
+            any |= reg[j].x != 0.0 || reg[j].y != 0.0;
+        }
     }
     if (!__syncthreads_or(any)) return;
     for (int ch = ps.a0; ch < ps.a1; ++ch) {
@@ -230,33 +217,24 @@ __global__ __launch_bounds__(NT) void k_tile_cross_real(const double *__restrict
             const ExAGroupT gr = lg[g - ck.g0];
             const uint32_t xl = __builtin_amdgcn_readfirstlane(gr.x);
             const int t0 = __builtin_amdgcn_readfirstlane(gr.t0) - ck.t0, t1 = __builtin_amdgcn_readfirstlane(gr.t1) - ck.t0;
-            // thread part of the ket's tile-local amplitude index (low log2(NT) + 1 bits: the thread's pair and the amplitude inside it),
-            // wave-uniform trip part above — see k_tile_cross; the real swizzle moves bits 4..6 into 1..3, inside the thread part
-            const uint32_t jt0 = (threadIdx.x << 1) ^ (xl & (uint32_t)(2 * NT - 1)), jt1 = jt0 ^ 1u;
-            const uint32_t a0 = tile_swz<true>(jt0) * 8u, a1 = tile_swz<true>(jt1) * 8u;
-            const uint32_t xhi = xl & ~(uint32_t)(2 * NT - 1);
-            const char *tb8 = reinterpret_cast<const char *>(tile);
+            uint32_t je0[TRIPS], je1[TRIPS];
             double k0[TRIPS], k1[TRIPS], d0[TRIPS], d1[TRIPS];
-            uint32_t hj[TRIPS];
 #pragma unroll
             for (int j = 0; j < TRIPS; ++j) {
-                hj[j] = ((uint32_t)(j * 2 * NT)) ^ xhi;
-                k0[j] = *reinterpret_cast<const double *>(tb8 + (a0 | (hj[j] << 3)));
-                k1[j] = *reinterpret_cast<const double *>(tb8 + (a1 | (hj[j] << 3)));
+                const uint32_t e = (threadIdx.x + j * NT) << 1;
+                je0[j] = e ^ xl;
+                je1[j] = (e | 1u) ^ xl;
+                k0[j] = tile[tile_swz<true>(je0[j])];
+                k1[j] = tile[tile_swz<true>(je1[j])];
                 d0[j] = 0.0;
                 d1[j] = 0.0;
             }
             for (int t = t0; t < t1; ++t) {
                 const ExTermLds l = lt[t];
-                const uint32_t zin = __builtin_amdgcn_readfirstlane(l.zin);
-                const uint32_t g0 = (uint32_t)__popc(jt0 & zin) << 31, g1 = g0 ^ ((zin & 1u) << 31);   // (jt1 = jt0 ^ 1)
-                const uint32_t clo = (uint32_t)__double2loint(l.cr);
-                const uint32_t c0h = (uint32_t)__double2hiint(l.cr) ^ g0, c1h = (uint32_t)__double2hiint(l.cr) ^ g1;
 #pragma unroll
                 for (int j = 0; j < TRIPS; ++j) {
-                    const uint32_t su = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_popcount(hj[j] & zin) << 31);
-                    d0[j] += __hiloint2double((int)(c0h ^ su), (int)clo);
-                    d1[j] += __hiloint2double((int)(c1h ^ su), (int)clo);
+                    d0[j] = fma(l.cr, parity_sign(je0[j] & l.zin), d0[j]);
+                    d1[j] = fma(l.cr, parity_sign(je1[j] & l.zin), d1[j]);
                 }
             }
 #pragma unroll
@@ -266,6 +244,10 @@ __global__ __launch_bounds__(NT) void k_tile_cross_real(const double *__restrict
             }
         }
     }
+    v2d breg[TRIPS];     // (the bra tile behind the groups: fewer registers while they run)
+#pragma unroll
+    for (int j = 0; j < TRIPS; ++j) breg[j] = NTL ? __builtin_nontemporal_load(&q[ob | glow | spread_bits((uint32_t)j, ps.mask_hi)])
+                                                  : q[ob | glow | spread_bits((uint32_t)j, ps.mask_hi)];
     double part = 0.0;
 #pragma unroll
     for (int j = 0; j < TRIPS; ++j) part += breg[j].x * acc0[j] + breg[j].y * acc1[j];

@@ -284,64 +284,45 @@ __device__ __forceinline__ double tile_sparse_pieces(const typename Amp<REAL>::T
 }
 
 // the pairs of one (group, pattern) entry — or of a piece of an unsplit group — with one or two merged terms: lanes over the free
-// index, four trips in flight.
-// Round 6: the index of a pair is i = dep(lane) | dep(k0 + 64 t) | ibits — the lane's six bits land on the six lowest free positions,
-// the trip counter's on the higher ones, DISJOINT — and both the bank swizzle and a term's sign (-1)^{|j & z|} are linear over XOR.  So
-// everything that depends on the lane (its part of the swizzled LDS address, its part of every term's parity folded into the
-// coefficient's high word) is computed ONCE per entry, everything that depends on the trip is wave-uniform (scalar unit), and a pair
-// costs one XOR for its address, one for the partner's, one per term for the sign, and the arithmetic — 6 vector instructions for a
-// one-term entry where the per-pair index walk, swizzle, mask, population count and shift took about 25 (the kernel was bound by their
-// issue: 0.31 of the HBM rate at 31 qubits, profiles/r5_tilexp).
+// index, four trips in flight.  The swizzle is linear over XOR (the partner's address is one XOR from the own one); a term's sign is one
+// XOR on the high word of its coefficient (round 5: the kernel is bound by the issue of these instructions once two workgroups share a CU).
 template <bool REAL, uint32_t NEL, bool ONE, bool RO, bool FULL>
 __device__ __forceinline__ double tile_entry_pairs(const typename Amp<REAL>::T *tile, const ExEntryT &en, const ExTermLds &l0, const ExTermLds &l1,
                                                    uint32_t lane) {
     typedef typename Amp<REAL>::T amp;
-    constexpr uint32_t AB = (uint32_t)sizeof(amp);
-    // (the entry and its terms are the same for every lane: pinned to scalar registers, so that the trip part below runs on the scalar unit)
-    const uint32_t x = __builtin_amdgcn_readfirstlane(en.x), ibits = __builtin_amdgcn_readfirstlane(en.ibits);
-    const uint32_t nk = __builtin_amdgcn_readfirstlane((uint32_t)en.nk);
-    const uint32_t xf = __builtin_amdgcn_readfirstlane(en.pad ? (uint32_t)en.pad : en.x);   // (an unsplit entry: en.x is the pivot bit, en.pad the whole x mask)
-    const uint32_t z0 = __builtin_amdgcn_readfirstlane(l0.zin), z1 = __builtin_amdgcn_readfirstlane(l1.zin);
-    // lane part: index bits, swizzled byte offset, parities folded into the high words of the coefficients
-    const uint32_t il = deposit_index(lane, x) & (NEL - 1u);
-    const uint32_t pl = tile_swz<REAL>(il) * AB;
-    const uint32_t g0 = (uint32_t)__popc(il & z0) << 31, g1 = (uint32_t)__popc(il & z1) << 31;
-    const uint32_t c0rh = (uint32_t)__double2hiint(l0.cr) ^ g0, c0rl = (uint32_t)__double2loint(l0.cr);
-    const uint32_t c1rh = (uint32_t)__double2hiint(l1.cr) ^ g1, c1rl = (uint32_t)__double2loint(l1.cr);
-    const uint32_t c0ih = (uint32_t)__double2hiint(l0.ci) ^ g0, c0il = (uint32_t)__double2loint(l0.ci);
-    const uint32_t c1ih = (uint32_t)__double2hiint(l1.ci) ^ g1, c1il = (uint32_t)__double2loint(l1.ci);
-    // trip part (wave-uniform): the free index advances by 64 per trip, x positions skipped
-    const uint32_t d64 = deposit_index(64u, x);  // k -> k + 64 never carries into lane bits
-    uint32_t ih = __builtin_amdgcn_readfirstlane(deposit_index((uint32_t)en.k0, x)) | ibits;
-    const uint32_t sxb = tile_swz<REAL>(xf) * AB;
-    const char *base = reinterpret_cast<const char *>(tile);
+    const uint32_t d64 = deposit_index(64u, en.x);  // k -> k + 64 never carries into lane bits
+    uint32_t i = deposit_index((uint32_t)en.k0 + lane, en.x) | en.ibits;
+    const uint32_t xf = en.pad ? (uint32_t)en.pad : en.x;   // (an unsplit entry: en.x is the pivot bit, en.pad the whole x mask)
+    const uint32_t sx = tile_swz<REAL>(xf);
+    const uint32_t c0rh = (uint32_t)__double2hiint(l0.cr), c0rl = (uint32_t)__double2loint(l0.cr);
+    const uint32_t c1rh = (uint32_t)__double2hiint(l1.cr), c1rl = (uint32_t)__double2loint(l1.cr);
+    const uint32_t c0ih = (uint32_t)__double2hiint(l0.ci), c0il = (uint32_t)__double2loint(l0.ci);
+    const uint32_t c1ih = (uint32_t)__double2hiint(l1.ci), c1il = (uint32_t)__double2loint(l1.ci);
     double part = 0.0;
-    for (uint32_t k = 0; k < nk; k += 256u) {
-        uint32_t ph[4], s0[4], s1[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t iu = ih & (NEL - 1u);
-            ih = (((ih | x) + d64) & ~x) | ibits;
-            ph[q] = tile_swz<REAL>(iu) * AB;
-            const uint32_t ju = iu ^ xf;                       // the partner's index, trip part (the lane part: g0 / g1 above)
-            // (pinned: the compiler otherwise merges the two parities of a term back into ONE per-lane population count)
-            s0[q] = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_popcount(ju & z0) << 31);
-            s1[q] = ONE ? 0u : __builtin_amdgcn_readfirstlane((uint32_t)__builtin_popcount(ju & z1) << 31);
-        }
+    for (uint32_t k = lane; k < (uint32_t)en.nk; k += 256u) {
+        uint32_t ii[4];
         amp a[4], c[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint32_t off = pl ^ ph[q];
-            a[q] = *reinterpret_cast<const amp *>(base + off);
-            c[q] = *reinterpret_cast<const amp *>(base + (off ^ sxb));
+            ii[q] = i & (NEL - 1u);
+            i = (((i | en.x) + d64) & ~en.x) | en.ibits;  // next free index, x positions skipped
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            double dr = __hiloint2double((int)(c0rh ^ s0[q]), (int)c0rl), di = 0.0;
-            if constexpr (!RO) di = __hiloint2double((int)(c0ih ^ s0[q]), (int)c0il);
+            const uint32_t pa = tile_swz<REAL>(ii[q]);
+            a[q] = tile[pa];
+            c[q] = tile[pa ^ sx];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t j = ii[q] ^ xf;
+            const uint32_t n0 = (uint32_t)__popc(j & l0.zin) << 31;
+            double dr = __hiloint2double((int)(c0rh ^ n0), (int)c0rl), di = 0.0;
+            if constexpr (!RO) di = __hiloint2double((int)(c0ih ^ n0), (int)c0il);
             if constexpr (!ONE) {
-                dr += __hiloint2double((int)(c1rh ^ s1[q]), (int)c1rl);
-                if constexpr (!RO) di += __hiloint2double((int)(c1ih ^ s1[q]), (int)c1il);
+                const uint32_t n1 = (uint32_t)__popc(j & l1.zin) << 31;
+                dr += __hiloint2double((int)(c1rh ^ n1), (int)c1rl);
+                if constexpr (!RO) di += __hiloint2double((int)(c1ih ^ n1), (int)c1il);
             }
             double v;
             if constexpr (REAL) {
@@ -352,7 +333,7 @@ __device__ __forceinline__ double tile_entry_pairs(const typename Amp<REAL>::T *
                 if constexpr (!RO) v -= di * (a[q].x * c[q].y - a[q].y * c[q].x);
             }
             if constexpr (FULL) part += v;
-            else part += (k + 64u * q + lane < nk) ? v : 0.0;
+            else part += (k + 64u * q < (uint32_t)en.nk) ? v : 0.0;
         }
     }
     return part;
@@ -871,49 +852,44 @@ __global__ __launch_bounds__(NT) void k_tile_apply(const amp_t *__restrict__ in,
             const ExAGroupT gr = lg[g - ck.g0];
             const uint32_t xl = __builtin_amdgcn_readfirstlane(gr.x);
             const int t0 = __builtin_amdgcn_readfirstlane(gr.t0) - ck.t0, t1 = __builtin_amdgcn_readfirstlane(gr.t1) - ck.t0;
-            // round 6: thread part / trip part of the input's tile-local index je = (tid ^ x_lo) | ((j NT) ^ x_hi) — the swizzle stays inside
-            // the thread part, a term's sign is linear over XOR: address and sign once per group for the thread, per trip on the scalar
-            // unit (see tile_entry_pairs)
-            const uint32_t jt = threadIdx.x ^ (xl & (uint32_t)(NT - 1));
-            const uint32_t al = tile_swz_v(jt) * 16u;
-            const uint32_t xhi = xl & ~(uint32_t)(NT - 1);
-            const char *tb8 = reinterpret_cast<const char *>(tile);
-            const bool real_c = __builtin_amdgcn_readfirstlane(gr.pad) & 1;   // real coefficients only (every group of a real-symmetric H)
+            uint32_t je[TRIPS];
             double2 k[TRIPS];
             double dr[TRIPS], di[TRIPS];
-            uint32_t hj[TRIPS];
 #pragma unroll
             for (int j = 0; j < TRIPS; ++j) {
-                hj[j] = ((uint32_t)(j * NT)) ^ xhi;
-                k[j] = *reinterpret_cast<const double2 *>(tb8 + (al | (hj[j] << 4)));
+                je[j] = (threadIdx.x + j * NT) ^ xl;
+                k[j] = tile[tile_swz_v(je[j])];
                 dr[j] = 0.0;
                 di[j] = 0.0;
             }
-            for (int t = t0; t < t1; ++t) {
-                const ExTermLds l = lt[t];
-                const uint32_t zin = __builtin_amdgcn_readfirstlane(l.zin);
-                const uint32_t gl = (uint32_t)__popc(jt & zin) << 31;
-                const uint32_t crh = (uint32_t)__double2hiint(l.cr) ^ gl, crl = (uint32_t)__double2loint(l.cr);
-                const uint32_t cih = (uint32_t)__double2hiint(l.ci) ^ gl, cil = (uint32_t)__double2loint(l.ci);
+            if (__builtin_amdgcn_readfirstlane(gr.pad) & 1) {   // real coefficients only (every group of a real-symmetric H)
+                for (int t = t0; t < t1; ++t) {
+                    const ExTermLds l = lt[t];
 #pragma unroll
-                for (int j = 0; j < TRIPS; ++j) {
-                    const uint32_t su = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_popcount(hj[j] & zin) << 31);
-                    dr[j] += __hiloint2double((int)(crh ^ su), (int)crl);
-                    if (!real_c) di[j] += __hiloint2double((int)(cih ^ su), (int)cil);
+                    for (int j = 0; j < TRIPS; ++j) dr[j] = fma(l.cr, parity_sign(je[j] & l.zin), dr[j]);
                 }
-            }
-            if (real_c) {
 #pragma unroll
                 for (int j = 0; j < TRIPS; ++j) {
                     acc[j].x += dr[j] * k[j].x;
                     acc[j].y += dr[j] * k[j].y;
                 }
-            } else {
+                continue;
+            }
+            for (int t = t0; t < t1; ++t) {
+                const ExTermLds l = lt[t];
 #pragma unroll
                 for (int j = 0; j < TRIPS; ++j) {
-                    acc[j].x += dr[j] * k[j].x - di[j] * k[j].y;
-                    acc[j].y += dr[j] * k[j].y + di[j] * k[j].x;
+                    // +-1.0 from the parity bit (3 integer ops), then one exact FMA per component: half the VALU work of
+                    // compare + select + add
+                    const double sg = parity_sign(je[j] & l.zin);
+                    dr[j] = fma(l.cr, sg, dr[j]);
+                    di[j] = fma(l.ci, sg, di[j]);
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < TRIPS; ++j) {
+                acc[j].x += dr[j] * k[j].x - di[j] * k[j].y;
+                acc[j].y += dr[j] * k[j].y + di[j] * k[j].x;
             }
         }
     }

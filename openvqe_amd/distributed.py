@@ -561,13 +561,16 @@ class ShardedStatevector:
             groups.setdefault(xp >> self.n_local, []).append((xp, zp, complex(c), t))
         return [(xg, groups[xg]) for xg in sorted(groups)]
 
-    #: log2 of the amplitudes per chunk of a partner-shard read (27: 2 GiB; the x bits of a term above the chunk cost extra passes of
-    #: the cross-shard kernels, so chunks are as large as the double buffers allow); OVQE_SHARD_CHUNK_BITS overrides it (tests)
-    CHUNK_BITS = 27
+    #: log2 of the amplitudes per chunk of a partner-shard read: at most 29 (8 GiB: the x bits of a term ABOVE the chunk cost extra
+    #: passes of the cross-shard kernels — 34 qubits on 8 ranks: 44 / 41 / 37 / 32 passes per chunk set at 26 / 27 / 28 / 29 bits — so
+    #: chunks are as large as the double buffers allow: 2 x 4 partners x 8 GiB beside a 32-GiB shard) and at least four chunks per
+    #: shard (the transfer of chunk c + 1 hides behind the contraction of chunk c); OVQE_SHARD_CHUNK_BITS overrides it (tests)
+    CHUNK_BITS = 29
 
     def _chunk_bits(self):
         import os
-        m = int(os.environ.get("OVQE_SHARD_CHUNK_BITS", self.CHUNK_BITS))
+        env = os.environ.get("OVQE_SHARD_CHUNK_BITS")
+        m = int(env) if env is not None else min(self.CHUNK_BITS, self.n_local - 2)
         return max(1, min(self.n_local, m))
 
     def _post_multi(self, items):
@@ -609,7 +612,7 @@ class ShardedStatevector:
 
         return _Pending()
 
-    def _partner_chunks(self, partners, send_to=None):
+    def _partner_chunks(self, partners, send_to=None, after_first_post=None):
         """generator over the chunks of the partners' psi shards: yields (c, [chunk c of the shard of rank ^ d for d in
         ``partners``]); this rank's own chunk c goes to rank ^ d for d in ``send_to`` (default: the same list — a symmetric read;
         the Hermitian halving of <H> reads from some partners and sends to others).  Chunk c + 1 of ALL partners is posted as one
@@ -627,6 +630,8 @@ class ShardedStatevector:
         stored_real = self._storage_real()
         real = self.real and self.real_transfers and not stored_real
         if self.dry:     # one rank alone: its own chunks stand in for the partners' (same kernels, same bytes counted)
+            if after_first_post is not None:
+                after_first_post()
             for c in range(nchunks):
                 own = self.engine.tensor[c * csize:(c + 1) * csize]
                 self.stats["chunk_reads"] += np_
@@ -664,6 +669,8 @@ class ShardedStatevector:
 
         _progress("partner-shard read")
         pending = post(0)
+        if after_first_post is not None:   # work that needs no partner data runs while the first chunks are on the links
+            after_first_post()
         for c in range(nchunks):
             _progress()
             t0 = time.perf_counter()
@@ -781,12 +788,19 @@ class ShardedStatevector:
         if plan["perm"] != tuple(self.perm):
             raise ValueError("the Hamiltonian was planned under another qubit permutation")
         sid = self._plan_sum(plan, "expect")
-        with self._compute("expectation_local"):
-            total = self.engine.sum_expect_local(sid)
-        for c, chunks in self._partner_chunks(plan["read_from"], plan["send_to"]):
+        local = []
+
+        def local_part():     # (posted first: the first chunk of every partner travels while the shard's own terms are evaluated)
+            with self._compute("expectation_local"):
+                local.append(self.engine.sum_expect_local(sid))
+
+        for c, chunks in self._partner_chunks(plan["read_from"], plan["send_to"], after_first_post=local_part):
             with self._compute("expectation_remote"):
                 for d, ket in zip(plan["read_from"], chunks):
                     self.engine.sum_expect_remote(sid, d, c, ket)
+        if not local:
+            local_part()      # (no partner at all: nothing was posted)
+        total = local[0]
         if plan["read_from"]:
             total += self.engine.sum_expect_finish(sid).real
         val = torch.tensor([total], dtype=torch.float64, device=self.engine.tensor.device)
