@@ -74,7 +74,9 @@ struct SecHSweep {    // one sweep of the materialised <H>: device pointers
 };
 constexpr int SEC_DICT_PACKED_MAX = 1023;   // magnitudes up to which a coded word fits 24 bits (slot 13, sign 1, entry 10: the null element is entry ndict)
 typedef uint32_t sec_u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t sec_u32x3 __attribute__((ext_vector_type(3)));
+// (aligned(4): the 24-bit elements are read at a 12-byte stride from 4-byte aligned addresses — without it the type claims 16-byte
+// alignment, which is undefined behaviour here and lets the compiler widen the load to a dwordx4)
+typedef uint32_t sec_u32x3 __attribute__((ext_vector_type(3), aligned(4)));
 // four 24-bit elements of a lane from their three dwords (the layout of the 32-bit words with the empty top byte dropped)
 __device__ __forceinline__ sec_u32x4 sec_unpack24(sec_u32x3 d) {
     sec_u32x4 w;
@@ -891,6 +893,11 @@ __global__ __launch_bounds__(256) void k_sec_wave_plan(const uint32_t *__restric
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < n; k += 256u) own[k] = wofc[own[k]];
         __syncthreads();
+        // NOTE on reproducibility: a pair word's rank inside its (op, wave) row set comes from an LDS atomic, i.e. from thread timing:
+        // WHICH lane (and, beyond 64 pairs, which row) of the op's rows a pair occupies can differ between two builds of the same
+        // tables.  The forward sweep (k_sector_sweep3) does not care — every pair is rotated exactly once, energies are bit-identical.
+        // The backward sweep (k_sector_adjoint3) sums its gradient terms per lane and per row, so the gradients of two builds of one
+        // handle agree to rounding (1e-16 relative), not bit for bit; within one build every call repeats the same order.
         for (int o = o0; o < o1; ++o) {   // (every (op, wave) has its own counter: nothing to wait for between the ops)
             for (uint32_t k = lpo[o] + threadIdx.x; k < lpo[o + 1]; k += 256u) {
                 const uint32_t pw = pairs[k], w = own[pw & mask];
@@ -2477,7 +2484,8 @@ __device__ __forceinline__ double sec_reduce8(const double (&c)[8]) {
 // barriers at the run boundaries only.  A row is one op (usually one table entry: its header says when not), so the gradient terms
 // sigma (lambda_i psi_j - lambda_j psi_i) of a BATCH of eight rows are summed over the wave together — a reduce-scatter (ten
 // additions for eight sums, sec_reduce8) whose four partial totals per entry are added to the wave's row of partial sums by LDS
-// atomics (rows of the same op share an entry).  psi / lambda come and go as in k_sector_adjoint2.
+// atomics (rows of the same op share an entry).  psi / lambda come and go as in k_sector_adjoint2.  (Order of summation: fixed for
+// a given build of the streams, not across builds — the lanes of a row are filled by LDS atomics, see k_sec_wave_plan.)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_sector_adjoint3(const double *__restrict__ psi_in, const double *__restrict__ lam_in,
                                                         double *__restrict__ psi_out, double *__restrict__ lam_out, int in_compact,

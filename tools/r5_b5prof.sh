@@ -1,4 +1,5 @@
 #!/bin/bash
+export OVQE_LIB=testing   # the measurement options these scripts pass exist in the -DOVQE_TESTING build only
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 for o in "sector_reg_b5=1" "sector_reg_b5=0"; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export OVQE_LIB=testing   # the measurement options these scripts pass exist in the -DOVQE_TESTING build only
 # round 5, first GPU call: the bench tests (compact line, watchdog, energy check), the default bench run, barrier experiment
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

@@ -1,4 +1,5 @@
 #!/bin/bash
+export OVQE_LIB=testing   # the measurement options these scripts pass exist in the -DOVQE_TESTING build only
 # quick check of the regular sweeps: QUCCSD oracle test, fuzz, timings (evaluation + gradient) with option variants given as arguments
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
