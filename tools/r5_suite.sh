@@ -1,5 +1,4 @@
 #!/bin/bash
-export OVQE_LIB=testing   # the measurement options these scripts pass exist in the -DOVQE_TESTING build only
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out/r5suite

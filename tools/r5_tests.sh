@@ -1,5 +1,4 @@
 #!/bin/bash
-export OVQE_LIB=testing   # the measurement options these scripts pass exist in the -DOVQE_TESTING build only
 # run a selection of GPU tests: arguments = pytest arguments
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
