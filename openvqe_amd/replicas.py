@@ -66,8 +66,12 @@ def partition_min_qubits():
 
 
 def partitioned(nbqbits):
+    """OVQE_PARTITION_FORCE=1: also under a one-rank process group (one shard = the register: the collectives of the partitioned
+    path over RCCL on a single GPU, tests/test_gpu_nccl.py)"""
     w = world()
-    return w > 1 and (w & (w - 1)) == 0 and int(nbqbits) >= partition_min_qubits()
+    if w == 1 and not (os.environ.get("OVQE_PARTITION_FORCE") and _dist() is not None):
+        return False
+    return (w & (w - 1)) == 0 and int(nbqbits) >= partition_min_qubits()
 
 
 def active(nbqbits):

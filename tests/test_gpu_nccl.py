@@ -122,3 +122,36 @@ def test_bench_distributed_path_over_rccl_at_world_size_one(gpu_lib):
     sh = json.load(open(os.path.join(ROOT, out["extra"])))["sharded"]     # the legs' detail is in bench_extra.json
     assert sh["weak"]["n_qubits"] == 24 and sh["weak"]["swaps"] == 0 and abs(sh["weak"]["norm2"] - 1.0) < 1e-10
     assert sh["strong"]["energy"] == sh["weak"]["energy"]
+
+
+def _nccl_api_worker(port, out):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OVQE_PARTITION_MIN_QUBITS="6",
+                      OVQE_PARTITION_FORCE="1", OVQE_SHARD_CHUNK_BITS="5")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import openvqe_amd.evaluator as ev
+        from openvqe_amd.partitioned import PartitionedStatevector
+        from tests.test_partitioned_api import FLOWS, run_flows
+        res = run_flows(FLOWS)
+        assert ev._BACKENDS and all(isinstance(sv, PartitionedStatevector) for sv in ev._BACKENDS.values())
+        out.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reference_entry_points_on_the_partitioned_register_over_rccl(gpu_lib):
+    """the partitioned register behind `ucc_action` / both ADAPT mirrors under an RCCL process group (world size 1 — RCCL refuses two
+    ranks on one device —: the device-tensor all-reduces of energies, norms and pool gradients go through RCCL): same results as the
+    single-process oracle engine"""
+    from tests.test_partitioned_api import FLOWS, _single_process_oracle, check_partitioned
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_nccl_api_worker, args=(_free_port(), out))
+    p.start()
+    got = out.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    check_partitioned(got, _single_process_oracle(FLOWS))
