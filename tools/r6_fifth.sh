@@ -14,3 +14,8 @@ bash tools/profile_bench.sh r6e/prof > gpurun_out/r6e/profile.log 2>&1
 echo "profile rc=$?" | tee -a gpurun_out/r6e/summary.txt
 python tools/summarize_profile.py gpurun_out/r6e/prof gpurun_out/r6e/summary_prof 2>&1 | tail -2
 tail -1 gpurun_out/r6e/prof/trace.log | cut -c1-600
+# keep the summaries, drop the raw traces (gpurun copies back at most 64 MiB)
+cp gpurun_out/r6e/prof/trace.log gpurun_out/r6e/summary_prof/bench_profiled_run.log 2>/dev/null
+tail -1 gpurun_out/r6e/prof/trace.log > gpurun_out/r6e/summary_prof/bench_profiled_run.json 2>/dev/null
+rm -rf gpurun_out/r6e/prof
+du -sh gpurun_out
