@@ -838,6 +838,34 @@ inline uint32_t extract_bits(uint64_t v, uint64_t mask) {  // pext
 static int achunks_g0(const std::vector<ExChunkT> &a, int a0, const ExChunkT &cur) { return a0 < (int)a.size() ? a[a0].g0 : cur.g0; }
 static int achunks_t0(const std::vector<ExChunkT> &a, int a0, const ExChunkT &cur) { return a0 < (int)a.size() ? a[a0].t0 : cur.t0; }
 
+// the trip part of an entry's pair index, for tile_entry_pairs (sv_tile.hpp ExEntryT::pb / tsign): deposit of the trip counter's bits
+// over the positions outside x, swizzled byte offsets, the terms' parities on the partner index
+inline uint32_t host_deposit(uint32_t k, uint32_t fixmask) {
+    for (uint32_t m = fixmask; m; m &= m - 1u) {
+        const uint32_t low = (m & (0u - m)) - 1u;
+        k = ((k & ~low) << 1) | (k & low);
+    }
+    return k;
+}
+inline uint32_t host_tile_swz(uint32_t e, bool real) { return real ? e ^ (((e >> 4) & 7u) << 1) : e ^ ((e >> 3) & 7u); }
+void fill_entry_basis(ExEntryT &en, const std::vector<ExTermT> &tterms, bool real, int M) {
+    const uint32_t nel = 1u << M, ab = real ? 8u : 16u;
+    const uint32_t xf = en.pad ? (uint32_t)en.pad : en.x;
+    const uint32_t iu0 = (host_deposit((uint32_t)en.k0, en.x) | en.ibits) & (nel - 1u);
+    uint32_t d[4];
+    for (int b = 0; b < 4; ++b) d[b] = host_deposit(64u << b, en.x) & (nel - 1u);
+    en.pb[0] = host_tile_swz(iu0, real) * ab;
+    for (int b = 0; b < 4; ++b) en.pb[1 + b] = host_tile_swz(d[b], real) * ab;
+    en.tsign = 0;
+    const int nt = std::min(2, en.t1 - en.t0);
+    for (int j = 0; j < nt; ++j) {
+        const uint32_t zin = tterms[(size_t)en.t0 + (j == 0 ? 0 : (en.t1 - en.t0 - 1))].zin;   // (the kernel takes the first and the LAST term)
+        uint32_t f = (uint32_t)__builtin_popcount((iu0 ^ xf) & zin) & 1u;
+        for (int b = 0; b < 4; ++b) f |= ((uint32_t)__builtin_popcount(d[b] & zin) & 1u) << (1 + b);
+        en.tsign |= f << (5 * j);
+    }
+}
+
 int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
     const int M = tile_bits(h, real), L = ham_tile_low(h, real);
     H.tile_bits = M;
@@ -978,17 +1006,18 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
                     if (et.ci != 0.0) real_only = false;
                     tterms.push_back(et);
                 }
-                const int npairs = 1 << (M - 1);
-                for (int k0 = 0; k0 < npairs; k0 += 512) {
+                const int npairs = 1 << (M - 1), piece = std::min(npairs, TILE_UNSPLIT_PAIRS);
+                for (int k0 = 0; k0 < npairs; k0 += piece) {
                     ExEntryT en = {};
                     en.x = 1u << xpos[w - 1];
                     en.ibits = 0;
                     en.t0 = t0;
                     en.t1 = (int32_t)tterms.size();
                     en.k0 = k0;
-                    en.nk = 512;
+                    en.nk = piece;
                     en.real_only = real_only ? 1 : 0;
                     en.pad = (int32_t)xl;
+                    fill_entry_basis(en, tterms, real, M);
                     tgroups.push_back(en);
                 }
                 continue;
@@ -1072,6 +1101,7 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
                         en.k0 = k0;
                         en.nk = std::min(TILE_ENTRY_PAIRS, nk_total - k0);
                         en.real_only = real_only ? 1 : 0;
+                        if (en.t1 - en.t0 <= 2) fill_entry_basis(en, tterms, real, M);
                         tgroups.push_back(en);
                     }
                 }

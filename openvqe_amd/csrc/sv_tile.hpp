@@ -209,10 +209,18 @@ struct ExEntryT {
     uint32_t x;       // tile-local x mask (0: diagonal group)
     uint32_t ibits;   // the pattern: bits of i on the non-pivot x positions (pivot bit of i is 0)
     int32_t t0, t1;   // merged terms (absolute)
-    int32_t k0, nk;   // free-index range [k0, k0 + nk), nk <= TILE_ENTRY_PAIRS
+    int32_t k0, nk;   // free-index range [k0, k0 + nk), nk <= TILE_ENTRY_PAIRS (unsplit entries: <= TILE_UNSPLIT_PAIRS)
     int32_t real_only;  // every ci == 0
     int32_t pad;
+    // Round 6, entries of one or two terms (tile_entry_pairs): the TRIP part of the pair index, host-side.  The index of pair k0 + lane +
+    // 64 t is dep(lane) | dep(k0 + 64 t) | ibits with disjoint bit sets, the bank swizzle and a term's sign are linear over XOR: trip t's
+    // share of the swizzled byte offset is pb[0] ^ (xor of pb[1 + b] over the set bits b of t), its share of term j's sign is bit 0 of
+    // tsign's 5-bit field j xor the bits 1 + b.  What remains per pair on the device is one XOR per address and one per term.
+    uint32_t pb[5];   // byte offsets: trip 0, then the basis of trip bits 0..3 (index bits 6..9 of k)
+    uint32_t tsign;   // bits 5 j .. 5 j + 4: term j's parity at trip 0 (partner index ^ z), then the basis parities
+    uint32_t pad2[2];
 };
+constexpr int TILE_UNSPLIT_PAIRS = 1024;   // pairs per piece of an unsplit entry (16 rows of a wave: the per-entry set-up amortised)
 struct ExTermT {
     uint64_t zout;    // z outside the tile
     uint32_t zin;     // z on the tile bits, x positions cleared
@@ -284,45 +292,56 @@ __device__ __forceinline__ double tile_sparse_pieces(const typename Amp<REAL>::T
 }
 
 // the pairs of one (group, pattern) entry — or of a piece of an unsplit group — with one or two merged terms: lanes over the free
-// index, four trips in flight.  The swizzle is linear over XOR (the partner's address is one XOR from the own one); a term's sign is one
-// XOR on the high word of its coefficient (round 5: the kernel is bound by the issue of these instructions once two workgroups share a CU).
+// index, four trips in flight.
+// Round 6: lane part / trip part.  The pair index is dep(lane) | dep(k0 + 64 t) | ibits; swizzle and signs are linear over XOR.  The
+// lane's share (swizzled byte offset, its parity on every term folded into the coefficient's high word) is computed once per entry;
+// the trip's share comes from the HOST (ExEntryT::pb / tsign: a trip-0 value and one basis value per bit of t) and is combined by
+// a handful of scalar XORs per group of four trips.  A pair costs: one XOR for its address, one for the partner's, one per term for
+// the sign, the arithmetic.  (A first form that walked the trip index on the scalar unit per trip, and one that computed the basis on
+// the device per entry, were SLOWER than the round-5 loop: an entry is 4 .. 8 rows of a wave, the set-up has to stay small — DESIGN §4.)
 template <bool REAL, uint32_t NEL, bool ONE, bool RO, bool FULL>
 __device__ __forceinline__ double tile_entry_pairs(const typename Amp<REAL>::T *tile, const ExEntryT &en, const ExTermLds &l0, const ExTermLds &l1,
                                                    uint32_t lane) {
     typedef typename Amp<REAL>::T amp;
-    const uint32_t d64 = deposit_index(64u, en.x);  // k -> k + 64 never carries into lane bits
-    uint32_t i = deposit_index((uint32_t)en.k0 + lane, en.x) | en.ibits;
+    constexpr uint32_t AB = (uint32_t)sizeof(amp);
+    const uint32_t x = en.x, nk = (uint32_t)en.nk;
     const uint32_t xf = en.pad ? (uint32_t)en.pad : en.x;   // (an unsplit entry: en.x is the pivot bit, en.pad the whole x mask)
-    const uint32_t sx = tile_swz<REAL>(xf);
-    const uint32_t c0rh = (uint32_t)__double2hiint(l0.cr), c0rl = (uint32_t)__double2loint(l0.cr);
-    const uint32_t c1rh = (uint32_t)__double2hiint(l1.cr), c1rl = (uint32_t)__double2loint(l1.cr);
-    const uint32_t c0ih = (uint32_t)__double2hiint(l0.ci), c0il = (uint32_t)__double2loint(l0.ci);
-    const uint32_t c1ih = (uint32_t)__double2hiint(l1.ci), c1il = (uint32_t)__double2loint(l1.ci);
+    const uint32_t il = deposit_index(lane, x) & (NEL - 1u);
+    const uint32_t pl = tile_swz<REAL>(il) * AB;
+    const uint32_t g0 = (uint32_t)__popc(il & l0.zin) << 31, g1 = (uint32_t)__popc(il & l1.zin) << 31;
+    const uint32_t c0rh = (uint32_t)__double2hiint(l0.cr) ^ g0, c0rl = (uint32_t)__double2loint(l0.cr);
+    const uint32_t c1rh = (uint32_t)__double2hiint(l1.cr) ^ g1, c1rl = (uint32_t)__double2loint(l1.cr);
+    const uint32_t c0ih = (uint32_t)__double2hiint(l0.ci) ^ g0, c0il = (uint32_t)__double2loint(l0.ci);
+    const uint32_t c1ih = (uint32_t)__double2hiint(l1.ci) ^ g1, c1il = (uint32_t)__double2loint(l1.ci);
+    const uint32_t sxb = tile_swz<REAL>(xf) * AB;
+    const uint32_t ts = en.tsign;
+    // the two low trip bits (inside a group of four trips) as ready-made words
+    const uint32_t p6 = en.pb[1], p7 = en.pb[2];
+    const uint32_t t06 = (ts << 30) & 0x80000000u, t07 = (ts << 29) & 0x80000000u;
+    const uint32_t t16 = (ts << 25) & 0x80000000u, t17 = (ts << 24) & 0x80000000u;
+    const char *base = reinterpret_cast<const char *>(tile);
     double part = 0.0;
-    for (uint32_t k = lane; k < (uint32_t)en.nk; k += 256u) {
-        uint32_t ii[4];
+    for (uint32_t k = 0; k < nk; k += 256u) {
+        const uint32_t pk = en.pb[0] ^ ((k & 256u) ? en.pb[3] : 0u) ^ ((k & 512u) ? en.pb[4] : 0u);
+        const uint32_t a0 = ((ts << 31) ^ ((k & 256u) ? (ts << 28) : 0u) ^ ((k & 512u) ? (ts << 27) : 0u)) & 0x80000000u;
+        const uint32_t a1 = ONE ? 0u : (((ts << 26) ^ ((k & 256u) ? (ts << 23) : 0u) ^ ((k & 512u) ? (ts << 22) : 0u)) & 0x80000000u);
+        const uint32_t ph[4] = {pk, pk ^ p6, pk ^ p7, pk ^ p6 ^ p7};
+        const uint32_t s0[4] = {a0, a0 ^ t06, a0 ^ t07, a0 ^ t06 ^ t07};
+        const uint32_t s1[4] = {a1, a1 ^ t16, a1 ^ t17, a1 ^ t16 ^ t17};
         amp a[4], c[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            ii[q] = i & (NEL - 1u);
-            i = (((i | en.x) + d64) & ~en.x) | en.ibits;  // next free index, x positions skipped
+            const uint32_t off = pl ^ ph[q];
+            a[q] = *reinterpret_cast<const amp *>(base + off);
+            c[q] = *reinterpret_cast<const amp *>(base + (off ^ sxb));
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint32_t pa = tile_swz<REAL>(ii[q]);
-            a[q] = tile[pa];
-            c[q] = tile[pa ^ sx];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t j = ii[q] ^ xf;
-            const uint32_t n0 = (uint32_t)__popc(j & l0.zin) << 31;
-            double dr = __hiloint2double((int)(c0rh ^ n0), (int)c0rl), di = 0.0;
-            if constexpr (!RO) di = __hiloint2double((int)(c0ih ^ n0), (int)c0il);
+            double dr = __hiloint2double((int)(c0rh ^ s0[q]), (int)c0rl), di = 0.0;
+            if constexpr (!RO) di = __hiloint2double((int)(c0ih ^ s0[q]), (int)c0il);
             if constexpr (!ONE) {
-                const uint32_t n1 = (uint32_t)__popc(j & l1.zin) << 31;
-                dr += __hiloint2double((int)(c1rh ^ n1), (int)c1rl);
-                if constexpr (!RO) di += __hiloint2double((int)(c1ih ^ n1), (int)c1il);
+                dr += __hiloint2double((int)(c1rh ^ s1[q]), (int)c1rl);
+                if constexpr (!RO) di += __hiloint2double((int)(c1ih ^ s1[q]), (int)c1il);
             }
             double v;
             if constexpr (REAL) {
@@ -333,7 +352,7 @@ __device__ __forceinline__ double tile_entry_pairs(const typename Amp<REAL>::T *
                 if constexpr (!RO) v -= di * (a[q].x * c[q].y - a[q].y * c[q].x);
             }
             if constexpr (FULL) part += v;
-            else part += (k + 64u * q < (uint32_t)en.nk) ? v : 0.0;
+            else part += (k + 64u * q + lane < nk) ? v : 0.0;
         }
     }
     return part;
