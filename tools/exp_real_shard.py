@@ -16,6 +16,10 @@ for label, opts in (("default", ""), ("entries_not_items", "tile_flat=0"), ("no_
     print(json.dumps({"variant": label, "options": opts, "rotations_s": leg["rotations_s"], "expectation_s": leg["expectation_s"],
                       "passes": leg["expectation_passes_executed"], "sweeps": leg["local_sweeps_executed"], "energy": leg["energy"],
                       "real_storage": leg.get("real_storage_through_the_leg")}), flush=True)
+os.environ["OVQE_OPTIONS"] = "expect_streams=1"
+leg = bench.sharded_leg(n, 0, 1, 0, real_state=False)
+print(json.dumps({"variant": "complex_state_one_stream", "rotations_s": leg["rotations_s"], "expectation_s": leg["expectation_s"],
+                  "passes": leg["expectation_passes_executed"]}), flush=True)
 os.environ["OVQE_OPTIONS"] = ""
 leg = bench.sharded_leg(n, 0, 1, 0, real_state=False)
 print(json.dumps({"variant": "complex_state", "rotations_s": leg["rotations_s"], "expectation_s": leg["expectation_s"],
