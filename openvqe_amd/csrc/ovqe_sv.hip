@@ -120,6 +120,9 @@ struct HamDev {  // grouped Pauli sum resident on the device
     DevBuf d_achunks, d_agroups, d_aterms;  // operator-application form of the cover (k_tile_apply, sparse tiles)
     std::vector<ExChunkT> h_achunks;        // host copy (launch geometry of the compact cover)
     int cover_id = 0;                       // bumped whenever the cover is rebuilt
+    // the diagonal group for k_tile_diag (Walsh-Hadamard form, dense registers): unique tile-local z masks, CSR of their terms
+    DevBuf d_dzin, d_doff, d_dterms;
+    int diag_nu = 0, diag_bits = 0, diag_sweep = -1;   // unique masks, tile bits of the form, the cover sweep that holds the group
 };
 
 // Pauli sum planned ONCE for a shard of the partitioned register (sv_cross.hpp, cross_host.inc): the terms without an x part on the
@@ -345,6 +348,7 @@ struct ovqe_sv {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int opt_expect_streams = 2;
+    int opt_expect_diag_wht = 1;  // dense registers of 25+ qubits: the diagonal group of a tiled <H> by a Walsh-Hadamard transform per tile (k_tile_diag)
     int opt_real_state = 0;       // option "real_state": the state buffer holds 2^n_local DOUBLES (a shard of the partitioned register while
                                   // every applied rotation has an odd number of Y): ovqe_apply_pauli_rotations, ovqe_init_basis, ovqe_norm2
                                   // and the ovqe_xsum_expect_* calls work on 8-byte amplitudes
@@ -497,7 +501,7 @@ int translate_exception(ovqe_handle h) noexcept {
 
 void free_hamdev(HamDev &H) {
     for (DevBuf *b : {&H.d_groups, &H.d_terms, &H.d_tchunks, &H.d_tgroups, &H.d_tterms, &H.d_tflats, &H.d_titems, &H.d_rest, &H.d_achunks,
-                      &H.d_agroups, &H.d_aterms})
+                      &H.d_agroups, &H.d_aterms, &H.d_dzin, &H.d_doff, &H.d_dterms})
         if (b->p) {
             (void)hipFree(b->p);
             *b = DevBuf{};
@@ -877,6 +881,8 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
     H.cover_id++;
     H.n_rest = 0;
     H.tile_work = 0;
+    H.diag_sweep = -1;
+    H.diag_nu = 0;
     const bool tiled = tile_ok(h, real) && H.groups.size() >= 3;
     if (!tiled) return OVQE_OK;
     const int G = (int)H.groups.size();
@@ -944,6 +950,7 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
             --remaining;
             ++took;
             const HGroup &gr = H.groups[g];
+            if (gr.x == 0) H.diag_sweep = (int)H.tsweeps.size();   // (this sweep; pushed below)
             const uint32_t xl = extract_bits(gr.x, S);
             {   // operator-application form (k_tile_apply; sparse tiles of k_tile_expect): the group's raw terms, split
                 // when they exceed a chunk.  Real state: strings with an imaginary folded coefficient (odd number of
@@ -1126,6 +1133,33 @@ int build_ham_tiles(ovqe_handle h, HamDev &H, bool real) {
         H.tsweep_terms.push_back((int)aterms.size() - achunks_t0(achunks, sw.a0, ak));
     }
     H.n_rest = (int)rest.size();
+    // the diagonal group in Walsh-Hadamard form (k_tile_diag): contiguous tiles of 2^12 amplitudes, the terms grouped by their z mask
+    // on the tile bits (ascending mask, the group's term order inside: a fixed summation order)
+    if (H.diag_sweep >= 0 && h->n_local >= 25 && h->opt_expect_diag_wht) {
+        const HGroup *dg = nullptr;
+        for (const HGroup &g : H.groups)
+            if (g.x == 0) dg = &g;
+        constexpr int DM = 12;
+        if (dg && dg->t1 - dg->t0 >= 12) {
+            std::map<uint32_t, std::vector<DiagTermT>> by_zin;
+            for (int t = dg->t0; t < dg->t1; ++t)
+                by_zin[(uint32_t)(H.terms[t].z & ((1ull << DM) - 1ull))].push_back(DiagTermT{H.terms[t].z >> DM << DM, H.terms[t].cr});
+            std::vector<uint32_t> uz;
+            std::vector<int32_t> uo = {0};
+            std::vector<DiagTermT> dt;
+            for (const auto &kv : by_zin) {
+                uz.push_back(kv.first);
+                dt.insert(dt.end(), kv.second.begin(), kv.second.end());
+                uo.push_back((int32_t)dt.size());
+            }
+            int rc = upload(h, H.d_dzin, uz.data(), uz.size() * sizeof(uint32_t));
+            if (!rc) rc = upload(h, H.d_doff, uo.data(), uo.size() * sizeof(int32_t));
+            if (!rc) rc = upload(h, H.d_dterms, dt.data(), dt.size() * sizeof(DiagTermT));
+            if (rc) return rc;
+            H.diag_nu = (int)uz.size();
+            H.diag_bits = DM;
+        }
+    }
     for (const ExEntryT &en : tgroups) H.tile_work += (int64_t)en.nk * (en.t1 - en.t0);
     H.tile_entries = (int64_t)(tgroups.size() + tflats.size());
     H.tile_terms = (int64_t)tterms.size();
@@ -1159,7 +1193,7 @@ inline int expect_ysplit(ovqe_handle h, int M) {  // workgroups per tile: fill t
 // out of the launch, and two workgroups share a CU — one loads its tile while the other computes
 template <int M, bool REAL>
 int launch_tile_expect(ovqe_handle h, const HamDev &H, const ExSweep &sw, double2 *partials, int accumulate,
-                       hipStream_t stream, bool dense_only = false, int *census = nullptr) {
+                       hipStream_t stream, bool dense_only = false, int *census = nullptr, bool skip_diag = false) {
     constexpr int NT = 1 << TILE_EXPECT_LOG_NT;
     static_assert(TILE_SPARSE_TERMS >= 2 * TILE_TERM_CAP && TILE_SPARSE_GROUPS >= 2 * TILE_APPLY_GROUPS, "two host chunks per pass");
     const size_t smem_full = ((size_t)(REAL ? 8 : 16) << M) + TILE_SPARSE_TERMS * sizeof(ExTermLds) +
@@ -1171,7 +1205,7 @@ int launch_tile_expect(ovqe_handle h, const HamDev &H, const ExSweep &sw, double
                               (NT / 64 + 2) * sizeof(int);
     const size_t smem = dense_only ? smem_dense : smem_full;
     const dim3 grid((unsigned)(h->namps >> M), (unsigned)expect_ysplit(h, M));
-    const int sparse_den = dense_only ? -1 : ((H.d_agroups.p && sw.a1 > sw.a0) ? h->opt_expect_sparse : 0);
+    const int sparse_den = dense_only ? (skip_diag ? -2 : -1) : ((H.d_agroups.p && sw.a1 > sw.a0) ? h->opt_expect_sparse : 0);
     static bool attr_done_dev[64] = {};  // function attributes are per device
     bool &attr_done = attr_done_dev[h->device & 63];
     if (!attr_done) {
@@ -1210,7 +1244,8 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bo
     // partial sums: one per workgroup of the tile sweeps (none when every group keeps its own sweep)
     const int64_t ntiles = H.tsweeps.empty() ? 0 : (int64_t)(h->namps >> M) * expect_ysplit(h, M);
     const int nb = reduce_blocks(h->namps);
-    int rc = ensure(h, h->d_partials, (size_t)(2 * ntiles + nb) * sizeof(double2));
+    const int64_t ndiag = H.diag_nu > 0 ? (int64_t)(h->namps >> H.diag_bits) : 0;   // workgroups of k_tile_diag (dense registers)
+    int rc = ensure(h, h->d_partials, (size_t)(2 * ntiles + nb + ndiag) * sizeof(double2));
     if (rc) return rc;
     rc = ensure(h, h->d_result, 64 * sizeof(double2));
     if (rc) return rc;
@@ -1236,21 +1271,24 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bo
     // (round 6: real states too — the float64 shards of the partitioned register: tiles of 2^13 doubles)
     const bool try_dense = ((!real && M == 12) || (real && M == 13)) && h->n_local >= 25 && ns >= 4 && h->opt_expect_sparse > 0 && h->opt_expect_dense;
     bool dense_only = false;
-    int k_start = 0;
+    int census_k = -1;      // the sweep that ran first, as the census
     if (try_dense) {
         rc = ensure(h, h->d_tile_cnt, sizeof(int));
         if (rc) return rc;
+        // (the census takes a sweep WITHOUT the diagonal group when that group has a Walsh-Hadamard form: on a dense register the
+        // group's hundreds of strings then never run term by term)
+        census_k = (ndiag && H.diag_sweep == 0 && ns > 1) ? 1 : 0;
         HIPC(h, hipMemsetAsync(h->d_tile_cnt.p, 0, sizeof(int), h->stream));
-        rc = real ? launch_tile_expect<13, true>(h, H, H.tsweeps[0], partials, 0, h->stream, false, (int *)h->d_tile_cnt.p)
-                  : launch_tile_expect<12, false>(h, H, H.tsweeps[0], partials, 0, h->stream, false, (int *)h->d_tile_cnt.p);
+        rc = real ? launch_tile_expect<13, true>(h, H, H.tsweeps[census_k], partials, 0, h->stream, false, (int *)h->d_tile_cnt.p)
+                  : launch_tile_expect<12, false>(h, H, H.tsweeps[census_k], partials, 0, h->stream, false, (int *)h->d_tile_cnt.p);
         if (rc) return rc;
         int census = 1;
         HIPC(h, hipMemcpyAsync(&census, h->d_tile_cnt.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPC(h, hipStreamSynchronize(h->stream));
         dense_only = census == 0;
         acc[0] = 1;
-        k_start = 1;
     }
+    const bool diag_wht = dense_only && ndiag > 0 && H.diag_sweep != census_k;
     if (dual) {
         const double mem = 16.0 * (double)h->namps * (real ? 0.5 : 1.0) / 2.8e6;        // us at ~2.8 TB/s
         const double per_term = 0.23 * (double)h->namps / (double)(1ull << 24);       // us, measured at 24 qubits
@@ -1266,7 +1304,8 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bo
         HIPC(h, hipEventRecord(h->ev_fork, h->stream));
         HIPC(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
     }
-    for (int k = k_start; k < ns; ++k) {
+    for (int k = 0; k < ns; ++k) {
+        if (k == census_k) continue;
         const ExSweep &sw = H.tsweeps[k];
         const int which = on_second[k];
         hipStream_t strm = which ? h->stream2 : h->stream;
@@ -1275,13 +1314,13 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bo
             switch (M) {
             case 11: rc = launch_tile_expect<11, true>(h, H, sw, part, acc[which], strm); break;
             case 12: rc = launch_tile_expect<12, true>(h, H, sw, part, acc[which], strm); break;
-            default: rc = launch_tile_expect<13, true>(h, H, sw, part, acc[which], strm, dense_only); break;
+            default: rc = launch_tile_expect<13, true>(h, H, sw, part, acc[which], strm, dense_only, nullptr, diag_wht); break;
             }
         } else {
             switch (M) {
             case 10: rc = launch_tile_expect<10, false>(h, H, sw, part, acc[which], strm); break;
             case 11: rc = launch_tile_expect<11, false>(h, H, sw, part, acc[which], strm); break;
-            default: rc = launch_tile_expect<12, false>(h, H, sw, part, acc[which], strm, dense_only); break;
+            default: rc = launch_tile_expect<12, false>(h, H, sw, part, acc[which], strm, dense_only, nullptr, diag_wht); break;
             }
         }
         if (rc) return rc;
@@ -1293,6 +1332,23 @@ int run_expectation_tiled(ovqe_handle h, HamDev &H, double2 *out, bool *used, bo
         HIPC(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
     }
     int64_t count = ntiles * nparts;
+    if (diag_wht) {   // the diagonal group: one pass over contiguous tiles, Walsh-Hadamard form (sv_tile.hpp k_tile_diag)
+        constexpr int DM = 12, DNT = 512;
+        const size_t dsm = ((size_t)8 << DM) + (DNT / 64) * sizeof(double2);
+        const bool ntl = h->n_local >= 25;
+        if (real) {
+            if (ntl) hipLaunchKernelGGL((k_tile_diag<DM, DNT, true, true>), dim3((unsigned)ndiag), dim3(DNT), dsm, h->stream, (const void *)h->state, h->base,
+                                        (const uint32_t *)H.d_dzin.p, (const int32_t *)H.d_doff.p, (const DiagTermT *)H.d_dterms.p, H.diag_nu, partials + count, 0);
+            else hipLaunchKernelGGL((k_tile_diag<DM, DNT, false, true>), dim3((unsigned)ndiag), dim3(DNT), dsm, h->stream, (const void *)h->state, h->base,
+                                    (const uint32_t *)H.d_dzin.p, (const int32_t *)H.d_doff.p, (const DiagTermT *)H.d_dterms.p, H.diag_nu, partials + count, 0);
+        } else {
+            if (ntl) hipLaunchKernelGGL((k_tile_diag<DM, DNT, true, false>), dim3((unsigned)ndiag), dim3(DNT), dsm, h->stream, (const void *)h->state, h->base,
+                                        (const uint32_t *)H.d_dzin.p, (const int32_t *)H.d_doff.p, (const DiagTermT *)H.d_dterms.p, H.diag_nu, partials + count, 0);
+            else hipLaunchKernelGGL((k_tile_diag<DM, DNT, false, false>), dim3((unsigned)ndiag), dim3(DNT), dsm, h->stream, (const void *)h->state, h->base,
+                                    (const uint32_t *)H.d_dzin.p, (const int32_t *)H.d_doff.p, (const DiagTermT *)H.d_dterms.p, H.diag_nu, partials + count, 0);
+        }
+        count += ndiag;
+    }
     if (H.n_rest) {
         if (real)
             hipLaunchKernelGGL(k_expect_pairs_real, dim3(nb), dim3(256), 0, h->stream, (const double *)h->state, h->namps,
@@ -3270,7 +3326,7 @@ int ovqe_destroy(ovqe_handle h) try {
     for (TilePlan *tp : {&h->tp, &h->tp_adhoc, &h->tp_real}) bufs.insert(bufs.end(), {&tp->d_tops, &tp->d_trots});
     for (HamDev *H : {&h->ham, &h->ham_adhoc, &h->ham_real, &h->ham_conj})
         bufs.insert(bufs.end(), {&H->d_groups, &H->d_terms, &H->d_tchunks, &H->d_tgroups, &H->d_tterms, &H->d_tflats,
-                                 &H->d_titems, &H->d_rest, &H->d_achunks, &H->d_agroups, &H->d_aterms});
+                                 &H->d_titems, &H->d_rest, &H->d_achunks, &H->d_agroups, &H->d_aterms, &H->d_dzin, &H->d_doff, &H->d_dterms});
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     free_sector(h->sec);
@@ -3433,6 +3489,12 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     else if (k == "sector_coset_first") h->opt_sector_coset_first = (int)value;
     else if (k == "sector_apply_seq") h->opt_sector_apply_seq = (int)value;
     else if (k == "expect_dense") h->opt_expect_dense = (int)value;
+    else if (k == "expect_diag_wht") {
+        h->opt_expect_diag_wht = (int)value;
+        for (HamDev *H : {&h->ham, &h->ham_adhoc, &h->ham_real, &h->ham_conj}) H->tile_bits = -1;   // covers rebuilt on their next use
+        for (CrossSum *X : h->xsums)
+            if (X) X->local.tile_bits = -1;
+    }
     else if (k == "fault_inject") h->fault_inject = (int)value;
 #endif
     else if (k == "real_stream") h->opt_real_stream = (int)value;

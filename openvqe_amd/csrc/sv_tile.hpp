@@ -381,6 +381,7 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
     // sparse_den < 0: DENSE layout — the launch left the sparse path's staging area and non-zero list out (launch_tile_expect):
     // [tile][term table of one chunk][reduction]
     const bool dense_layout = sparse_den < 0;
+    const bool skip_diag = sparse_den == -2;   // the diagonal group is evaluated by k_tile_diag (dense registers, run_expectation_tiled)
     ExTermLds *lt = reinterpret_cast<ExTermLds *>(smem + (size_t)NELV * sizeof(double2));
     ExTermLds *spt = lt;                                             // sparse path: staged terms ...
     ExAGroupT *spg = reinterpret_cast<ExAGroupT *>(spt + (dense_layout ? TILE_TERM_CAP : TILE_SPARSE_TERMS));  // ... and pieces of a pass
@@ -554,6 +555,7 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
         // small registers have fewer tiles than the chip has CUs: gridDim.y workgroups share a tile's entries
         for (int g = ck.g0 + wave + (NT / 64) * (int)blockIdx.y; g < ck.g1; g += (NT / 64) * (int)gridDim.y) {
             const ExEntryT en = entries[g];
+            if (skip_diag && en.x == 0u) continue;
             const ExTermLds *gt = lt + (en.t0 - ck.t0);
             const int nt = en.t1 - en.t0;
             double part = 0.0;
@@ -624,6 +626,99 @@ __global__ __launch_bounds__(NT) void k_tile_expect(const void *__restrict__ st,
             partials[slot] = make_double2(o.x + t.x, o.y);
         } else {
             partials[slot] = t;
+        }
+    }
+}
+
+// ---- the DIAGONAL group by a fast Walsh-Hadamard transform (round 6) ------------------------------------------------------------
+// The x = 0 group of a Hermitian sum is D(i) |a_i|^2 with D(i) = sum_t c_t (-1)^{|i & z_t|}: hundreds of Z strings (a JW Hamiltonian's
+// number operators and Coulomb terms; 30 % of the bench's random strings) evaluated for EVERY amplitude — as many term evaluations
+// as all the other groups of the cover together.  On a contiguous tile of 2^M amplitudes i = (tile, e) the sign splits into a
+// per-tile sign (z bits above the tile) and (-1)^{|e & zin|}: D over the tile is the Walsh-Hadamard transform of the sparse vector
+// W[zin] = sum of the signed coefficients with that zin — M 2^M additions instead of T 2^M term evaluations (M = 12, T = 300: 25 x).
+// One workgroup per tile: |a|^2 in registers, W in LDS (32 KB), unique zin values filled from a host-built CSR (deterministic
+// order), M butterfly stages, dot product.  Launched for dense registers only (the census of run_expectation_tiled): there the
+// sweeps of k_tile_expect skip their x = 0 entries (sparse_den = -2).
+struct DiagTermT {
+    uint64_t zout;   // z above the tile bits
+    double c;
+};
+template <int M, int NT, bool NTL, bool REAL>
+__global__ __launch_bounds__(NT) void k_tile_diag(const void *__restrict__ st, uint64_t base, const uint32_t *__restrict__ uzin,
+                                                  const int32_t *__restrict__ uoff, const DiagTermT *__restrict__ dterms, int nu,
+                                                  double2 *__restrict__ partials, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t NEL = 1u << M;
+    constexpr int K = NEL / NT;          // amplitudes per thread
+    double *W = reinterpret_cast<double *>(smem);
+    double2 *red = reinterpret_cast<double2 *>(W + NEL);
+    const uint64_t gbase = base | ((uint64_t)blockIdx.x << M);
+    double w2[K];
+    bool any = false;
+    if constexpr (REAL) {
+        const v2d *p = reinterpret_cast<const v2d *>(st) + ((size_t)blockIdx.x << (M - 1));
+#pragma unroll
+        for (int k = 0; k < K / 2; ++k) {     // pair v = tid + k NT: amplitudes 2 v, 2 v + 1
+            const v2d r = NTL ? __builtin_nontemporal_load(&p[threadIdx.x + k * NT]) : p[threadIdx.x + k * NT];
+            w2[2 * k] = r.x * r.x;
+            w2[2 * k + 1] = r.y * r.y;
+            any |= r.x != 0.0 || r.y != 0.0;
+        }
+    } else {
+        const v2d *p = reinterpret_cast<const v2d *>(st) + ((size_t)blockIdx.x << M);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const v2d r = NTL ? __builtin_nontemporal_load(&p[threadIdx.x + k * NT]) : p[threadIdx.x + k * NT];
+            w2[k] = r.x * r.x + r.y * r.y;
+            any |= r.x != 0.0 || r.y != 0.0;
+        }
+    }
+    if (!__syncthreads_or(any)) {          // a tile of zeros (a sector-sparse state on the dense path)
+        if (threadIdx.x == 0 && !accumulate) partials[blockIdx.x] = make_double2(0.0, 0.0);
+        return;
+    }
+    for (uint32_t e = threadIdx.x; e < NEL; e += NT) W[e] = 0.0;
+    __syncthreads();
+    for (int u = (int)threadIdx.x; u < nu; u += NT) {
+        double w = 0.0;
+        for (int j = uoff[u]; j < uoff[u + 1]; ++j) {
+            const DiagTermT dt = dterms[j];
+            w += parity64(gbase & dt.zout) ? -dt.c : dt.c;
+        }
+        W[uzin[u]] = w;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int b = 0; b < M; ++b) {
+#pragma unroll
+        for (int k = 0; k < K / 2; ++k) {
+            const uint32_t q = threadIdx.x + (uint32_t)k * NT;
+            const uint32_t low = (1u << b) - 1u;
+            const uint32_t i = ((q & ~low) << 1) | (q & low), j = i | (1u << b);
+            const double v = W[i], w = W[j];
+            W[i] = v + w;
+            W[j] = v - w;
+        }
+        __syncthreads();
+    }
+    double acc = 0.0;
+    if constexpr (REAL) {
+#pragma unroll
+        for (int k = 0; k < K / 2; ++k) {
+            const uint32_t e = 2u * (threadIdx.x + (uint32_t)k * NT);
+            acc += w2[2 * k] * W[e] + w2[2 * k + 1] * W[e + 1];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc += w2[k] * W[threadIdx.x + (uint32_t)k * NT];
+    }
+    const double2 t = block_sum<NT>(make_double2(acc, 0.0), red);
+    if (threadIdx.x == 0) {
+        if (accumulate) {
+            const double2 o = partials[blockIdx.x];
+            partials[blockIdx.x] = make_double2(o.x + t.x, o.y);
+        } else {
+            partials[blockIdx.x] = t;
         }
     }
 }

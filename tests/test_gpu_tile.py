@@ -360,3 +360,53 @@ def test_tiled_operator_application_in_screen_and_lanczos(SV, m, o, bits):
     assert np.abs(res[bits] - np.array(want)).max() < 1e-10 * scale
     assert np.abs(res[bits] - res[0]).max() < 1e-11 * scale
     assert resid < 1e-6 * scale
+
+
+@pytest.mark.parametrize("real", [False, True])
+def test_dense_register_expectation_with_walsh_hadamard_diagonal_against_oracle(gpu_lib, real):
+    """A DENSE 25-qubit state (the synthetic state of the sharded legs; real = True: its real parts on a float64 shard): <H> of a sum with
+    a 90-string diagonal group — evaluated per contiguous tile by a Walsh-Hadamard transform (k_tile_diag) while the cover's sweeps skip
+    their x = 0 entries — and 40 off-diagonal strings (entries with the trip part of the pair index from the host, unsplit entries of
+    1024 pairs) against the bit-mask oracle on the same amplitudes"""
+    import torch
+
+    import bench
+    from openvqe_amd import synth
+    from openvqe_amd.distributed import ShardedStatevector
+    n = 25
+    rng = np.random.default_rng(2525 + int(real))
+    hx, hz, hc = [], [], []
+    for _ in range(90):                       # diagonal strings: random Z sets of weight 1 .. 6, some reaching the top (per-tile sign) bits
+        qs = rng.choice(n, int(rng.integers(1, 7)), replace=False)
+        hx.append(0)
+        hz.append(sum(1 << int(q) for q in qs))
+        hc.append(float(rng.normal()))
+    for _ in range(40):                       # JW-like off-diagonal strings with an even number of Y (a real-symmetric sum)
+        x, z = bench.two_body_string(rng, n)
+        if bin(x & z).count("1") & 1:
+            z ^= x & -x
+        hx.append(x)
+        hz.append(z)
+        hc.append(float(rng.normal()))
+    psi = synth.amplitudes(bench.SHARDED_SEED, np.arange(1 << n, dtype=np.uint64))
+    if real:
+        psi = psi.real.astype(complex)
+    psi = psi / np.linalg.norm(psi)
+    # the C oracle's x-grouped expectation (OpenMP; the numpy oracle needs a minute per case at this size; the two are pinned against each
+    # other in tests/test_oracle.py)
+    from oracle import cref
+    sx, sz, sc = cref.sort_by_x(np.array(hx, np.uint64), np.array(hz, np.uint64), np.array(hc, np.float64))
+    want = cref.lib().orc_expectation_grouped(np.ascontiguousarray(psi), n, len(sx), sx, sz, sc) + 0.25
+    sv = ShardedStatevector(n, device=0)      # (one rank without a process group: the shard is the register)
+    sv.randomize(bench.SHARDED_SEED)
+    if real:
+        sv.engine.set_real(True)
+        sv.real = True
+        sv.engine.tensor.mul_(1.0 / sv.norm2() ** 0.5)
+    got = sv.expectation(hx, hz, hc, 0.25)
+    again = sv.expectation(hx, hz, hc, 0.25)
+    assert sv._storage_real() == real
+    l1 = float(np.abs(hc).sum())
+    assert abs(got - want) < 1e-11 * l1 and got == again, (got, want)
+    del sv
+    torch.cuda.empty_cache()
