@@ -30,7 +30,7 @@ _screens = {}
 
 def _screen_backend(nbqbits):
     if nbqbits not in _screens:
-        _screens[nbqbits] = make_backend(nbqbits)    # this rank's GPU, or the partitioned register (partitioned.make_backend)
+        _screens[nbqbits] = make_backend(nbqbits, None, Statevector)    # this rank's GPU, or the partitioned register (partitioned.make_backend)
     return _screens[nbqbits]
 
 

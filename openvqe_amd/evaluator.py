@@ -7,7 +7,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import replicas
-from .backend import Statevector  # noqa: F401  (the one-device handle: what make_backend builds on a single GPU)
+from .backend import Statevector  # (the one-device handle: what make_backend builds on a single GPU)
 from .partitioned import make_backend
 
 _BACKENDS = {}
@@ -18,7 +18,7 @@ def shared_backend(nbqbits, device=None):
     ``replicas.partition_min_qubits()`` qubits or more — the index-bit-partitioned register (partitioned.PartitionedStatevector)"""
     key = (int(nbqbits), -1 if device is None else int(device))
     if key not in _BACKENDS:
-        _BACKENDS[key] = make_backend(nbqbits, device)
+        _BACKENDS[key] = make_backend(nbqbits, device, Statevector)
     return _BACKENDS[key]
 
 

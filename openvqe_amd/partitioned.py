@@ -218,11 +218,13 @@ class PartitionedStatevector:
         return 0
 
 
-def make_backend(nbqbits, device=None):
+def make_backend(nbqbits, device=None, statevector_cls=None):
     """the statevector object for a register of ``nbqbits`` qubits in THIS process: partitioned across the ranks of the process group
-    when ``replicas.partitioned`` says so, else the one-device handle on this rank's GPU"""
+    when ``replicas.partitioned`` says so, else the one-device handle on this rank's GPU (``statevector_cls``: the caller module's
+    ``Statevector`` name — what the CPU tests replace by their oracle-backed stand-in)"""
     from . import replicas
     if replicas.partitioned(nbqbits):
         return PartitionedStatevector(nbqbits, device=replicas.device() if device is None else device)
-    from .backend import Statevector
-    return Statevector(nbqbits, device=replicas.device() if device is None else device)
+    if statevector_cls is None:
+        from .backend import Statevector as statevector_cls
+    return statevector_cls(nbqbits, device=replicas.device() if device is None else device)
