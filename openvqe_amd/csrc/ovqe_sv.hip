@@ -858,15 +858,17 @@ void fill_entry_basis(ExEntryT &en, const std::vector<ExTermT> &tterms, bool rea
     const uint32_t iu0 = (host_deposit((uint32_t)en.k0, en.x) | en.ibits) & (nel - 1u);
     uint32_t d[4];
     for (int b = 0; b < 4; ++b) d[b] = host_deposit(64u << b, en.x) & (nel - 1u);
-    en.pb[0] = host_tile_swz(iu0, real) * ab;
-    for (int b = 0; b < 4; ++b) en.pb[1 + b] = host_tile_swz(d[b], real) * ab;
     en.tsign = 0;
     const int nt = std::min(2, en.t1 - en.t0);
-    for (int j = 0; j < nt; ++j) {
-        const uint32_t zin = tterms[(size_t)en.t0 + (j == 0 ? 0 : (en.t1 - en.t0 - 1))].zin;   // (the kernel takes the first and the LAST term)
-        uint32_t f = (uint32_t)__builtin_popcount((iu0 ^ xf) & zin) & 1u;
-        for (int b = 0; b < 4; ++b) f |= ((uint32_t)__builtin_popcount(d[b] & zin) & 1u) << (1 + b);
-        en.tsign |= f << (5 * j);
+    for (uint32_t t = 0; t < 16u; ++t) {
+        uint32_t iu = iu0;                                  // trip t's share of the pair index: trip 0's XOR one basis value per set bit of t
+        for (int b = 0; b < 4; ++b)
+            if ((t >> b) & 1u) iu ^= d[b];
+        en.ph[t] = host_tile_swz(iu, real) * ab;
+        for (int j = 0; j < nt; ++j) {
+            const uint32_t zin = tterms[(size_t)en.t0 + (j == 0 ? 0 : (en.t1 - en.t0 - 1))].zin;   // (the kernel takes the first and the LAST term)
+            en.tsign |= ((uint32_t)__builtin_popcount((iu ^ xf) & zin) & 1u) << (16 * j + t);
+        }
     }
 }
 

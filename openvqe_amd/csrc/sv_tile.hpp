@@ -12,6 +12,7 @@
 // qubits) and the 2-/4-qubit x masks of JW excitations are exactly this shape.
 #pragma once
 #include "sv_small.hpp"
+#include <type_traits>
 
 namespace ovqe {
 
@@ -214,12 +215,14 @@ struct ExEntryT {
     int32_t pad;
     // Round 6, entries of one or two terms (tile_entry_pairs): the TRIP part of the pair index, host-side.  The index of pair k0 + lane +
     // 64 t is dep(lane) | dep(k0 + 64 t) | ibits with disjoint bit sets, the bank swizzle and a term's sign are linear over XOR: trip t's
-    // share of the swizzled byte offset is pb[0] ^ (xor of pb[1 + b] over the set bits b of t), its share of term j's sign is bit 0 of
-    // tsign's 5-bit field j xor the bits 1 + b.  What remains per pair on the device is one XOR per address and one per term.
-    uint32_t pb[5];   // byte offsets: trip 0, then the basis of trip bits 0..3 (index bits 6..9 of k)
-    uint32_t tsign;   // bits 5 j .. 5 j + 4: term j's parity at trip 0 (partner index ^ z), then the basis parities
-    uint32_t pad2[2];
+    // share of the swizzled byte offset and of every term's sign is wave-uniform and tile-independent — tabulated here.  What remains
+    // per pair on the device is one XOR per address and one three-input bit operation per term.
+    uint32_t ph[16];  // swizzled byte offset of trip t's share of the pair index, t = 0 .. nk / 64 - 1 (the XOR combinations of the
+                      // trip-0 offset with one basis offset per set bit of t, made by the host: the device loads them as scalars)
+    uint32_t tsign;   // bit t: term 0's parity on trip t's share of the PARTNER index (lane share excluded); bit 16 + t: term 1's
+    uint32_t pad2[7];
 };
+static_assert(sizeof(ExEntryT) == 128, "one entry = two cache lines of scalar loads");
 constexpr int TILE_UNSPLIT_PAIRS = 1024;   // pairs per piece of an unsplit entry (16 rows of a wave: the per-entry set-up amortised)
 struct ExTermT {
     uint64_t zout;    // z outside the tile
@@ -315,33 +318,31 @@ __device__ __forceinline__ double tile_entry_pairs(const typename Amp<REAL>::T *
     const uint32_t c1ih = (uint32_t)__double2hiint(l1.ci) ^ g1, c1il = (uint32_t)__double2loint(l1.ci);
     const uint32_t sxb = tile_swz<REAL>(xf) * AB;
     const uint32_t ts = en.tsign;
-    // the two low trip bits (inside a group of four trips) as ready-made words
-    const uint32_t p6 = en.pb[1], p7 = en.pb[2];
-    const uint32_t t06 = (ts << 30) & 0x80000000u, t07 = (ts << 29) & 0x80000000u;
-    const uint32_t t16 = (ts << 25) & 0x80000000u, t17 = (ts << 24) & 0x80000000u;
     const char *base = reinterpret_cast<const char *>(tile);
     double part = 0.0;
-    for (uint32_t k = 0; k < nk; k += 256u) {
-        const uint32_t pk = en.pb[0] ^ ((k & 256u) ? en.pb[3] : 0u) ^ ((k & 512u) ? en.pb[4] : 0u);
-        const uint32_t a0 = ((ts << 31) ^ ((k & 256u) ? (ts << 28) : 0u) ^ ((k & 512u) ? (ts << 27) : 0u)) & 0x80000000u;
-        const uint32_t a1 = ONE ? 0u : (((ts << 26) ^ ((k & 256u) ? (ts << 23) : 0u) ^ ((k & 512u) ? (ts << 22) : 0u)) & 0x80000000u);
-        const uint32_t ph[4] = {pk, pk ^ p6, pk ^ p7, pk ^ p6 ^ p7};
-        const uint32_t s0[4] = {a0, a0 ^ t06, a0 ^ t07, a0 ^ t06 ^ t07};
-        const uint32_t s1[4] = {a1, a1 ^ t16, a1 ^ t17, a1 ^ t16 ^ t17};
+    // groups of four trips, written out four times: the table entries are scalar registers by NAME (a loop over r would index the
+    // table through memory)
+    auto four = [&](auto rc) {
+        constexpr uint32_t r = decltype(rc)::value, k = 256u * r;
         amp a[4], c[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint32_t off = pl ^ ph[q];
+            const uint32_t off = pl ^ en.ph[4 * r + q];
             a[q] = *reinterpret_cast<const amp *>(base + off);
             c[q] = *reinterpret_cast<const amp *>(base + (off ^ sxb));
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            double dr = __hiloint2double((int)(c0rh ^ s0[q]), (int)c0rl), di = 0.0;
-            if constexpr (!RO) di = __hiloint2double((int)(c0ih ^ s0[q]), (int)c0il);
+            constexpr uint32_t t0 = 4u * r;
+            const uint32_t t = t0 + (uint32_t)q;
+            // sign bit of trip t into the coefficient's high word: c ^ ((ts << (31 - t)) & 0x80000000) — one shift on the scalar unit,
+            // one three-input bit operation on the vector unit
+            const uint32_t m0 = (ts << (31u - t)) & 0x80000000u, m1 = (ts << (15u - t)) & 0x80000000u;
+            double dr = __hiloint2double((int)(c0rh ^ m0), (int)c0rl), di = 0.0;
+            if constexpr (!RO) di = __hiloint2double((int)(c0ih ^ m0), (int)c0il);
             if constexpr (!ONE) {
-                dr += __hiloint2double((int)(c1rh ^ s1[q]), (int)c1rl);
-                if constexpr (!RO) di += __hiloint2double((int)(c1ih ^ s1[q]), (int)c1il);
+                dr += __hiloint2double((int)(c1rh ^ m1), (int)c1rl);
+                if constexpr (!RO) di += __hiloint2double((int)(c1ih ^ m1), (int)c1il);
             }
             double v;
             if constexpr (REAL) {
@@ -353,6 +354,14 @@ __device__ __forceinline__ double tile_entry_pairs(const typename Amp<REAL>::T *
             }
             if constexpr (FULL) part += v;
             else part += (k + 64u * q + lane < nk) ? v : 0.0;
+        }
+    };
+    four(std::integral_constant<uint32_t, 0>{});
+    if (nk > 256u) {
+        four(std::integral_constant<uint32_t, 1>{});
+        if (nk > 512u) {
+            four(std::integral_constant<uint32_t, 2>{});
+            if (nk > 768u) four(std::integral_constant<uint32_t, 3>{});
         }
     }
     return part;

@@ -789,3 +789,76 @@ def test_fused_gradient_on_the_compact_support(SV, molecule):
         tp[k] += h
         tm[k] -= h
         assert abs(out["fused"][1][k] - (e_oracle(tp) - e_oracle(tm)) / (2 * h)) < 2e-7 * scale
+
+
+@pytest.mark.parametrize("n,g,chunk_bits", [(14, 1, 12), (15, 2, 11), (13, 2, 10), (12, 3, 7), (16, 1, 15)])
+def test_planned_cross_shard_sums_against_oracle(SV, n, g, chunk_bits):
+    """The ovqe_xsum_* exports straight through the binding, several shard handles on one GPU standing for the ranks: a Pauli sum
+    planned once per shard — <H> (d = 0 terms by the tile cover / pair trick, cross terms by k_tile_cross passes over (partner
+    chunk, own shard), chunks of 2^chunk_bits amplitudes: tiles of 2^10 / 2^11 / 2^12 and the streaming fall-back over the cases)
+    and sigma = (H + c) psi — against the bit-mask oracle on the whole register; then the error paths of the boundary."""
+    import torch
+    from openvqe_amd._lib import BackendError
+    rng = np.random.default_rng(77 * n + g)
+    nl = n - g
+    W = 1 << g
+    T = 60
+    xs = np.array([int(v) for v in rng.integers(0, 1 << n, T)], np.uint64)
+    xs[:8] = 0                                                   # a diagonal group
+    xs[8:16] &= np.uint64((1 << nl) - 1)                         # local off-diagonal groups
+    xs[16:20] = xs[16]                                           # a group of four terms
+    zs = np.array([int(v) for v in rng.integers(0, 1 << n, T)], np.uint64)
+    even = np.array([bin(int(x) & int(z)).count("1") % 2 == 0 for x, z in zip(xs, zs)])
+    zs = np.where(even, zs, zs ^ (xs & (~xs + np.uint64(1))))      # an even number of Y: real coefficients, Hermitian terms
+    cs = rng.normal(size=T)
+    psi = random_state(rng, n)
+    want_e = masks.expectation(psi, xs, zs, cs, 0.0)
+    want_sigma = 0.3 * psi + masks.apply_pauli_sum(psi, xs, zs, cs)
+    shards = [SV(nl, n_global=g, shard_index=s) for s in range(W)]
+    bufs = [torch.from_numpy(psi[s << nl:(s + 1) << nl].copy()).cuda() for s in range(W)]
+    outs = [torch.zeros(1 << nl, dtype=torch.complex128, device="cuda") for _ in range(W)]
+    try:
+        for sv, b in zip(shards, bufs):
+            sv.adopt_state(b.data_ptr())
+        total = 0.0
+        csize = 1 << chunk_bits
+        for s, sv in enumerate(shards):
+            sid = sv.xsum_create(xs, zs, cs, chunk_bits)
+            info = sv.xsum_info(sid)
+            partners = sv.xsum_partners(sid)
+            assert info["partners"] == len(partners) == len({int(x) >> nl for x in xs if int(x) >> nl})
+            assert info["streaming_fallback"] == (1 if chunk_bits < 10 else 0)
+            total += sv.xsum_expect_local(sid)
+            sv.xsum_apply_local(sid, outs[s].data_ptr(), 0.3)
+            for d, _ in partners:
+                ket = bufs[s ^ d]
+                for c in range(1 << (nl - chunk_bits)):
+                    chunk = ket[c * csize:(c + 1) * csize]
+                    sv.xsum_expect_remote(sid, d, c, chunk.data_ptr())
+                    sv.xsum_apply_remote(sid, d, c, chunk.data_ptr(), outs[s].data_ptr())
+            v = sv.xsum_expect_finish(sid)
+            total += v.real
+            assert abs(sv.xsum_expect_finish(sid)) == 0.0            # the accumulator was reset
+            # the boundary says no: a rank difference without terms, a chunk beyond the shard, an unknown plan
+            missing = next(d for d in range(1, 2 * W) if d not in [p[0] for p in partners])
+            with pytest.raises(BackendError, match="no terms for this rank difference|chunk index"):
+                sv.xsum_expect_remote(sid, missing, 0, bufs[s].data_ptr())
+            with pytest.raises(BackendError, match="chunk index beyond the shard"):
+                sv.xsum_expect_remote(sid, partners[0][0], 1 << (nl - chunk_bits), bufs[s].data_ptr())
+            sv.xsum_destroy(sid)
+            with pytest.raises(BackendError, match="no such planned sum"):
+                sv.xsum_expect_local(sid)
+        torch.cuda.synchronize()
+        l1 = float(np.abs(cs).sum())
+        assert abs(total - want_e) < 1e-11 * l1
+        got_sigma = np.concatenate([o.cpu().numpy() for o in outs])
+        assert np.abs(got_sigma - want_sigma).max() < 1e-11 * l1
+        # complex coefficients: sigma only; an expectation value of a non-Hermitian sum is refused
+        sid = shards[0].xsum_create(xs[:4], zs[:4], cs[:4] * (1.0 + 0.5j), chunk_bits)
+        with pytest.raises(BackendError, match="complex coefficients"):
+            shards[0].xsum_expect_local(sid)
+        with pytest.raises(BackendError, match="bits beyond the register"):
+            shards[0].xsum_create(np.array([1 << n], np.uint64), np.array([0], np.uint64), np.array([1.0]), chunk_bits)
+    finally:
+        for sv in shards:
+            sv.close()

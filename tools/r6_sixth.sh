@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r6g
-timeout 1500 python -m pytest tests/test_gpu_tile.py tests/test_gpu_distributed.py -x -q > gpurun_out/r6g/tests.log 2>&1
+timeout 1500 python -m pytest tests/test_gpu_tile.py tests/test_gpu_kernels.py tests/test_gpu_distributed.py -x -q > gpurun_out/r6g/tests.log 2>&1
 echo "tile+kernels+distributed rc=$?" | tee -a gpurun_out/r6g/summary.txt
 grep -E "passed|failed|Error" gpurun_out/r6g/tests.log | tail -3
 timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -k "30_qubit or sparse_oracle or tiled" > gpurun_out/r6g/tests30.log 2>&1
