@@ -862,3 +862,54 @@ def test_planned_cross_shard_sums_against_oracle(SV, n, g, chunk_bits):
     finally:
         for sv in shards:
             sv.close()
+
+
+@pytest.mark.parametrize("n", [9, 15, 17])
+def test_real_state_option_on_the_handle_against_oracle(SV, n):
+    """Option "real_state" straight through the binding: the adopted buffer holds 2^n DOUBLES — ovqe_init_basis, odd-Y rotations (pair
+    sweeps at 9 qubits, real tile sweeps of 2^12 doubles from 14 qubits on), ovqe_norm2 and a planned sum's <H> on 8-byte amplitudes
+    against the bit-mask oracle; a rotation that would make the amplitudes complex is refused with the handle left intact"""
+    import torch
+    from openvqe_amd._lib import BackendError
+    rng = np.random.default_rng(31 * n)
+    R = 24
+    xs, zs = [], []
+    for _ in range(R):
+        bits = [int(b) for b in rng.choice(n, int(rng.integers(2, 5)), replace=False)]
+        x = sum(1 << b for b in bits)
+        z = (1 << bits[0]) | int(rng.integers(0, 1 << n)) & ~x          # one Y, Z anywhere else
+        xs.append(x)
+        zs.append(z)
+    xs[5] = xs[4]                                                          # a fusable pair
+    phis = rng.uniform(-1, 1, R)
+    hf = int(rng.integers(0, 1 << n))
+    T = 30
+    hx = np.array([int(v) for v in rng.integers(0, 1 << n, T)], np.uint64)
+    hx[:6] = 0
+    hz = np.array([int(v) for v in rng.integers(0, 1 << n, T)], np.uint64)
+    odd = np.array([bin(int(x) & int(z)).count("1") % 2 == 1 for x, z in zip(hx, hz)])
+    hz = np.where(odd, hz ^ (hx & (~hx + np.uint64(1))), hz)               # even number of Y: a real-symmetric sum
+    hc = rng.normal(size=T)
+    psi = np.zeros(1 << n, complex)
+    psi[hf] = 1
+    for x, z, p in zip(xs, zs, phis):
+        psi = masks.rotate(psi, x, z, p)
+    assert np.abs(psi.imag).max() < 1e-15
+    buf = torch.zeros(1 << n, dtype=torch.float64, device="cuda")
+    with SV(n) as sv:
+        sv.adopt_state(buf.data_ptr())
+        sv.set_option("real_state", 1)
+        sv.init_basis(hf)
+        sv.apply_pauli_rotations(xs, zs, phis)
+        torch.cuda.synchronize()
+        assert np.abs(buf.cpu().numpy() - psi.real).max() < 1e-12 and abs(sv.norm2() - 1.0) < 1e-12
+        sid = sv.xsum_create(hx, hz, hc, min(n, 12))
+        got = sv.xsum_expect_local(sid)
+        assert abs(got - masks.expectation(psi, hx, hz, hc, 0.0)) < 1e-11 * np.abs(hc).sum()
+        with pytest.raises(BackendError, match="even number of Y"):
+            sv.apply_pauli_rotations([3], [0], [0.1])                    # XX: complex amplitudes
+        with pytest.raises(BackendError, match="complex amplitudes"):
+            sv.xsum_apply_local(sid, buf.data_ptr() + 8, 0.0)            # sigma = H psi needs the complex layout
+        torch.cuda.synchronize()
+        assert np.abs(buf.cpu().numpy() - psi.real).max() < 1e-12        # nothing was touched
+        sv.set_option("real_state", 0)
