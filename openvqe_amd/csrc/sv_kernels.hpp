@@ -451,13 +451,13 @@ __global__ __launch_bounds__(256) void k_apply_sum(amp_t *__restrict__ out, cons
 }
 
 // The same step for the listed output indices only (Taylor steps of exp(theta A) on a state of a few determinants: every
-// index the series can reach is in the list, k_support_expand; the buffers hold zeros elsewhere).  Same arithmetic, same
+// index the series can reach is in the list, k_support_expand; the buffers hold zeros elsewhere, or `listed` says where they count).  Same arithmetic, same
 // order: the listed amplitudes equal k_apply_sum's bit for bit.
 __global__ __launch_bounds__(256) void k_apply_sum_list(amp_t *__restrict__ out, const amp_t *__restrict__ in,
                                                         amp_t *__restrict__ acc, const uint64_t *__restrict__ idx,
                                                         uint64_t count, uint64_t base, const HGroup *__restrict__ groups,
                                                         int ngroups, const HTerm *__restrict__ terms, double scale_re,
-                                                        double scale_im) {
+                                                        double scale_im, const uint32_t *__restrict__ listed) {
     const uint64_t e = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (e >= count) return;
     const uint64_t i = idx[e];
@@ -465,7 +465,9 @@ __global__ __launch_bounds__(256) void k_apply_sum_list(amp_t *__restrict__ out,
     for (int g = 0; g < ngroups; ++g) {
         const HGroup gr = groups[g];
         const uint64_t jl = i ^ gr.x;
-        const amp_t k = in[jl];
+        // `listed` (bitmap of the list): `in` is defined on the list only — a ket outside it holds an exact zero of the series
+        amp_t k = make_double2(0.0, 0.0);
+        if (!listed || ((listed[jl >> 5] >> (jl & 31)) & 1u)) k = in[jl];
         const uint64_t gj = base | jl;
         double dr = 0.0, di = 0.0;
         for (int t = gr.t0; t < gr.t1; ++t) {
@@ -488,6 +490,13 @@ __global__ __launch_bounds__(256) void k_apply_sum_list(amp_t *__restrict__ out,
         a.y += r.y;
         acc[i] = a;
     }
+}
+
+// dst[i] = src[i] for the listed indices i
+__global__ __launch_bounds__(256) void k_list_copy(amp_t *__restrict__ dst, const amp_t *__restrict__ src, const uint64_t *__restrict__ idx,
+                                                   uint64_t count) {
+    const uint64_t e = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (e < count) dst[idx[e]] = src[idx[e]];
 }
 
 // bitmap of the listed indices

@@ -270,6 +270,41 @@ def test_exact_exponentials_on_the_reachable_support(SV, m, o):
         assert np.abs(states[16] - ref).max() < 1e-11
 
 
+@pytest.mark.parametrize("m,o", [(6, 2), (8, 3)])
+def test_chain_of_exponentials_keeps_its_support_list(SV, m, o):
+    """back-to-back ovqe_apply_exp_pauli_sum calls after ovqe_init_basis (prepare_adapt_state of the ADAPT mirrors) extend the list
+    the previous call left instead of scanning the register again; any other entry point in between drops the list.  Both ways,
+    and the pass over the whole register, give the same amplitudes bit for bit; a state pointer handed out ends the shortcut"""
+    from openvqe_amd import fermion, pools
+    n = 2 * m
+    _, _, hf = fermion.synthetic_molecule(m, o, seed=5)
+    _, _, pool = pools.singlet_sd(2 * o, m)
+    rng = np.random.default_rng(10 * m + o)
+    picks = rng.choice(len(pool), size=8, replace=False)
+    thetas = rng.uniform(-0.9, 0.9, len(picks))
+    thetas[3] = 0.0                                   # (a call that leaves the state alone keeps the list)
+    states, reach = {}, {}
+    for mode in ("chain", "interrupted", "exposed", "register"):
+        with SV(n) as sv:
+            sv.set_option("screen_sparse", 0 if mode == "register" else 4)
+            if mode == "exposed":
+                sv.state_ptr()
+            sv.init_basis(hf)
+            for k, th in zip(picks, thetas):
+                sv.apply_exp_pauli_sum(pool[k], th)
+                if mode == "interrupted":
+                    assert abs(sv.norm2() - 1.0) < 1e-12
+            reach[mode] = sv.last_exp_support()
+            states[mode] = sv.get_state()
+    for mode in ("interrupted", "exposed", "register"):
+        assert np.array_equal(states["chain"], states[mode]), mode
+    # the kept list is a superset of the scanned one (amplitudes that cancelled to zero stay listed), both inside the cap
+    assert reach["register"] == -1 and 0 < reach["interrupted"] <= reach["chain"] <= (1 << n) // 4, reach
+    assert reach["exposed"] == reach["interrupted"]
+    occupied = np.flatnonzero(states["chain"])
+    assert 1 < len(occupied) <= reach["chain"] and all(bin(int(i)).count("1") == 2 * o for i in occupied)
+
+
 def test_errors_are_reported(SV):
     from openvqe_amd._lib import BackendError
     with SV(3) as sv:
@@ -880,7 +915,7 @@ def test_real_state_option_on_the_handle_against_oracle(SV, n):
         z = (1 << bits[0]) | int(rng.integers(0, 1 << n)) & ~x          # one Y, Z anywhere else
         xs.append(x)
         zs.append(z)
-    xs[5] = xs[4]                                                          # a fusable pair
+    xs[5], zs[5] = xs[4], zs[4] ^ (int(rng.integers(0, 1 << n)) & ~xs[4])  # a fusable pair (same x, Z elsewhere differs)
     phis = rng.uniform(-1, 1, R)
     hf = int(rng.integers(0, 1 << n))
     T = 30
