@@ -496,6 +496,8 @@ def sharded_leg(n, local_rank, world, rank, rotations=64, terms=1000, barrier=No
     stall = os.environ.get("OVQE_BENCH_INJECT_STALL_RANK")      # tests: this rank never posts its half of the first exchange
     if stall is not None and int(stall) == rank:
         time.sleep(10 ** 6)
+    if os.environ.get("OVQE_BENCH_INJECT_SHARDED_ERROR"):        # tests: the leg fails on every rank (what a collective's error does)
+        raise RuntimeError("injected failure of the sharded leg")
 
     from openvqe_amd.distributed import _progress
 
@@ -1040,12 +1042,25 @@ def main():
 
         if use_dist:
             _dd.watchdog = _dd.DistWatchdog(on_expire=expired)
+        sharded_error = None
         try:
             out["sharded"] = sharded_block(args, local_rank, world, rank, dist.barrier if use_dist else None)
+        except Exception as exc:   # the replica figures above are measured: the line carries them, and what went wrong here
+            sharded_error = f"rank {rank}: {type(exc).__name__}: {exc}"[:400]
+            out["sharded"] = {"error": sharded_error}
+            sys.stderr.write(f"bench.py rank {rank}: sharded leg failed: {sharded_error}\n")
         finally:
             if _dd.watchdog is not None:
                 _dd.watchdog.stop()
                 _dd.watchdog = None
+        if sharded_error is not None and use_dist:
+            # several ranks and a failed collective path: the ranks are no longer in step (and the process group may be unusable) — no
+            # further barrier; rank 0 prints the line, every rank leaves with the exit code of the watchdog's way out
+            if rank == 0:
+                emit(out)
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(3)
     if rank == 0:
         e_last = float(e[0])
         # kernel-only figures of the timed region (HIP events around the fused launch)

@@ -155,7 +155,7 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  *   op of the sweep's largest tile; 1, 2, 4, 8, 16), "sector_stream_arrange" (1: the lanes of a row chosen for the LDS banks), "sector_h_pack" (1: <H> sweeps with at most 1023
  *   magnitudes keep their coded words as 24-bit elements), "sector_chunk",
  *   "sector_depth2", "sector_many_tiles",
- *   "sector_h_lpt", "sector_h_threads", "sector_h_groups", "sector_apply_threads", "sector_row_banks", "sector_eager_rots",
+ *   "sector_h_lpt", "sector_h_threads", "sector_h_groups", "sector_apply_threads", "sector_eager_rots",
  *   "screen_tables", "sector_batch_threads" / "_nb" / "_sweep_threads" / "_dst_lds" / "_zfast", "tile_flat" (tiled <H>: entries of one
  *   or two merged terms as per-lane items 1 / per-wave entries 0 / items for real states only 2, the default), "sector_apply_seq" (1: lambda = H psi on the sector tables runs one launch per sweep in sequence with plain
  *   additions where one sweep fills the chip; 0: one launch, global atomics), "tile_unsplit" (1: tiled <H> of complex states takes groups
@@ -164,7 +164,9 @@ int ovqe_set_stream(ovqe_handle h, void *hip_stream);
  *   first sweep of a tiled <H> of a complex register of 25+ qubits counts its sparse tiles; none: the other sweeps run without the
  *   sparse path's LDS, two workgroups per CU) */
 int ovqe_set_option(ovqe_handle h, const char *name, int64_t value);
-/* device pointer to the 2^n_local amplitudes (for RCCL exchange by the host layer) */
+/* device pointer to the 2^n_local amplitudes (for RCCL exchange by the host layer).  The caller may write them between calls: from
+ * here on the handle keeps nothing it learnt about the state from one call to the next (the support list that a chain of
+ * ovqe_apply_exp_pauli_sum calls otherwise carries over is listed afresh per call) */
 int ovqe_state_ptr(ovqe_handle h, void **dev_ptr);
 /* use caller-owned device memory (e.g. a torch tensor) of 2^n_local*16 bytes as the state buffer */
 int ovqe_adopt_state(ovqe_handle h, void *dev_ptr);
@@ -355,7 +357,11 @@ int ovqe_last_batch_ms(ovqe_handle h, double *ms);
  * returns OVQE_ERR_STATE instead of diagonalising a truncated block when the search does not saturate).  which = 4 / 5:
  * passes over the state (kernel launches that stream the shard) of the last ovqe_apply_pauli_rotations / ovqe_bilinear /
  * ovqe_expectation call, and the bytes those passes move by construction (fused runs and tile covers make both smaller
- * than one sweep per rotation / x-group: what bench.py's `sharded` block reports next to its formula rates) */
+ * than one sweep per rotation / x-group: what bench.py's `sharded` block reports next to its formula rates).  which = 6: the kernel
+ * forms of the sector path that served the handle since the program was set, as bits — 0 / 1 / 2 / 3 forward sweeps on pair words /
+ * 64-bit words with rounds / per-wave streams / regular supports by bit arithmetic, 4..7 the backward sweeps of
+ * ovqe_energy_gradient in the same order, 8 / 9 first / second form of the pair-table builder (the tests name the geometry behind
+ * every form: DESIGN.md section 4) */
 int ovqe_last_support(ovqe_handle h, int32_t which, int64_t *support);
 /* shape of the compiled program (diagnostics / tests), up to `count` entries of:
  *   [0] ops of the sequential program  [1] Pauli rotations  [2] literal X/H/CNOT ops  [3] streaming sweeps per

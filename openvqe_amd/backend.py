@@ -371,6 +371,15 @@ class Statevector:
         self._ck(self._L.ovqe_last_support(self._h, 5, ctypes.byref(b)))
         return a.value, b.value
 
+    SECTOR_FORMS = ("sweep_pairs", "sweep_wide", "sweep_streams", "sweep_regular", "adjoint_pairs", "adjoint_wide", "adjoint_streams",
+                    "adjoint_regular", "pair_builder_first", "pair_builder_staged")
+
+    def sector_forms(self):
+        """names of the sector-path kernel forms that served this handle since its program was set (ovqe_last_support, which = 6)"""
+        out = ctypes.c_int64()
+        self._ck(self._L.ovqe_last_support(self._h, 6, ctypes.byref(out)))
+        return {name for bit, name in enumerate(self.SECTOR_FORMS) if (out.value >> bit) & 1}
+
     def last_exp_support(self):
         """amplitudes the Taylor steps of the last ``apply_exp_pauli_sum`` call ran over (-1: the register)"""
         out = ctypes.c_int64()

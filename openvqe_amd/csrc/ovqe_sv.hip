@@ -342,6 +342,11 @@ struct ovqe_sv {
     std::vector<int32_t> prev_pidx;
     uint64_t prev_hf = 0;
     bool prog_extends_prev = false;
+    // which kernel forms of the sector path served this handle since the last ovqe_set_program / ovqe_set_gate_program (ovqe_last_support
+    // which = 6; the tests name the geometry that selects each form): bit 0 first sweep form (pair words), 1 second (64-bit words + rounds),
+    // 2 third (per-wave streams), 3 regular supports (bit arithmetic); 4..7 the backward sweeps of ovqe_energy_gradient in the same order;
+    // 8 / 9 the first / second form of the pair-table builder
+    uint32_t forms_used = 0;
     bool nz_super = false, nz_super_prev = false, state_exposed = false;
     uint64_t nz_super_count = 0;
     DevBuf d_tile_smasks, d_tile_lists, d_tile_counts;   // non-empty tiles per sweep of H psi on a listed state (k_tile_lists)  // support list of the screened state (k_pool_grad_nz)
@@ -408,7 +413,6 @@ struct ovqe_sv {
     int opt_sector_adjoint = 3;   // backward sweeps of the gradient: 3 = on the per-wave streams (k_sector_adjoint3) where a sweep has them; 2 = on the 64-bit tables (k_sector_adjoint2) where they exist and fit; 1 = first form
     int opt_sector_apply_threads = 0; // threads per workgroup of k_sector_apply (0 = automatic, 512, 1024)
     int opt_sector_h_threads = 512; // threads per workgroup of k_sector_expect (512 or 1024)
-    int opt_sector_row_banks = 0; // materialised <H>: the elements of every row ordered against LDS bank conflicts (k_sec_row_banks)
     int opt_sector_batch_sweep_threads = 512;    // workgroup size of a batch's circuit sweeps (512, 1024)
     int opt_sector_batch_dst_lds = 0;            // their scatter indices staged in LDS (0: read when the tile is written — 44 instead of 64 KB
                                                  // per workgroup at 24 qubits: three 512-thread workgroups per CU; B = 64: 0.82 -> 0.70 ms per evaluation)
@@ -1328,7 +1332,6 @@ int ovqe_set_option(ovqe_handle h, const char *name, int64_t value) try {
     else if (k == "sector_batch_zfast") h->opt_sector_batch_zfast = (int)value;
     else if (k == "sector_batch_nb") h->opt_sector_batch_nb = value == 3 ? 3 : 2;
     else if (k == "sector_batch_threads") h->opt_sector_batch_threads = value == 512 ? 512 : 1024;
-    else if (k == "sector_row_banks") h->opt_sector_row_banks = (int)value;
     else if (k == "sector_debug") h->opt_sector_debug = (int)value;
     else if (k == "sector_sweep") h->opt_sector_sweep = value == 1 ? 1 : (value == 2 ? 2 : (value == 4 ? 4 : 3));   // (2 on tables built under 3: the second form on the same tables; 4: the streams for batches too)
     else if (k == "sector_sweep_dbg") h->opt_sector_sweep_dbg = (int)value;
@@ -1639,8 +1642,9 @@ int ovqe_get_rotation_program(ovqe_handle h, int64_t capacity, uint64_t *x, uint
 
 int ovqe_last_support(ovqe_handle h, int32_t which, int64_t *support) try {
     OVQE_ENTER(h);
-    if (!h || !support || which < 0 || which > 5) return OVQE_ERR_INVALID;
-    const int64_t v[6] = {h->last_screen_support, h->last_exp_support, h->last_screen_sector, h->last_fci_rounds, h->last_passes, h->last_pass_bytes};
+    if (!h || !support || which < 0 || which > 6) return OVQE_ERR_INVALID;
+    const int64_t v[7] = {h->last_screen_support, h->last_exp_support, h->last_screen_sector, h->last_fci_rounds, h->last_passes, h->last_pass_bytes,
+                          (int64_t)h->forms_used};
     *support = v[which];
     return OVQE_OK;
 } OVQE_CATCH(h)

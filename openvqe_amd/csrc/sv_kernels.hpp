@@ -913,18 +913,6 @@ __global__ __launch_bounds__(256) void k_init_basis_real(double *__restrict__ st
     for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < namps; i += stride) st[i] = i == index ? 1.0 : 0.0;
 }
 
-// in-place widening real -> complex of the amplitudes [lo, hi): complex[i] = one * real[i].  Called for the index
-// ranges [2^k, 2^(k+1)) from the top down (the complex image of a range lies beyond the reals still to be read), then [0,1).
-__global__ __launch_bounds__(256) void k_widen(void *__restrict__ st, uint64_t lo, uint64_t hi, double2 one) {
-    const double *re = reinterpret_cast<const double *>(st);
-    amp_t *cx = reinterpret_cast<amp_t *>(st);
-    const uint64_t stride = (uint64_t)gridDim.x * 256u;
-    for (uint64_t i = lo + (uint64_t)blockIdx.x * 256u + threadIdx.x; i < hi; i += stride) {
-        const double a = re[i];
-        cx[i] = make_double2(a * one.x, a * one.y);
-    }
-}
-
 // ---- adjoint (reverse-mode) gradient of E(theta) = <psi(theta)|H|psi(theta)>  (ovqe_energy_gradient) ----------
 // Backward pass over one same-x run, rotations in REVERSE order.  psi holds U_r...U_1|hf>, lam holds
 // U_{r+1}^+...U_R^+ H|psi_R>; for every rotation r of the run the kernel accumulates

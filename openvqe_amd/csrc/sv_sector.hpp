@@ -1331,40 +1331,6 @@ __global__ __launch_bounds__(256) void k_sec_encode(uint32_t *__restrict__ words
     words[e] = (words[e] & SEC_HSLOT_MASK) | (v < 0.0 ? 1u << SEC_HSLOT_BITS : 0u) | ((uint32_t)lo << 14);
 }
 
-// LDS banks of the coded stream's amplitude reads.  A wave reads, per element position q, 64 amplitudes tile[slot_j] at once
-// (ds_read_b64: two groups of 32 lanes, bank pair = slot mod 32); in construction order the 32 slots of a group are random
-// and about 3.5 of them share the busiest bank pair.  The order of the elements INSIDE a row is free (a sum), so every row
-// is sorted by (slot mod 32 - lane) mod 32: at position q lane l then reads bank ~ (l + 32 q / L) mod 32 — distinct across
-// the 32 lanes of a group wherever the rows of the slice are about equally long and their slots spread over the banks.
-// One wave per slice, counting sort per lane through LDS histograms; out of place (in -> out, same slice layout).
-__global__ __launch_bounds__(256) void k_sec_row_banks(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                       const uint32_t *__restrict__ cbase, const uint32_t *__restrict__ clen,
-                                                       uint32_t nslices, int ndict) {
-    __shared__ uint16_t hist[4][32][64];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t sl = blockIdx.x * 4u + wave;
-    if (sl >= nslices) return;
-    const uint32_t L = clen[sl];
-    if (L == 0) return;
-    const uint32_t *wp = in + cbase[sl] + 4u * lane;
-    uint32_t *op = out + cbase[sl] + 4u * lane;
-    auto at = [](uint32_t q) { return 256u * (q >> 2) + (q & 3u); };
-    auto key_of = [&](uint32_t w) { return (w >> 14) == (uint32_t)ndict ? 31u : (((w & SEC_HSLOT_MASK) - lane) & 31u); };
-    for (int k = 0; k < 32; ++k) hist[wave][k][lane] = 0;
-    for (uint32_t q = 0; q < L; ++q) ++hist[wave][key_of(wp[at(q)])][lane];
-    uint32_t run = 0;
-    for (int k = 0; k < 32; ++k) {
-        const uint32_t c = hist[wave][k][lane];
-        hist[wave][k][lane] = (uint16_t)run;
-        run += c;
-    }
-    for (uint32_t q = 0; q < L; ++q) {
-        const uint32_t w = wp[at(q)];
-        const uint32_t pos = hist[wave][key_of(w)][lane]++;
-        op[at(pos)] = w;
-    }
-}
-
 // ---- materialised <H>: evaluation --------------------------------------------------------------------------------------
 // The sum over the elements of the lane's row: sum_e value_e a[slot_j]  (APPLY: also lambda[slot_j] += H_ij a_i for the
 // off-diagonal elements, f64 LDS atomics on scattered slots)

@@ -120,3 +120,28 @@ def test_tiled_expectation_of_a_dense_complex_register_census_and_forms(testing_
     ref = got["one_pass_per_group"]
     for label, e in got.items():
         assert abs(e - ref) < 1e-12 * l1 * max(1.0, n2), (label, e, ref, n2)
+
+
+def test_one_wave_form_of_the_fused_gradient(testing_lib):
+    """ovqe_energy_gradient on the compact support takes the workgroup kernel (k_sparse_grad_wg) whenever the row tables exist; the
+    one-wave kernel behind it (k_sparse_grad: programs whose row tables are not built) is reached here by switching the workgroup form
+    off (testing option "sparse_wg") — same energy, same derivatives up to the order of the additions"""
+    from openvqe_amd import chem, fermion
+    from openvqe_amd.backend import Statevector
+    mol = chem.molecule("LIH")
+    mol.rhf()
+    ham = mol.jw_hamiltonian()
+    gens = fermion.uccsd_generators(mol.nao, mol.n_elec // 2)
+    hf = mol.hf_init()
+    theta = np.random.default_rng(8).uniform(-0.2, 0.2, len(gens))
+    out = {}
+    for wg in (1, 0):
+        with Statevector(ham.nbqbits) as sv:
+            sv.set_option("sparse_wg", wg)
+            sv.set_hamiltonian(ham)
+            sv.set_ucc_program(gens, hf)
+            out[wg] = sv.energy_gradient(theta)
+            assert sv.program_info()["support"] > 0
+    scale = float(np.abs(ham.packed()[2]).sum())
+    assert abs(out[0][0] - out[1][0]) < 1e-12 * scale and np.abs(out[0][1] - out[1][1]).max() < 1e-12 * scale
+    assert np.abs(out[0][1]).max() > 1e-3

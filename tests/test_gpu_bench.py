@@ -111,6 +111,22 @@ def test_stalled_rank_ends_the_sharded_leg_with_a_line_and_exit_code_3(gpu_lib):
     assert "no progress" in out["sharded"]["error"] and "OVQE_DIST_TIMEOUT_S" in out["sharded"]["error"]
 
 
+def test_failing_sharded_leg_still_prints_the_line(gpu_lib):
+    """An exception inside the partitioned block (injected on every rank; a failed collective looks like this) must not cost the line:
+    rank 0 prints it with the replica figures and "sharded": {"error": ...}, the processes leave with a non-zero exit code at once"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OVQE_BENCH_BACKEND="gloo", OVQE_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               OVQE_BENCH_INJECT_SHARDED_ERROR="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "1024", "--no-roofline", "--no-cpu", "--no-extra", "--sharded-qubits", "15", "--sharded-rotations", "24",
+           "--sharded-terms", "80"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0
+    last = r.stdout.strip().splitlines()[-1]
+    out = _strict_json(last)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and "injected failure" in out["sharded"]["error"]
+
+
 def test_single_gpu_sharded_leg_checks_its_energy_against_the_value_on_record(gpu_lib):
     """`sharded.energy_check`: the 31-qubit energy of configs[4]'s strong leg does not depend on the number of GPUs; the value of the
     one-GPU run is on record (bench.SHARDED_KNOWN) and every run compares with it to 1e-11 |H|_1.  Here: the record mechanism on a

@@ -11,6 +11,19 @@ from openvqe_amd.operators import pack_string
 pytestmark = pytest.mark.gpu
 N = 30
 
+_N2 = []
+
+
+def _n2_problem():
+    """N2 / cc-pVDZ, (10 electrons, 12 orbitals) active space: integrals, RHF and the frozen core once per session (2.8 s a time, eight
+    tests) -> (RHF energy, CAS problem).  The tests only read it."""
+    if not _N2:
+        from openvqe_amd import chem
+        mol = chem.molecule("N2-CCPVDZ")
+        e_rhf = mol.rhf()
+        _N2.append((e_rhf, chem.cas_problem(mol, 2, 12)))
+    return _N2[0]
+
 
 def _strings(n):
     return [("XXXY", [0, 1, 2, 3]), ("XXXY", [n - 4, n - 3, n - 2, n - 1]), ("YXXX", [0, 9, 19, n - 1]),
@@ -176,14 +189,11 @@ def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
     LDS-tiled sweeps, Clifford-frame form on real-amplitude streams (the third evaluation comes from the sector tables on the
     coset of the program's Z2 symmetries, sweeps from bit arithmetic: asserted), Clifford-frame form on the complex state; three components of ovqe_energy_gradient
     on the gate program against central differences of the oracle."""
-    from openvqe_amd import chem
     from openvqe_amd.backend import GATE_OPCODES, Statevector
     from openvqe_amd.common_files.circuit import quccsd_gate_list
     from openvqe_amd.operators import Hamiltonian
     from oracle import cref
-    mol = chem.molecule("N2-CCPVDZ")
-    mol.rhf()
-    prob = chem.cas_problem(mol, 2, 12)
+    _, prob = _n2_problem()
     n = prob.nbqbits
     assert n == 24
     size, cluster_ops, _, theta_mp2, hf = prob.uccsd()
@@ -228,7 +238,7 @@ def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
     idx = np.concatenate([big, rng.integers(0, 1 << n, 5000).astype(np.uint64)])
     want = psi_ref[idx.astype(np.int64)]
     l1 = float(np.abs(hc).sum())
-    res = {}
+    res, forms = {}, {}
     with Statevector(n) as sv:
         sv.set_hamiltonian(ham)
         for label, frame, real in (("literal_tiled", 0, 1), ("frame_real", 1, 1), ("frame_complex", 1, 0)):
@@ -241,6 +251,7 @@ def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
             e_third = sv.energy(theta)                                    # third call: an evaluation that comes FROM the tables
             info_after = sv.program_info()
             grad = sv.energy_gradient(theta) if label == "frame_real" else None
+            forms[label] = sv.sector_forms()
             sv.prepare_state(theta)
             res[label] = (e, sv.get_amplitudes(idx), sv.norm2(), info, e_again, e_third, info_after, grad)
     assert res["literal_tiled"][3]["literal_gates"] > 0 and res["literal_tiled"][3]["tiled_sweeps"] > 0
@@ -251,6 +262,8 @@ def test_24_qubit_quccsd_gate_program_against_c_oracle(gpu_lib):
     after = res["frame_real"][6]
     assert after["sector_support"] == 1 << 22 and after["sector_free_bits"] == 2, after
     assert after["sector_h_elements"] > 0 and after["sector_regular_slot_bits"] > 0, after
+    # ... forwards and backwards by the kernels of the regular supports (k_sector_sweep_reg / k_sector_adjoint_reg), no pair words at all
+    assert forms["frame_real"] == {"sweep_regular", "adjoint_regular"}, forms
     for label, (e, amps, n2, _, e_again, e_third, _, _) in res.items():
         assert abs(e - e_ref) < 1e-10 * max(1.0, l1), (label, e, e_ref)
         assert abs(e_again - e_ref) < 1e-10 * max(1.0, l1), (label, e_again, e_ref)
@@ -276,13 +289,10 @@ def test_24_qubit_full_quccsd_list_against_c_oracle(gpu_lib):
     and the plain-C oracle evaluates that sequence with its fused mask sweeps and x-grouped expectation.  Nothing on the oracle's side
     comes from the product.  The product's compiled sequence (ovqe_get_rotation_program) must equal the oracle's rotation for
     rotation; its energies (streaming path, table build, sector tables on the 2^22 coset) must equal the oracle's number."""
-    from openvqe_amd import chem
     from openvqe_amd.backend import Statevector
     from openvqe_amd.common_files.circuit import quccsd_gate_list
     from oracle import cref
-    mol = chem.molecule("N2-CCPVDZ")
-    mol.rhf()
-    prob = chem.cas_problem(mol, 2, 12)
+    _, prob = _n2_problem()
     n = prob.nbqbits
     size, cluster_ops, _, theta_mp2, hf = prob.uccsd()
     gates, K, _ = quccsd_gate_list(12, 5, 1, excitations=[op.terms[0].qbits for op in cluster_ops])
@@ -371,11 +381,8 @@ def test_24_qubit_uccsd_sector_path_on_n2(gpu_lib):
     """N2 / cc-pVDZ (10e, 12o), UCCSD in the reference's operator order (1715 cluster operators, 6464-term JW Hamiltonian) through
     the sector path: (5 alpha, 5 beta) sector = 627 264 amplitudes, against the dense-state kernels on the same handle inputs,
     and E(theta = 0) against the RHF energy of the SCF front-end (an independent number)"""
-    from openvqe_amd import chem
     from openvqe_amd.backend import Statevector
-    mol = chem.molecule("N2-CCPVDZ")
-    e_rhf = mol.rhf()
-    prob = chem.cas_problem(mol, 2, 12)
+    e_rhf, prob = _n2_problem()
     ham = prob.jw_hamiltonian()
     size, _, spin_ops, theta_mp2, hf = prob.uccsd()
     rng = np.random.default_rng(2412)
@@ -403,12 +410,9 @@ def test_24_qubit_sector_path_against_c_oracle(gpu_lib):
     x-grouped expectation): (1) the FULL N2 / cc-pVDZ (10e,12o) UCCSD program — 1715 generators = 13 300 rotations, 6464-term
     Hamiltonian — at the MP2 amplitudes + noise; (2) every 8th generator: energy and sampled components of the exact gradient
     against central differences of the oracle's energy."""
-    from openvqe_amd import chem
     from openvqe_amd.backend import Statevector, compile_ucc_program
     from oracle import cref
-    mol = chem.molecule("N2-CCPVDZ")
-    mol.rhf()
-    prob = chem.cas_problem(mol, 2, 12)
+    _, prob = _n2_problem()
     n = prob.nbqbits
     ham = prob.jw_hamiltonian()
     size, _, spin_ops, theta_mp2, hf = prob.uccsd()
@@ -426,7 +430,10 @@ def test_24_qubit_sector_path_against_c_oracle(gpu_lib):
         sv.set_ucc_program(spin_ops, hf)
         es = [sv.energy(theta) for _ in range(3)]
         info = sv.program_info()
+        forms = sv.sector_forms()
     assert info["sector_support"] == 792 ** 2 and info["sector_h_elements"] > 10 ** 8
+    # 24 qubits, 46 sweeps of ~1.8 M pairs: every sweep on the per-wave streams (k_sector_sweep3), tables by the staged builder
+    assert forms == {"sweep_streams", "pair_builder_staged"}, forms
     for e in es:                                                  # dense first call, table-building call, sector call
         assert abs(e - e_ref) < 1e-10 * max(1.0, l1), (e, e_ref)
     # thinned program: gradient components
@@ -442,9 +449,10 @@ def test_24_qubit_sector_path_against_c_oracle(gpu_lib):
         e8 = sv.energy(th8)
         e8g, g8 = sv.energy_gradient(th8)
         assert sv.program_info()["sector_support"] > 0
+        assert "adjoint_streams" in sv.sector_forms()          # (k_sector_adjoint3: the backward twin of the streams)
     assert abs(e8 - e8_ref) < 1e-10 * max(1.0, l1) and abs(e8g - e8_ref) < 1e-10 * max(1.0, l1)
     h = 1e-4
-    for k in (0, K8 - 1):       # (two components: each costs the oracle two 24-qubit circuits)
+    for k in (K8 - 1,):         # (one component: it costs the oracle two 24-qubit circuits; the 22-qubit test samples more)
         tp, tm = th8.copy(), th8.copy()
         tp[k] += h
         tm[k] -= h
@@ -488,11 +496,8 @@ def test_24_qubit_uccsd_vqe_on_n2_with_exact_gradients(gpu_lib):
     below E(theta_MP2) to the converged value of a longer run, the final gradient is small, and at the optimum the
     dense-state kernels (sector = 0) return the same energy and the same gradient"""
     from scipy.optimize import minimize
-    from openvqe_amd import chem
     from openvqe_amd.backend import Statevector
-    mol = chem.molecule("N2-CCPVDZ")
-    e_rhf = mol.rhf()
-    prob = chem.cas_problem(mol, 2, 12)
+    e_rhf, prob = _n2_problem()
     ham = prob.jw_hamiltonian()
     size, _, spin_ops, theta_mp2, hf = prob.uccsd()
     trace = []
@@ -526,11 +531,8 @@ def test_24_qubit_quccsd_entry_point_on_n2(gpu_lib, capsys):
     ref:openvqe/ucc_family/get_energy_qucc.py:136-244: BFGS, tol 1e-5, from the MP2 guess and from the constant guess) on
     N2 / cc-pVDZ (10e,12o), 1715 cluster operators, with the opt-in exact Jacobian: both runs reach the minimum that L-BFGS-B on
     the C ABI finds (tools/exp_n2_vqe.py --quccsd: -109.0689753850), result schema and CNOT count as the reference's"""
-    from openvqe_amd import chem
     from openvqe_amd.ucc_family.get_energy_qucc import EnergyUCC
-    mol = chem.molecule("N2-CCPVDZ")
-    mol.rhf()
-    prob = chem.cas_problem(mol, 2, 12)
+    _, prob = _n2_problem()
     ham = prob.jw_hamiltonian()
     size, cluster_ops, _, theta_mp2, hf = prob.uccsd()
     old = EnergyUCC.adjoint_gradient
@@ -566,13 +568,56 @@ def test_26_qubit_uccsd_sector_path(gpu_lib):
             sv.set_option("sector", sector)
             sv.set_hamiltonian(ham)
             sv.set_ucc_program(gens, hf)
-            res[sector] = ([sv.energy(t) for t in thetas], sv.program_info())
+            res[sector] = ([sv.energy(t) for t in thetas], sv.program_info(), sv.sector_forms())
     info = res[1][1]
     assert info["sector_support"] == 1716 ** 2 and info["sector_h_elements"] > 3 * 10 ** 9 and res[0][1]["sector_support"] == 0
+    # 66 sweeps of ~8.8 M pairs on 1024+ tiles each: the 64-bit words with rounds (k_sector_sweep2, 512-thread workgroups); no streams
+    assert res[1][2] == {"sweep_wide", "pair_builder_staged"} and not res[0][2], res[1][2]
     l1 = float(np.abs(hc).sum())
     for a, b in zip(res[1][0], res[0][0]):
         assert abs(a - b) < 1e-10 * l1
     assert abs(res[1][0][1] - e_hf) < 1e-10 * l1
+
+
+def test_28_qubit_uccsd_takes_the_pair_word_forms(gpu_lib):
+    """molecule-shaped UCCSD at 28 qubits (14 orbitals, 7 + 7 electrons: 3381 generators, 3432^2 = 11.8 M determinants, 3.1 G pair words,
+    21.8 G matrix elements = 97 GB of tables): a sweep's pair stream passes 16 M words, where the 64-bit words and the streams are not
+    built any more — the automatic selection runs the FIRST sweep form (k_sector_sweep on 32-bit pair words) and its backward twin
+    (k_sector_adjoint).  Energies against the dense-state kernels of a second handle, one gradient component against their central
+    difference."""
+    from openvqe_amd import fermion
+    from openvqe_amd.backend import Statevector
+    m, o = 14, 7
+    ham, gens, hf = fermion.synthetic_molecule(m, o, seed=14)
+    rng = np.random.default_rng(14)
+    theta = rng.uniform(-0.1, 0.1, len(gens))
+    l1 = float(np.abs(ham.packed()[2]).sum())
+    with Statevector(2 * m) as sv:
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, hf)
+        es = [sv.energy(theta) for _ in range(3)]
+        forms_e = sv.sector_forms()
+        e_g, g = sv.energy_gradient(theta)
+        forms_g = sv.sector_forms() - forms_e
+        info = sv.program_info()
+    assert info["sector_support"] == 3432 ** 2 and info["sector_pairs"] > 3 * 10 ** 9 and info["sector_h_elements"] > 2 * 10 ** 10
+    assert forms_e == {"sweep_pairs", "pair_builder_staged"} and forms_g == {"adjoint_pairs"}, (forms_e, forms_g)
+    k = int(np.argmax(np.abs(g)))
+    h = 1e-4
+    with Statevector(2 * m) as sv:
+        sv.set_option("sector", 0)
+        sv.set_option("compact", 0)
+        sv.set_hamiltonian(ham)
+        sv.set_ucc_program(gens, hf)
+        e_dense = sv.energy(theta)
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += h
+        tm[k] -= h
+        fd = (sv.energy(tp) - sv.energy(tm)) / (2 * h)
+        assert not sv.sector_forms()
+    for e in es + [e_g]:
+        assert abs(e - e_dense) < 1e-10 * l1, (e, e_dense)
+    assert abs(g[k] - fd) < 2e-7 * l1, (k, g[k], fd)
 
 
 def test_24_qubit_adapt_screens_and_qubit_adapt_on_n2(gpu_lib, capsys):
@@ -580,12 +625,10 @@ def test_24_qubit_adapt_screens_and_qubit_adapt_on_n2(gpu_lib, capsys):
     five spin-adapted generators and both screens (fermionic 2 Re, qubit 2 |.|) over the support of psi against the passes over the
     whole 2^24 register (bit-identical state, screens to 1e-12); then three macro-iterations of the qubit-ADAPT mirror
     (ref:openvqe/adapt/qubit_adapt_vqe.py:310-605): energies fall monotonically from the RHF energy and stay above FCI"""
-    from openvqe_amd import chem, pools
+    from openvqe_amd import pools
     from openvqe_amd.adapt import qubit_adapt_vqe as qav
     from openvqe_amd.backend import GRAD_FERMIONIC, GRAD_QUBIT, Statevector
-    mol = chem.molecule("N2-CCPVDZ")
-    e_rhf = mol.rhf()
-    prob = chem.cas_problem(mol, 2, 12)
+    e_rhf, prob = _n2_problem()
     ham = prob.jw_hamiltonian()
     _, _, spin_ops, _, hf = prob.uccsd()
     _, _, singlets = pools.singlet_sd(10, 12)
@@ -628,11 +671,9 @@ def test_24_qubit_spin_adapted_ansatz_gets_its_tables_from_the_second_probe(gpu_
     (one angle per parameter) does not hold, the orphan check drops those tables at the first evaluation, and the second probe
     (one angle per rotation: nothing cancels) lists a superset on which the tables are exact — energies and the gradient equal the
     dense kernels', and evaluations stay on the tables afterwards"""
-    from openvqe_amd import chem, pools
+    from openvqe_amd import pools
     from openvqe_amd.backend import Statevector
-    mol = chem.molecule("N2-CCPVDZ")
-    mol.rhf()
-    prob = chem.cas_problem(mol, 2, 12)
+    _, prob = _n2_problem()
     ham = prob.jw_hamiltonian()
     _, _, _, _, hf = prob.uccsd()
     _, _, singlets = pools.singlet_sd(10, 12)

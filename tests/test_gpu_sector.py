@@ -475,9 +475,9 @@ def test_batched_evaluations_on_the_sector_tables_match_c_oracle(SV, m, o):
     thetas[5] = 0.0
     rx, rz, rc, pidx, _ = compile_ucc_program(n, gens)
     hx, hz, hc = ham.packed()
-    # the oracle sees every vector at 16 qubits, the first 48 at 18 and the first 24 at 20 (141 evaluations there = three minutes of the suite's budget),
+    # the oracle sees every vector at 16 qubits, the first 32 at 18 and the first 16 at 20 (141 evaluations there = three minutes of the suite's budget),
     # the rest of the big batch is held against one evaluation at a time on the same handle (the serial path has its own oracle tests)
-    n_oracle = 141 if m < 9 else (48 if m < 10 else 24)
+    n_oracle = 141 if m < 9 else (32 if m < 10 else 16)      # (16: one evaluation per core of the GPU box's host, one round)
     want = cref.ucc_energy_batch(n, hf, rx, rz, rc, pidx, thetas[:n_oracle], hx, hz, hc.real.copy(), ham.constant_coeff)
     l1 = float(np.abs(hc).sum())
     with SV(n) as sv:
@@ -488,6 +488,7 @@ def test_batched_evaluations_on_the_sector_tables_match_c_oracle(SV, m, o):
         first = sv.energy_batch(thetas[:8])                  # fresh handle: the batch builds the tables itself
         info = sv.program_info()
         got = {B: sv.energy_batch(thetas[:B]) for B in (1, 3, 8, 141)}
+        assert "sweep_wide" in sv.sector_forms()             # batches: one workgroup per (tile, state) on the 64-bit words (k_sector_sweep2)
         serial = np.array([sv.energy(t) for t in thetas[:9]])
         serial_rest = np.array([sv.energy(t) for t in thetas[n_oracle:]])
         # parameters and energies resident on the device (ovqe_energy_batch_device beyond the fused kernels' 16 qubits): the same
@@ -508,7 +509,7 @@ def test_batched_evaluations_on_the_sector_tables_match_c_oracle(SV, m, o):
         sv.energy_batch_device(5, th_dev.data_ptr(), en5.data_ptr())
         resident5 = en5.cpu().numpy()
     assert np.abs(resident - got[141]).max() < 1e-13 * max(1.0, l1)
-    assert np.abs(resident7 - want[10:17]).max() < 1e-10 * max(1.0, l1) and np.abs(resident5 - serial[:5]).max() < 1e-13 * max(1.0, l1)
+    assert np.abs(resident7[:6] - want[10:16]).max() < 1e-10 * max(1.0, l1) and abs(resident7[6] - got[141][16]) < 1e-13 * max(1.0, l1) and np.abs(resident5 - serial[:5]).max() < 1e-13 * max(1.0, l1)
     assert info["sector_support"] == comb(m, o) ** 2
     assert np.abs(first - want[:8]).max() < 1e-10 * max(1.0, l1)
     for B, e in got.items():
@@ -595,7 +596,7 @@ def test_sector_ground_state_on_a_hopping_chain_needs_more_than_64_rounds(SV):
 
 
 def test_differential_fuzz_of_the_sector_path(gpu_lib):
-    """tools/fuzz_sector.py, 40 cases: random UCC-type programs and QUCCSD template lists at 14-20 qubits under random tile geometry,
+    """tools/fuzz_sector.py, 30 cases: random UCC-type programs and QUCCSD template lists at 14-20 qubits under random tile geometry,
     workgroup sizes, coding and sweep forms (pair words / bit arithmetic / blocks of two ops / runs without barriers): energies and all
     gradient components of the sector path against the dense-state kernels of the same handle (1e-11 / 1e-10 |H|_1).  The superseded
     kernel forms that no default selects are reached only through these option draws."""
@@ -603,24 +604,24 @@ def test_differential_fuzz_of_the_sector_path(gpu_lib):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_sector.py"), "40", "2025"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_sector.py"), "30", "2025"], capture_output=True, text=True,
                        timeout=900, cwd=root)
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-2000:]
     assert r.returncode == 0 and "MISMATCH" not in r.stdout, tail
     assert "bit-arithmetic sweeps" in tail
     regular = int(tail.split("(")[1].split(" ")[0])
-    assert regular >= 5, tail      # the regular-support kernels were among the draws
+    assert regular >= 3, tail      # the regular-support kernels were among the draws
 
 
 def test_differential_fuzz_with_the_per_wave_streams_forced(gpu_lib):
-    """the same tool on the testing build (OVQE_LIB=testing), 30 cases: the draws add the third sweep form's streams forced on small
+    """the same tool on the testing build (OVQE_LIB=testing), 22 cases: the draws add the third sweep form's streams forced on small
     tiles — 1 to 16 waves per tile, lanes of a row arranged for the LDS banks or in list order, words without partner, ops of several
     patterns (single-string and multi-term generators) — and the first / second forms, forwards and backwards"""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_sector.py"), "30", "77"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_sector.py"), "22", "77"], capture_output=True, text=True,
                        timeout=900, cwd=root, env=dict(os.environ, OVQE_LIB="testing"))
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-2000:]
     assert r.returncode == 0 and "MISMATCH" not in r.stdout, tail
