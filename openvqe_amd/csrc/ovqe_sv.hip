@@ -1459,12 +1459,15 @@ int ovqe_init_basis(ovqe_handle h, uint64_t index) try {
     }
     if (rc) return rc;
     // the support is this one index: the start of the list the exact exponentials extend (see nz_super)
-    const bool keep_list = !h->opt_real_state && h->own_state && !h->state_exposed && h->n_global == 0 && h->namps >= 4096 &&
-                           h->opt_screen_sparse > 0;
+    bool keep_list = !h->opt_real_state && h->own_state && !h->state_exposed && h->n_global == 0 && h->namps >= 4096 &&
+                     h->n_local <= 28 && h->opt_screen_sparse > 0;   // (28 qubits: a list buffer of at most 2^24 indices = 128 MB)
     if (keep_list) {
-        rc = ensure(h, h->d_nz_idx, (size_t)(h->namps / (uint64_t)h->opt_screen_sparse) * sizeof(uint64_t));
-        if (rc) return rc;
-        HIPC(h, hipMemcpyAsync(h->d_nz_idx.p, &index, sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+        if (ensure(h, h->d_nz_idx, (size_t)(h->namps / (uint64_t)h->opt_screen_sparse) * sizeof(uint64_t)) != OVQE_OK) {
+            (void)hipGetLastError();   // no room for the list: the exponentials scan the register as before
+            keep_list = false;
+        } else {
+            HIPC(h, hipMemcpyAsync(h->d_nz_idx.p, &index, sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+        }
     }
     HIPC(h, hipStreamSynchronize(h->stream));
     if (keep_list) {
