@@ -467,7 +467,7 @@ SHARDED_SEED = 20250227
 # Energies of the sharded workload that are on record: (qubits, rotations, terms) -> <H> after the rotations.  The synthetic state is
 # defined per GLOBAL index and the operators per qubit count, so the value cannot depend on the number of GPUs; any N compares its
 # strong leg (and its weak leg where a value is on record) with these to 1e-11 |H|_1.  Source: profiles/r4b/bench.json (1 GPU, 31 q);
-# confirmed by the C oracle on a 32-GiB host state (tools/oracle_sharded_energy.py, profiles/r6_oracle31/: 0.0006064921993098272,
+# confirmed by the C oracle on a 32-GiB host state (tests/oracle_sharded_energy.py, profiles/r6_oracle31/: 0.0006064921993098272,
 # 7.4e-18 |H|_1 away).
 SHARDED_KNOWN = {(31, 64, 1000): 0.0006064921993039994}
 

@@ -1,7 +1,7 @@
-"""The energy bench.py keeps on record for configs[4]'s strong leg (bench.SHARDED_KNOWN) from the C ORACLE, on the host: the synthetic
+"""CHECKER (imports oracle/: lives under tests/, not a test pytest collects).  The energy bench.py keeps on record for configs[4]'s strong leg (bench.SHARDED_KNOWN) from the C ORACLE, on the host: the synthetic
 state of 2^n amplitudes (openvqe_amd/synth.py, generated in chunks), bench.sharded_workload's rotations one fused mask sweep each
 (oracle/c orc_pauli_rotation) and <H> x-group by x-group (orc_expectation_grouped).  n = 31: a 32-GiB host state, about ten minutes on 16
-cores.  usage: oracle_sharded_energy.py [n] [rotations] [terms]"""
+cores.  usage: python tests/oracle_sharded_energy.py [n] [rotations] [terms]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -4,4 +4,4 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r6j
 grep -E "MemTotal|MemAvailable" /proc/meminfo; nproc
 python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
-timeout 3000 python tools/oracle_sharded_energy.py 31 64 1000 2>&1 | tee gpurun_out/r6j/oracle_31_qubits.log
+timeout 3000 python tests/oracle_sharded_energy.py 31 64 1000 2>&1 | tee gpurun_out/r6j/oracle_31_qubits.log
