@@ -1,11 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r6h
-R=$GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-for v in 1 0; do
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf$v -- python3 $R/tools/exp_quccsd_reg.py reps=4 grad=6 sector_apply_full=$v > /tmp/pf$v.log 2>&1
-f=$(find /tmp/pf$v -name "*kernel_stats.csv" | head -1)
-echo "== sector_apply_full=$v"; grep -E "k_sector_apply|k_sector_adjoint_reg|k_sector_sweep_reg|k_sector_expect" $f | sed 's/(.*)"/"/' | cut -c1-200
-done | tee $R/gpurun_out/r6h/apply_full_kernels.log
-rm -rf /tmp/pf0 /tmp/pf1
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_gpu_sector.py tests/test_gpu_abi.py -x -q -m gpu -k "adjoint or gradient or abi or forms or one_wave" > gpurun_out/r6h/t1.log 2>&1
+grep -E "passed|failed|Error" gpurun_out/r6h/t1.log | tail -3
